@@ -1,0 +1,308 @@
+"""Generate the golden fixtures in this directory FROM THE REFERENCE ITSELF.
+
+Run in the build container only (needs /root/reference):  ``python tests/golden/make_golden.py``.
+It imports the upstream modules through ``oracle/load_reference.py`` (stub package, no
+torchvision), runs them on seeded CPU inputs and saves inputs + expected outputs as small
+``.pt`` files (plain dicts of tensors / python scalars, loadable with ``weights_only=True``).
+No reference source travels: fixtures are data only.  Coverage follows SURVEY.md §8c G1-G8.
+"""
+import json
+import os
+import sys
+
+import torch
+import torch.nn.functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+from oracle import load_reference as LR          # noqa: E402
+from oracle import unet_ref as U                 # noqa: E402
+from tests.golden.recipes import rnd, pack, pack_dict, digest   # noqa: E402
+
+torch.set_num_threads(1)                          # single-thread: reproducible reductions
+ref = LR.load()
+TINY = dict(in_channels=3, hid_channels=32, out_channels=3, ch_multipliers=[1, 2], num_res_blocks=1,
+            apply_attn=[False, True], drop_rate=0.0)
+
+
+def save(name, obj):
+    path = os.path.join(HERE, name)
+    torch.save(obj, path)
+    print(f"{name}: {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def randomized(module, seed):
+    sd = U.randomize_state_dict(module.state_dict(), seed)
+    module.load_state_dict(sd)
+    return sd
+
+
+# ----------------------------------------------------------------------------- G1 op level
+def g1_ops():
+    out = {}
+    # GroupNorm(32, eps 1e-6) (+SiLU): unet.py:18-20,85
+    for B, C, hw in [(2, 128, 4), (1, 384, 16), (2, 768, 4), (1, 128, 16)]:
+        gn = ref.unet.DEFAULT_NORMALIZER(C)
+        sd = randomized(gn, 100 + C + hw)
+        rec = dict(shape=(B, C, hw, hw), seed=C * 7 + hw, scale=1.7, shift=0.3)      # x = recipes.rnd(*shape, seed=.., ..)
+        x = rnd(*rec["shape"], seed=rec["seed"], scale=rec["scale"], shift=rec["shift"])
+        y = gn(x)
+        out[f"gn_C{C}_hw{hw}"] = dict(x_recipe=rec, x_digest=digest(x), weight=sd["weight"], bias=sd["bias"], y=y.detach(),
+                                      y_silu_digest=digest(F.silu(y)))
+    # 3x3 s1 p1 convs incl. Cin=3 and Cout=3: modules.py:66-123
+    for ci, co, hw in [(3, 32, 8), (32, 3, 8), (64, 32, 8)]:
+        conv = ref.modules.Conv2d(ci, co, 3, 1, 1)
+        sd = randomized(conv, 200 + ci)
+        x = rnd(2, ci, hw, hw, seed=300 + ci)
+        out[f"conv3_{ci}_{co}"] = dict(x=x, weight=sd["weight"], bias=sd["bias"], y=conv(x).detach())
+    # SAME-pad stride-2 conv on even and odd H: modules.py:145-160, unet.py:165-167
+    for hw in (8, 9):
+        pad, conv = ref.modules.SamePad2d(3, 2), ref.modules.Conv2d(32, 32, 3, 2)
+        sd = randomized(conv, 400 + hw)
+        x = rnd(2, 32, hw, hw, seed=410 + hw)
+        out[f"down_hw{hw}"] = dict(x=x, weight=sd["weight"], bias=sd["bias"], y=conv(pad(x)).detach())
+    # 1x1 conv
+    conv = ref.modules.Conv2d(64, 96, 1)
+    sd = randomized(conv, 500)
+    x = rnd(2, 64, 4, 4, seed=501)
+    out["conv1x1"] = dict(x=x, weight=sd["weight"], bias=sd["bias"], y=conv(x).detach())
+    # attention core: unet.py:43-51
+    for C, h in [(64, 4), (256, 16)]:
+        shp = (1 if C == 256 else 2, C, h, h)
+        q, k, v = (rnd(*shp, seed=600 + i + C) for i in range(3))
+        o = ref.unet.AttentionBlock.qkv(q, k, v)
+        out[f"qkv_C{C}_L{h * h}"] = dict(shape=shp, seeds=[600 + i + C for i in range(3)], q_digest=digest(q), out=o)
+    # nearest 2x upsample + conv: unet.py:199-202
+    conv = ref.modules.Conv2d(32, 32, 3, 1, 1)
+    sd = randomized(conv, 700)
+    x = rnd(2, 32, 4, 4, seed=701)
+    out["up_conv"] = dict(x=x, weight=sd["weight"], bias=sd["bias"],
+                          y=conv(torch.nn.Upsample(scale_factor=2, mode="nearest")(x)).detach())
+    # timestep embedding: functions.py:10-26
+    t = torch.tensor([0, 1, 500, 999])
+    for dim in (128, 127):
+        out[f"temb_{dim}"] = dict(t=t, emb=ref.functions.get_timestep_embedding(t, dim))
+    save("g1_ops.pt", out)
+
+
+# ----------------------------------------------------------------------------- G2 block level
+def _grads(module, loss):
+    loss.backward()
+    return {k: p.grad.detach().clone() for k, p in module.named_parameters()}
+
+
+def g2_blocks():
+    out = {}
+    res = ref.unet.ResidualBlock(32, 64, embed_dim=128, drop_rate=0.0)
+    sd = randomized(res, 11)
+    x = rnd(2, 32, 8, 8, seed=12).requires_grad_(True)
+    te = rnd(2, 128, seed=13).requires_grad_(True)
+    gy = rnd(2, 64, 8, 8, seed=14)
+    y = res(x, t_emb=te)
+    g = _grads(res, (y * gy).sum())
+    out["res"] = dict(sd=sd, x=x.detach(), t_emb=te.detach(), gy=gy, y=y.detach(), gx=x.grad, gt_emb=te.grad, grads=g)
+    att = ref.unet.AttentionBlock(64)
+    sd = randomized(att, 21)
+    x = rnd(2, 64, 4, 4, seed=22).requires_grad_(True)
+    gy = rnd(2, 64, 4, 4, seed=23)
+    y = att(x)
+    g = _grads(att, (y * gy).sum())
+    out["attn"] = dict(sd=sd, x=x.detach(), gy=gy, y=y.detach(), gx=x.grad, grads=g)
+    save("g2_blocks.pt", out)
+
+
+# ----------------------------------------------------------------------------- G3 model level
+def tiny_model(seed=1234):
+    torch.manual_seed(seed)
+    m = ref.UNet(**TINY)
+    init = {k: v.clone() for k, v in m.state_dict().items()}
+    sd = randomized(m, 31)
+    return m, init, sd
+
+
+def g3_model():
+    out = {"tiny_cfg": TINY}
+    m, init, sd = tiny_model()
+    out["tiny_init_seed"], out["tiny_rand_seed"] = 1234, 31     # sd == randomize_state_dict(init(seed 1234), 31)
+    out["tiny_init_sd"] = pack_dict(init)
+    out["tiny_sd"] = pack_dict(sd)
+    x = rnd(2, 3, 8, 8, seed=32)
+    t = torch.tensor([7, 912])
+    gy = rnd(2, 3, 8, 8, seed=33)
+    m.train()
+    y = m(x, t)
+    (y * gy).sum().backward()
+    full = ("in_conv.weight", "downsamples.level_0.0.conv1.weight", "upsamples.level_0.1.conv1.weight", "out_conv.2.weight",
+            "middle.1.project_in.weight", "downsamples.level_0.1.1.weight", "upsamples.level_1.2.1.weight")
+    out["tiny"] = dict(x=x, t=t, gy=gy, y=y.detach(),
+                       grads=pack_dict({k: p.grad for k, p in m.named_parameters()}, full_keys=full))
+    # the reference's own __main__ smoke config (unet.py:237): output checksum only
+    torch.manual_seed(99)
+    big = ref.UNet(3, 128, 3, (1, 2, 3), 2, (False, True, False))
+    randomized(big, 41)
+    big.eval()
+    xs = rnd(2, 3, 32, 32, seed=42)
+    ts = torch.tensor([0, 999])
+    with torch.no_grad():
+        ys = big(xs, ts)
+    out["smoke"] = dict(init_seed=99, rand_seed=41, x_seed=42, t=ts, y_sum=ys.double().sum(), y_abs_sum=ys.double().abs().sum(),
+                        y_corner=ys[:, :, :4, :4].clone())
+    # state-dict key lists + shapes for the shipped configs
+    for name in ("cifar10", "celeba", "celebahq"):
+        cfg = json.load(open(os.path.join(LR.REFERENCE_ROOT, "configs", name + ".json")))
+        mc = dict(cfg["model"]); mc.pop("block_size", None)
+        mc["out_channels"] = mc["in_channels"]
+        with torch.device("meta"):
+            net = ref.UNet(**mc)
+        out["keys_" + name] = [(k, tuple(v.shape)) for k, v in net.state_dict().items()]
+        out["cfg_" + name] = cfg
+    # init parity for the CIFAR net: checksums of every tensor under seed 1234
+    cfg = dict(out["cfg_cifar10"]["model"]); cfg["out_channels"] = 3
+    torch.manual_seed(1234)
+    net = ref.UNet(**cfg)
+    out["cifar_init_sums"] = {k: float(v.double().sum()) for k, v in net.state_dict().items()}
+    save("g3_model.pt", out)
+
+
+# ----------------------------------------------------------------------------- G4 tables
+def _tables(obj):
+    return {k: (v.clone() if torch.is_tensor(v) else v) for k, v in obj.__dict__.items()}
+
+
+def g4_tables():
+    out = {}
+    betas = ref.get_beta_schedule("linear", 1e-4, 0.02, 1000)
+    for vt in ("fixed-small", "fixed-large"):
+        out["ddpm_" + vt] = _tables(ref.GaussianDiffusion(betas, "eps", vt, "mse"))
+    out["toy_fixed-large"] = _tables(ref.GaussianDiffusion(ref.get_beta_schedule("linear", 1e-3, 0.2, 100), "eps", "fixed-large", "mse"))
+    for kind in ("quad", "warmup10", "warmup50", "const", "jsd"):
+        out["betas_" + kind] = ref.get_beta_schedule(kind, 1e-4, 0.02, 1000)
+    for sched, size in (("linear", 50), ("quadratic", 100), ("quadratic", 50)):
+        sub = ref.get_selection_schedule(sched, size, 1000)
+        out[f"sel_{sched}_{size}"] = sub
+        if (sched, size) == ("quadratic", 50):
+            continue
+        for eta in (0.0, 1.0):
+            for vt in ("fixed-small", "fixed-large"):
+                out[f"ddim_{sched}_{size}_eta{eta}_{vt}"] = _tables(ref.DDIM(betas, "eps", vt, "mse", eta=eta, subsequence=sub))
+    save("g4_tables.pt", out)
+
+
+# ----------------------------------------------------------------------------- G5 step level
+def g5_steps():
+    out = {}
+    betas = ref.get_beta_schedule("linear", 1e-4, 0.02, 1000)
+    m, _, _ = tiny_model()
+    m.eval()
+    x0 = rnd(4, 3, 8, 8, seed=51).clamp(-1, 1)
+    noise = rnd(4, 3, 8, 8, seed=52)
+    z = rnd(4, 3, 8, 8, seed=53)
+    t = torch.tensor([0, 1, 500, 999])
+    lin = lambda x, t: 0.1 * x + 0.01 * t.reshape(-1, 1, 1, 1).to(x)        # closed-form denoiser
+    for vt in ("fixed-small", "fixed-large"):
+        dif = ref.GaussianDiffusion(betas, "eps", vt, "mse")
+        x_t = dif.q_sample(x0, t, noise)
+        rec = dict(x0=x0, noise=noise, z=z, t=t, x_t=x_t)
+        for name, fn in (("lin", lin), ("unet", m)):
+            with torch.no_grad():
+                rec["loss_" + name] = dif.train_losses(fn, x0, t, noise=noise)
+                mean, var, logvar, px0 = dif.p_mean_var(fn, x_t, t, clip_denoised=True, return_pred=True)
+                rec["mean_" + name], rec["pred_x0_" + name] = mean, px0
+                rec["var"], rec["logvar"] = var, logvar
+
+                class G:    # inject z instead of the generator draw (diffusion.py:155)
+                    pass
+                orig = torch.Tensor.normal_
+                torch.Tensor.normal_ = lambda self, *a, **k: self.copy_(z)
+                try:
+                    rec["x_prev_" + name] = dif.p_sample_step(fn, x_t, t)
+                finally:
+                    torch.Tensor.normal_ = orig
+        out[vt] = rec
+    save("g5_steps.pt", out)
+
+
+# ----------------------------------------------------------------------------- G6 loop level
+def g6_loops():
+    out = {}
+    betas = ref.get_beta_schedule("linear", 1e-4, 0.02, 1000)
+    m, _, _ = tiny_model()
+    m.eval()
+    shape = (1, 3, 8, 8)
+    for vt in ("fixed-large", "fixed-small"):
+        dif = ref.GaussianDiffusion(betas, "eps", vt, "mse")
+        x = dif.p_sample(m, shape=shape, device=torch.device("cpu"), seed=7)
+        # the noise stream the reference consumed: x_T first, then one z per step (diffusion.py:164-173)
+        g = torch.Generator("cpu").manual_seed(7)
+        x_T = torch.empty(shape).normal_(generator=g)
+        zs = torch.stack([torch.empty(shape).normal_(generator=g) for _ in range(1000)])
+        out["ddpm_" + vt] = dict(seed=7, shape=shape, x_0=x, x_T=x_T, zs_sum=zs.double().sum(), zs_abs_sum=zs.double().abs().sum(),
+                                 z_first=zs[0].clone(), z_last=zs[-1].clone())
+    base = ref.GaussianDiffusion(betas, "eps", "fixed-small", "mse")
+    for sched, size, eta in (("linear", 50, 0.0), ("quadratic", 100, 1.0)):
+        sub = ref.get_selection_schedule(sched, size, 1000)
+        ddim = ref.DDIM.from_ddpm(base, eta=eta, subsequence=sub)
+        x = ddim.p_sample(m, shape=(2, 3, 8, 8), device=torch.device("cpu"), seed=11)
+        out[f"ddim_{sched}_{size}_eta{eta}"] = dict(seed=11, shape=(2, 3, 8, 8), x_0=x)
+    save("g6_loops.pt", out)
+
+
+# ----------------------------------------------------------------------------- G7 train steps
+def g7_train():
+    betas = ref.get_beta_schedule("linear", 1e-4, 0.02, 1000)
+    dif = ref.GaussianDiffusion(betas, "eps", "fixed-large", "mse")
+    m, _, sd0 = tiny_model()
+    opt = torch.optim.Adam(m.parameters(), lr=2e-4, betas=(0.9, 0.999))
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lr_lambda=lambda t: min((t + 1) / 5000, 1.0))
+    tr = ref.Trainer(m, opt, dif, epochs=1, trainloader=None, scheduler=sched, use_ema=True, grad_norm=1.0,
+                     shape=(3, 8, 8), device=torch.device("cpu"), ema_decay=0.9999)
+    m.train()
+    xs = [(torch.rand(4, 3, 8, 8, generator=torch.Generator().manual_seed(70 + i)) * 2 - 1) for i in range(3)]
+    losses = []
+    for i, x in enumerate(xs):
+        tr.stats.reset()
+        tr.step(x, global_steps=i + 1)
+        losses.append(tr.current_stats["loss"])
+    out = dict(cfg=TINY, init_seed=1234, rand_seed=31, sd0=pack_dict(sd0), xs=xs, losses=torch.tensor(losses, dtype=torch.float64), lr=2e-4, warmup=5000, gen_seed=8191,
+               params=pack_dict(m.state_dict()), shadow=pack_dict(tr.ema.shadow), num_updates=tr.ema.num_updates,
+               last_lr=sched.get_last_lr()[0])
+    save("g7_train.pt", out)
+
+
+# ----------------------------------------------------------------------------- G8 toy plumbing
+def g8_toy():
+    torch.manual_seed(1234)
+    dec = ref.toy_model.Decoder(2, 128, 3)
+    sd = {k: v.clone() for k, v in dec.state_dict().items()}
+    x = rnd(16, 2, seed=81)
+    t = torch.arange(16) * 6
+    gy = rnd(16, 2, seed=82)
+    y = dec(x, t)
+    (y * gy).sum().backward()
+    grads = {k: p.grad.clone() for k, p in dec.named_parameters()}
+    nparams = sum(p.numel() for p in dec.parameters())
+    dif = ref.toy_diffusion.GaussianDiffusion(ref.get_beta_schedule("linear", 1e-3, 0.2, 100), "eps", "fixed-large", "mse")
+    dec.zero_grad()
+    opt = torch.optim.Adam(dec.parameters(), lr=1e-3)
+    g = torch.Generator().manual_seed(83)
+    # gaussian8-like data: 8 modes on a circle (shape of the toy data, not the reference's streamer)
+    ang = torch.randint(8, (10, 1000), generator=g).double() * (3.141592653589793 / 4)
+    data = (torch.stack([ang.cos(), ang.sin()], -1) * 2 + 0.1 * torch.randn(10, 1000, 2, generator=g, dtype=torch.float64)).float()
+    ts = torch.randint(100, (10, 1000), generator=g)
+    noises = torch.randn(10, 1000, 2, generator=g)
+    losses = []
+    for i in range(10):
+        loss = dif.train_losses(dec, data[i], ts[i], noise=noises[i]).mean()
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    out = dict(sd=sd, x=x, t=t, gy=gy, y=y.detach(), grads=pack_dict(grads), nparams=nparams,
+               data_seed=83, losses=torch.tensor(losses, dtype=torch.float64),
+               sd_after=pack_dict(dec.state_dict()))
+    save("g8_toy.pt", out)
+
+
+if __name__ == "__main__":
+    g1_ops(); g2_blocks(); g3_model(); g4_tables(); g5_steps(); g6_loops(); g7_train(); g8_toy()

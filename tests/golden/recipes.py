@@ -1,0 +1,54 @@
+"""Shared by make_golden.py and the tests: seeded input recipes and tensor digests.
+
+A *recipe* regenerates an input from a CPU seed (torch's CPU RNG stream is stable); the fixture
+keeps its digest so drift is detected.  A *digest* stands in for a tensor too large to commit:
+(sum, |.|-sum, squares-sum in fp64 + 32-element head/tail).  Small tensors are stored whole.
+"""
+import torch
+
+FULL_LIMIT = 4096
+
+
+def rnd(*shape, seed, scale=1.0, shift=0.0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale + shift
+
+
+def digest(t):
+    d = t.detach().double().reshape(-1)
+    return dict(shape=tuple(t.shape), sum=float(d.sum()), abs_sum=float(d.abs().sum()), sq_sum=float((d * d).sum()),
+                head=t.detach().reshape(-1)[:32].clone(), tail=t.detach().reshape(-1)[-32:].clone())
+
+
+def pack(t, full=False):
+    """Store small tensors whole, large ones as digests."""
+    if full or t.numel() <= FULL_LIMIT:
+        return t.detach().clone()
+    return digest(t)
+
+
+def pack_dict(d, full_keys=()):
+    return {k: pack(v, full=k in full_keys) for k, v in d.items()}
+
+
+def check(actual, packed, rtol, atol=0.0, name=""):
+    """Assert ``actual`` matches a packed tensor/digest; tolerances are relative to the max magnitude."""
+    if torch.is_tensor(packed):
+        scale = float(packed.abs().max()) or 1.0
+        err = float((actual.detach().cpu().to(packed.dtype) - packed).abs().max())
+        assert err <= rtol * scale + atol, f"{name}: max err {err:.3e} vs scale {scale:.3e}"
+        return err / scale
+    a = actual.detach().cpu()
+    assert tuple(a.shape) == packed["shape"], f"{name}: shape {tuple(a.shape)} != {packed['shape']}"
+    got = digest(a)
+    n = a.numel()
+    rtol = max(rtol, 1e-12)          # fp64 reduction order differs with thread count
+    rms = (packed["sq_sum"] / n) ** 0.5 or 1.0
+    # sums of n terms each within rtol*rms: allow sqrt(n)-ish growth generously (n * rtol * rms is the hard bound)
+    assert abs(got["sum"] - packed["sum"]) <= rtol * rms * n ** 0.5 * 4 + atol * n, f"{name}: sum {got['sum']} vs {packed['sum']}"
+    assert abs(got["abs_sum"] - packed["abs_sum"]) <= rtol * packed["abs_sum"] + atol * n, f"{name}: abs_sum"
+    assert abs(got["sq_sum"] - packed["sq_sum"]) <= 2 * rtol * packed["sq_sum"] + atol * n, f"{name}: sq_sum"
+    scale = max(float(packed["head"].abs().max()), float(packed["tail"].abs().max()), rms)
+    for part in ("head", "tail"):
+        err = float((got[part].to(packed[part].dtype) - packed[part]).abs().max())
+        assert err <= rtol * scale * 4 + atol, f"{name}: {part} err {err:.3e} vs scale {scale:.3e}"
+    return 0.0
