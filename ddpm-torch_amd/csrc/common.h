@@ -1,0 +1,117 @@
+// Shared device helpers for the gfx950 (MI355X / CDNA4) kernels of the DDPM hot path.
+// Wave = 64 lanes everywhere in this tree; nothing here is meant to build for another target.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define DDPM_OK 0
+#define DDPM_ERR_SHAPE 1      // dimension / divisibility contract violated
+#define DDPM_ERR_DTYPE 2      // unknown dtype enum
+#define DDPM_ERR_ALIGN 3      // pointer or pitch not 16-byte aligned
+#define DDPM_ERR_LAUNCH 4     // hipGetLastError() after launch
+#define DDPM_ERR_NULL 5
+
+#define DDPM_F32 0
+#define DDPM_BF16 1
+
+typedef unsigned short bf16_t;   // raw bfloat16 bits
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((unsigned)v) << 16); }
+// round-to-nearest-even, NaN preserved
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    unsigned u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ unsigned pack_bf2(float lo, float hi) { return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16); }
+
+// Element traits: VEC = elements per 16-byte vector.
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+    static constexpr int VEC = 4;
+    __device__ static __forceinline__ float ld(const float* p) { return *p; }
+    __device__ static __forceinline__ void st(float* p, float v) { *p = v; }
+    __device__ static __forceinline__ void unpack(const u32x4& v, float* f) {
+        f[0] = __uint_as_float(v.x); f[1] = __uint_as_float(v.y); f[2] = __uint_as_float(v.z); f[3] = __uint_as_float(v.w);
+    }
+    __device__ static __forceinline__ u32x4 pack(const float* f) {
+        u32x4 v; v.x = __float_as_uint(f[0]); v.y = __float_as_uint(f[1]); v.z = __float_as_uint(f[2]); v.w = __float_as_uint(f[3]);
+        return v;
+    }
+};
+template <> struct Elem<bf16_t> {
+    static constexpr int VEC = 8;
+    __device__ static __forceinline__ float ld(const bf16_t* p) { return bf2f(*p); }
+    __device__ static __forceinline__ void st(bf16_t* p, float v) { *p = f2bf(v); }
+    __device__ static __forceinline__ void unpack(const u32x4& v, float* f) {
+        f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+        f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+        f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
+        f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+    }
+    __device__ static __forceinline__ u32x4 pack(const float* f) {
+        u32x4 v; v.x = pack_bf2(f[0], f[1]); v.y = pack_bf2(f[2], f[3]); v.z = pack_bf2(f[4], f[5]); v.w = pack_bf2(f[6], f[7]);
+        return v;
+    }
+};
+
+__device__ __forceinline__ u32x4 ldg16(const void* p) { return *reinterpret_cast<const u32x4*>(p); }
+__device__ __forceinline__ void stg16(void* p, const u32x4& v) { *reinterpret_cast<u32x4*>(p) = v; }
+__device__ __forceinline__ u32x4 zero16() { u32x4 v; v.x = v.y = v.z = v.w = 0u; return v; }
+
+// 64-lane wave reductions (butterfly over the whole wavefront).
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+__device__ __forceinline__ float sigmoidf_(float z) { return 1.0f / (1.0f + __expf(-z)); }
+__device__ __forceinline__ float siluf_(float z) { return z * sigmoidf_(z); }
+// d/dz [z*sigmoid(z)] = s*(1 + z*(1-s))
+__device__ __forceinline__ float silu_gradf_(float z) { float s = sigmoidf_(z); return s * (1.0f + z * (1.0f - s)); }
+
+// Exact unsigned division by a runtime constant chosen on the host, valid for n < 2^31.
+// Power of two: q = n >> shift (mul == 0).  Otherwise q = (n * mul) >> shift with
+// l = ceil(log2 d), shift = 31 + l, mul = floor(2^shift / d) + 1  (< 2^32 because d is not a power of 2).
+struct FastDiv {
+    unsigned mul, shift, d;
+};
+__device__ __forceinline__ unsigned fdiv(unsigned n, const FastDiv& f) {
+    return f.mul ? (unsigned)(((unsigned long long)n * f.mul) >> f.shift) : (n >> f.shift);
+}
+static inline FastDiv make_fastdiv(unsigned d) {
+    FastDiv f; f.d = d ? d : 1; f.mul = 0; f.shift = 0;
+    if (d <= 1) return f;
+    unsigned l = 0; while ((1ull << l) < d) ++l;
+    if ((1ull << l) == d) { f.shift = l; return f; }
+    f.shift = 31 + l;
+    f.mul = (unsigned)((1ull << f.shift) / d + 1);
+    return f;
+}
+
+// Counter-based dropout RNG shared by forward and backward (and by the test hook that dumps the mask):
+// keep(seed, idx) is a pure function, so backward regenerates the mask instead of storing it.
+__device__ __forceinline__ unsigned mix32(unsigned x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ bool dropout_keep(unsigned long long seed, unsigned long long idx, unsigned thresh24) {
+    unsigned lo = (unsigned)idx, hi = (unsigned)(idx >> 32);
+    unsigned h = mix32(lo ^ mix32(hi + (unsigned)seed) ^ (unsigned)(seed >> 32) * 0x9E3779B9u);
+    return (h >> 8) >= thresh24;          // P(keep) = 1 - thresh24 / 2^24
+}
+
+static inline int check_launch() { return hipGetLastError() == hipSuccess ? DDPM_OK : DDPM_ERR_LAUNCH; }
+static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }

@@ -1,0 +1,403 @@
+// HBM-bound helpers of the DDPM hot path (gfx950): timestep embedding, layout/pack kernels, the fused
+// diffusion algebra (q_sample, eps-MSE, ancestral / DDIM step), softmax rows for attention, reductions.
+// Every kernel is a grid-stride or one-row-per-wave stream with coalesced accesses; no device allocation,
+// no synchronisation — all entry points enqueue on the caller's stream and return.
+#include "common.h"
+
+static inline int grid_for(long long n, int block = 256, int cap = 256 * 16) {
+    long long g = (n + block - 1) / block;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+// ------------------------------------------------------------------ timestep embedding (functions.py:10-26)
+// freqs[half] = exp(-i*ln(1e4)/(half-1)) is a host-built fp32 table (same values as the reference's torch.exp);
+// the fp32 product t*f is formed first (like torch.outer), then sin / cos.  t*f reaches ~1e3 rad.
+__global__ void temb_kernel(const long long* __restrict__ t, const float* __restrict__ freqs, float* __restrict__ out, int B, int dim) {
+    const int half = dim / 2;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B * dim; i += gridDim.x * blockDim.x) {
+        const int b = i / dim, j = i - b * dim;
+        float v = 0.f;                                 // odd dim: last column is the zero pad
+        if (j < 2 * half) {
+            const float arg = __fmul_rn((float)t[b], freqs[j < half ? j : j - half]);
+            v = j < half ? sinf(arg) : cosf(arg);
+        }
+        out[i] = v;
+    }
+}
+extern "C" int ddpm_timestep_embedding(const long long* t, const float* freqs, float* out, int B, int dim, void* stream) {
+    if (!t || !out || !freqs) return DDPM_ERR_NULL;
+    if (B <= 0 || dim < 4) return DDPM_ERR_SHAPE;
+    hipLaunchKernelGGL(temb_kernel, dim3(grid_for((long long)B * dim)), dim3(256), 0, (hipStream_t)stream, t, freqs, out, B, dim);
+    return check_launch();
+}
+
+// ------------------------------------------------------------------ NCHW fp32 -> NHWC (channel-padded) T
+template <typename T>
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, T* __restrict__ y, int B, int C, int HW, int Cp) {
+    const long long n = (long long)B * HW * Cp;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % Cp);
+        const long long bp = i / Cp;
+        const int p = (int)(bp % HW);
+        const long long b = bp / HW;
+        Elem<T>::st(y + i, c < C ? x[(b * C + c) * HW + p] : 0.f);
+    }
+}
+extern "C" int ddpm_nchw_to_nhwc(const float* x, void* y, int B, int C, int HW, int Cp, int dtype, void* stream) {
+    if (!x || !y) return DDPM_ERR_NULL;
+    if (B <= 0 || C <= 0 || HW <= 0 || Cp < C) return DDPM_ERR_SHAPE;
+    const int g = grid_for((long long)B * HW * Cp);
+    if (dtype == DDPM_BF16) hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)y, B, C, HW, Cp);
+    else if (dtype == DDPM_F32) hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(g), dim3(256), 0, (hipStream_t)stream, x, (float*)y, B, C, HW, Cp);
+    else return DDPM_ERR_DTYPE;
+    return check_launch();
+}
+
+// ------------------------------------------------------------------ weight packing
+// master fp32 [N][C][R][S]  ->  fwd  [N][R][S][Cp]          (k = (r,s,c), c contiguous; zero channel pad)
+//                           ->  dgrad [C][R][S][Np] with taps flipped: wd[c][r][s][n] = w[n][c][R-1-r][S-1-s]
+template <typename T>
+__global__ void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ wf, T* __restrict__ wd, int N, int C, int R, int S, int Cp, int Np) {
+    const int RS = R * S;
+    if (wf) {
+        const long long n = (long long)N * RS * Cp;
+        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+            const int c = (int)(i % Cp); const long long r1 = i / Cp;
+            const int tap = (int)(r1 % RS); const int nn = (int)(r1 / RS);
+            Elem<T>::st(wf + i, c < C ? w[((long long)nn * C + c) * RS + tap] : 0.f);
+        }
+    }
+    if (wd) {
+        const long long n = (long long)C * RS * Np;
+        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+            const int nn = (int)(i % Np); const long long r1 = i / Np;
+            const int tap = (int)(r1 % RS); const int c = (int)(r1 / RS);
+            Elem<T>::st(wd + i, nn < N ? w[((long long)nn * C + c) * RS + (RS - 1 - tap)] : 0.f);
+        }
+    }
+}
+extern "C" int ddpm_pack_weight(const float* w, void* wf, void* wd, int N, int C, int R, int S, int Cp, int Np, int dtype, void* stream) {
+    if (!w || (!wf && !wd)) return DDPM_ERR_NULL;
+    if (Cp < C || Np < N) return DDPM_ERR_SHAPE;
+    const long long big = (long long)(Cp > C ? Cp : C) * R * S * (Np > N ? Np : N);
+    const int g = grid_for(big);
+    if (dtype == DDPM_BF16) hipLaunchKernelGGL(pack_weight_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, w, (bf16_t*)wf, (bf16_t*)wd, N, C, R, S, Cp, Np);
+    else if (dtype == DDPM_F32) hipLaunchKernelGGL(pack_weight_kernel<float>, dim3(g), dim3(256), 0, (hipStream_t)stream, w, (float*)wf, (float*)wd, N, C, R, S, Cp, Np);
+    else return DDPM_ERR_DTYPE;
+    return check_launch();
+}
+
+// ------------------------------------------------------------------ diffusion algebra (fp32, per-sample coefficients gathered by t)
+// q_sample: x_t = a[t]*x0 + b[t]*noise   (diffusion.py:92-97); separate roundings like the reference's op chain
+__global__ void q_sample_kernel(const float* __restrict__ x0, const float* __restrict__ noise, const long long* __restrict__ t,
+                                const float* __restrict__ ca, const float* __restrict__ cb, float* __restrict__ xt, int B, int n) {
+    const long long tot = (long long)B * n;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += (long long)gridDim.x * blockDim.x) {
+        const int b = (int)(i / n);
+        const long long tt = t[b];
+        xt[i] = __fadd_rn(__fmul_rn(ca[tt], x0[i]), __fmul_rn(cb[tt], noise[i]));
+    }
+}
+extern "C" int ddpm_q_sample(const float* x0, const float* noise, const long long* t, const float* sqrt_ab, const float* sqrt_1mab,
+                             float* xt, int B, int n, void* stream) {
+    if (!x0 || !noise || !t || !sqrt_ab || !sqrt_1mab || !xt) return DDPM_ERR_NULL;
+    if (B <= 0 || n <= 0) return DDPM_ERR_SHAPE;
+    hipLaunchKernelGGL(q_sample_kernel, dim3(grid_for((long long)B * n)), dim3(256), 0, (hipStream_t)stream, x0, noise, t, sqrt_ab, sqrt_1mab, xt, B, n);
+    return check_launch();
+}
+
+// per-sample mean of (target - pred)^2 (diffusion.py:239, functions.py:99-101): one block per sample
+__global__ void mse_fwd_kernel(const float* __restrict__ pred, const float* __restrict__ target, float* __restrict__ loss, int n) {
+    __shared__ float sh[4];
+    const int b = blockIdx.x;
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const float d = target[(long long)b * n + i] - pred[(long long)b * n + i];
+        acc += d * d;
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) loss[b] = (sh[0] + sh[1] + sh[2] + sh[3]) / (float)n;
+}
+__global__ void mse_bwd_kernel(const float* __restrict__ pred, const float* __restrict__ target, const float* __restrict__ gloss,
+                               float* __restrict__ gpred, int B, int n) {
+    const long long tot = (long long)B * n;
+    const float inv = 2.0f / (float)n;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += (long long)gridDim.x * blockDim.x) {
+        const int b = (int)(i / n);
+        gpred[i] = (pred[i] - target[i]) * inv * gloss[b];
+    }
+}
+extern "C" int ddpm_mse_fwd(const float* pred, const float* target, float* loss, int B, int n, void* stream) {
+    if (!pred || !target || !loss) return DDPM_ERR_NULL;
+    if (B <= 0 || n <= 0) return DDPM_ERR_SHAPE;
+    hipLaunchKernelGGL(mse_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, pred, target, loss, n);
+    return check_launch();
+}
+extern "C" int ddpm_mse_bwd(const float* pred, const float* target, const float* gloss, float* gpred, int B, int n, void* stream) {
+    if (!pred || !target || !gloss || !gpred) return DDPM_ERR_NULL;
+    if (B <= 0 || n <= 0) return DDPM_ERR_SHAPE;
+    hipLaunchKernelGGL(mse_bwd_kernel, dim3(grid_for((long long)B * n)), dim3(256), 0, (hipStream_t)stream, pred, target, gloss, gpred, B, n);
+    return check_launch();
+}
+
+// One fused sampling step for model_mean_type in {eps, x_0, mean} with a fixed variance table
+// (diffusion.py:107-158): pred_x0 -> clamp -> posterior mean -> + 1[t>0]*exp(0.5*logvar)*z.
+// tab = 7 fp32 tables of length T, concatenated: recip, recip_m1, coef1, coef2, logvar, (unused), (unused)
+struct StepTables { const float *recip, *recip_m1, *coef1, *coef2, *logvar; };
+__global__ void p_step_kernel(const float* __restrict__ x_t, const float* __restrict__ out, const float* __restrict__ z,
+                              const long long* __restrict__ t, StepTables tb, float* __restrict__ x_prev, float* __restrict__ pred_x0,
+                              int B, int n, int mean_type, int clip) {
+    const long long tot = (long long)B * n;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += (long long)gridDim.x * blockDim.x) {
+        const int b = (int)(i / n);
+        const long long tt = t[b];
+        const float xt = x_t[i], o = out[i];
+        float x0, mean;
+        if (mean_type == 0) {            // eps (diffusion.py:145-148)
+            x0 = __fsub_rn(__fmul_rn(tb.recip[tt], xt), __fmul_rn(tb.recip_m1[tt], o));
+        } else if (mean_type == 1) {     // x_0
+            x0 = o;
+        } else {                         // mean (diffusion.py:140-143)
+            const float c1 = tb.coef1[tt], c2 = tb.coef2[tt];
+            x0 = __fsub_rn(__fdiv_rn(o, c1), __fmul_rn(__fdiv_rn(c2, c1), xt));
+        }
+        if (clip) x0 = fminf(fmaxf(x0, -1.f), 1.f);
+        if (mean_type == 2) mean = o;
+        else mean = __fadd_rn(__fmul_rn(tb.coef1[tt], x0), __fmul_rn(tb.coef2[tt], xt));
+        const float mask = tt > 0 ? 1.f : 0.f;
+        const float sd = expf(__fmul_rn(0.5f, tb.logvar[tt]));
+        x_prev[i] = __fadd_rn(mean, __fmul_rn(__fmul_rn(mask, sd), z[i]));
+        if (pred_x0) pred_x0[i] = x0;
+    }
+}
+extern "C" int ddpm_p_sample_step(const float* x_t, const float* model_out, const float* z, const long long* t,
+                                  const float* sqrt_recip_ab, const float* sqrt_recip_m1_ab, const float* post_coef1, const float* post_coef2,
+                                  const float* logvar, float* x_prev, float* pred_x0, int B, int n, int mean_type, int clip, void* stream) {
+    if (!x_t || !model_out || !z || !t || !x_prev || !sqrt_recip_ab || !sqrt_recip_m1_ab || !post_coef1 || !post_coef2 || !logvar) return DDPM_ERR_NULL;
+    if (B <= 0 || n <= 0 || mean_type < 0 || mean_type > 2) return DDPM_ERR_SHAPE;
+    StepTables tb{sqrt_recip_ab, sqrt_recip_m1_ab, post_coef1, post_coef2, logvar};
+    hipLaunchKernelGGL(p_step_kernel, dim3(grid_for((long long)B * n)), dim3(256), 0, (hipStream_t)stream, x_t, model_out, z, t, tb, x_prev, pred_x0, B, n, mean_type, clip);
+    return check_launch();
+}
+
+// t[b] = map[t_idx[b]] (DDIM sub-sequence, ddim.py:101) and in-place decrement for graph-captured loops
+__global__ void gather_i64_kernel(const long long* __restrict__ idx, const long long* __restrict__ map, long long* __restrict__ out, int B) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B) out[i] = map[idx[i]];
+}
+__global__ void add_i64_kernel(long long* __restrict__ t, int B, long long delta) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B) t[i] += delta;
+}
+extern "C" int ddpm_gather_i64(const long long* idx, const long long* map, long long* out, int B, void* stream) {
+    if (!idx || !map || !out) return DDPM_ERR_NULL;
+    hipLaunchKernelGGL(gather_i64_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, idx, map, out, B);
+    return check_launch();
+}
+extern "C" int ddpm_add_i64(long long* t, int B, long long delta, void* stream) {
+    if (!t) return DDPM_ERR_NULL;
+    hipLaunchKernelGGL(add_i64_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, t, B, delta);
+    return check_launch();
+}
+
+// ------------------------------------------------------------------ SiLU on the (tiny, fp32) time-embedding path
+__global__ void silu_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) y[i] = siluf_(x[i]);
+}
+__global__ void silu_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx, long long n, int accumulate) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float g = dy[i] * silu_gradf_(x[i]);
+        dx[i] = accumulate ? dx[i] + g : g;
+    }
+}
+extern "C" int ddpm_silu_fwd(const float* x, float* y, long long n, void* stream) {
+    if (!x || !y) return DDPM_ERR_NULL;
+    hipLaunchKernelGGL(silu_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, y, n);
+    return check_launch();
+}
+extern "C" int ddpm_silu_bwd(const float* x, const float* dy, float* dx, long long n, int accumulate, void* stream) {
+    if (!x || !dy || !dx) return DDPM_ERR_NULL;
+    hipLaunchKernelGGL(silu_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, dy, dx, n, accumulate);
+    return check_launch();
+}
+
+// ------------------------------------------------------------------ column sums of an NHWC gradient (bias / time-bias grads)
+// per_sample[b][c] = sum_p dy[b][p][c]  (store, pitch ps_ld)   and/or   total[c] += sum_{b,p} dy (atomic)
+template <typename T>
+__global__ void colsum_kernel(const T* __restrict__ dy, long long ld, float* __restrict__ per_sample, long long ps_ld,
+                              float* __restrict__ total, int HW, int C) {
+    constexpr int VEC = Elem<T>::VEC;
+    __shared__ float sh[2048];
+    const int b = blockIdx.x;
+    const int cx = threadIdx.x, py = threadIdx.y;
+    const int t = threadIdx.y * blockDim.x + threadIdx.x, nt = blockDim.x * blockDim.y;
+    for (int c = t; c < C; c += nt) sh[c] = 0.f;
+    __syncthreads();
+    float acc[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
+    const T* base = dy + (long long)b * HW * ld + cx * VEC;
+    for (int p = py; p < HW; p += blockDim.y) {
+        float f[VEC];
+        Elem<T>::unpack(ldg16(base + (long long)p * ld), f);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) acc[j] += f[j];
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) atomicAdd(&sh[cx * VEC + j], acc[j]);
+    __syncthreads();
+    for (int c = t; c < C; c += nt) {
+        if (per_sample) per_sample[(long long)b * ps_ld + c] = sh[c];
+        if (total) atomicAdd(total + c, sh[c]);
+    }
+}
+extern "C" int ddpm_colsum(const void* dy, long long ld, float* per_sample, long long ps_ld, float* total, int B, int HW, int C, int dtype, void* stream) {
+    if (!dy || (!per_sample && !total)) return DDPM_ERR_NULL;
+    const int vec = dtype == DDPM_BF16 ? 8 : 4;
+    if (C % vec || ld % vec || C > 2048 || C / vec > 256) return DDPM_ERR_SHAPE;
+    if (!aligned16(dy)) return DDPM_ERR_ALIGN;
+    const int cv = C / vec;
+    int py = 256 / cv; if (py > HW) py = HW; if (py < 1) py = 1;
+    if (dtype == DDPM_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3(B), dim3(cv, py), 0, (hipStream_t)stream, (const bf16_t*)dy, ld, per_sample, ps_ld, total, HW, C);
+    else if (dtype == DDPM_F32) hipLaunchKernelGGL(colsum_kernel<float>, dim3(B), dim3(cv, py), 0, (hipStream_t)stream, (const float*)dy, ld, per_sample, ps_ld, total, HW, C);
+    else return DDPM_ERR_DTYPE;
+    return check_launch();
+}
+
+// ------------------------------------------------------------------ backward of nearest-2x upsample: dx[y][x] = sum of the 2x2 block
+template <typename T>
+__global__ void upsample_bwd_kernel(const T* __restrict__ dyu, T* __restrict__ dx, int B, int H, int W, int C, long long dx_ld, int accumulate) {
+    constexpr int VEC = Elem<T>::VEC;
+    const int cv = C / VEC;
+    const long long n = (long long)B * H * W * cv;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cv) * VEC;
+        long long r = i / cv;
+        const int x = (int)(r % W); r /= W;
+        const int y = (int)(r % H); const long long b = r / H;
+        float acc[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dxx = 0; dxx < 2; ++dxx) {
+                float f[VEC];
+                Elem<T>::unpack(ldg16(dyu + (((b * 2 * H + 2 * y + dy) * 2 * W) + 2 * x + dxx) * C + c), f);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) acc[j] += f[j];
+            }
+        T* o = dx + ((b * H + y) * W + x) * dx_ld + c;
+        if (accumulate) {
+            float f[VEC];
+            Elem<T>::unpack(ldg16(o), f);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) acc[j] += f[j];
+        }
+        stg16(o, Elem<T>::pack(acc));
+    }
+}
+extern "C" int ddpm_upsample2x_bwd(const void* dy_up, void* dx, long long dx_ld, int B, int H, int W, int C, int accumulate, int dtype, void* stream) {
+    if (!dy_up || !dx) return DDPM_ERR_NULL;
+    const int vec = dtype == DDPM_BF16 ? 8 : 4;
+    if (C % vec || dx_ld % vec) return DDPM_ERR_SHAPE;
+    const int g = grid_for((long long)B * H * W * (C / vec));
+    if (dtype == DDPM_BF16) hipLaunchKernelGGL(upsample_bwd_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy_up, (bf16_t*)dx, B, H, W, C, dx_ld, accumulate);
+    else if (dtype == DDPM_F32) hipLaunchKernelGGL(upsample_bwd_kernel<float>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const float*)dy_up, (float*)dx, B, H, W, C, dx_ld, accumulate);
+    else return DDPM_ERR_DTYPE;
+    return check_launch();
+}
+
+// ------------------------------------------------------------------ y (+)= x over NHWC slices with pitches (gradient fan-in)
+template <typename T>
+__global__ void add_kernel(const T* __restrict__ x, long long x_ld, T* __restrict__ y, long long y_ld, long long rows, int C, int accumulate) {
+    constexpr int VEC = Elem<T>::VEC;
+    const int cv = C / VEC;
+    const long long n = rows * cv;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cv) * VEC; const long long r = i / cv;
+        float a[VEC];
+        Elem<T>::unpack(ldg16(x + r * x_ld + c), a);
+        if (accumulate) {
+            float b[VEC];
+            Elem<T>::unpack(ldg16(y + r * y_ld + c), b);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) a[j] += b[j];
+        }
+        stg16(y + r * y_ld + c, Elem<T>::pack(a));
+    }
+}
+extern "C" int ddpm_add_rows(const void* x, long long x_ld, void* y, long long y_ld, long long rows, int C, int accumulate, int dtype, void* stream) {
+    if (!x || !y) return DDPM_ERR_NULL;
+    const int vec = dtype == DDPM_BF16 ? 8 : 4;
+    if (C % vec || x_ld % vec || y_ld % vec) return DDPM_ERR_SHAPE;
+    const int g = grid_for(rows * (C / vec));
+    if (dtype == DDPM_BF16) hipLaunchKernelGGL(add_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, x_ld, (bf16_t*)y, y_ld, rows, C, accumulate);
+    else if (dtype == DDPM_F32) hipLaunchKernelGGL(add_kernel<float>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const float*)x, x_ld, (float*)y, y_ld, rows, C, accumulate);
+    else return DDPM_ERR_DTYPE;
+    return check_launch();
+}
+
+// ------------------------------------------------------------------ attention softmax rows (unet.py:47-49) — one wave per row
+// fwd: P = softmax(S) with S fp32 logits already scaled by 1/sqrt(C);  bwd: dS = P * (dP - sum(dP*P))
+template <typename T>
+__global__ void softmax_fwd_kernel(const float* __restrict__ s, T* __restrict__ p, long long rows, int L) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* sr = s + row * L;
+    float m = -INFINITY;
+    for (int i = lane; i < L; i += 64) m = fmaxf(m, sr[i]);
+    m = wave_max(m);
+    float sum = 0.f;
+    for (int i = lane; i < L; i += 64) sum += __expf(sr[i] - m);
+    sum = wave_sum(sum);
+    const float inv = 1.0f / sum;
+    for (int i = lane; i < L; i += 64) Elem<T>::st(p + row * L + i, __expf(sr[i] - m) * inv);
+}
+template <typename T>
+__global__ void softmax_bwd_kernel(const T* __restrict__ p, const float* __restrict__ dp, T* __restrict__ ds, long long rows, int L) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float dot = 0.f;
+    for (int i = lane; i < L; i += 64) dot += Elem<T>::ld(p + row * L + i) * dp[row * L + i];
+    dot = wave_sum(dot);
+    for (int i = lane; i < L; i += 64) {
+        const float pv = Elem<T>::ld(p + row * L + i);
+        Elem<T>::st(ds + row * L + i, pv * (dp[row * L + i] - dot));
+    }
+}
+extern "C" int ddpm_softmax_fwd(const float* s, void* p, long long rows, int L, int dtype, void* stream) {
+    if (!s || !p) return DDPM_ERR_NULL;
+    const int g = (int)((rows + 3) / 4);
+    if (dtype == DDPM_BF16) hipLaunchKernelGGL(softmax_fwd_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, s, (bf16_t*)p, rows, L);
+    else if (dtype == DDPM_F32) hipLaunchKernelGGL(softmax_fwd_kernel<float>, dim3(g), dim3(256), 0, (hipStream_t)stream, s, (float*)p, rows, L);
+    else return DDPM_ERR_DTYPE;
+    return check_launch();
+}
+extern "C" int ddpm_softmax_bwd(const void* p, const float* dp, void* ds, long long rows, int L, int dtype, void* stream) {
+    if (!p || !dp || !ds) return DDPM_ERR_NULL;
+    const int g = (int)((rows + 3) / 4);
+    if (dtype == DDPM_BF16) hipLaunchKernelGGL(softmax_bwd_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)p, dp, (bf16_t*)ds, rows, L);
+    else if (dtype == DDPM_F32) hipLaunchKernelGGL(softmax_bwd_kernel<float>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const float*)p, dp, (float*)ds, rows, L);
+    else return DDPM_ERR_DTYPE;
+    return check_launch();
+}
+
+// ------------------------------------------------------------------ test hook: the dropout keep-mask the GN kernels regenerate
+__global__ void dropout_mask_kernel(float* __restrict__ mask, long long n, unsigned long long seed, unsigned thresh24) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        mask[i] = dropout_keep(seed, (unsigned long long)i, thresh24) ? 1.f : 0.f;
+}
+extern "C" int ddpm_dropout_mask(float* mask, long long n, float p, unsigned long long seed, void* stream) {
+    if (!mask) return DDPM_ERR_NULL;
+    double th = (double)p * 16777216.0;
+    unsigned t24 = th <= 0 ? 0u : (th >= 16777216.0 ? 16777216u : (unsigned)(th + 0.5));
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, mask, n, seed, t24);
+    return check_launch();
+}

@@ -1,0 +1,462 @@
+// Universal MFMA GEMM / implicit-GEMM convolution for gfx950 (MI355X).
+//
+//   C[b][m][n] = alpha * sum_k A[b][m][k] * B[b][n][k]   (+ fused epilogue)
+//
+// One kernel template covers every contraction on the DDPM hot path (SURVEY.md §8a rows a2,a3,a4,a5,a7,a9,
+// and their dgrad / wgrad):
+//   * 3x3 / 1x1 convolution forward and dgrad over NHWC activations: the A operand is an implicit im2col
+//     gather (rows = output pixels, k = (r,s,c)), with TF-SAME stride-2, nearest-2x-upsample and
+//     dilated (transposed-conv) index maps folded into the tile loader — no pad / upsample / cat tensors;
+//   * wgrad: both operands are read "transposed" (reduction index is the slow memory index) and the
+//     epilogue scatters fp32 atomics straight into the [Cout][Cin][R][S] gradient;
+//   * Linear layers and the attention matmuls (QK^T, PV and their four backward products) as batched GEMMs.
+//
+// Tiling: 128x128 block tile, 256 threads = 4 waves (2x2), each wave 64x64 = 2x2 MFMA 32x32 accumulators
+// (64 accumulator registers), K-step BK = 8 vectors of 16 bytes (64 bf16 / 32 fp32), double-buffered LDS
+// (register-staged: global -> VGPR -> LDS, loads of step s+1 in flight while step s computes).
+//   bf16: v_mfma_f32_32x32x16_bf16 (8 bf16 per lane per operand, fp32 accumulate)
+//   fp32: v_mfma_f32_32x32x2_f32   (exact fp32 — the 1e-3 parity path; lanes hold 4 consecutive k, the
+//         k-permutation is the same for A and B so the contraction is unchanged)
+// LDS rows are 144 bytes (BK*sizeof(T) + 16): the 16-lane groups of ds_read_b128 hit distinct 16-B slots.
+#include "common.h"
+#include <string.h>
+
+struct MatDesc {
+    const void* p;
+    long long batch_stride;   // elements
+    long long ld;             // pitch (elements) of the slow memory index
+    int trans;                // 0: slow index = M/N index, fast (contiguous) = K.  1: slow = K, fast = M/N
+    int conv;                 // 1: slow = output pixel, fast = (r*S+s)*C + c gathered from NHWC (pixel pitch ld)
+    int n_slow, n_fast;       // logical extents (rows beyond are zero)
+    int H, W, C, Ho, Wo, R, S, stride, pad_t, pad_l;
+    int sh;                   // 1 when the virtual input grid is 2x the stored one (upsample or dilation)
+    int dmask;                // 1 for dilation-2 (only even virtual coordinates exist), else 0
+    FastDiv dHoWo, dWo, dC, dS;
+};
+
+struct Epilogue {
+    void* out;
+    long long out_batch_stride, ldc;
+    int mode;                 // 0 store T | 1 store f32 | 2 atomic-add f32 | 3 store f32 NCHW | 4 wgrad scatter atomic f32
+    float alpha;
+    const float* bias;        // [N] or null
+    const float* rowbias;     // [M / rows_per_group][rowbias_ld] or null (time bias per sample)
+    long long rowbias_ld;
+    FastDiv dgroup;           // rows per group (H*W of the output)
+    const void* residual;     // T, [M][res_ld] or null
+    long long res_ld, res_batch_stride;
+    int accumulate;           // modes 0/1: out += result
+    int Cpad, Creal, RS;      // mode 4: col = tap*Cpad + c -> dst[(row*Creal + c)*RS + tap]
+    FastDiv dCpad;
+    FastDiv dHW;              // mode 3: row -> (b, pixel)
+    int HW;
+};
+
+template <int I> struct IC { static constexpr int v = I; };
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (N > 0) { static_for<N - 1>(f); f(IC<N - 1>{}); }
+}
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+    typedef __bf16 frag_t __attribute__((ext_vector_type(8)));
+    static constexpr int KF = 16;    // k covered per fragment step
+    __device__ static __forceinline__ void run(const u32x4& a, const u32x4& b, f32x16& c) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(frag_t, a), __builtin_bit_cast(frag_t, b), c, 0, 0, 0);
+    }
+};
+template <> struct Mma<float> {
+    static constexpr int KF = 8;
+    __device__ static __forceinline__ void run(const u32x4& a, const u32x4& b, f32x16& c) {
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.x), __uint_as_float(b.x), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.y), __uint_as_float(b.y), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.z), __uint_as_float(b.z), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(a.w), __uint_as_float(b.w), c, 0, 0, 0);
+    }
+};
+
+constexpr int TILE = 128;      // BM == BN
+constexpr int NTHREADS = 256;
+constexpr int ROW_BYTES = 144; // LDS row pitch: 128 B of K data + 16 B pad
+constexpr int NVEC = 4;        // 16-byte vectors per thread per operand per K-step
+
+// Per-thread loader state for one operand tile (TILE rows x BK k).
+template <typename T, bool TRANS>
+struct Loader {
+    static constexpr int VEC = Elem<T>::VEC;
+    static constexpr int BK = 8 * VEC;
+    static constexpr int FV = TILE / VEC;            // fast vectors per slow row when TRANS
+    static constexpr int SROWS = NTHREADS / FV;      // slow rows covered per pass when TRANS
+
+    const MatDesc& d;
+    const T* base;
+    int tile0;        // first M/N index of the tile
+    // !TRANS: vector i covers (row = tid/8 + 32 i, kv = tid%8).  TRANS: (srow = tid/FV + SROWS i, fv = tid%FV)
+    int kv, row0, fv, srow0;
+    // conv, !TRANS: per-row pixel origin;  conv, TRANS: fixed tap/channel
+    int pb[NVEC], py[NVEC], px[NVEC];
+    bool rvalid[NVEC];
+    int tr, ts, tc; bool fvalid;
+
+    __device__ __forceinline__ Loader(const MatDesc& d_, int batch, int tile0_, int tid) : d(d_) {
+        base = reinterpret_cast<const T*>(d.p) + (long long)batch * d.batch_stride;
+        tile0 = tile0_;
+        if (!TRANS) {
+            kv = tid & 7; row0 = tid >> 3;
+#pragma unroll
+            for (int i = 0; i < NVEC; ++i) {
+                int m = tile0 + row0 + 32 * i;
+                rvalid[i] = m < d.n_slow;
+                if (d.conv) decode_pixel(rvalid[i] ? m : 0, pb[i], py[i], px[i]);
+            }
+        } else {
+            fv = tid % FV; srow0 = tid / FV;
+            int f = tile0 + fv * VEC;
+            fvalid = f < d.n_fast;
+            if (d.conv) {
+                unsigned tap = fdiv((unsigned)(fvalid ? f : 0), d.dC);
+                tc = (fvalid ? f : 0) - (int)tap * d.C;
+                tr = (int)fdiv(tap, d.dS); ts = (int)tap - tr * d.S;
+            }
+        }
+    }
+
+    __device__ __forceinline__ void decode_pixel(int m, int& b, int& y0, int& x0) const {
+        unsigned bb = fdiv((unsigned)m, d.dHoWo);
+        unsigned rem = (unsigned)m - bb * (unsigned)(d.Ho * d.Wo);
+        unsigned oy = fdiv(rem, d.dWo);
+        unsigned ox = rem - oy * (unsigned)d.Wo;
+        b = (int)bb; y0 = (int)oy * d.stride - d.pad_t; x0 = (int)ox * d.stride - d.pad_l;
+    }
+
+    __device__ __forceinline__ u32x4 gather(int b, int y0, int x0, int r, int s, int c) const {
+        unsigned uy = (unsigned)(y0 + r), ux = (unsigned)(x0 + s);
+        bool ok = ((uy | ux) & (unsigned)d.dmask) == 0;
+        uy >>= d.sh; ux >>= d.sh;
+        ok = ok && uy < (unsigned)d.H && ux < (unsigned)d.W;
+        if (!ok) return zero16();
+        long long off = ((long long)(b * d.H + (int)uy) * d.W + (int)ux) * d.ld + c;
+        return ldg16(base + off);
+    }
+
+    // fetch this thread's vectors of the K-step starting at k0 (global loads only)
+    __device__ __forceinline__ void load(int k0, int k_end, u32x4 (&v)[NVEC]) const {
+        if (!TRANS) {
+            int k = k0 + kv * VEC;
+            bool kok = k < k_end;
+            if (d.conv) {
+                unsigned tap = fdiv((unsigned)k, d.dC);
+                int c = k - (int)tap * d.C;
+                int r = (int)fdiv(tap, d.dS), s = (int)tap - r * d.S;
+#pragma unroll
+                for (int i = 0; i < NVEC; ++i)
+                    v[i] = (kok && rvalid[i]) ? gather(pb[i], py[i], px[i], r, s, c) : zero16();
+            } else {
+#pragma unroll
+                for (int i = 0; i < NVEC; ++i) {
+                    long long off = (long long)(tile0 + row0 + 32 * i) * d.ld + k;
+                    v[i] = (kok && rvalid[i]) ? ldg16(base + off) : zero16();
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NVEC; ++i) {
+                int k = k0 + srow0 + SROWS * i;
+                bool ok = fvalid && k < k_end;
+                if (!ok) { v[i] = zero16(); continue; }
+                if (d.conv) {
+                    int b, y0, x0;
+                    decode_pixel(k, b, y0, x0);
+                    v[i] = gather(b, y0, x0, tr, ts, tc);
+                } else {
+                    v[i] = ldg16(base + (long long)k * d.ld + tile0 + fv * VEC);
+                }
+            }
+        }
+    }
+
+    // write the staged vectors into the K-contiguous LDS tile
+    __device__ __forceinline__ void store(char* lds, const u32x4 (&v)[NVEC]) const {
+        if (!TRANS) {
+#pragma unroll
+            for (int i = 0; i < NVEC; ++i)
+                *reinterpret_cast<u32x4*>(lds + (row0 + 32 * i) * ROW_BYTES + kv * 16) = v[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < NVEC; ++i) {
+                int kk = srow0 + SROWS * i;
+                const T* e = reinterpret_cast<const T*>(&v[i]);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j)
+                    *reinterpret_cast<T*>(lds + (fv * VEC + j) * ROW_BYTES + kk * (int)sizeof(T)) = e[j];
+            }
+        }
+    }
+};
+
+template <typename T>
+__device__ __forceinline__ void epilogue_store(const Epilogue& ep, int batch, int row, int col, int M, int N, float v) {
+    if (row >= M || col >= N) return;
+    v *= ep.alpha;
+    if (ep.bias) v += ep.bias[col];
+    if (ep.rowbias) v += ep.rowbias[(long long)fdiv((unsigned)row, ep.dgroup) * ep.rowbias_ld + col];
+    if (ep.residual)
+        v += Elem<T>::ld(reinterpret_cast<const T*>(ep.residual) + (long long)batch * ep.res_batch_stride + (long long)row * ep.res_ld + col);
+    switch (ep.mode) {
+    case 0: {
+        T* o = reinterpret_cast<T*>(ep.out) + (long long)batch * ep.out_batch_stride + (long long)row * ep.ldc + col;
+        if (ep.accumulate) v += Elem<T>::ld(o);
+        Elem<T>::st(o, v);
+    } break;
+    case 1: {
+        float* o = reinterpret_cast<float*>(ep.out) + (long long)batch * ep.out_batch_stride + (long long)row * ep.ldc + col;
+        if (ep.accumulate) v += *o;
+        *o = v;
+    } break;
+    case 2:
+        atomicAdd(reinterpret_cast<float*>(ep.out) + (long long)batch * ep.out_batch_stride + (long long)row * ep.ldc + col, v);
+        break;
+    case 3: {   // NCHW fp32: row = b*HW + p  ->  out[(b*N + col)*HW + p]
+        unsigned b = fdiv((unsigned)row, ep.dHW);
+        unsigned p = (unsigned)row - b * (unsigned)ep.HW;
+        float* o = reinterpret_cast<float*>(ep.out) + ((long long)b * N + col) * ep.HW + p;
+        if (ep.accumulate) v += *o;
+        *o = v;
+    } break;
+    case 4: {   // wgrad: row = cout, col = tap*Cpad + c
+        unsigned tap = fdiv((unsigned)col, ep.dCpad);
+        int c = col - (int)tap * ep.Cpad;
+        if (c < ep.Creal)
+            atomicAdd(reinterpret_cast<float*>(ep.out) + ((long long)row * ep.Creal + c) * ep.RS + tap, v);
+    } break;
+    }
+}
+
+template <typename T, bool TA, bool TB>
+__global__ __launch_bounds__(NTHREADS, 2)
+void gemm_kernel(MatDesc A, MatDesc B, Epilogue ep, int M, int N, int K, int k_per_split, int tiles_n) {
+    constexpr int VEC = Elem<T>::VEC;
+    constexpr int BK = 8 * VEC;
+    constexpr int KF = Mma<T>::KF;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TILE_BYTES = TILE * ROW_BYTES;          // one operand tile
+    // layout: [buf][A | B]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tm = blockIdx.x / tiles_n, tn = blockIdx.x - tm * tiles_n;
+    const int batch = blockIdx.z;
+    const int k_begin = blockIdx.y * k_per_split;
+    const int k_end = min(K, k_begin + k_per_split);
+    if (k_begin >= k_end) return;
+
+    Loader<T, TA> la(A, batch, tm * TILE, tid);
+    Loader<T, TB> lb(B, batch, tn * TILE, tid);
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x16)(0.f);
+
+    u32x4 va[NVEC], vb[NVEC];
+    la.load(k_begin, k_end, va);
+    lb.load(k_begin, k_end, vb);
+    la.store(smem, va);
+    lb.store(smem + TILE_BYTES, vb);
+    __syncthreads();
+
+    const int nsteps = (k_end - k_begin + BK - 1) / BK;
+    // fragment read offsets: row (lane&31), 16-byte k-slot (lane>>5)
+    const int frag_off = (lane & 31) * ROW_BYTES + (lane >> 5) * 16;
+    for (int s = 0; s < nsteps; ++s) {
+        const char* cur = smem + (s & 1) * 2 * TILE_BYTES;
+        char* nxt = smem + ((s + 1) & 1) * 2 * TILE_BYTES;
+        const bool more = s + 1 < nsteps;
+        if (more) {
+            la.load(k_begin + (s + 1) * BK, k_end, va);
+            lb.load(k_begin + (s + 1) * BK, k_end, vb);
+        }
+        const char* pa = cur + (wm * 64) * ROW_BYTES + frag_off;
+        const char* pb = cur + TILE_BYTES + (wn * 64) * ROW_BYTES + frag_off;
+#pragma unroll
+        for (int kc = 0; kc < BK / KF; ++kc) {
+            u32x4 fa[2], fb[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                fa[i] = *reinterpret_cast<const u32x4*>(pa + i * 32 * ROW_BYTES + kc * 32);
+                fb[i] = *reinterpret_cast<const u32x4*>(pb + i * 32 * ROW_BYTES + kc * 32);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) Mma<T>::run(fa[i], fb[j], acc[i][j]);
+        }
+        if (more) {
+            la.store(nxt, va);
+            lb.store(nxt + TILE_BYTES, vb);
+        }
+        __syncthreads();
+    }
+
+    // accumulator (reg r, lane l) -> row (r&3) + 8*(r>>2) + 4*(l>>5), col l&31 of its 32x32 tile.
+    // static_for keeps every accumulator index a compile-time constant (no scratch).
+    const int row_base = tm * TILE + wm * 64 + 4 * (lane >> 5);
+    const int col_base = tn * TILE + wn * 64 + (lane & 31);
+    static_for<64>([&](auto ic) {
+        constexpr int idx = decltype(ic)::v;
+        constexpr int i = idx >> 5, j = (idx >> 4) & 1, r = idx & 15;
+        epilogue_store<T>(ep, batch, row_base + i * 32 + (r & 3) + 8 * (r >> 2), col_base + j * 32, M, N, acc[i][j][r]);
+    });
+}
+
+// ---------------------------------------------------------------------------------------------- host side
+
+struct GemmArgs {          // plain-C mirror filled by the extern "C" entry points
+    MatDesc A, B;
+    Epilogue ep;
+    int M, N, K, batch, splits, dtype;
+};
+
+static void finish_desc(MatDesc& d) {
+    if (d.conv) {
+        d.dHoWo = make_fastdiv((unsigned)(d.Ho * d.Wo));
+        d.dWo = make_fastdiv((unsigned)d.Wo);
+        d.dC = make_fastdiv((unsigned)d.C);
+        d.dS = make_fastdiv((unsigned)d.S);
+    }
+}
+
+template <typename T>
+static int launch_t(GemmArgs& g, hipStream_t st) {
+    constexpr int BK = 8 * Elem<T>::VEC;
+    const int tiles_m = (g.M + TILE - 1) / TILE, tiles_n = (g.N + TILE - 1) / TILE;
+    int splits = g.splits < 1 ? 1 : g.splits;
+    int ksteps = (g.K + BK - 1) / BK;
+    int steps_per = (ksteps + splits - 1) / splits;
+    splits = (ksteps + steps_per - 1) / steps_per;
+    if (splits > 1 && g.ep.mode != 2 && g.ep.mode != 4) return DDPM_ERR_SHAPE;
+    dim3 grid(tiles_m * tiles_n, splits, g.batch);
+    size_t lds = 4 * TILE * ROW_BYTES;
+    const int kps = steps_per * BK;
+#define LAUNCH(TA, TB)                                                                                                   \
+    do {                                                                                                                 \
+        static bool attr_set = false;   /* 72 KiB of dynamic LDS needs the opt-in once per instantiation */             \
+        if (!attr_set) {                                                                                                 \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, TA, TB>),                              \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)                \
+                return DDPM_ERR_LAUNCH;                                                                                  \
+            attr_set = true;                                                                                             \
+        }                                                                                                                \
+        LAUNCH_(TA, TB);                                                                                                 \
+    } while (0)
+#define LAUNCH_(TA, TB) hipLaunchKernelGGL((gemm_kernel<T, TA, TB>), grid, dim3(NTHREADS), lds, st, g.A, g.B, g.ep, g.M, g.N, g.K, kps, tiles_n)
+    if (!g.A.trans && !g.B.trans) LAUNCH(false, false);
+    else if (!g.A.trans && g.B.trans) LAUNCH(false, true);
+    else if (g.A.trans && !g.B.trans) LAUNCH(true, false);
+    else LAUNCH(true, true);
+#undef LAUNCH
+#undef LAUNCH_
+    return check_launch();
+}
+
+static int validate(const MatDesc& d, int esize) {
+    if (!d.p) return DDPM_ERR_NULL;
+    const int vec = 16 / esize;
+    if (!aligned16(d.p)) return DDPM_ERR_ALIGN;
+    if (d.ld % vec || d.batch_stride % vec) return DDPM_ERR_ALIGN;
+    if (d.conv) { if (d.C % vec) return DDPM_ERR_SHAPE; }
+    else if (d.n_fast % vec) return DDPM_ERR_SHAPE;
+    return DDPM_OK;
+}
+
+int ddpm_gemm_launch(GemmArgs& g, hipStream_t st) {
+    if (g.M <= 0 || g.N <= 0 || g.K <= 0 || g.batch <= 0) return DDPM_ERR_SHAPE;
+    if (g.dtype != DDPM_F32 && g.dtype != DDPM_BF16) return DDPM_ERR_DTYPE;
+    const int es = g.dtype == DDPM_BF16 ? 2 : 4;
+    int rc;
+    if ((rc = validate(g.A, es)) != DDPM_OK) return rc;
+    if ((rc = validate(g.B, es)) != DDPM_OK) return rc;
+    if (!g.ep.out) return DDPM_ERR_NULL;
+    finish_desc(g.A); finish_desc(g.B);
+    return g.dtype == DDPM_BF16 ? launch_t<bf16_t>(g, st) : launch_t<float>(g, st);
+}
+
+// ---------------------------------------------------------------------------------------------- C ABI
+static void zero_args(GemmArgs& g) { memset(&g, 0, sizeof(g)); g.batch = 1; g.splits = 1; g.ep.alpha = 1.f; }
+
+static void conv_desc(MatDesc& d, const void* x, long long x_ld, int npix_out, int H, int W, int C, int Ho, int Wo, int R, int S,
+                      int stride, int pad_t, int pad_l, int upsample, int dilate) {
+    d.p = x; d.ld = x_ld; d.batch_stride = 0; d.conv = 1;
+    d.n_slow = npix_out; d.n_fast = R * S * C;
+    d.H = H; d.W = W; d.C = C; d.Ho = Ho; d.Wo = Wo; d.R = R; d.S = S; d.stride = stride; d.pad_t = pad_t; d.pad_l = pad_l;
+    d.sh = (upsample || dilate) ? 1 : 0; d.dmask = dilate ? 1 : 0;
+}
+
+// Convolution over NHWC activations as implicit GEMM (forward and, with flipped weights, dgrad).
+//   y[b,oy,ox,n] = sum_{r,s,c} x[b, f(oy*stride + r - pad_t), f(ox*stride + s - pad_l), c] * w[n][r][s][c]  (+ epilogue)
+// f = identity, >>1 (nearest-2x upsample fused: upsample=1) or /2-if-even (transposed conv: dilate=1).
+extern "C" int ddpm_conv2d_nhwc(const void* x, long long x_ld, const void* w, void* y, long long y_ld,
+                                const float* bias, const float* rowbias, long long rowbias_ld,
+                                const void* residual, long long res_ld,
+                                int B, int H, int W, int C, int Ho, int Wo, int N, int R, int S,
+                                int stride, int pad_t, int pad_l, int upsample, int dilate,
+                                int accumulate, int out_mode, int dtype, void* stream) {
+    if (!x || !w || !y) return DDPM_ERR_NULL;
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || Ho <= 0 || Wo <= 0 || N <= 0 || R <= 0 || S <= 0 || stride <= 0) return DDPM_ERR_SHAPE;
+    if (upsample && dilate) return DDPM_ERR_SHAPE;
+    if (out_mode != 0 && out_mode != 1 && out_mode != 3) return DDPM_ERR_SHAPE;
+    GemmArgs g; zero_args(g);
+    g.dtype = dtype;
+    g.M = B * Ho * Wo; g.N = N; g.K = R * S * C;
+    conv_desc(g.A, x, x_ld, g.M, H, W, C, Ho, Wo, R, S, stride, pad_t, pad_l, upsample, dilate);
+    g.A.trans = 0;
+    g.B.p = w; g.B.ld = g.K; g.B.trans = 0; g.B.n_slow = N; g.B.n_fast = g.K;
+    g.ep.out = y; g.ep.ldc = y_ld; g.ep.mode = out_mode; g.ep.bias = bias;
+    g.ep.rowbias = rowbias; g.ep.rowbias_ld = rowbias_ld; g.ep.dgroup = make_fastdiv((unsigned)(Ho * Wo));
+    g.ep.residual = residual; g.ep.res_ld = res_ld; g.ep.accumulate = accumulate;
+    g.ep.HW = Ho * Wo; g.ep.dHW = make_fastdiv((unsigned)(Ho * Wo));
+    return ddpm_gemm_launch(g, (hipStream_t)stream);
+}
+
+// Weight gradient: dw[n][c][r][s] += sum_{b,oy,ox} dy[b,oy,ox,n] * x[b, f(..), f(..), c]   (fp32 atomics, n < Nreal, c < Creal)
+extern "C" int ddpm_conv2d_wgrad_nhwc(const void* dy, long long dy_ld, const void* x, long long x_ld, float* dw,
+                                      int B, int H, int W, int C, int Creal, int Ho, int Wo, int N, int Nreal, int R, int S,
+                                      int stride, int pad_t, int pad_l, int upsample, int splits, int dtype, void* stream) {
+    if (!dy || !x || !dw) return DDPM_ERR_NULL;
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || Creal <= 0 || Creal > C || Ho <= 0 || Wo <= 0 || N <= 0 || Nreal <= 0 || Nreal > N) return DDPM_ERR_SHAPE;
+    const int vec = dtype == DDPM_BF16 ? 8 : 4;
+    if (N % vec) return DDPM_ERR_SHAPE;      // dy is read as 16-byte vectors along n
+    GemmArgs g; zero_args(g);
+    g.dtype = dtype; g.splits = splits;
+    g.M = Nreal; g.N = R * S * C; g.K = B * Ho * Wo;    // dy may carry zero-padded channels beyond Nreal (<= N)
+    g.A.p = dy; g.A.ld = dy_ld; g.A.trans = 1; g.A.n_slow = g.K; g.A.n_fast = N;
+    conv_desc(g.B, x, x_ld, g.K, H, W, C, Ho, Wo, R, S, stride, pad_t, pad_l, upsample, 0);
+    g.B.trans = 1;
+    g.ep.out = dw; g.ep.mode = 4; g.ep.Cpad = C; g.ep.Creal = Creal; g.ep.RS = R * S; g.ep.dCpad = make_fastdiv((unsigned)C);
+    return ddpm_gemm_launch(g, (hipStream_t)stream);
+}
+
+// Batched GEMM  C[b][m][n] = alpha * sum_k A[b][m][k] * B[b][n][k]  (+bias[n]) (+residual) (+= when accumulate).
+// a_trans / b_trans = 1 when the operand is stored with k as the slow index ([k][m] / [k][n]).
+// out_mode: 0 store dtype | 1 store fp32 | 2 atomic-add fp32 (required when splits > 1).
+extern "C" int ddpm_gemm(const void* a, long long a_ld, long long a_bs, int a_trans,
+                         const void* b, long long b_ld, long long b_bs, int b_trans,
+                         void* c, long long c_ld, long long c_bs,
+                         const float* bias, const void* residual, long long res_ld, long long res_bs,
+                         int M, int N, int K, int batch, float alpha, int accumulate, int out_mode, int splits,
+                         int dtype, void* stream) {
+    if (!a || !b || !c) return DDPM_ERR_NULL;
+    if (out_mode < 0 || out_mode > 2) return DDPM_ERR_SHAPE;
+    GemmArgs g; zero_args(g);
+    g.dtype = dtype; g.M = M; g.N = N; g.K = K; g.batch = batch; g.splits = splits;
+    g.A.p = a; g.A.ld = a_ld; g.A.batch_stride = a_bs; g.A.trans = a_trans;
+    g.A.n_slow = a_trans ? K : M; g.A.n_fast = a_trans ? M : K;
+    g.B.p = b; g.B.ld = b_ld; g.B.batch_stride = b_bs; g.B.trans = b_trans;
+    g.B.n_slow = b_trans ? K : N; g.B.n_fast = b_trans ? N : K;
+    g.ep.out = c; g.ep.ldc = c_ld; g.ep.out_batch_stride = c_bs; g.ep.mode = out_mode; g.ep.alpha = alpha;
+    g.ep.bias = bias; g.ep.residual = residual; g.ep.res_ld = res_ld; g.ep.res_batch_stride = res_bs;
+    g.ep.accumulate = accumulate;
+    return ddpm_gemm_launch(g, (hipStream_t)stream);
+}

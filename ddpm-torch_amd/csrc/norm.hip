@@ -1,0 +1,313 @@
+// Fused GroupNorm(32, eps) [+ SiLU] [+ dropout] forward / backward over NHWC activations (gfx950).
+// Reference semantics: nn.GroupNorm(32, C, eps=1e-6) -> SiLU -> Dropout (ddpm_torch/models/unet.py:18-20,85-87).
+//
+// HBM-bound: algorithmic traffic is one read of x + one write of y per element.  Two launches:
+//   gn_stats : grid (S, B) — each block reduces a slab of pixels of one sample to per-group partial
+//              (sum, sum of squares) with 16-byte coalesced loads and a wavefront/LDS reduction;
+//   gn_apply : grid (S, B) — combines the S partials (fp64), builds per-channel scale/shift in LDS and
+//              streams y = silu(x*a_c + b_c) [* keep/(1-p)]; the second read of x is an L2/MALL hit at
+//              the CIFAR sizes (<= 64 MB per tensor vs 256 MB Infinity Cache).
+// Backward mirrors it: gn_bwd_reduce (per-channel sums of dz and dz*xhat), gn_bwd_coef (per-sample group
+// coefficients + dgamma/dbeta atomics), gn_bwd_apply (dx).  SiLU and the dropout mask are recomputed.
+#include "common.h"
+
+constexpr int GN_THREADS = 256;
+constexpr int GN_MAXC = 2048;
+
+struct GnShape {
+    int B, HW, C, G, cpg;       // cpg = C / G
+    long long x_ld, y_ld;       // pixel pitches (elements)
+    int S;                      // pixel slabs per sample
+    int pix_per_slab;
+};
+
+// thread (cx, py): channel-vector cx fixed, pixels py, py+PY, ...  (blockDim = (CV, PY))
+template <typename T>
+__global__ void gn_stats_kernel(const T* __restrict__ x, GnShape s, float* __restrict__ partial /*[B][S][G][2]*/) {
+    constexpr int VEC = Elem<T>::VEC;
+    __shared__ float sh_sum[GN_MAXC], sh_sq[GN_MAXC];
+    const int b = blockIdx.y, slab = blockIdx.x;
+    const int cx = threadIdx.x, py = threadIdx.y, PY = blockDim.y;
+    const int p0 = slab * s.pix_per_slab, p1 = min(s.HW, p0 + s.pix_per_slab);
+    float sum[VEC], sq[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) sum[j] = sq[j] = 0.f;
+    const T* xb = x + ((long long)b * s.HW) * s.x_ld + cx * VEC;
+    for (int p = p0 + py; p < p1; p += PY) {
+        float f[VEC];
+        Elem<T>::unpack(ldg16(xb + (long long)p * s.x_ld), f);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) { sum[j] += f[j]; sq[j] += f[j] * f[j]; }
+    }
+    for (int c = threadIdx.y * blockDim.x + threadIdx.x; c < s.C; c += blockDim.x * blockDim.y) { sh_sum[c] = 0.f; sh_sq[c] = 0.f; }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { atomicAdd(&sh_sum[cx * VEC + j], sum[j]); atomicAdd(&sh_sq[cx * VEC + j], sq[j]); }
+    __syncthreads();
+    const int t = threadIdx.y * blockDim.x + threadIdx.x;
+    if (t < s.G) {
+        float a = 0.f, q = 0.f;
+        for (int c = t * s.cpg; c < (t + 1) * s.cpg; ++c) { a += sh_sum[c]; q += sh_sq[c]; }
+        float* o = partial + (((long long)b * s.S + slab) * s.G + t) * 2;
+        o[0] = a; o[1] = q;
+    }
+}
+
+struct GnApply {
+    const float* gamma; const float* beta;
+    float eps; int silu;
+    float drop_p; unsigned thresh24; unsigned long long seed;   // dropout after SiLU (unet.py:87); p = 0 disables
+    float* stats;              // [B][G][2] (mean, rstd) saved for backward, or null
+};
+
+template <typename T>
+__global__ void gn_apply_kernel(const T* __restrict__ x, T* __restrict__ y, GnShape s, const float* __restrict__ partial, GnApply a) {
+    constexpr int VEC = Elem<T>::VEC;
+    __shared__ float sh_a[GN_MAXC], sh_b[GN_MAXC];
+    __shared__ float sh_mean[64], sh_rstd[64];
+    const int b = blockIdx.y, slab = blockIdx.x;
+    const int t = threadIdx.y * blockDim.x + threadIdx.x, nt = blockDim.x * blockDim.y;
+    if (t < s.G) {
+        double sum = 0.0, sq = 0.0;
+        for (int i = 0; i < s.S; ++i) {
+            const float* o = partial + (((long long)b * s.S + i) * s.G + t) * 2;
+            sum += o[0]; sq += o[1];
+        }
+        const double n = (double)s.HW * s.cpg;
+        const double mean = sum / n;
+        double var = sq / n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float rstd = (float)(1.0 / sqrt(var + (double)a.eps));
+        sh_mean[t] = (float)mean; sh_rstd[t] = rstd;
+        if (a.stats && slab == 0) { a.stats[((long long)b * s.G + t) * 2] = (float)mean; a.stats[((long long)b * s.G + t) * 2 + 1] = rstd; }
+    }
+    __syncthreads();
+    for (int c = t; c < s.C; c += nt) {
+        const int g = c / s.cpg;
+        const float sc = sh_rstd[g] * a.gamma[c];
+        sh_a[c] = sc; sh_b[c] = a.beta[c] - sh_mean[g] * sc;
+    }
+    __syncthreads();
+    const int cx = threadIdx.x, py = threadIdx.y, PY = blockDim.y;
+    const int p0 = slab * s.pix_per_slab, p1 = min(s.HW, p0 + s.pix_per_slab);
+    float ca[VEC], cb[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { ca[j] = sh_a[cx * VEC + j]; cb[j] = sh_b[cx * VEC + j]; }
+    const T* xb = x + ((long long)b * s.HW) * s.x_ld + cx * VEC;
+    T* yb = y + ((long long)b * s.HW) * s.y_ld + cx * VEC;
+    const float keep_scale = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
+    for (int p = p0 + py; p < p1; p += PY) {
+        float f[VEC];
+        Elem<T>::unpack(ldg16(xb + (long long)p * s.x_ld), f);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            float z = f[j] * ca[j] + cb[j];
+            if (a.silu) z = siluf_(z);
+            if (a.drop_p > 0.f) {
+                unsigned long long idx = ((unsigned long long)b * s.HW + p) * s.C + cx * VEC + j;
+                z = dropout_keep(a.seed, idx, a.thresh24) ? z * keep_scale : 0.f;
+            }
+            f[j] = z;
+        }
+        stg16(yb + (long long)p * s.y_ld, Elem<T>::pack(f));
+    }
+}
+
+// ---- backward
+// dz = dy * mask/(1-p) * silu'(z), z = gamma*xhat + beta.  Per (b, c): A1 = sum dz*xhat, A2 = sum dz.
+template <typename T>
+__global__ void gn_bwd_reduce_kernel(const T* __restrict__ x, const T* __restrict__ dy, GnShape s, long long dy_ld,
+                                     const float* __restrict__ stats, GnApply a, float* __restrict__ partial /*[B][S][C][2]*/) {
+    constexpr int VEC = Elem<T>::VEC;
+    __shared__ float sh1[GN_MAXC], sh2[GN_MAXC];
+    const int b = blockIdx.y, slab = blockIdx.x;
+    const int cx = threadIdx.x, py = threadIdx.y, PY = blockDim.y;
+    const int t = threadIdx.y * blockDim.x + threadIdx.x, nt = blockDim.x * blockDim.y;
+    for (int c = t; c < s.C; c += nt) { sh1[c] = 0.f; sh2[c] = 0.f; }
+    __syncthreads();
+    const int p0 = slab * s.pix_per_slab, p1 = min(s.HW, p0 + s.pix_per_slab);
+    float mean[VEC], rstd[VEC], gm[VEC], bt[VEC], a1[VEC], a2[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        const int c = cx * VEC + j, g = c / s.cpg;
+        mean[j] = stats[((long long)b * s.G + g) * 2]; rstd[j] = stats[((long long)b * s.G + g) * 2 + 1];
+        gm[j] = a.gamma[c]; bt[j] = a.beta[c]; a1[j] = a2[j] = 0.f;
+    }
+    const float keep_scale = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
+    const T* xb = x + ((long long)b * s.HW) * s.x_ld + cx * VEC;
+    const T* db = dy + ((long long)b * s.HW) * dy_ld + cx * VEC;
+    for (int p = p0 + py; p < p1; p += PY) {
+        float f[VEC], d[VEC];
+        Elem<T>::unpack(ldg16(xb + (long long)p * s.x_ld), f);
+        Elem<T>::unpack(ldg16(db + (long long)p * dy_ld), d);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const float xh = (f[j] - mean[j]) * rstd[j];
+            float dz = d[j];
+            if (a.drop_p > 0.f) {
+                unsigned long long idx = ((unsigned long long)b * s.HW + p) * s.C + cx * VEC + j;
+                dz = dropout_keep(a.seed, idx, a.thresh24) ? dz * keep_scale : 0.f;
+            }
+            if (a.silu) dz *= silu_gradf_(gm[j] * xh + bt[j]);
+            a1[j] += dz * xh; a2[j] += dz;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { atomicAdd(&sh1[cx * VEC + j], a1[j]); atomicAdd(&sh2[cx * VEC + j], a2[j]); }
+    __syncthreads();
+    float* o = partial + (((long long)b * s.S + slab) * s.C) * 2;
+    for (int c = t; c < s.C; c += nt) { o[2 * c] = sh1[c]; o[2 * c + 1] = sh2[c]; }
+}
+
+// one block per sample: combine slabs, group coefficients, dgamma/dbeta atomics
+__global__ void gn_bwd_coef_kernel(GnShape s, const float* __restrict__ partial, const float* __restrict__ gamma,
+                                   float* __restrict__ coef /*[B][G][2]*/, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    __shared__ float sh1[GN_MAXC], sh2[GN_MAXC];
+    const int b = blockIdx.x, t = threadIdx.x;
+    for (int c = t; c < s.C; c += blockDim.x) {
+        float a1 = 0.f, a2 = 0.f;
+        for (int i = 0; i < s.S; ++i) {
+            const float* o = partial + (((long long)b * s.S + i) * s.C + c) * 2;
+            a1 += o[0]; a2 += o[1];
+        }
+        sh1[c] = a1 * gamma[c]; sh2[c] = a2 * gamma[c];
+        if (dgamma) atomicAdd(dgamma + c, a1);
+        if (dbeta) atomicAdd(dbeta + c, a2);
+    }
+    __syncthreads();
+    if (t < s.G) {
+        float d1 = 0.f, d2 = 0.f;
+        for (int c = t * s.cpg; c < (t + 1) * s.cpg; ++c) { d1 += sh1[c]; d2 += sh2[c]; }
+        const float inv_n = 1.0f / ((float)s.HW * s.cpg);
+        coef[((long long)b * s.G + t) * 2] = d1 * inv_n;       // mean(dz*gamma*xhat) over the group
+        coef[((long long)b * s.G + t) * 2 + 1] = d2 * inv_n;   // mean(dz*gamma)
+    }
+}
+
+// dx = rstd * (dz*gamma - xhat*c1 - c2)   [+= when accumulate]
+template <typename T>
+__global__ void gn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx, GnShape s, long long dy_ld,
+                                    long long dx_ld, const float* __restrict__ stats, const float* __restrict__ coef, GnApply a, int accumulate) {
+    constexpr int VEC = Elem<T>::VEC;
+    const int b = blockIdx.y, slab = blockIdx.x;
+    const int cx = threadIdx.x, py = threadIdx.y, PY = blockDim.y;
+    const int p0 = slab * s.pix_per_slab, p1 = min(s.HW, p0 + s.pix_per_slab);
+    float mean[VEC], rstd[VEC], gm[VEC], bt[VEC], c1[VEC], c2[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        const int c = cx * VEC + j, g = c / s.cpg;
+        mean[j] = stats[((long long)b * s.G + g) * 2]; rstd[j] = stats[((long long)b * s.G + g) * 2 + 1];
+        c1[j] = coef[((long long)b * s.G + g) * 2]; c2[j] = coef[((long long)b * s.G + g) * 2 + 1];
+        gm[j] = a.gamma[c]; bt[j] = a.beta[c];
+    }
+    const float keep_scale = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
+    const T* xb = x + ((long long)b * s.HW) * s.x_ld + cx * VEC;
+    const T* db = dy + ((long long)b * s.HW) * dy_ld + cx * VEC;
+    T* ob = dx + ((long long)b * s.HW) * dx_ld + cx * VEC;
+    for (int p = p0 + py; p < p1; p += PY) {
+        float f[VEC], d[VEC], o[VEC];
+        Elem<T>::unpack(ldg16(xb + (long long)p * s.x_ld), f);
+        Elem<T>::unpack(ldg16(db + (long long)p * dy_ld), d);
+        if (accumulate) Elem<T>::unpack(ldg16(ob + (long long)p * dx_ld), o);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const float xh = (f[j] - mean[j]) * rstd[j];
+            float dz = d[j];
+            if (a.drop_p > 0.f) {
+                unsigned long long idx = ((unsigned long long)b * s.HW + p) * s.C + cx * VEC + j;
+                dz = dropout_keep(a.seed, idx, a.thresh24) ? dz * keep_scale : 0.f;
+            }
+            if (a.silu) dz *= silu_gradf_(gm[j] * xh + bt[j]);
+            const float r = rstd[j] * (dz * gm[j] - xh * c1[j] - c2[j]);
+            o[j] = accumulate ? o[j] + r : r;
+        }
+        stg16(ob + (long long)p * dx_ld, Elem<T>::pack(o));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- host side
+static int gn_geometry(int B, int HW, int C, int G, long long x_ld, long long y_ld, int esize, GnShape& s, dim3& block, dim3& grid) {
+    const int vec = 16 / esize;
+    if (B <= 0 || HW <= 0 || C <= 0 || G <= 0 || G > 64 || C % G || C % vec || C > GN_MAXC) return DDPM_ERR_SHAPE;
+    if (x_ld % vec || y_ld % vec) return DDPM_ERR_ALIGN;
+    const int cv = C / vec;
+    if (cv > GN_THREADS) return DDPM_ERR_SHAPE;
+    int py = GN_THREADS / cv; if (py < 1) py = 1;
+    if (py > HW) py = HW;
+    block = dim3(cv, py);
+    // enough slabs to give every CU several blocks, but at least ~4 pixel-iterations of work each
+    int S = (1024 + B - 1) / B;
+    int maxS = (HW + 4 * py - 1) / (4 * py);
+    if (S > maxS) S = maxS;
+    if (S < 1) S = 1;
+    if (S > 256) S = 256;
+    int pps = (HW + S - 1) / S;
+    S = (HW + pps - 1) / pps;
+    s.B = B; s.HW = HW; s.C = C; s.G = G; s.cpg = C / G; s.x_ld = x_ld; s.y_ld = y_ld; s.S = S; s.pix_per_slab = pps;
+    grid = dim3(S, B);
+    return DDPM_OK;
+}
+
+static GnApply make_apply(const float* gamma, const float* beta, float eps, int silu, float drop_p, unsigned long long seed, float* stats) {
+    GnApply a; a.gamma = gamma; a.beta = beta; a.eps = eps; a.silu = silu; a.drop_p = drop_p; a.seed = seed; a.stats = stats;
+    double th = (double)drop_p * 16777216.0;
+    a.thresh24 = th <= 0 ? 0u : (th >= 16777216.0 ? 16777216u : (unsigned)(th + 0.5));
+    return a;
+}
+
+// floats of scratch the forward ([B][S][G][2]) and backward ([B][S][C][2] + [B][G][2]) launches need
+extern "C" long long ddpm_gn_workspace_floats(int B, int HW, int C, int G, int dtype) {
+    GnShape s; dim3 block, grid;
+    if (gn_geometry(B, HW, C, G, C, C, dtype == DDPM_BF16 ? 2 : 4, s, block, grid)) return -1;
+    return (long long)B * s.S * C * 2 + (long long)B * G * 2;
+}
+
+extern "C" int ddpm_groupnorm_silu_fwd(const void* x, long long x_ld, void* y, long long y_ld, const float* gamma, const float* beta,
+                                       float* stats, float* workspace, int B, int HW, int C, int G, float eps, int silu,
+                                       float drop_p, unsigned long long seed, int dtype, void* stream) {
+    if (!x || !y || !gamma || !beta || !workspace) return DDPM_ERR_NULL;
+    if (!aligned16(x) || !aligned16(y)) return DDPM_ERR_ALIGN;
+    GnShape s; dim3 block, grid;
+    const int es = dtype == DDPM_BF16 ? 2 : 4;
+    if (dtype != DDPM_BF16 && dtype != DDPM_F32) return DDPM_ERR_DTYPE;
+    int rc = gn_geometry(B, HW, C, G, x_ld, y_ld, es, s, block, grid);
+    if (rc) return rc;
+    GnApply a = make_apply(gamma, beta, eps, silu, drop_p, seed, stats);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == DDPM_BF16) {
+        hipLaunchKernelGGL(gn_stats_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)x, s, workspace);
+        hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)x, (bf16_t*)y, s, workspace, a);
+    } else {
+        hipLaunchKernelGGL(gn_stats_kernel<float>, grid, block, 0, st, (const float*)x, s, workspace);
+        hipLaunchKernelGGL(gn_apply_kernel<float>, grid, block, 0, st, (const float*)x, (float*)y, s, workspace, a);
+    }
+    return check_launch();
+}
+
+extern "C" int ddpm_groupnorm_silu_bwd(const void* x, long long x_ld, const void* dy, long long dy_ld, void* dx, long long dx_ld,
+                                       const float* gamma, const float* beta, const float* stats, float* dgamma, float* dbeta,
+                                       float* workspace, int B, int HW, int C, int G, int silu, float drop_p, unsigned long long seed,
+                                       int accumulate, int dtype, void* stream) {
+    if (!x || !dy || !dx || !gamma || !beta || !stats || !workspace) return DDPM_ERR_NULL;
+    if (!aligned16(x) || !aligned16(dy) || !aligned16(dx)) return DDPM_ERR_ALIGN;
+    if (dtype != DDPM_BF16 && dtype != DDPM_F32) return DDPM_ERR_DTYPE;
+    GnShape s; dim3 block, grid;
+    const int es = dtype == DDPM_BF16 ? 2 : 4;
+    int rc = gn_geometry(B, HW, C, G, x_ld, x_ld, es, s, block, grid);
+    if (rc) return rc;
+    if (dy_ld % (16 / es) || dx_ld % (16 / es)) return DDPM_ERR_ALIGN;
+    GnApply a = make_apply(gamma, beta, 0.f, silu, drop_p, seed, nullptr);
+    hipStream_t st = (hipStream_t)stream;
+    float* partial = workspace;                                   // [B][S][C][2]
+    float* coef = workspace + (long long)B * s.S * C * 2;         // [B][G][2]
+    if (dtype == DDPM_BF16)
+        hipLaunchKernelGGL(gn_bwd_reduce_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)x, (const bf16_t*)dy, s, dy_ld, stats, a, partial);
+    else
+        hipLaunchKernelGGL(gn_bwd_reduce_kernel<float>, grid, block, 0, st, (const float*)x, (const float*)dy, s, dy_ld, stats, a, partial);
+    hipLaunchKernelGGL(gn_bwd_coef_kernel, dim3(B), dim3(256), 0, st, s, partial, gamma, coef, dgamma, dbeta);
+    if (dtype == DDPM_BF16)
+        hipLaunchKernelGGL(gn_bwd_apply_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx, s, dy_ld, dx_ld, stats, coef, a, accumulate);
+    else
+        hipLaunchKernelGGL(gn_bwd_apply_kernel<float>, grid, block, 0, st, (const float*)x, (const float*)dy, (float*)dx, s, dy_ld, dx_ld, stats, coef, a, accumulate);
+    return check_launch();
+}

@@ -1,0 +1,71 @@
+// Fused optimizer-side kernels over flat fp32 buffers: global-norm partials, and one pass that
+// applies clip scale + Adam + EMA.  Reference semantics: nn.utils.clip_grad_norm_(max_norm) -> torch.optim.Adam
+// (train.py:128: lr, betas, eps=1e-8, no weight decay) -> EMA.update (ddpm_torch/utils/train.py:300-305).
+#include "common.h"
+
+// partial[blockIdx] = sum of squares of a slice (fp32 accumulate per thread, wave + LDS reduce)
+__global__ void sumsq_kernel(const float* __restrict__ g, long long n, float* __restrict__ partial) {
+    __shared__ float sh[4];
+    float acc = 0.f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) acc += g[i] * g[i];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+// out[0] += sum(partial[0..nblk))   (single block)
+__global__ void sum_partials_kernel(const float* __restrict__ partial, int nblk, float* __restrict__ out) {
+    __shared__ float sh[4];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < nblk; i += blockDim.x) acc += partial[i];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] += sh[0] + sh[1] + sh[2] + sh[3];
+}
+// total_sq[0] += ||g||^2 ; workspace needs >= 1024 floats
+extern "C" int ddpm_sumsq_accumulate(const float* g, long long n, float* total_sq, float* workspace, void* stream) {
+    if (!g || !total_sq || !workspace) return DDPM_ERR_NULL;
+    if (n <= 0) return DDPM_OK;
+    long long want = (n + 255) / 256;
+    const int nblk = (int)(want > 1024 ? 1024 : want);
+    hipLaunchKernelGGL(sumsq_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, g, n, workspace);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, workspace, nblk, total_sq);
+    return check_launch();
+}
+
+// One pass over a parameter tensor: g *= clip ; Adam(m, v) ; p -= step ; shadow += (1-d)(p - shadow).
+// clip = min(1, max_norm / (sqrt(total_sq[0]) + 1e-6)) is computed on the device from the norm accumulated above,
+// so there is no host synchronisation between backward and the update.
+__global__ void adam_ema_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                float* __restrict__ shadow, long long n, const float* __restrict__ total_sq, float max_norm,
+                                float lr, float beta1, float beta2, float eps, float bc1, float bc2, float ema_w) {
+    float clip = 1.f;
+    if (total_sq && max_norm > 0.f) {
+        const float c = max_norm / (sqrtf(total_sq[0]) + 1e-6f);
+        clip = c < 1.f ? c : 1.f;
+    }
+    const float step = lr / bc1;
+    const float inv_sqrt_bc2 = rsqrtf(bc2);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float gi = g[i] * clip;
+        const float mi = beta1 * m[i] + (1.f - beta1) * gi;
+        const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
+        const float pi = p[i] - step * (mi / denom);
+        p[i] = pi;
+        if (shadow) shadow[i] += ema_w * (pi - shadow[i]);
+    }
+}
+extern "C" int ddpm_adam_ema_step(float* p, const float* g, float* m, float* v, float* shadow, long long n, const float* total_sq,
+                                  float max_norm, float lr, float beta1, float beta2, float eps, float bias_corr1, float bias_corr2,
+                                  float ema_w, void* stream) {
+    if (!p || !g || !m || !v) return DDPM_ERR_NULL;
+    if (n <= 0) return DDPM_OK;
+    long long want = (n + 255) / 256;
+    const int nblk = (int)(want > 4096 ? 4096 : want);
+    hipLaunchKernelGGL(adam_ema_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, p, g, m, v, shadow, n, total_sq, max_norm, lr, beta1, beta2,
+                       eps, bias_corr1, bias_corr2, ema_w);
+    return check_launch();
+}

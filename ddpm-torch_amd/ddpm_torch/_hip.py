@@ -1,0 +1,98 @@
+"""ctypes binding of the C-ABI library ``csrc/libddpm_hip.so`` (declared in ``include/ddpm_hip.h``).
+
+The product path has NO fallback: if the shared object is missing or a symbol is absent this module
+raises, and every op raises on non-CUDA tensors.  Build with ``python ddpm-torch_amd/csrc/build.py``
+(``hipcc --offload-arch=gfx950``); ``__graft_entry__.build()`` does the same.
+"""
+import ctypes
+import os
+from ctypes import c_float, c_int, c_longlong, c_ulonglong, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libddpm_hip.so")
+
+F32, BF16 = 0, 1
+_ERR = {1: "bad shape / divisibility", 2: "unsupported dtype", 3: "misaligned pointer or pitch",
+        4: "kernel launch failed", 5: "null pointer"}
+
+P, I, L, F, U = c_void_p, c_int, c_longlong, c_float, c_ulonglong
+
+# name -> argtypes; every function returns int status (0 = OK) except ddpm_gn_workspace_floats.
+PROTOTYPES = {
+    "ddpm_conv2d_nhwc": [P, L, P, P, L, P, P, L, P, L] + [I] * 14 + [I, I, I, P],
+    "ddpm_conv2d_wgrad_nhwc": [P, L, P, L, P] + [I] * 17 + [P],
+    "ddpm_gemm": [P, L, L, I, P, L, L, I, P, L, L, P, P, L, L, I, I, I, I, F, I, I, I, I, P],
+    "ddpm_groupnorm_silu_fwd": [P, L, P, L, P, P, P, P, I, I, I, I, F, I, F, U, I, P],
+    "ddpm_groupnorm_silu_bwd": [P, L, P, L, P, L, P, P, P, P, P, P, I, I, I, I, I, F, U, I, I, P],
+    "ddpm_gn_workspace_floats": [I, I, I, I, I],
+    "ddpm_timestep_embedding": [P, P, P, I, I, P],
+    "ddpm_nchw_to_nhwc": [P, P, I, I, I, I, I, P],
+    "ddpm_pack_weight": [P, P, P, I, I, I, I, I, I, I, P],
+    "ddpm_q_sample": [P, P, P, P, P, P, I, I, P],
+    "ddpm_mse_fwd": [P, P, P, I, I, P],
+    "ddpm_mse_bwd": [P, P, P, P, I, I, P],
+    "ddpm_p_sample_step": [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, P],
+    "ddpm_gather_i64": [P, P, P, I, P],
+    "ddpm_add_i64": [P, I, L, P],
+    "ddpm_silu_fwd": [P, P, L, P],
+    "ddpm_silu_bwd": [P, P, P, L, I, P],
+    "ddpm_colsum": [P, L, P, L, P, I, I, I, I, P],
+    "ddpm_upsample2x_bwd": [P, P, L, I, I, I, I, I, I, P],
+    "ddpm_add_rows": [P, L, P, L, L, I, I, I, P],
+    "ddpm_softmax_fwd": [P, P, L, I, I, P],
+    "ddpm_softmax_bwd": [P, P, P, L, I, I, P],
+    "ddpm_dropout_mask": [P, L, F, U, P],
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded library (loads on first use; raises if it was never built)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"ddpm_torch (MI355X build): HIP library not found at {LIB_PATH}. "
+                "Build it with `python ddpm-torch_amd/csrc/build.py` — there is no CPU fallback.")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, argtypes in PROTOTYPES.items():
+            try:
+                fn = getattr(handle, name)
+            except AttributeError as e:
+                raise RuntimeError(f"{LIB_PATH} does not export {name}; rebuild it") from e
+            fn.argtypes = argtypes
+            fn.restype = c_longlong if name == "ddpm_gn_workspace_floats" else c_int
+        _lib = handle
+    return _lib
+
+
+def call(name, *args):
+    rc = getattr(lib(), name)(*args)
+    if rc != 0:
+        raise RuntimeError(f"{name} failed: {_ERR.get(rc, rc)}")
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def dt(t):
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise TypeError(f"unsupported dtype {t.dtype}")
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("ddpm_torch (MI355X build) runs on CUDA/HIP tensors only; "
+                               "got a CPU tensor and there is no CPU fallback")
+
+
+def ptr(t):
+    return 0 if t is None else t.data_ptr()

@@ -1,0 +1,98 @@
+"""Thin Python wrappers over the C-ABI (one function per entry point family).
+
+Activations are NHWC; a ``View`` is (base tensor kept alive, device pointer, pixel pitch, dims) so that
+channel slices of a shared buffer (the zero-copy decoder concat, q/k/v inside project_in's output) are
+first-class operands.  Nothing here allocates or synchronises except where noted.
+"""
+import torch
+
+from . import _hip
+
+GN_GROUPS = 32
+GN_EPS = 1e-6
+
+
+class View:
+    """NHWC activation view: element (b, y, x, c) lives at ptr + ((b*H + y)*W + x)*ld + c (in elements)."""
+    __slots__ = ("base", "ptr", "ld", "B", "H", "W", "C", "dtype", "grad", "ginit")
+
+    def __init__(self, base, B, H, W, C, ld=None, offset=0):
+        self.base = base
+        self.ptr = base.data_ptr() + offset * base.element_size()
+        self.ld = C if ld is None else ld
+        self.B, self.H, self.W, self.C = B, H, W, C
+        self.dtype = _hip.dt(base)
+        self.grad = None        # View holding d(loss)/d(this) during backward
+        self.ginit = False      # has .grad been written yet (else the first writer stores, later ones accumulate)
+
+    @staticmethod
+    def new(B, H, W, C, dtype, device):
+        return View(torch.empty((B, H, W, C), dtype=dtype, device=device), B, H, W, C)
+
+    def chan_slice(self, c0, c1):
+        v = View.__new__(View)
+        v.base = self.base
+        v.ptr = self.ptr + c0 * self.base.element_size()
+        v.ld, v.B, v.H, v.W, v.C, v.dtype = self.ld, self.B, self.H, self.W, c1 - c0, self.dtype
+        v.grad, v.ginit = None, False
+        return v
+
+    @property
+    def rows(self):
+        return self.B * self.H * self.W
+
+    def to_nchw(self):
+        """Debug/test helper: materialise as a contiguous NCHW fp32 tensor (uses torch indexing, not a kernel)."""
+        es = self.base.element_size()
+        off = (self.ptr - self.base.data_ptr()) // es
+        flat = self.base.reshape(-1)
+        idx = torch.as_strided(flat, (self.B, self.H, self.W, self.C), (self.H * self.W * self.ld, self.W * self.ld, self.ld, 1), off)
+        return idx.permute(0, 3, 1, 2).float().contiguous()
+
+
+def conv2d(x, w_ptr, y_ptr, y_ld, N, R, S, Ho, Wo, stride=1, pad_t=0, pad_l=0, upsample=0, dilate=0,
+           bias=0, rowbias=0, rowbias_ld=0, res_ptr=0, res_ld=0, accumulate=0, out_mode=0):
+    """x: View (its H, W are the STORED input dims)."""
+    _hip.call("ddpm_conv2d_nhwc", x.ptr, x.ld, w_ptr, y_ptr, y_ld, bias, rowbias, rowbias_ld, res_ptr, res_ld,
+         x.B, x.H, x.W, x.C, Ho, Wo, N, R, S, stride, pad_t, pad_l, upsample, dilate, accumulate, out_mode, x.dtype, _hip.stream())
+
+
+def conv2d_wgrad(dy, x, dw_ptr, Creal, Nreal, R, S, stride=1, pad_t=0, pad_l=0, upsample=0, splits=1):
+    _hip.call("ddpm_conv2d_wgrad_nhwc", dy.ptr, dy.ld, x.ptr, x.ld, dw_ptr, x.B, x.H, x.W, x.C, Creal, dy.H, dy.W, dy.C, Nreal, R, S,
+         stride, pad_t, pad_l, upsample, splits, x.dtype, _hip.stream())
+
+
+def gemm(a_ptr, a_ld, a_bs, a_trans, b_ptr, b_ld, b_bs, b_trans, c_ptr, c_ld, c_bs, M, N, K, dtype, batch=1, alpha=1.0,
+         bias=0, res_ptr=0, res_ld=0, res_bs=0, accumulate=0, out_mode=0, splits=1):
+    _hip.call("ddpm_gemm", a_ptr, a_ld, a_bs, a_trans, b_ptr, b_ld, b_bs, b_trans, c_ptr, c_ld, c_bs, bias, res_ptr, res_ld, res_bs,
+         M, N, K, batch, alpha, accumulate, out_mode, splits, dtype, _hip.stream())
+
+
+def gn_workspace_floats(B, HW, C, dtype):
+    n = _hip.lib().ddpm_gn_workspace_floats(B, HW, C, GN_GROUPS, dtype)
+    if n < 0:
+        raise RuntimeError(f"GroupNorm geometry unsupported: B={B} HW={HW} C={C}")
+    return n
+
+
+def gn_fwd(x, y, gamma, beta, stats, ws, silu, drop_p=0.0, seed=0):
+    _hip.call("ddpm_groupnorm_silu_fwd", x.ptr, x.ld, y.ptr, y.ld, _hip.ptr(gamma), _hip.ptr(beta), _hip.ptr(stats), _hip.ptr(ws),
+         x.B, x.H * x.W, x.C, GN_GROUPS, GN_EPS, int(silu), float(drop_p), seed, x.dtype, _hip.stream())
+
+
+def gn_bwd(x, dy, dx, gamma, beta, stats, dgamma_ptr, dbeta_ptr, ws, silu, drop_p=0.0, seed=0, accumulate=0):
+    _hip.call("ddpm_groupnorm_silu_bwd", x.ptr, x.ld, dy.ptr, dy.ld, dx.ptr, dx.ld, _hip.ptr(gamma), _hip.ptr(beta), _hip.ptr(stats), dgamma_ptr, dbeta_ptr,
+         _hip.ptr(ws), x.B, x.H * x.W, x.C, GN_GROUPS, int(silu), float(drop_p), seed, accumulate, x.dtype, _hip.stream())
+
+
+def colsum(dy, per_sample_ptr, ps_ld, total_ptr):
+    """per_sample[b][c] = sum_pixels dy (store);  total[c] += sum_{b,pixels} dy (atomic).  <= 2048 channels per launch."""
+    es = 2 if dy.dtype == _hip.BF16 else 4
+    for c0 in range(0, dy.C, 2048):
+        c1 = min(dy.C, c0 + 2048)
+        _hip.call("ddpm_colsum", dy.ptr + c0 * es, dy.ld, per_sample_ptr + c0 * 4 if per_sample_ptr else 0, ps_ld,
+             total_ptr + c0 * 4 if total_ptr else 0, dy.B, dy.H * dy.W, c1 - c0, dy.dtype, _hip.stream())
+
+
+def add_rows(x, y, accumulate):
+    _hip.call("ddpm_add_rows", x.ptr, x.ld, y.ptr, y.ld, x.rows, x.C, accumulate, x.dtype, _hip.stream())

@@ -1,0 +1,250 @@
+"""Gaussian diffusion process with the reference's constructor and method contract
+(``ddpm_torch/diffusion.py:13-243`` of tqch/ddpm-torch), re-built around device-resident tables.
+
+The reference re-uploads an fp64 table from the host on every ``_extract`` call (two per ``q_sample``,
+six or more per sampling step).  Here the fp64 tables are kept as attributes (same names; ``DDIM.from_ddpm``
+and checkpoints of hyper-parameters read them), an fp32 copy is uploaded ONCE per device, and each of
+``q_sample``, the eps-MSE loss and the ancestral step is a single fused HIP kernel that gathers its
+per-sample coefficients by ``t`` on the device:
+
+    x_t      = sqrt(ab_t) x_0 + sqrt(1 - ab_t) eps                                  (diffusion.py:92-97)
+    loss_b   = mean_chw (eps - eps_hat)^2                                           (:236-239)
+    x_{t-1}  = c1_t clamp(r_t x_t - m_t eps_hat, -1, 1) + c2_t x_t + 1[t>0] exp(logvar_t / 2) z   (:99-158)
+
+Arithmetic is fp32 with the reference's operation order (no fused multiply-add contraction) so identical
+(x_t, t, noise) give matching results.  No CPU path: CPU tensors raise.
+"""
+import torch
+
+from . import _hip
+
+__all__ = ["get_beta_schedule", "GaussianDiffusion"]
+
+_F64 = torch.float64
+
+
+def get_beta_schedule(beta_schedule, beta_start, beta_end, timesteps, dtype=_F64):
+    """Same schedules and names as diffusion.py:13-29."""
+    def ramp(frac):
+        out = torch.full((timesteps,), beta_end, dtype=dtype)
+        k = int(timesteps * frac)
+        out[:k] = torch.linspace(beta_start, beta_end, k, dtype=dtype)
+        return out
+
+    table = {
+        "quad": lambda: torch.linspace(beta_start ** 0.5, beta_end ** 0.5, timesteps, dtype=dtype) ** 2,
+        "linear": lambda: torch.linspace(beta_start, beta_end, timesteps, dtype=dtype),
+        "warmup10": lambda: ramp(0.1),
+        "warmup50": lambda: ramp(0.5),
+        "const": lambda: torch.full((timesteps,), beta_end, dtype=dtype),
+        "jsd": lambda: 1.0 / torch.linspace(timesteps, 1, timesteps, dtype=dtype),
+    }
+    if beta_schedule not in table:
+        raise NotImplementedError(beta_schedule)
+    betas = table[beta_schedule]()
+    assert betas.shape == (timesteps,)
+    return betas
+
+
+_MEAN_CODE = {"eps": 0, "x_0": 1, "mean": 2}
+_STEP_TABLES = ("sqrt_recip_alphas_bar", "sqrt_recip_m1_alphas_bar", "posterior_mean_coef1", "posterior_mean_coef2", "fixed_model_logvar")
+
+
+class _AutogradMSE(torch.autograd.Function):
+    """Per-sample eps-MSE with a fused backward (d/d pred only; the target is data)."""
+
+    @staticmethod
+    def forward(ctx, pred, target):
+        B, n = pred.shape[0], pred[0].numel()
+        loss = torch.empty(B, dtype=torch.float32, device=pred.device)
+        _hip.call("ddpm_mse_fwd", pred.data_ptr(), target.data_ptr(), loss.data_ptr(), B, n, _hip.stream())
+        ctx.save_for_backward(pred, target)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gloss):
+        pred, target = ctx.saved_tensors
+        B, n = pred.shape[0], pred[0].numel()
+        g = torch.empty_like(pred)
+        _hip.call("ddpm_mse_bwd", pred.data_ptr(), target.data_ptr(), gloss.contiguous().float().data_ptr(), g.data_ptr(), B, n, _hip.stream())
+        return g, None
+
+
+class GaussianDiffusion:
+    def __init__(self, betas, model_mean_type, model_var_type, loss_type, **kwargs):
+        assert isinstance(betas, torch.Tensor) and betas.dtype == _F64          # diffusion.py:42-43
+        assert (betas > 0).all() and (betas <= 1).all()
+        self.betas = betas
+        self.model_mean_type = model_mean_type
+        self.model_var_type = model_var_type
+        self.loss_type = loss_type
+        self.timesteps = len(betas)
+        self._build_tables(betas, torch.cumprod(1.0 - betas, dim=0), eta2=None)
+
+    def _build_tables(self, betas, alphas_bar, eta2):
+        """fp64 host tables under the reference's attribute names.
+
+        eta2 is None : DDPM posterior (diffusion.py:49-73).
+        eta2 given   : DDIM generalisation on a sub-sequence (ddim.py:61-92): variance scaled by eta^2,
+                       logs floored at 1e-20, mean coefficients from Song et al. eq. 12.
+        """
+        one = torch.ones(1, dtype=_F64)
+        ab, ab_prev = alphas_bar, torch.cat([one, alphas_bar[:-1]])
+        ddim = eta2 is not None
+        self.alphas_bar = ab
+        self.sqrt_alphas_bar = ab.sqrt()
+        self.sqrt_one_minus_alphas_bar = (1.0 - ab).sqrt()
+        self.sqrt_recip_alphas_bar = (1.0 / ab).sqrt()
+        self.sqrt_recip_m1_alphas_bar = (1.0 / ab - 1.0).sqrt()
+        self.posterior_var = betas * (1.0 - ab_prev) / (1.0 - ab) * (eta2 if ddim else 1.0)
+
+        def log_patched(head, tail):               # entry 0 takes the value of entry 1 (diffusion.py:65,71)
+            v = torch.cat([head, tail])
+            return torch.log(v.clip(min=1e-20) if ddim else v)
+
+        self.posterior_logvar_clipped = log_patched(self.posterior_var[1:2], self.posterior_var[1:])
+        if ddim:
+            alphas = ab / ab_prev
+            self.posterior_mean_coef2 = torch.sqrt(1 - ab - eta2 * betas) * torch.sqrt(1 - ab_prev) / (1.0 - ab)
+            self.posterior_mean_coef1 = ab_prev.sqrt() * (1.0 - alphas.sqrt() * self.posterior_mean_coef2)
+        else:
+            self.posterior_mean_coef1 = betas * ab_prev.sqrt() / (1.0 - ab)
+            self.posterior_mean_coef2 = (1.0 - betas).sqrt() * (1.0 - ab_prev) / (1.0 - ab)
+        if self.model_var_type == "fixed-large":
+            self.fixed_model_var = betas
+            self.fixed_model_logvar = log_patched(self.posterior_var[1:2], betas[1:])
+        elif self.model_var_type == "fixed-small":
+            self.fixed_model_var = self.posterior_var
+            self.fixed_model_logvar = self.posterior_logvar_clipped
+        else:
+            raise KeyError(self.model_var_type)        # "learned" is dead in the reference too (diffusion.py:70-73)
+        self._dev = {}                                  # (table name, device) -> fp32 device copy
+        return ab_prev
+
+    # ------------------------------------------------------------------ device tables
+    def _tab(self, name, device):
+        key = (name, device)
+        if key not in self._dev:
+            self._dev[key] = getattr(self, name).to(torch.float32).to(device).contiguous()   # cast THEN gather (diffusion.py:83)
+        return self._dev[key]
+
+    @staticmethod
+    def _extract(arr, t, x, dtype=torch.float32, device=torch.device("cpu"), ndim=4):
+        """diffusion.py:75-84 (kept for callers that use it directly; the fused kernels do not)."""
+        if x is not None:
+            dtype, device, ndim = x.dtype, x.device, x.ndim
+        out = torch.as_tensor(arr, dtype=dtype, device=device).gather(0, t)
+        return out.reshape((-1,) + (1,) * (ndim - 1))
+
+    @staticmethod
+    def _prep(*tensors):
+        _hip.require_cuda(*tensors)
+        return [None if v is None else v.contiguous().float() for v in tensors]
+
+    # ------------------------------------------------------------------ forward process / loss
+    def q_sample(self, x_0, t, noise=None):
+        if noise is None:
+            noise = torch.randn_like(x_0)
+        x_0, noise = self._prep(x_0, noise)
+        t = t.contiguous()
+        out = torch.empty_like(x_0)
+        B = x_0.shape[0]
+        _hip.call("ddpm_q_sample", x_0.data_ptr(), noise.data_ptr(), t.data_ptr(), self._tab("sqrt_alphas_bar", x_0.device).data_ptr(),
+             self._tab("sqrt_one_minus_alphas_bar", x_0.device).data_ptr(), out.data_ptr(), B, x_0[0].numel(), _hip.stream())
+        return out
+
+    def q_posterior_mean_var(self, x_0, x_t, t):
+        e = self._extract
+        mean = e(self.posterior_mean_coef1, t, x_0) * x_0 + e(self.posterior_mean_coef2, t, x_0) * x_t
+        return mean, e(self.posterior_var, t, x_0), e(self.posterior_logvar_clipped, t, x_0)
+
+    def train_losses(self, denoise_fn, x_0, t, noise=None):
+        """mse branch of diffusion.py:217-243 -> per-sample losses [B]."""
+        if self.loss_type != "mse":
+            raise NotImplementedError("only loss_type='mse' is on the accelerated path (all shipped configs use it)")
+        if noise is None:
+            noise = torch.randn_like(x_0)
+        x_t = self.q_sample(x_0, t, noise=noise)
+        if self.model_mean_type == "eps":
+            target = noise
+        elif self.model_mean_type == "x_0":
+            target = x_0
+        elif self.model_mean_type == "mean":
+            target = self.q_posterior_mean_var(x_0=x_0, x_t=x_t, t=t)[0]
+        else:
+            raise NotImplementedError(self.model_mean_type)
+        model_out = denoise_fn(x_t, t)
+        pred, target = self._prep(model_out, target)
+        return _AutogradMSE.apply(pred, target)
+
+    # ------------------------------------------------------------------ reverse process
+    def _step(self, x_t, model_out, z, t, clip_denoised, want_pred):
+        x_t, model_out, z = self._prep(x_t, model_out, z)
+        dev = x_t.device
+        out = torch.empty_like(x_t)
+        pred = torch.empty_like(x_t) if want_pred else None
+        tabs = [self._tab(n, dev).data_ptr() for n in _STEP_TABLES]
+        _hip.call("ddpm_p_sample_step", x_t.data_ptr(), model_out.data_ptr(), z.data_ptr(), t.data_ptr(), *tabs, out.data_ptr(),
+             _hip.ptr(pred), x_t.shape[0], x_t[0].numel(), _MEAN_CODE[self.model_mean_type], int(bool(clip_denoised)), _hip.stream())
+        return out, pred
+
+    def p_mean_var(self, denoise_fn, x_t, t, clip_denoised, return_pred):
+        """diffusion.py:107-138 (mean / variance are read off a zero-noise fused step)."""
+        out = denoise_fn(x_t, t)
+        mean, pred = self._step(x_t, out, torch.zeros_like(x_t), t, clip_denoised, True)
+        var = self._tab("fixed_model_var", x_t.device).gather(0, t).reshape((-1,) + (1,) * (x_t.ndim - 1))
+        logvar = self._tab("fixed_model_logvar", x_t.device).gather(0, t).reshape((-1,) + (1,) * (x_t.ndim - 1))
+        return (mean, var, logvar, pred) if return_pred else (mean, var, logvar)
+
+    def p_sample_step(self, denoise_fn, x_t, t, clip_denoised=True, return_pred=False, generator=None):
+        """diffusion.py:152-158: one model call, one noise draw (also at t = 0, then masked), one fused update."""
+        out = denoise_fn(x_t, t)
+        noise = torch.empty_like(x_t).normal_(generator=generator)
+        sample, pred = self._step(x_t, out, noise, t, clip_denoised, return_pred)
+        return (sample, pred) if return_pred else sample
+
+    def _model_t(self, t):
+        return t
+
+    def _sample_loop(self, denoise_fn, shape, device, noise, seed, on_step=None):
+        device = torch.device(device)
+        _hip.require_cuda(torch.empty(0, device=device))        # no CPU fallback: sampling runs on the GPU only
+        B = (shape or noise.shape)[0]
+        rng = torch.Generator(device).manual_seed(seed) if seed is not None else None       # diffusion.py:164-166
+        if noise is None:
+            x_t = torch.empty(shape, device=device).normal_(generator=rng)                  # x_T first, then one z per step
+        else:
+            x_t = noise.to(device)
+        t = torch.empty((B,), dtype=torch.int64, device=device)
+        for ti in range(self._num_steps() - 1, -1, -1):
+            t.fill_(ti)
+            out = denoise_fn(x_t, self._model_t(t))
+            z = torch.empty_like(x_t).normal_(generator=rng)
+            x_t, pred = self._step(x_t, out, z, t, True, on_step is not None)
+            if on_step is not None:
+                on_step(ti, pred)
+        return x_t
+
+    def _num_steps(self):
+        return self.timesteps
+
+    @torch.inference_mode()
+    def p_sample(self, denoise_fn, shape=None, device=torch.device("cpu"), noise=None, seed=None):
+        """diffusion.py:160-174."""
+        return self._sample_loop(denoise_fn, shape, device, noise, seed)
+
+    @torch.inference_mode()
+    def p_sample_progressive(self, denoise_fn, shape, device=torch.device("cpu"), noise=None, pred_freq=10, seed=None):
+        """diffusion.py:176-198: also returns pred_x0 every ``pred_freq`` steps (on the host)."""
+        B = (shape or noise.shape)[0]
+        L = self.timesteps // pred_freq
+        preds = torch.zeros((L, B) + tuple(shape[1:]), dtype=torch.float32)
+        box = [L]
+
+        def keep(ti, pred):
+            if (ti + 1) % pred_freq == 0:
+                box[0] -= 1
+                preds[box[0]] = pred.cpu()
+
+        x = self._sample_loop(denoise_fn, shape, device, noise, seed, on_step=keep)
+        return x.cpu(), preds

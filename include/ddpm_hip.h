@@ -1,0 +1,115 @@
+/* ddpm_hip.h — C ABI of libddpm_hip.so: the MI355X (gfx950) kernels behind the ddpm-torch hot path.
+ *
+ * The reference (tqch/ddpm-torch) is pure Python on ATen; it has no FFI of its own.  Each entry point below
+ * replaces the ATen op class the reference invokes at the cited site (paths relative to the upstream repo);
+ * the binding a maintainer would add is the ctypes table in ddpm-torch_amd/ddpm_torch/_hip.py.
+ *
+ * Conventions
+ *   - Every pointer is a DEVICE pointer owned by the caller (PyTorch's caching allocator); the library never
+ *     allocates, frees or retains memory.  "stream" is a hipStream_t; all work is enqueued on it and the call
+ *     returns immediately (no synchronisation, hipGraph-capturable).  Re-entrant and thread-safe.
+ *   - dtype: 0 = fp32, 1 = bf16 (activations / packed weights); parameters, statistics and gradients are fp32.
+ *   - Activations are NHWC: element (b, y, x, c) at  base + ((b*H + y)*W + x)*ld + c  with a caller-chosen pixel
+ *     pitch ld >= C (in elements), so channel slices of a wider buffer are valid operands (zero-copy concat).
+ *     Pointers and pitches must be 16-byte aligned; channel counts are multiples of 16/sizeof(dtype).
+ *   - Return value: 0 OK, 1 bad shape, 2 bad dtype, 3 misaligned, 4 launch failure, 5 null pointer.
+ */
+#ifndef DDPM_HIP_H
+#define DDPM_HIP_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* F.conv2d 3x3/1x1 (ddpm_torch/modules.py:120-123; sites models/unet.py:36,37,41,76,79,80,127,141,201), with
+ * SamePad2d(3,2)+stride 2 (modules.py:153-160, unet.py:165-167), nn.Upsample(2,"nearest") (unet.py:199),
+ * the per-sample time-bias add (unet.py:86) and the residual add (unet.py:60,89) fused:
+ *   y[b,oy,ox,n] = sum_{r,s,c} x[b, f(oy*stride+r-pad_t), f(ox*stride+s-pad_l), c] * w[n][r][s][c]
+ *                  + bias[n] + rowbias[b*rowbias_ld + n] + residual[b,oy,ox,n]      (+ y when accumulate)
+ * f = identity | v>>1 (upsample=1, H/W are the stored low-res dims) | v/2 for even v only (dilate=1: the dgrad
+ * of a stride-2 conv).  w is packed [N][R][S][C] in dtype (ddpm_pack_weight).  dgrad = same call on dy with the
+ * flipped/transposed pack and pad = R-1-pad.  out_mode: 0 NHWC dtype (pitch y_ld) | 1 NHWC fp32 | 3 NCHW fp32. */
+int ddpm_conv2d_nhwc(const void* x, long long x_ld, const void* w, void* y, long long y_ld,
+                     const float* bias, const float* rowbias, long long rowbias_ld,
+                     const void* residual, long long res_ld,
+                     int B, int H, int W, int C, int Ho, int Wo, int N, int R, int S,
+                     int stride, int pad_t, int pad_l, int upsample, int dilate,
+                     int accumulate, int out_mode, int dtype, void* stream);
+
+/* convolution_backward w.r.t. the weight (autograd of the sites above):
+ *   dw[n][c][r][s] += sum_{b,oy,ox} dy[b,oy,ox,n] * x[b, f(..), f(..), c]      n < Nreal, c < Creal (fp32 atomics)
+ * dy has N (>= Nreal) channels, x has C (>= Creal) channels (zero padding beyond the real counts). */
+int ddpm_conv2d_wgrad_nhwc(const void* dy, long long dy_ld, const void* x, long long x_ld, float* dw,
+                           int B, int H, int W, int C, int Creal, int Ho, int Wo, int N, int Nreal, int R, int S,
+                           int stride, int pad_t, int pad_l, int upsample, int splits, int dtype, void* stream);
+
+/* F.linear (modules.py:58-59; unet.py:77,123,125) and torch.einsum in AttentionBlock.qkv (unet.py:46,50):
+ *   C[b][m][n] = alpha * sum_k A[b][m][k] * B[b][n][k] + bias[n] + residual[b][m][n]   (+ C when accumulate)
+ * a_trans/b_trans = 1: the operand is stored [k][m] / [k][n].  out_mode: 0 dtype | 1 fp32 | 2 fp32 atomic add. */
+int ddpm_gemm(const void* a, long long a_ld, long long a_bs, int a_trans,
+              const void* b, long long b_ld, long long b_bs, int b_trans,
+              void* c, long long c_ld, long long c_bs,
+              const float* bias, const void* residual, long long res_ld, long long res_bs,
+              int M, int N, int K, int batch, float alpha, int accumulate, int out_mode, int splits,
+              int dtype, void* stream);
+
+/* nn.GroupNorm(32, C, eps=1e-6) -> SiLU -> Dropout(p) (unet.py:18-20,15,81,85-87,139-140; :57 without SiLU):
+ *   y = drop(silu((x - mean_g) * rstd_g * gamma_c + beta_c)),  biased variance over (C/G)*HW elements.
+ * stats (optional) receives [B][G][2] = (mean, rstd) for the backward.  workspace: ddpm_gn_workspace_floats().
+ * Dropout keep-mask = hash(seed, linear NHWC index) (see ddpm_dropout_mask); scale 1/(1-p). */
+int ddpm_groupnorm_silu_fwd(const void* x, long long x_ld, void* y, long long y_ld, const float* gamma, const float* beta,
+                            float* stats, float* workspace, int B, int HW, int C, int G, float eps, int silu,
+                            float drop_p, unsigned long long seed, int dtype, void* stream);
+/* backward of the above: dx (+= when accumulate), dgamma/dbeta += (fp32 atomics). */
+int ddpm_groupnorm_silu_bwd(const void* x, long long x_ld, const void* dy, long long dy_ld, void* dx, long long dx_ld,
+                            const float* gamma, const float* beta, const float* stats, float* dgamma, float* dbeta,
+                            float* workspace, int B, int HW, int C, int G, int silu, float drop_p, unsigned long long seed,
+                            int accumulate, int dtype, void* stream);
+long long ddpm_gn_workspace_floats(int B, int HW, int C, int G, int dtype);
+
+/* get_timestep_embedding (ddpm_torch/functions.py:10-26): out[b] = cat(sin(t_b f), cos(t_b f)) (zero pad if dim odd);
+ * freqs[dim/2] = exp(-i ln(1e4)/(dim/2 - 1)) is supplied by the host in fp32. */
+int ddpm_timestep_embedding(const long long* t, const float* freqs, float* out, int B, int dim, void* stream);
+
+/* layout / packing helpers (no reference counterpart: the NHWC + packed-weight layout is this library's) */
+int ddpm_nchw_to_nhwc(const float* x, void* y, int B, int C, int HW, int Cp, int dtype, void* stream);
+int ddpm_pack_weight(const float* w, void* w_fwd /*[N][R][S][Cp]*/, void* w_dgrad /*[C][R][S][Np], taps flipped*/,
+                     int N, int C, int R, int S, int Cp, int Np, int dtype, void* stream);
+
+/* GaussianDiffusion.q_sample (ddpm_torch/diffusion.py:92-97): xt = sqrt_ab[t]*x0 + sqrt_1mab[t]*noise  (fp32, [B][n]) */
+int ddpm_q_sample(const float* x0, const float* noise, const long long* t, const float* sqrt_ab, const float* sqrt_1mab,
+                  float* xt, int B, int n, void* stream);
+/* flat_mean((target - pred)^2) (diffusion.py:239, functions.py:99-101) and its gradient w.r.t. pred */
+int ddpm_mse_fwd(const float* pred, const float* target, float* loss, int B, int n, void* stream);
+int ddpm_mse_bwd(const float* pred, const float* target, const float* gloss, float* gpred, int B, int n, void* stream);
+/* p_mean_var + p_sample_step (diffusion.py:107-158; ddim.py inherits it): one fused update
+ *   x0 = clamp(recip[t]*x_t - recip_m1[t]*out)   (mean_type 0 = eps; 1: x0 = out; 2: out is the mean)
+ *   x_prev = coef1[t]*x0 + coef2[t]*x_t + 1[t>0]*exp(0.5*logvar[t])*z ;  pred_x0 optional. */
+int ddpm_p_sample_step(const float* x_t, const float* model_out, const float* z, const long long* t,
+                       const float* sqrt_recip_ab, const float* sqrt_recip_m1_ab, const float* post_coef1, const float* post_coef2,
+                       const float* logvar, float* x_prev, float* pred_x0, int B, int n, int mean_type, int clip, void* stream);
+/* subsequence.gather(0, t) (ddim.py:101) and t += delta (t.fill_ in diffusion.py:172, device-side for graph replay) */
+int ddpm_gather_i64(const long long* idx, const long long* map, long long* out, int B, void* stream);
+int ddpm_add_i64(long long* t, int B, long long delta, void* stream);
+
+/* nn.SiLU on the time-embedding path (unet.py:86,124) */
+int ddpm_silu_fwd(const float* x, float* y, long long n, void* stream);
+int ddpm_silu_bwd(const float* x, const float* dy, float* dx, long long n, int accumulate, void* stream);
+
+/* bias / time-bias gradients: per_sample[b][c] = sum_pixels dy (store), total[c] += sum_{b,pixels} dy (atomic); C <= 2048 */
+int ddpm_colsum(const void* dy, long long ld, float* per_sample, long long ps_ld, float* total, int B, int HW, int C, int dtype, void* stream);
+/* backward of nn.Upsample(2,"nearest"): dx[b,y,x,c] (+)= sum of the 2x2 block of dy_up */
+int ddpm_upsample2x_bwd(const void* dy_up, void* dx, long long dx_ld, int B, int H, int W, int C, int accumulate, int dtype, void* stream);
+/* y (+)= x over [rows][C] slices with pitches (gradient fan-in of the residual / skip connections) */
+int ddpm_add_rows(const void* x, long long x_ld, void* y, long long y_ld, long long rows, int C, int accumulate, int dtype, void* stream);
+
+/* torch.softmax over the keys (unet.py:47-49) and its backward dS = P*(dP - sum(dP*P)); rows of length L */
+int ddpm_softmax_fwd(const float* s, void* p, long long rows, int L, int dtype, void* stream);
+int ddpm_softmax_bwd(const void* p, const float* dp, void* ds, long long rows, int L, int dtype, void* stream);
+
+/* test hook: the keep-mask (1/0) the GroupNorm kernels regenerate for element indices 0..n-1 */
+int ddpm_dropout_mask(float* mask, long long n, float p, unsigned long long seed, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,328 @@
+"""TEST INFRASTRUCTURE: a host-memory emulator of the C ABI in include/ddpm_hip.h.
+
+Purpose: exercise the product's HOST logic (engine orchestration, pitches, gradient fan-in, weight caches, the
+autograd wiring, Trainer / EMA) in the CPU-only container, where the HIP kernels cannot run.  Each ``ddpm_*`` entry
+point is re-stated with numpy/torch over the raw host pointers the engine passes (CPU tensors have real addresses).
+It is installed by monkeypatching ``ddpm_torch._hip`` from a test fixture; the product never imports this file and
+has no switch to enable it.  It says nothing about the kernels themselves — those are checked on the GPU (-m gpu).
+"""
+import ctypes
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+F32, BF16 = 0, 1
+
+
+def _np(ptr, count, ctype, nptype):
+    if count <= 0:
+        return np.zeros(0, dtype=nptype)
+    return np.frombuffer((ctype * count).from_address(ptr), dtype=nptype)
+
+
+def f32(ptr, count):
+    return _np(ptr, count, ctypes.c_float, np.float32)
+
+
+def i64(ptr, count):
+    return _np(ptr, count, ctypes.c_longlong, np.int64)
+
+
+def _bf16_to_f32(u16):
+    return (u16.astype(np.uint32) << 16).view(np.float32)
+
+
+def _f32_to_bf16(x):
+    u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32)
+    r = u + (0x7FFF + ((u >> 16) & 1))
+    return (r >> 16).astype(np.uint16)
+
+
+class Mat:
+    """[rows][cols] matrix with a row pitch, in fp32 or bf16 host memory."""
+
+    def __init__(self, ptr, rows, cols, ld, dcode):
+        self.rows, self.cols, self.ld, self.dcode = rows, cols, ld, dcode
+        n = (rows - 1) * ld + cols if rows > 0 else 0
+        raw = _np(ptr, n, ctypes.c_uint16, np.uint16) if dcode == BF16 else f32(ptr, n)
+        self.view = np.lib.stride_tricks.as_strided(raw, (rows, cols), (ld * raw.itemsize, raw.itemsize), writeable=True) if n else raw.reshape(0, cols)
+
+    def get(self):
+        return _bf16_to_f32(self.view) if self.dcode == BF16 else self.view.astype(np.float32)
+
+    def set(self, values):
+        values = np.asarray(values, dtype=np.float32).reshape(self.rows, self.cols)
+        self.view[...] = _f32_to_bf16(values).reshape(self.rows, self.cols) if self.dcode == BF16 else values
+
+
+def _keep_mask(seed, idx, thresh24):
+    """numpy mirror of dropout_keep() in csrc/common.h."""
+    def mix32(x):
+        x = x.astype(np.uint32)
+        x ^= x >> np.uint32(16); x = (x * np.uint32(0x7FEB352D)).astype(np.uint32)
+        x ^= x >> np.uint32(15); x = (x * np.uint32(0x846CA68B)).astype(np.uint32)
+        x ^= x >> np.uint32(16)
+        return x
+    idx = idx.astype(np.uint64)
+    lo = (idx & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+    hi = (idx >> np.uint64(32)).astype(np.uint32)
+    s_lo, s_hi = np.uint32(seed & 0xFFFFFFFF), np.uint32((seed >> 32) & 0xFFFFFFFF)
+    with np.errstate(over="ignore"):
+        h = mix32(lo ^ mix32((hi + s_lo).astype(np.uint32)) ^ np.uint32((int(s_hi) * 0x9E3779B9) & 0xFFFFFFFF))
+    return (h >> np.uint32(8)) >= np.uint32(thresh24)
+
+
+def _thresh(p):
+    th = p * 16777216.0
+    return 0 if th <= 0 else (16777216 if th >= 16777216.0 else int(th + 0.5))
+
+
+def _canvas(x_nchw, Ho, Wo, R, S, stride, pad_t, pad_l, upsample, dilate):
+    """Zero canvas on which a plain VALID stride-`stride` correlation reproduces the virtual-grid gather."""
+    B, C, H, W = x_nchw.shape
+    if upsample:
+        xv = x_nchw.repeat_interleave(2, 2).repeat_interleave(2, 3)
+    elif dilate:
+        xv = torch.zeros(B, C, 2 * H - 1, 2 * W - 1, dtype=x_nchw.dtype)
+        xv[:, :, ::2, ::2] = x_nchw
+    else:
+        xv = x_nchw
+    need_h, need_w = (Ho - 1) * stride + R, (Wo - 1) * stride + S
+    can = torch.zeros(B, C, need_h, need_w, dtype=x_nchw.dtype)
+    hv, wv = xv.shape[2], xv.shape[3]
+    # canvas index = v + pad
+    y0, x0 = pad_t, pad_l
+    ys, xs = max(0, -y0), max(0, -x0)
+    ye, xe = min(hv, need_h - y0), min(wv, need_w - x0)
+    if ye > ys and xe > xs:
+        can[:, :, y0 + ys:y0 + ye, x0 + xs:x0 + xe] = xv[:, :, ys:ye, xs:xe]
+    return can
+
+
+class Emulator:
+    """Callable table name -> python implementation; ``call(name, *args)`` mimics ddpm_torch._hip.call."""
+
+    def __init__(self, real_lib=None):
+        self.real_lib = real_lib
+        self.log = []
+
+    def call(self, name, *args):
+        self.log.append(name)
+        getattr(self, name)(*args)
+
+    # ------------------------------------------------------------------ conv / gemm
+    def ddpm_conv2d_nhwc(self, x, x_ld, w, y, y_ld, bias, rowbias, rb_ld, res, res_ld, B, H, W, C, Ho, Wo, N, R, S,
+                         stride, pad_t, pad_l, ups, dil, acc, mode, dt, st):
+        xin = torch.from_numpy(Mat(x, B * H * W, C, x_ld, dt).get()).reshape(B, H, W, C).permute(0, 3, 1, 2)
+        wt = torch.from_numpy(Mat(w, N, R * S * C, R * S * C, dt).get()).reshape(N, R, S, C).permute(0, 3, 1, 2)
+        can = _canvas(xin, Ho, Wo, R, S, stride, pad_t, pad_l, ups, dil)
+        out = F.conv2d(can, wt, stride=stride)                      # [B, N, Ho, Wo]
+        assert out.shape[2:] == (Ho, Wo), (out.shape, Ho, Wo)
+        out = out.permute(0, 2, 3, 1).reshape(B * Ho * Wo, N).numpy().copy()
+        if bias:
+            out += f32(bias, N)[None, :]
+        if rowbias:
+            rb = Mat(rowbias, B, N, rb_ld, F32).get()
+            out += np.repeat(rb, Ho * Wo, axis=0)
+        if res:
+            out += Mat(res, B * Ho * Wo, N, res_ld, dt).get()
+        if mode == 0:
+            dst = Mat(y, B * Ho * Wo, N, y_ld, dt)
+        elif mode == 1:
+            dst = Mat(y, B * Ho * Wo, N, y_ld, F32)
+        else:
+            arr = f32(y, B * N * Ho * Wo).reshape(B, N, Ho * Wo)
+            val = out.reshape(B, Ho * Wo, N).transpose(0, 2, 1)
+            arr[...] = arr + val if acc else val
+            return
+        dst.set(dst.get() + out if acc else out)
+
+    def ddpm_conv2d_wgrad_nhwc(self, dy, dy_ld, x, x_ld, dw, B, H, W, C, Creal, Ho, Wo, N, Nreal, R, S, stride, pad_t, pad_l, ups,
+                               splits, dt, st):
+        xin = torch.from_numpy(Mat(x, B * H * W, C, x_ld, dt).get()).reshape(B, H, W, C).permute(0, 3, 1, 2)
+        g = torch.from_numpy(Mat(dy, B * Ho * Wo, N, dy_ld, dt).get()).reshape(B, Ho, Wo, N).permute(0, 3, 1, 2)[:, :Nreal]
+        can = _canvas(xin, Ho, Wo, R, S, stride, pad_t, pad_l, ups, 0)
+        gw = torch.nn.grad.conv2d_weight(can.contiguous(), (Nreal, C, R, S), g.contiguous(), stride=stride)
+        arr = f32(dw, Nreal * Creal * R * S).reshape(Nreal, Creal, R, S)
+        arr += gw[:, :Creal].numpy()
+
+    def _operand(self, p, ld, bs, trans, rows, K, batch, dt):
+        es = 2 if dt == BF16 else 4
+        mats = []
+        for b in range(batch):
+            base = p + b * bs * es
+            m = Mat(base, K, rows, ld, dt).get().T if trans else Mat(base, rows, K, ld, dt).get()
+            mats.append(m)
+        return np.stack(mats)
+
+    def ddpm_gemm(self, a, a_ld, a_bs, a_tr, b, b_ld, b_bs, b_tr, c, c_ld, c_bs, bias, res, res_ld, res_bs, M, N, K, batch, alpha,
+                  acc, mode, splits, dt, st):
+        A = self._operand(a, a_ld, a_bs, a_tr, M, K, batch, dt)
+        Bm = self._operand(b, b_ld, b_bs, b_tr, N, K, batch, dt)
+        out = alpha * np.einsum("bmk,bnk->bmn", A.astype(np.float64), Bm.astype(np.float64)).astype(np.float32)
+        if bias:
+            out += f32(bias, N)[None, None, :]
+        odt = dt if mode == 0 else F32
+        es_r = 2 if dt == BF16 else 4
+        es_o = 2 if odt == BF16 else 4
+        for i in range(batch):
+            v = out[i]
+            if res:
+                v = v + Mat(res + i * res_bs * es_r, M, N, res_ld, dt).get()
+            dst = Mat(c + i * c_bs * es_o, M, N, c_ld, odt)
+            dst.set(dst.get() + v if (acc or mode == 2) else v)
+
+    # ------------------------------------------------------------------ group norm
+    def _gn(self, x, gamma, beta, G, eps, silu, drop_p, seed, B, HW, C):
+        t = x.reshape(B, HW, C).permute(0, 2, 1).reshape(B, C, HW, 1)
+        y = F.group_norm(t, G, gamma, beta, eps)
+        if silu:
+            y = F.silu(y)
+        if drop_p > 0:
+            idx = np.arange(B * HW * C, dtype=np.uint64)
+            keep = torch.from_numpy(_keep_mask(seed, idx, _thresh(drop_p)).astype(np.float32)).reshape(B, HW, C).permute(0, 2, 1).reshape(B, C, HW, 1)
+            y = y * keep / (1.0 - drop_p)
+        return y.reshape(B, C, HW).permute(0, 2, 1).reshape(B * HW, C)
+
+    def ddpm_groupnorm_silu_fwd(self, x, x_ld, y, y_ld, gamma, beta, stats, ws, B, HW, C, G, eps, silu, drop_p, seed, dt, st):
+        xin = torch.from_numpy(Mat(x, B * HW, C, x_ld, dt).get())
+        g, b = torch.from_numpy(f32(gamma, C).copy()), torch.from_numpy(f32(beta, C).copy())
+        out = self._gn(xin, g, b, G, eps, silu, drop_p, seed, B, HW, C)
+        Mat(y, B * HW, C, y_ld, dt).set(out.numpy())
+        if stats:
+            xg = xin.reshape(B, HW, G, C // G).permute(0, 2, 1, 3).reshape(B, G, -1).double()
+            mean, var = xg.mean(-1), xg.var(-1, unbiased=False)
+            s = f32(stats, B * G * 2).reshape(B, G, 2)
+            s[..., 0] = mean.float().numpy(); s[..., 1] = (1.0 / torch.sqrt(var + eps)).float().numpy()
+
+    def ddpm_groupnorm_silu_bwd(self, x, x_ld, dy, dy_ld, dx, dx_ld, gamma, beta, stats, dgamma, dbeta, ws, B, HW, C, G, silu, drop_p,
+                                seed, acc, dt, st):
+        xin = torch.from_numpy(Mat(x, B * HW, C, x_ld, dt).get()).requires_grad_(True)
+        g = torch.from_numpy(f32(gamma, C).copy()).requires_grad_(True)
+        b = torch.from_numpy(f32(beta, C).copy()).requires_grad_(True)
+        gy = torch.from_numpy(Mat(dy, B * HW, C, dy_ld, dt).get())
+        with torch.enable_grad():                  # we are called from inside an autograd.Function.backward
+            self._gn(xin, g, b, G, 1e-6, silu, drop_p, seed, B, HW, C).backward(gy)
+        dst = Mat(dx, B * HW, C, dx_ld, dt)
+        dst.set(dst.get() + xin.grad.numpy() if acc else xin.grad.numpy())
+        if dgamma:
+            f32(dgamma, C)[...] += g.grad.numpy()
+        if dbeta:
+            f32(dbeta, C)[...] += b.grad.numpy()
+
+    # ------------------------------------------------------------------ elementwise
+    def ddpm_timestep_embedding(self, t, freqs, out, B, dim, st):
+        tt = i64(t, B).astype(np.float32)
+        fr = f32(freqs, dim // 2)
+        arg = (tt[:, None] * fr[None, :]).astype(np.float32)
+        o = f32(out, B * dim).reshape(B, dim)
+        o[...] = 0
+        o[:, :dim // 2] = np.sin(arg); o[:, dim // 2:2 * (dim // 2)] = np.cos(arg)
+
+    def ddpm_nchw_to_nhwc(self, x, y, B, C, HW, Cp, dt, st):
+        src = f32(x, B * C * HW).reshape(B, C, HW).transpose(0, 2, 1)
+        out = np.zeros((B, HW, Cp), dtype=np.float32)
+        out[..., :C] = src
+        Mat(y, B * HW, Cp, Cp, dt).set(out.reshape(B * HW, Cp))
+
+    def ddpm_pack_weight(self, w, wf, wd, N, C, R, S, Cp, Np, dt, st):
+        src = f32(w, N * C * R * S).reshape(N, C, R, S)
+        if wf:
+            out = np.zeros((N, R, S, Cp), dtype=np.float32)
+            out[..., :C] = src.transpose(0, 2, 3, 1)
+            Mat(wf, N, R * S * Cp, R * S * Cp, dt).set(out.reshape(N, -1))
+        if wd:
+            out = np.zeros((C, R, S, Np), dtype=np.float32)
+            out[..., :N] = src[:, :, ::-1, ::-1].transpose(1, 2, 3, 0)
+            Mat(wd, C, R * S * Np, R * S * Np, dt).set(out.reshape(C, -1))
+
+    def ddpm_q_sample(self, x0, noise, t, ca, cb, xt, B, n, st):
+        tt = i64(t, B)
+        T = int(tt.max()) + 1
+        a, b = f32(ca, T)[tt], f32(cb, T)[tt]
+        f32(xt, B * n).reshape(B, n)[...] = a[:, None] * f32(x0, B * n).reshape(B, n) + b[:, None] * f32(noise, B * n).reshape(B, n)
+
+    def ddpm_mse_fwd(self, pred, target, loss, B, n, st):
+        d = f32(target, B * n).reshape(B, n) - f32(pred, B * n).reshape(B, n)
+        f32(loss, B)[...] = (d * d).mean(1)
+
+    def ddpm_mse_bwd(self, pred, target, gloss, gpred, B, n, st):
+        d = f32(pred, B * n).reshape(B, n) - f32(target, B * n).reshape(B, n)
+        f32(gpred, B * n).reshape(B, n)[...] = d * (2.0 / n) * f32(gloss, B)[:, None]
+
+    def ddpm_p_sample_step(self, x_t, out, z, t, recip, recip_m1, c1, c2, logvar, x_prev, pred, B, n, mean_type, clip, st):
+        tt = i64(t, B)
+        T = int(tt.max()) + 1
+        g = lambda p: f32(p, T)[tt][:, None]
+        xt, o, zz = (f32(p, B * n).reshape(B, n) for p in (x_t, out, z))
+        if mean_type == 0:
+            x0 = g(recip) * xt - g(recip_m1) * o
+        elif mean_type == 1:
+            x0 = o.copy()
+        else:
+            x0 = o / g(c1) - g(c2) / g(c1) * xt
+        if clip:
+            x0 = np.clip(x0, -1.0, 1.0)
+        mean = o if mean_type == 2 else g(c1) * x0 + g(c2) * xt
+        mask = (tt > 0).astype(np.float32)[:, None]
+        f32(x_prev, B * n).reshape(B, n)[...] = mean + mask * np.exp(0.5 * g(logvar)) * zz
+        if pred:
+            f32(pred, B * n).reshape(B, n)[...] = x0
+
+    def ddpm_gather_i64(self, idx, mp, out, B, st):
+        ii = i64(idx, B)
+        i64(out, B)[...] = i64(mp, int(ii.max()) + 1)[ii]
+
+    def ddpm_add_i64(self, t, B, delta, st):
+        i64(t, B)[...] += delta
+
+    def ddpm_silu_fwd(self, x, y, n, st):
+        v = torch.from_numpy(f32(x, n).copy())
+        f32(y, n)[...] = F.silu(v).numpy()
+
+    def ddpm_silu_bwd(self, x, dy, dx, n, acc, st):
+        v = torch.from_numpy(f32(x, n).copy()).requires_grad_(True)
+        with torch.enable_grad():
+            F.silu(v).backward(torch.from_numpy(f32(dy, n).copy()))
+        d = f32(dx, n)
+        d[...] = d + v.grad.numpy() if acc else v.grad.numpy()
+
+    def ddpm_colsum(self, dy, ld, per_sample, ps_ld, total, B, HW, C, dt, st):
+        v = Mat(dy, B * HW, C, ld, dt).get().reshape(B, HW, C).sum(1)
+        if per_sample:
+            Mat(per_sample, B, C, ps_ld, F32).set(v)
+        if total:
+            f32(total, C)[...] += v.sum(0)
+
+    def ddpm_upsample2x_bwd(self, dyu, dx, dx_ld, B, H, W, C, acc, dt, st):
+        v = Mat(dyu, B * 4 * H * W, C, C, dt).get().reshape(B, H, 2, W, 2, C).sum((2, 4)).reshape(B * H * W, C)
+        dst = Mat(dx, B * H * W, C, dx_ld, dt)
+        dst.set(dst.get() + v if acc else v)
+
+    def ddpm_add_rows(self, x, x_ld, y, y_ld, rows, C, acc, dt, st):
+        v = Mat(x, rows, C, x_ld, dt).get()
+        dst = Mat(y, rows, C, y_ld, dt)
+        dst.set(dst.get() + v if acc else v)
+
+    def ddpm_softmax_fwd(self, s, p, rows, L, dt, st):
+        v = torch.softmax(torch.from_numpy(f32(s, rows * L).reshape(rows, L).copy()), -1)
+        Mat(p, rows, L, L, dt).set(v.numpy())
+
+    def ddpm_softmax_bwd(self, p, dp, ds, rows, L, dt, st):
+        P = Mat(p, rows, L, L, dt).get()
+        d = f32(dp, rows * L).reshape(rows, L)
+        Mat(ds, rows, L, L, dt).set(P * (d - (d * P).sum(1, keepdims=True)))
+
+    def ddpm_dropout_mask(self, mask, n, p, seed, st):
+        f32(mask, n)[...] = _keep_mask(seed, np.arange(n, dtype=np.uint64), _thresh(p)).astype(np.float32)
+
+
+def install(monkeypatch, hip_module):
+    """Route the product's ABI calls to the emulator for the duration of a test."""
+    emu = Emulator()
+    real_lib = hip_module.lib()                      # the real .so still answers host-side geometry queries
+    monkeypatch.setattr(hip_module, "call", emu.call)
+    monkeypatch.setattr(hip_module, "stream", lambda: 0)
+    monkeypatch.setattr(hip_module, "require_cuda", lambda *a: None)
+    return emu

@@ -1,0 +1,169 @@
+"""Host-logic tests (CPU): the product's engine / diffusion / trainer code runs unmodified, with the C-ABI calls
+routed to tests/abi_emulator.py (a numpy restatement of include/ddpm_hip.h over host pointers).  This checks the
+orchestration — pitches, zero-copy concat, gradient fan-in, weight caches, autograd wiring, state-dict layout —
+against the oracle.  The HIP kernels themselves are checked by the -m gpu tests."""
+import json
+import os
+
+import pytest
+import torch
+
+import ddim as ddim_mod
+import ddpm_torch
+from ddpm_torch import _hip
+from oracle import diffusion_ref as D
+from oracle import unet_ref as U
+from tests import abi_emulator
+from tests.golden.recipes import check, rnd
+
+TINY = dict(in_channels=3, hid_channels=32, out_channels=3, ch_multipliers=[1, 2], num_res_blocks=1, apply_attn=[False, True], drop_rate=0.0)
+TINY3 = dict(in_channels=3, hid_channels=32, out_channels=3, ch_multipliers=[1, 2, 2], num_res_blocks=2, apply_attn=[False, True, False], drop_rate=0.1)
+
+pytestmark = pytest.mark.skipif(not os.path.exists(_hip.LIB_PATH), reason="libddpm_hip.so not built")
+
+
+@pytest.fixture
+def emu(monkeypatch):
+    return abi_emulator.install(monkeypatch, _hip)
+
+
+def make(cfg, seed=5, dtype=torch.float32):
+    torch.manual_seed(seed)
+    m = ddpm_torch.UNet(**cfg)
+    sd = U.randomize_state_dict(m.state_dict(), 17)
+    m.load_state_dict(sd)
+    m.set_compute_dtype(dtype)
+    return m, sd
+
+
+@pytest.mark.parametrize("cfg", [TINY, TINY3])
+def test_forward_fp32_matches_oracle(emu, cfg):
+    m, sd = make(cfg)
+    m.eval()
+    x, t = rnd(2, 3, 16, 16, seed=1), torch.tensor([3, 977])
+    with torch.no_grad():
+        y = m(x, t)
+        ref = U.unet_forward(sd, cfg, x, t)
+    check(y, ref, 2e-5, name="fwd")
+    assert "ddpm_conv2d_nhwc" in emu.log and "ddpm_groupnorm_silu_fwd" in emu.log
+
+
+def test_forward_bf16_close(emu):
+    m, sd = make(TINY, dtype=torch.bfloat16)
+    m.eval()
+    x, t = rnd(2, 3, 8, 8, seed=2), torch.tensor([10, 500])
+    with torch.no_grad():
+        y = m(x, t)
+        ref = U.unet_forward(sd, TINY, x, t)
+    check(y, ref, 5e-2, name="fwd_bf16")      # bf16 storage of every activation: loose, documented tolerance
+
+
+@pytest.mark.parametrize("cfg", [TINY, TINY3])
+def test_backward_fp32_matches_oracle(emu, cfg):
+    m, sd = make(cfg)
+    m.train()
+    x, t, gy = rnd(2, 3, 16, 16, seed=3), torch.tensor([7, 912]), rnd(2, 3, 16, 16, seed=4)
+    y = m(x, t)
+    (y * gy).sum().backward()
+    # the oracle consumes the very dropout masks the engine used
+    masks = {}
+    if cfg["drop_rate"] > 0:
+        eng = m.engine()
+        rec = {id(r[1]): r for r in eng.last_tape if r[0] == "res"}
+        names = {id(mod): name for name, mod in m.named_modules()}
+        for rb_id, r in rec.items():
+            h1, seed = r[6], r[9]
+            n = h1.B * h1.H * h1.W * h1.C
+            mk = torch.empty(n)
+            emu.ddpm_dropout_mask(mk.data_ptr(), n, cfg["drop_rate"], seed, 0)
+            masks[names[rb_id] + "."] = mk.reshape(h1.B, h1.H, h1.W, h1.C).permute(0, 3, 1, 2)
+    p = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref = U.unet_forward(p, cfg, x, t, training=True, masks=masks)
+    check(y, ref, 2e-5, name="train fwd")
+    (ref * gy).sum().backward()
+    for k, prm in m.named_parameters():
+        check(prm.grad, p[k].grad, 2e-4, atol=2e-5, name="grad." + k)
+
+
+def test_state_dict_roundtrip_and_cache_refresh(emu):
+    m, sd = make(TINY)
+    m.eval()
+    x, t = rnd(1, 3, 8, 8, seed=6), torch.tensor([42])
+    with torch.no_grad():
+        y0 = m(x, t)
+        sd2 = U.randomize_state_dict(sd, 99)
+        m.load_state_dict(sd2)                      # in-place parameter writes must invalidate the packed copies
+        y1 = m(x, t)
+        ref = U.unet_forward(sd2, TINY, x, t)
+    check(y1, ref, 2e-5, name="after load")
+    assert float((y1 - y0).abs().max()) > 1e-3
+
+
+def test_diffusion_kernels_and_loops(emu, golden):
+    g = golden("g5_steps.pt")
+    betas = ddpm_torch.get_beta_schedule("linear", 1e-4, 0.02, 1000)
+    for vt in ("fixed-small", "fixed-large"):
+        r = g[vt]
+        dif = ddpm_torch.GaussianDiffusion(betas, "eps", vt, "mse")
+        check(dif.q_sample(r["x0"], r["t"], r["noise"]), r["x_t"], 1e-6, name="x_t")
+        lin = lambda x, t: 0.1 * x + 0.01 * t.reshape(-1, 1, 1, 1).to(x)
+        check(dif.train_losses(lin, r["x0"], r["t"], noise=r["noise"]), r["loss_lin"], 1e-5, name="loss")
+        xp, px0 = dif._step(r["x_t"], lin(r["x_t"], r["t"]), r["z"], r["t"], True, True)
+        check(xp, r["x_prev_lin"], 1e-5, name="x_prev")
+        check(px0, r["pred_x0_lin"], 1e-5, name="pred_x0")
+        mean, var, logvar, _ = dif.p_mean_var(lin, r["x_t"], r["t"], True, True)
+        check(mean, r["mean_lin"], 1e-5, name="mean")
+        check(logvar, r["logvar"], 1e-6, name="logvar")
+    # DDIM: the model is evaluated at subsequence[t]
+    sub = ddim_mod.get_selection_schedule("linear", 50, 1000)
+    dd = ddim_mod.DDIM.from_ddpm(ddpm_torch.GaussianDiffusion(betas, "eps", "fixed-small", "mse"), eta=0.0, subsequence=sub)
+    seen = []
+    dd.p_sample(lambda x, t: (seen.append(int(t[0])), 0.1 * x)[1], shape=(2, 3, 4, 4), device="cpu", seed=3)
+    assert seen == list(range(980, -1, -20))
+
+
+def test_sampling_loop_matches_oracle_with_reference_noise_stream(emu, golden):
+    g6, g3 = golden("g6_loops.pt"), golden("g3_model.pt")
+    torch.manual_seed(g3["tiny_init_seed"])
+    m = ddpm_torch.UNet(**g3["tiny_cfg"])
+    m.load_state_dict(U.randomize_state_dict(m.state_dict(), g3["tiny_rand_seed"]))
+    m.eval()
+    betas = ddpm_torch.get_beta_schedule("linear", 1e-4, 0.02, 1000)
+    sub = ddim_mod.get_selection_schedule("linear", 50, 1000)
+    dd = ddim_mod.DDIM(betas, "eps", "fixed-small", "mse", eta=0.0, subsequence=sub)
+    r = g6["ddim_linear_50_eta0.0"]
+    x = dd.p_sample(m, shape=tuple(r["shape"]), device="cpu", seed=r["seed"])      # CPU generator == the reference's stream
+    check(x, r["x_0"], 5e-4, name="ddim50")
+
+
+def test_trainer_steps_match_reference_fixture(emu, golden):
+    g = golden("g7_train.pt")
+    torch.manual_seed(g["init_seed"])
+    m = ddpm_torch.UNet(**g["cfg"])
+    m.load_state_dict(U.randomize_state_dict(m.state_dict(), g["rand_seed"]))
+    dif = ddpm_torch.GaussianDiffusion(ddpm_torch.get_beta_schedule("linear", 1e-4, 0.02, 1000), "eps", "fixed-large", "mse")
+    opt = torch.optim.Adam(m.parameters(), lr=g["lr"], betas=(0.9, 0.999))
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lr_lambda=lambda s: min((s + 1) / g["warmup"], 1.0))
+    tr = ddpm_torch.Trainer(m, opt, dif, epochs=1, trainloader=None, scheduler=sched, use_ema=True, grad_norm=1.0, shape=(3, 8, 8),
+                            device=torch.device("cpu"), ema_decay=0.9999)
+    m.train()
+    losses = []
+    for i, x in enumerate(g["xs"]):
+        tr.stats.reset()
+        tr.step(x, global_steps=i + 1)
+        losses.append(tr.current_stats["loss"])
+    assert torch.allclose(torch.tensor(losses, dtype=torch.float64), g["losses"], rtol=2e-5)
+    assert tr.ema.num_updates == g["num_updates"]
+    for k, v in g["params"].items():
+        check(m.state_dict()[k], v, 2e-5, name="param." + k)
+    for k, v in g["shadow"].items():
+        check(tr.ema.shadow[k], v, 2e-5, name="shadow." + k)
+
+
+def test_cpu_tensors_fail_loudly_without_emulation():
+    m = ddpm_torch.UNet(**TINY)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.zeros(1, 3, 8, 8), torch.zeros(1, dtype=torch.int64))
+    dif = ddpm_torch.GaussianDiffusion(ddpm_torch.get_beta_schedule("linear", 1e-4, 0.02, 10), "eps", "fixed-small", "mse")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        dif.q_sample(torch.zeros(1, 3, 4, 4), torch.zeros(1, dtype=torch.int64), torch.zeros(1, 3, 4, 4))
