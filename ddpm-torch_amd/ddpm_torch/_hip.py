@@ -44,6 +44,8 @@ PROTOTYPES = {
     "ddpm_softmax_fwd": [P, P, L, I, I, P],
     "ddpm_softmax_bwd": [P, P, P, L, I, I, P],
     "ddpm_dropout_mask": [P, L, F, U, P],
+    "ddpm_sumsq_accumulate": [P, L, P, P, P],
+    "ddpm_adam_ema_step": [P, P, P, P, P, L, P, F, F, F, F, F, F, F, F, P],
 }
 
 _lib = None

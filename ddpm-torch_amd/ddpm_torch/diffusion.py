@@ -206,7 +206,9 @@ class GaussianDiffusion:
     def _model_t(self, t):
         return t
 
-    def _sample_loop(self, denoise_fn, shape, device, noise, seed, on_step=None):
+    def _sample_loop(self, denoise_fn, shape, device, noise, seed, on_step=None, z_stream=None):
+        """The T-step (or S-step) loop.  ``z_stream`` (parity tests only) is an iterator of per-step noise tensors
+        that replaces the generator draws, so an identical (x_T, z_1..z_T) stream can be injected."""
         device = torch.device(device)
         _hip.require_cuda(torch.empty(0, device=device))        # no CPU fallback: sampling runs on the GPU only
         B = (shape or noise.shape)[0]
@@ -219,7 +221,7 @@ class GaussianDiffusion:
         for ti in range(self._num_steps() - 1, -1, -1):
             t.fill_(ti)
             out = denoise_fn(x_t, self._model_t(t))
-            z = torch.empty_like(x_t).normal_(generator=rng)
+            z = torch.empty_like(x_t).normal_(generator=rng) if z_stream is None else next(z_stream).to(x_t)
             x_t, pred = self._step(x_t, out, z, t, True, on_step is not None)
             if on_step is not None:
                 on_step(ti, pred)

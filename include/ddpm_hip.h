@@ -106,6 +106,15 @@ int ddpm_add_rows(const void* x, long long x_ld, void* y, long long y_ld, long l
 int ddpm_softmax_fwd(const float* s, void* p, long long rows, int L, int dtype, void* stream);
 int ddpm_softmax_bwd(const void* p, const float* dp, void* ds, long long rows, int L, int dtype, void* stream);
 
+/* nn.utils.clip_grad_norm_ + torch.optim.Adam + EMA.update (ddpm_torch/utils/train.py:159-165,300-305; train.py:128)
+ * over one fp32 tensor: total_sq[0] += ||g||^2 (workspace >= 1024 floats); then one fused pass
+ *   g' = g * min(1, max_norm/(sqrt(total_sq)+1e-6)); m,v <- Adam moments; p -= lr/bc1 * m/(sqrt(v/bc2)+eps);
+ *   shadow += ema_w * (p - shadow)      (total_sq null or max_norm <= 0: no clipping; shadow null: no EMA). */
+int ddpm_sumsq_accumulate(const float* g, long long n, float* total_sq, float* workspace, void* stream);
+int ddpm_adam_ema_step(float* p, const float* g, float* m, float* v, float* shadow, long long n, const float* total_sq,
+                       float max_norm, float lr, float beta1, float beta2, float eps, float bias_corr1, float bias_corr2,
+                       float ema_w, void* stream);
+
 /* test hook: the keep-mask (1/0) the GroupNorm kernels regenerate for element indices 0..n-1 */
 int ddpm_dropout_mask(float* mask, long long n, float p, unsigned long long seed, void* stream);
 

@@ -1,0 +1,281 @@
+"""-m gpu: every C-ABI entry point, run on the MI355X through ctypes, against the numpy restatement of the same
+contract (tests/abi_emulator.py) on identical inputs.  fp32 results must agree to ~1e-5 relative (the fp32 MFMA path
+is exact per product; only the summation order differs); bf16 results to 1 bf16 ulp-ish (2^-7 relative to the tensor
+maximum after identical rounding of the stored outputs).  Integer / mask outputs are bit-exact."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from ddpm_torch import _hip
+from tests.abi_emulator import Emulator
+
+pytestmark = pytest.mark.gpu
+DT = {0: torch.float32, 1: torch.bfloat16}
+TOL = {0: 2e-5, 1: 1.2e-2}
+
+
+class A:
+    """tensor argument: host master copy `t`, element offset, and whether the kernel writes it."""
+
+    def __init__(self, t, out=False, off=0, name=""):
+        self.t, self.out, self.off, self.name = t.contiguous(), out, off, name
+
+
+def both(name, *args, tol=None, atol=0.0):
+    emu = Emulator()
+    hp, dp, outs, keep = [], [], [], []
+    for a in args:
+        if isinstance(a, A):
+            d = a.t.cuda()
+            keep.append(d)                        # device copies must outlive the launch (caching allocator reuse)
+            hp.append(a.t.data_ptr() + a.off * a.t.element_size())
+            dp.append(d.data_ptr() + a.off * a.t.element_size())
+            if a.out:
+                outs.append((a, d))
+        elif a is None:
+            hp.append(0); dp.append(0)
+        else:
+            hp.append(a); dp.append(a)
+    _hip.call(name, *dp, _hip.stream())
+    torch.cuda.synchronize()
+    emu.call(name, *hp, 0)
+    worst = 0.0
+    for a, d in outs:
+        ref, got = a.t.float(), d.cpu().float()
+        assert torch.isfinite(got).all(), f"{name}:{a.name} not finite"
+        scale = float(ref.abs().max()) or 1.0
+        err = float((ref - got).abs().max())
+        rt = tol if tol is not None else 2e-5
+        assert err <= rt * scale + atol, f"{name}:{a.name} max err {err:.3e} (scale {scale:.3e}, tol {rt:.1e})"
+        worst = max(worst, err / scale)
+    return worst
+
+
+def r(*shape, seed, dt=0, scale=1.0):
+    return (torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale).to(DT[dt])
+
+
+CONV_CASES = [
+    # B, H, W, C, N, R, stride, pad_t, pad_l, ups, dil, Ho, Wo
+    ("3x3", 2, 8, 8, 32, 64, 3, 1, 1, 1, 0, 0, 8, 8),
+    ("3x3_multi_tile", 3, 16, 16, 128, 256, 3, 1, 1, 1, 0, 0, 16, 16),
+    ("1x1", 2, 4, 4, 64, 96, 1, 1, 0, 0, 0, 0, 4, 4),
+    ("s2_even", 2, 8, 8, 32, 32, 3, 2, 0, 0, 0, 0, 4, 4),
+    ("s2_odd", 2, 9, 9, 32, 32, 3, 2, 1, 1, 0, 0, 5, 5),
+    ("upsample", 2, 4, 4, 32, 32, 3, 1, 1, 1, 1, 0, 8, 8),
+    ("dgrad_s2", 2, 4, 4, 32, 32, 3, 1, 2, 2, 0, 1, 8, 8),
+    ("ktail_c8", 2, 8, 8, 8, 128, 3, 1, 1, 1, 0, 0, 8, 8),
+    ("k4608", 1, 4, 4, 512, 256, 3, 1, 1, 1, 0, 0, 4, 4),
+]
+
+
+@pytest.mark.parametrize("dt", [0, 1])
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv_fwd(case, dt):
+    _, B, H, W, C, N, R, stride, pt, pl, ups, dil, Ho, Wo = case
+    ld, yld = C + 16, N + 32                                   # exercise pitches
+    x = r(B * H * W, ld, seed=1, dt=dt)
+    w = r(N, R * R * C, seed=2, dt=dt, scale=1.0 / math.sqrt(R * R * C))
+    bias, rowb = r(N, seed=3), r(B, N + 8, seed=4)
+    res = r(B * Ho * Wo, yld, seed=5, dt=dt)
+    y = r(B * Ho * Wo, yld, seed=6, dt=dt)
+    for acc in (0, 1):
+        both("ddpm_conv2d_nhwc", A(x), ld, A(w), A(y.clone(), out=True, name="y"), yld, A(bias), A(rowb), N + 8, A(res), yld,
+             B, H, W, C, Ho, Wo, N, R, R, stride, pt, pl, ups, dil, acc, 0, dt, tol=TOL[dt])
+    # fp32 output modes (NHWC fp32, NCHW fp32) without the optional operands
+    y32 = torch.zeros(B * Ho * Wo, N)
+    both("ddpm_conv2d_nhwc", A(x), ld, A(w), A(y32, out=True, name="y32"), N, None, None, 0, None, 0,
+         B, H, W, C, Ho, Wo, N, R, R, stride, pt, pl, ups, dil, 0, 1, dt, tol=TOL[0] if dt == 0 else 4e-3)
+    ynchw = torch.zeros(B, N, Ho, Wo)
+    both("ddpm_conv2d_nhwc", A(x), ld, A(w), A(ynchw, out=True, name="nchw"), 0, A(bias), None, 0, None, 0,
+         B, H, W, C, Ho, Wo, N, R, R, stride, pt, pl, ups, dil, 0, 3, dt, tol=TOL[0] if dt == 0 else 4e-3)
+
+
+@pytest.mark.parametrize("dt", [0, 1])
+def test_conv_out3_channels_nchw(dt):
+    B, H, C, N = 2, 8, 128, 3                                   # out_conv: N = 3 rows of weights, NCHW fp32 result
+    x, w = r(B * H * H, C, seed=1, dt=dt), r(N, 9 * C, seed=2, dt=dt, scale=0.03)
+    y = torch.zeros(B, N, H, H)
+    both("ddpm_conv2d_nhwc", A(x), C, A(w), A(y, out=True, name="y"), 0, A(r(N, seed=3)), None, 0, None, 0,
+         B, H, H, C, H, H, N, 3, 3, 1, 1, 1, 0, 0, 0, 3, dt, tol=TOL[0] if dt == 0 else 4e-3)
+
+
+WGRAD_CASES = [
+    # B, H, W, C, Creal, N, Nreal, R, stride, pt, pl, ups, Ho, Wo, splits
+    ("3x3", 2, 8, 8, 32, 32, 64, 64, 3, 1, 1, 1, 0, 8, 8, 1),
+    ("3x3_split", 4, 16, 16, 64, 64, 128, 128, 3, 1, 1, 1, 0, 16, 16, 4),
+    ("1x1", 2, 4, 4, 64, 64, 96, 96, 1, 1, 0, 0, 0, 4, 4, 1),
+    ("s2", 2, 8, 8, 32, 32, 32, 32, 3, 2, 0, 0, 0, 4, 4, 2),
+    ("upsample", 2, 4, 4, 32, 32, 32, 32, 3, 1, 1, 1, 1, 8, 8, 1),
+    ("in_conv", 2, 8, 8, 8, 3, 32, 32, 3, 1, 1, 1, 0, 8, 8, 1),
+    ("out_conv", 2, 8, 8, 32, 32, 8, 3, 3, 1, 1, 1, 0, 8, 8, 1),
+]
+
+
+@pytest.mark.parametrize("dt", [0, 1])
+@pytest.mark.parametrize("case", WGRAD_CASES, ids=[c[0] for c in WGRAD_CASES])
+def test_conv_wgrad(case, dt):
+    _, B, H, W, C, Creal, N, Nreal, R, stride, pt, pl, ups, Ho, Wo, splits = case
+    if dt == 0 and (C % 4 or N % 4):
+        pytest.skip("vector width")
+    xld, yld = C + 8, N + 8
+    x, dy = r(B * H * W, xld, seed=1, dt=dt), r(B * Ho * Wo, yld, seed=2, dt=dt)
+    dw = r(Nreal, Creal, R, R, seed=3)                          # accumulates on top of existing content
+    both("ddpm_conv2d_wgrad_nhwc", A(dy), yld, A(x), xld, A(dw, out=True, name="dw"), B, H, W, C, Creal, Ho, Wo, N, Nreal, R, R,
+         stride, pt, pl, ups, splits, dt, tol=1e-4 if dt == 0 else 3e-3)
+
+
+@pytest.mark.parametrize("dt", [0, 1])
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize("M,N,K,batch", [(16, 16, 16, 3), (256, 256, 64, 2), (300, 136, 200, 1), (128, 512, 128, 1)])
+def test_gemm(dt, ta, tb, M, N, K, batch):
+    v = 8 if dt else 4
+    if (ta and M % v) or (tb and N % v) or K % v:
+        pytest.skip("vector width")
+    a = r(batch, *((K, M) if ta else (M, K)), seed=1, dt=dt)
+    b = r(batch, *((K, N) if tb else (N, K)), seed=2, dt=dt)
+    c = r(batch, M, N, seed=3, dt=dt)
+    res, bias = r(batch, M, N, seed=4, dt=dt), r(N, seed=5)
+    a_ld, b_ld = (M if ta else K), (N if tb else K)
+    for acc in (0, 1):
+        both("ddpm_gemm", A(a), a_ld, a[0].numel(), ta, A(b), b_ld, b[0].numel(), tb, A(c.clone(), out=True, name="c"), N, M * N,
+             A(bias), A(res), N, M * N, M, N, K, batch, 0.37, acc, 0, 1, dt, tol=TOL[dt] * 4)
+    c32 = r(batch, M, N, seed=6)
+    both("ddpm_gemm", A(a), a_ld, a[0].numel(), ta, A(b), b_ld, b[0].numel(), tb, A(c32, out=True, name="c32"), N, M * N,
+         None, None, 0, 0, M, N, K, batch, 1.0, 0, 1, 1, dt, tol=TOL[0] * 4 if dt == 0 else 4e-3)
+    if K >= 128:                                                 # split-K with atomics
+        c32 = r(batch, M, N, seed=7)
+        both("ddpm_gemm", A(a), a_ld, a[0].numel(), ta, A(b), b_ld, b[0].numel(), tb, A(c32, out=True, name="c_atomic"), N, M * N,
+             None, None, 0, 0, M, N, K, batch, 1.0, 0, 2, 2, dt, tol=TOL[0] * 4 if dt == 0 else 4e-3)
+
+
+GN_CASES = [(2, 16, 32), (2, 64, 128), (3, 1024, 128), (2, 256, 384), (2, 16, 768), (1, 4096, 64), (130, 16, 256)]
+
+
+@pytest.mark.parametrize("dt", [0, 1])
+@pytest.mark.parametrize("B,HW,C", GN_CASES)
+@pytest.mark.parametrize("silu,drop", [(1, 0.0), (0, 0.0), (1, 0.1)])
+def test_groupnorm_fwd_bwd(dt, B, HW, C, silu, drop):
+    ld = C + 16
+    x = (r(B * HW, ld, seed=1, scale=1.5) + 0.4).to(DT[dt])
+    gamma, beta = 1 + 0.2 * r(C, seed=2), 0.1 * r(C, seed=3)
+    nws = int(_hip.lib().ddpm_gn_workspace_floats(B, HW, C, 32, dt))
+    assert nws > 0
+    ws, stats = torch.zeros(nws), torch.zeros(B, 32, 2)
+    y = torch.zeros(B * HW, ld, dtype=DT[dt])
+    seed = 0x1234567 if drop else 0
+    both("ddpm_groupnorm_silu_fwd", A(x), ld, A(y, out=True, name="y"), ld, A(gamma), A(beta), A(stats, out=True, name="stats"), A(ws),
+         B, HW, C, 32, 1e-6, silu, drop, seed, dt, tol=TOL[dt] * (5 if dt == 0 else 1.5))
+    dy = r(B * HW, ld, seed=4, dt=dt)
+    # exact statistics from fp64 for the backward inputs
+    xg = x.float().reshape(B, HW, ld)[:, :, :C].reshape(B, HW, 32, C // 32).permute(0, 2, 1, 3).reshape(B, 32, -1).double()
+    stats = torch.stack([xg.mean(-1), 1.0 / torch.sqrt(xg.var(-1, unbiased=False) + 1e-6)], -1).float()
+    dgamma, dbeta = r(C, seed=5), r(C, seed=6)
+    for acc in (0, 1):
+        dx = r(B * HW, ld, seed=7, dt=dt)
+        both("ddpm_groupnorm_silu_bwd", A(x), ld, A(dy), ld, A(dx, out=True, name="dx"), ld, A(gamma), A(beta), A(stats),
+             A(dgamma.clone(), out=True, name="dgamma"), A(dbeta.clone(), out=True, name="dbeta"), A(ws), B, HW, C, 32, silu, drop, seed, acc, dt,
+             tol=2e-4 if dt == 0 else 2e-2)
+
+
+def test_dropout_mask_bit_exact_and_rate():
+    n = 1 << 20
+    m = torch.zeros(n)
+    both("ddpm_dropout_mask", A(m, out=True, name="mask"), n, 0.1, 0xDEADBEEFCAFE, tol=0.0)
+    d = torch.zeros(n).cuda()
+    _hip.call("ddpm_dropout_mask", d.data_ptr(), n, 0.1, 0xDEADBEEFCAFE, _hip.stream())
+    keep = float(d.mean())
+    assert abs(keep - 0.9) < 3e-3
+
+
+def test_timestep_embedding_and_layout_kernels():
+    for dim in (128, 127):
+        half = dim // 2
+        t = torch.tensor([0, 1, 500, 999, 37])
+        fr = torch.exp(-torch.arange(half, dtype=torch.float32) * (math.log(10000) / (half - 1)))
+        out = torch.zeros(5, dim)
+        both("ddpm_timestep_embedding", A(t), A(fr), A(out, out=True, name="temb"), 5, dim, tol=2e-5)
+    for dt in (0, 1):
+        x = r(2, 3, 6, 6, seed=1)
+        y = torch.zeros(2 * 36, 8, dtype=DT[dt])
+        both("ddpm_nchw_to_nhwc", A(x), A(y, out=True, name="nhwc"), 2, 3, 36, 8, dt, tol=TOL[dt] if dt else 0.0)
+        w = r(5, 3, 3, 3, seed=2)
+        wf, wd = torch.zeros(5, 9 * 8, dtype=DT[dt]), torch.zeros(3, 9 * 8, dtype=DT[dt])
+        both("ddpm_pack_weight", A(w), A(wf, out=True, name="wf"), A(wd, out=True, name="wd"), 5, 3, 3, 3, 8, 8, dt, tol=TOL[dt] if dt else 0.0)
+
+
+def test_diffusion_algebra_kernels():
+    B, n, T = 5, 3 * 8 * 8, 1000
+    x0, noise, z, out = (r(B, n, seed=s) for s in (1, 2, 3, 4))
+    t = torch.tensor([0, 1, 500, 999, 250])
+    tabs = [torch.rand(T, generator=torch.Generator().manual_seed(10 + i)) + 0.1 for i in range(4)]
+    logvar = -torch.rand(T, generator=torch.Generator().manual_seed(20)) * 9
+    xt = torch.zeros(B, n)
+    both("ddpm_q_sample", A(x0), A(noise), A(t), A(tabs[0]), A(tabs[1]), A(xt, out=True, name="xt"), B, n, tol=1e-6)
+    loss = torch.zeros(B)
+    both("ddpm_mse_fwd", A(out), A(noise), A(loss, out=True, name="loss"), B, n, tol=1e-5)
+    g = torch.zeros(B, n)
+    both("ddpm_mse_bwd", A(out), A(noise), A(r(B, seed=5)), A(g, out=True, name="gpred"), B, n, tol=1e-6)
+    for mean_type in (0, 1, 2):
+        for clip in (0, 1):
+            xp, px0 = torch.zeros(B, n), torch.zeros(B, n)
+            both("ddpm_p_sample_step", A(x0), A(out), A(z), A(t), A(tabs[0]), A(tabs[1]), A(tabs[2]), A(tabs[3]), A(logvar),
+                 A(xp, out=True, name="x_prev"), A(px0, out=True, name="pred_x0"), B, n, mean_type, clip, tol=2e-6)
+    idx, mp, o = torch.tensor([3, 0, 49]), torch.arange(0, 1000, 20), torch.zeros(3, dtype=torch.int64)
+    both("ddpm_gather_i64", A(idx), A(mp), A(o, out=True, name="gather"), 3, tol=0.0)
+    tt = torch.tensor([5, 5, 5])
+    both("ddpm_add_i64", A(tt, out=True, name="t"), 3, -1, tol=0.0)
+
+
+@pytest.mark.parametrize("dt", [0, 1])
+def test_reductions_and_fanin(dt):
+    B, HW, C, ld = 3, 64, 256, 272
+    dy = r(B * HW, ld, seed=1, dt=dt)
+    ps, tot = torch.zeros(B, C + 4), r(C, seed=2)
+    both("ddpm_colsum", A(dy), ld, A(ps, out=True, name="per_sample"), C + 4, A(tot, out=True, name="total"), B, HW, C, dt, tol=2e-5 if dt == 0 else 1e-4)
+    up = r(B * 4 * 16, 64, seed=3, dt=dt)
+    for acc in (0, 1):
+        dx = r(B * 16, 80, seed=4, dt=dt)
+        both("ddpm_upsample2x_bwd", A(up), A(dx, out=True, name="dx"), 80, B, 4, 4, 64, acc, dt, tol=TOL[dt])
+        y = r(40, 80, seed=5, dt=dt)
+        both("ddpm_add_rows", A(r(40, 72, seed=6, dt=dt)), 72, A(y, out=True, name="y"), 80, 40, 64, acc, dt, tol=TOL[dt])
+    for L in (16, 64, 256):
+        s = r(6 * L, L, seed=7, scale=2.0)
+        p = torch.zeros(6 * L, L, dtype=DT[dt])
+        both("ddpm_softmax_fwd", A(s), A(p, out=True, name="p"), 6 * L, L, dt, tol=TOL[dt])
+        pp = torch.softmax(s, -1).to(DT[dt])
+        ds = torch.zeros(6 * L, L, dtype=DT[dt])
+        both("ddpm_softmax_bwd", A(pp), A(r(6 * L, L, seed=8)), A(ds, out=True, name="ds"), 6 * L, L, dt, tol=TOL[dt] * 2)
+    x = r(1000, seed=9)
+    y = torch.zeros(1000)
+    both("ddpm_silu_fwd", A(x), A(y, out=True, name="silu"), 1000, tol=1e-6)
+    for acc in (0, 1):
+        dx = r(1000, seed=10)
+        both("ddpm_silu_bwd", A(x), A(r(1000, seed=11)), A(dx, out=True, name="dsilu"), 1000, acc, tol=2e-6)
+
+
+def test_fused_adam_ema_matches_torch_adam():
+    n = 10007
+    p0, g = r(n, seed=1), r(n, seed=2, scale=3.0)
+    ref = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([ref], lr=2e-4, betas=(0.9, 0.999), eps=1e-8)
+    p, m, v, sh = p0.cuda(), torch.zeros(n).cuda(), torch.zeros(n).cuda(), p0.cuda().clone()
+    shadow_ref = p0.clone()
+    tot, ws = torch.zeros(1).cuda(), torch.zeros(1024).cuda()
+    for step in range(1, 4):
+        gs = g * step
+        ref.grad = gs.clone()
+        torch.nn.utils.clip_grad_norm_([ref], 1.0)
+        opt.step()
+        d = min(0.9999, step / (9 + step))
+        shadow_ref += (1 - d) * (ref.detach() - shadow_ref)
+        gd = gs.cuda()
+        tot.zero_()
+        _hip.call("ddpm_sumsq_accumulate", gd.data_ptr(), n, tot.data_ptr(), ws.data_ptr(), _hip.stream())
+        _hip.call("ddpm_adam_ema_step", p.data_ptr(), gd.data_ptr(), m.data_ptr(), v.data_ptr(), sh.data_ptr(), n, tot.data_ptr(), 1.0,
+                  2e-4, 0.9, 0.999, 1e-8, 1 - 0.9 ** step, 1 - 0.999 ** step, 1 - d, _hip.stream())
+        assert abs(float(tot.sqrt()) - float(gs.norm())) < 1e-3 * float(gs.norm())
+    assert float((p.cpu() - ref.detach()).abs().max()) < 2e-6
+    assert float((sh.cpu() - shadow_ref).abs().max()) < 2e-6

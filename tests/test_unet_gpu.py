@@ -1,0 +1,222 @@
+"""-m gpu: end-to-end parity of the HIP engine with the oracle and the reference-generated fixtures.
+
+Bars (BASELINE.json north_star): UNet forward and the sampling loop within 1e-3 relative (max-abs over the tensor
+maximum) in the fp32 path on identical (x_t, t, noise); the bf16 throughput path gets its own documented, looser
+bound (bf16 storage of every activation; the survey measured 1.3e-2 for bf16 autocast of the reference itself)."""
+import json
+import os
+
+import pytest
+import torch
+
+import ddim as ddim_mod
+import ddpm_torch
+from ddpm_torch import _hip
+from oracle import diffusion_ref as D
+from oracle import unet_ref as U
+from tests.golden.recipes import check, rnd
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+FP32_BAR = 1e-3
+CIFAR = dict(in_channels=3, hid_channels=128, out_channels=3, ch_multipliers=[1, 2, 2, 2], num_res_blocks=2,
+             apply_attn=[False, True, False, False], drop_rate=0.1)
+TINY3 = dict(in_channels=3, hid_channels=32, out_channels=3, ch_multipliers=[1, 2, 2], num_res_blocks=2, apply_attn=[False, True, False], drop_rate=0.1)
+
+
+def make(cfg, seed=5, dtype=torch.float32, rand=17):
+    torch.manual_seed(seed)
+    m = ddpm_torch.UNet(**cfg)
+    sd = U.randomize_state_dict(m.state_dict(), rand)
+    m.load_state_dict(sd)
+    return m.to(DEV).set_compute_dtype(dtype), sd
+
+
+def tiny_from_golden(g3, dtype=torch.float32):
+    torch.manual_seed(g3["tiny_init_seed"])
+    m = ddpm_torch.UNet(**g3["tiny_cfg"])
+    sd = U.randomize_state_dict(m.state_dict(), g3["tiny_rand_seed"])
+    m.load_state_dict(sd)
+    return m.to(DEV).set_compute_dtype(dtype), sd
+
+
+def test_tiny_unet_forward_backward_vs_reference_fixture(golden):
+    g = golden("g3_model.pt")
+    m, _ = tiny_from_golden(g)
+    r = g["tiny"]
+    m.train()
+    y = m(r["x"].to(DEV), r["t"].to(DEV))
+    check(y, r["y"], 1e-4, name="tiny.y")
+    (y * r["gy"].to(DEV)).sum().backward()
+    for k, p in m.named_parameters():
+        check(p.grad, r["grads"][k], 5e-4, atol=2e-5, name="grad." + k)
+
+
+@pytest.mark.parametrize("dtype,bar", [(torch.float32, FP32_BAR), (torch.bfloat16, 6e-2)])
+def test_cifar_unet_forward_vs_oracle(dtype, bar):
+    m, sd = make(CIFAR, dtype=dtype)
+    m.eval()
+    x, t = rnd(2, 3, 32, 32, seed=1), torch.tensor([3, 977])
+    with torch.no_grad():
+        y = m(x.to(DEV), t.to(DEV))
+        ref = U.unet_forward(sd, CIFAR, x, t)
+    rel = float((y.cpu() - ref).abs().max() / ref.abs().max())
+    print(f"cifar fwd {dtype}: rel err {rel:.3e}")
+    assert rel < bar
+
+
+def test_reference_smoke_config_checksum(golden):
+    r = golden("g3_model.pt")["smoke"]
+    cfg = dict(in_channels=3, hid_channels=128, out_channels=3, ch_multipliers=(1, 2, 3), num_res_blocks=2, apply_attn=(False, True, False))
+    m, _ = make(cfg, seed=r["init_seed"], rand=r["rand_seed"])
+    m.eval()
+    with torch.no_grad():
+        y = m(rnd(2, 3, 32, 32, seed=r["x_seed"]).to(DEV), r["t"].to(DEV)).cpu()
+    check(y[:, :, :4, :4], r["y_corner"], FP32_BAR, name="smoke.corner")
+    assert abs(float(y.double().abs().sum()) - float(r["y_abs_sum"])) <= 1e-3 * float(r["y_abs_sum"])
+
+
+@pytest.mark.parametrize("dtype,bar", [(torch.float32, 1e-3), (torch.bfloat16, 1.5e-1)])
+def test_backward_with_dropout_vs_oracle(dtype, bar):
+    cfg = TINY3
+    m, sd = make(cfg, dtype=dtype)
+    m.train()
+    x, t, gy = rnd(2, 3, 16, 16, seed=3), torch.tensor([7, 912]), rnd(2, 3, 16, 16, seed=4)
+    y = m(x.to(DEV), t.to(DEV))
+    (y * gy.to(DEV)).sum().backward()
+    eng = m.engine()
+    names = {id(mod): name for name, mod in m.named_modules()}
+    masks = {}
+    for rec in eng.last_tape:
+        if rec[0] != "res":
+            continue
+        h1, seed = rec[6], rec[9]
+        n = h1.B * h1.H * h1.W * h1.C
+        mk = torch.empty(n, device=DEV)
+        _hip.call("ddpm_dropout_mask", mk.data_ptr(), n, cfg["drop_rate"], seed, _hip.stream())
+        masks[names[id(rec[1])] + "."] = mk.cpu().reshape(h1.B, h1.H, h1.W, h1.C).permute(0, 3, 1, 2)
+    p = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref = U.unet_forward(p, cfg, x, t, training=True, masks=masks)
+    (ref * gy).sum().backward()
+    rel = float((y.detach().cpu() - ref.detach()).abs().max() / ref.detach().abs().max())
+    assert rel < bar, rel
+    worst = 0.0
+    for k, prm in m.named_parameters():
+        gref = p[k].grad
+        scale = max(float(gref.abs().max()), 1e-3)
+        worst = max(worst, float((prm.grad.cpu() - gref).abs().max()) / scale)
+    print(f"bwd {dtype}: fwd rel {rel:.3e}, worst grad rel {worst:.3e}")
+    assert worst < bar * 3
+
+
+def _noise_stream(seed, shape, steps):
+    g = torch.Generator("cpu").manual_seed(seed)
+    x_T = torch.empty(shape).normal_(generator=g)
+    return x_T, [torch.empty(shape).normal_(generator=g) for _ in range(steps)]
+
+
+def test_sampling_loops_vs_reference_fixture(golden):
+    g6, g3 = golden("g6_loops.pt"), golden("g3_model.pt")
+    m, _ = tiny_from_golden(g3)
+    m.eval()
+    betas = ddpm_torch.get_beta_schedule("linear", 1e-4, 0.02, 1000)
+    r = g6["ddpm_fixed-large"]
+    dif = ddpm_torch.GaussianDiffusion(betas, "eps", "fixed-large", "mse")
+    x_T, zs = _noise_stream(r["seed"], tuple(r["shape"]), 1000)
+    with torch.inference_mode():
+        x = dif._sample_loop(m, tuple(r["shape"]), DEV, x_T, None, z_stream=iter(zs))
+    check(x, r["x_0"], FP32_BAR, name="ddpm1000")
+    r = g6["ddim_linear_50_eta0.0"]
+    sub = ddim_mod.get_selection_schedule("linear", 50, 1000)
+    dd = ddim_mod.DDIM(betas, "eps", "fixed-small", "mse", eta=0.0, subsequence=sub)
+    x_T, zs = _noise_stream(r["seed"], tuple(r["shape"]), 50)
+    with torch.inference_mode():
+        x = dd._sample_loop(m, tuple(r["shape"]), DEV, x_T, None, z_stream=iter(zs))
+    check(x, r["x_0"], FP32_BAR, name="ddim50")
+    # public API smoke: seeded generator path, right shape/device, finite, deterministic
+    a = dd.p_sample(m, shape=(2, 3, 8, 8), device=DEV, seed=11)
+    b = dd.p_sample(m, shape=(2, 3, 8, 8), device=DEV, seed=11)
+    assert a.is_cuda and a.shape == (2, 3, 8, 8) and torch.isfinite(a).all() and torch.equal(a, b)
+
+
+def test_trainer_steps_vs_reference_fixture(golden):
+    g = golden("g7_train.pt")
+    torch.manual_seed(g["init_seed"])
+    m = ddpm_torch.UNet(**g["cfg"])
+    m.load_state_dict(U.randomize_state_dict(m.state_dict(), g["rand_seed"]))
+    m.to(DEV)
+    dif = ddpm_torch.GaussianDiffusion(ddpm_torch.get_beta_schedule("linear", 1e-4, 0.02, 1000), "eps", "fixed-large", "mse")
+    opt = torch.optim.Adam(m.parameters(), lr=g["lr"], betas=(0.9, 0.999))
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lr_lambda=lambda s: min((s + 1) / g["warmup"], 1.0))
+    tr = ddpm_torch.Trainer(m, opt, dif, epochs=1, trainloader=None, scheduler=sched, use_ema=True, grad_norm=1.0, shape=(3, 8, 8),
+                            device=torch.device(DEV), ema_decay=0.9999)
+    gen = torch.Generator("cpu").manual_seed(g["gen_seed"])       # inject the reference's CPU (t, noise) stream
+
+    def get_input(x):
+        t = torch.empty((x.shape[0],), dtype=torch.int64).random_(to=1000, generator=gen)
+        noise = torch.empty_like(x.cpu()).normal_(generator=gen)
+        return {"x_0": x.to(DEV), "t": t.to(DEV), "noise": noise.to(DEV)}
+
+    tr.get_input = get_input
+    m.train()
+    losses = []
+    for i, x in enumerate(g["xs"]):
+        tr.stats.reset()
+        tr.step(x, global_steps=i + 1)
+        losses.append(tr.current_stats["loss"])
+    assert torch.allclose(torch.tensor(losses, dtype=torch.float64), g["losses"], rtol=1e-4)
+    for k, v in g["params"].items():
+        check(m.state_dict()[k], v, 1e-4, name="param." + k)
+    for k, v in g["shadow"].items():
+        check(tr.ema.shadow[k], v, 1e-4, name="shadow." + k)
+
+
+def test_full_size_properties_bf16():
+    """BASELINE config 2 sizes (B=128, 32x32): size-independent properties instead of an oracle run."""
+    m, _ = make(CIFAR, dtype=torch.bfloat16)
+    m.eval()
+    g = torch.Generator().manual_seed(1234)
+    x = (torch.rand(128, 3, 32, 32, generator=g) * 2 - 1).to(DEV)
+    t = torch.randint(0, 1000, (128,), generator=g).to(DEV)
+    with torch.no_grad():
+        y = m(x, t)
+        y_head = m(x[:8].contiguous(), t[:8].contiguous())          # every op is per-sample: batch-slicing invariance
+        y_perm = m(x.flip(0).contiguous(), t.flip(0).contiguous())
+    assert y.shape == (128, 3, 32, 32) and torch.isfinite(y).all()
+    s = float(y.abs().max())
+    assert float((y[:8] - y_head).abs().max()) <= 2e-2 * s
+    assert float((y - y_perm.flip(0)).abs().max()) <= 2e-2 * s
+    # training step at full size: gradients finite, loss finite, parameters move
+    m.train()
+    dif = ddpm_torch.GaussianDiffusion(ddpm_torch.get_beta_schedule("linear", 1e-4, 0.02, 1000), "eps", "fixed-large", "mse")
+    opt = torch.optim.Adam(m.parameters(), lr=2e-4)
+    tr = ddpm_torch.Trainer(m, opt, dif, epochs=1, trainloader=None, use_ema=True, shape=(3, 32, 32), device=torch.device(DEV))
+    before = m.in_conv.weight.detach().clone()
+    tr.step(x)
+    assert all(torch.isfinite(p).all() for p in m.parameters())
+    assert float((m.in_conv.weight - before).abs().max()) > 0
+    assert 0 < tr.current_stats["loss"] < 10
+
+
+def test_toy_config_plumbing_on_device(golden):
+    """BASELINE config 1 (gaussian8 MLP, T=100): the diffusion kernels are shape-agnostic ([B, n]); the MLP denoiser is
+    plain torch (no HIP kernels are owed for it).  Loss decreases and sampling is finite."""
+    g = golden("g8_toy.pt")
+    betas = ddpm_torch.get_beta_schedule("linear", 1e-3, 0.2, 100)
+    dif = ddpm_torch.GaussianDiffusion(betas, "eps", "fixed-large", "mse")
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(3, 128), torch.nn.SiLU(), torch.nn.Linear(128, 128), torch.nn.SiLU(), torch.nn.Linear(128, 2)).to(DEV)
+    fn = lambda x, t: net(torch.cat([x, t[:, None].float() / 100], 1))
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+    gen = torch.Generator().manual_seed(g["data_seed"])
+    losses = []
+    for i in range(30):
+        ang = torch.randint(8, (1000,), generator=gen).double() * (3.141592653589793 / 4)
+        x0 = (torch.stack([ang.cos(), ang.sin()], -1) * 2).float().to(DEV)
+        t = torch.randint(100, (1000,), generator=gen).to(DEV)
+        loss = dif.train_losses(fn, x0, t).mean()
+        opt.zero_grad(); loss.backward(); opt.step()
+        losses.append(float(loss))
+    assert losses[-1] < losses[0]
+    x = dif.p_sample(fn, shape=(1000, 2), device=DEV, seed=1)
+    assert x.shape == (1000, 2) and torch.isfinite(x).all()
