@@ -235,8 +235,6 @@ __global__ void colsum_kernel(const T* __restrict__ dy, long long ld, float* __r
     const int b = blockIdx.x;
     const int cx = threadIdx.x, py = threadIdx.y;
     const int t = threadIdx.y * blockDim.x + threadIdx.x, nt = blockDim.x * blockDim.y;
-    for (int c = t; c < C; c += nt) sh[c] = 0.f;
-    __syncthreads();
     float acc[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
@@ -248,7 +246,13 @@ __global__ void colsum_kernel(const T* __restrict__ dy, long long ld, float* __r
         for (int j = 0; j < VEC; ++j) acc[j] += f[j];
     }
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) atomicAdd(&sh[cx * VEC + j], acc[j]);
+    for (int j = 0; j < VEC; ++j) sh[py * C + cx * VEC + j] = acc[j];          // [PY][C] scratch, PY*C <= 2048
+    __syncthreads();
+    for (int c = t; c < C; c += nt) {
+        float a = 0.f;
+        for (int r = 0; r < (int)blockDim.y; ++r) a += sh[r * C + c];
+        sh[c] = a;
+    }
     __syncthreads();
     for (int c = t; c < C; c += nt) {
         if (per_sample) per_sample[(long long)b * ps_ld + c] = sh[c];

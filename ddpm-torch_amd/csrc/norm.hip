@@ -39,10 +39,15 @@ __global__ void gn_stats_kernel(const T* __restrict__ x, GnShape s, float* __res
 #pragma unroll
         for (int j = 0; j < VEC; ++j) { sum[j] += f[j]; sq[j] += f[j] * f[j]; }
     }
-    for (int c = threadIdx.y * blockDim.x + threadIdx.x; c < s.C; c += blockDim.x * blockDim.y) { sh_sum[c] = 0.f; sh_sq[c] = 0.f; }
-    __syncthreads();
+    // ordered (deterministic) cross-thread reduction: row py of the [PY][C] scratch, then a fixed-order column sum
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) { atomicAdd(&sh_sum[cx * VEC + j], sum[j]); atomicAdd(&sh_sq[cx * VEC + j], sq[j]); }
+    for (int j = 0; j < VEC; ++j) { sh_sum[py * s.C + cx * VEC + j] = sum[j]; sh_sq[py * s.C + cx * VEC + j] = sq[j]; }
+    __syncthreads();
+    for (int c = threadIdx.y * blockDim.x + threadIdx.x; c < s.C; c += blockDim.x * blockDim.y) {
+        float a = 0.f, q = 0.f;
+        for (int r = 0; r < PY; ++r) { a += sh_sum[r * s.C + c]; q += sh_sq[r * s.C + c]; }
+        sh_sum[c] = a; sh_sq[c] = q;
+    }
     __syncthreads();
     const int t = threadIdx.y * blockDim.x + threadIdx.x;
     if (t < s.G) {
@@ -123,8 +128,6 @@ __global__ void gn_bwd_reduce_kernel(const T* __restrict__ x, const T* __restric
     const int b = blockIdx.y, slab = blockIdx.x;
     const int cx = threadIdx.x, py = threadIdx.y, PY = blockDim.y;
     const int t = threadIdx.y * blockDim.x + threadIdx.x, nt = blockDim.x * blockDim.y;
-    for (int c = t; c < s.C; c += nt) { sh1[c] = 0.f; sh2[c] = 0.f; }
-    __syncthreads();
     const int p0 = slab * s.pix_per_slab, p1 = min(s.HW, p0 + s.pix_per_slab);
     float mean[VEC], rstd[VEC], gm[VEC], bt[VEC], a1[VEC], a2[VEC];
 #pragma unroll
@@ -153,7 +156,13 @@ __global__ void gn_bwd_reduce_kernel(const T* __restrict__ x, const T* __restric
         }
     }
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) { atomicAdd(&sh1[cx * VEC + j], a1[j]); atomicAdd(&sh2[cx * VEC + j], a2[j]); }
+    for (int j = 0; j < VEC; ++j) { sh1[py * s.C + cx * VEC + j] = a1[j]; sh2[py * s.C + cx * VEC + j] = a2[j]; }
+    __syncthreads();
+    for (int c = t; c < s.C; c += nt) {
+        float u = 0.f, w = 0.f;
+        for (int r = 0; r < PY; ++r) { u += sh1[r * s.C + c]; w += sh2[r * s.C + c]; }
+        sh1[c] = u; sh2[c] = w;
+    }
     __syncthreads();
     float* o = partial + (((long long)b * s.S + slab) * s.C) * 2;
     for (int c = t; c < s.C; c += nt) { o[2 * c] = sh1[c]; o[2 * c + 1] = sh2[c]; }

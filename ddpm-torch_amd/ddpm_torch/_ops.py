@@ -11,6 +11,21 @@ from . import _hip
 GN_GROUPS = 32
 GN_EPS = 1e-6
 
+# Optional per-launch timing (bench.py's roofline leg): when a list, every MFMA launch appends
+# (kernel id, algorithmic flops, start event, end event) recorded on the launch stream.
+PROFILE = None
+
+
+def _timed(kind, flops, fn):
+    if PROFILE is None:
+        fn()
+        return
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    fn()
+    b.record()
+    PROFILE.append((kind, flops, a, b))
+
 
 class View:
     """NHWC activation view: element (b, y, x, c) lives at ptr + ((b*H + y)*W + x)*ld + c (in elements)."""
@@ -53,19 +68,22 @@ class View:
 def conv2d(x, w_ptr, y_ptr, y_ld, N, R, S, Ho, Wo, stride=1, pad_t=0, pad_l=0, upsample=0, dilate=0,
            bias=0, rowbias=0, rowbias_ld=0, res_ptr=0, res_ld=0, accumulate=0, out_mode=0):
     """x: View (its H, W are the STORED input dims)."""
-    _hip.call("ddpm_conv2d_nhwc", x.ptr, x.ld, w_ptr, y_ptr, y_ld, bias, rowbias, rowbias_ld, res_ptr, res_ld,
-         x.B, x.H, x.W, x.C, Ho, Wo, N, R, S, stride, pad_t, pad_l, upsample, dilate, accumulate, out_mode, x.dtype, _hip.stream())
+    _timed("gemm_nn", 2.0 * x.B * Ho * Wo * N * R * S * x.C, lambda: _hip.call(
+        "ddpm_conv2d_nhwc", x.ptr, x.ld, w_ptr, y_ptr, y_ld, bias, rowbias, rowbias_ld, res_ptr, res_ld,
+        x.B, x.H, x.W, x.C, Ho, Wo, N, R, S, stride, pad_t, pad_l, upsample, dilate, accumulate, out_mode, x.dtype, _hip.stream()))
 
 
 def conv2d_wgrad(dy, x, dw_ptr, Creal, Nreal, R, S, stride=1, pad_t=0, pad_l=0, upsample=0, splits=1):
-    _hip.call("ddpm_conv2d_wgrad_nhwc", dy.ptr, dy.ld, x.ptr, x.ld, dw_ptr, x.B, x.H, x.W, x.C, Creal, dy.H, dy.W, dy.C, Nreal, R, S,
-         stride, pad_t, pad_l, upsample, splits, x.dtype, _hip.stream())
+    _timed("gemm_tt", 2.0 * dy.rows * Nreal * R * S * x.C, lambda: _hip.call(
+        "ddpm_conv2d_wgrad_nhwc", dy.ptr, dy.ld, x.ptr, x.ld, dw_ptr, x.B, x.H, x.W, x.C, Creal, dy.H, dy.W, dy.C, Nreal, R, S,
+        stride, pad_t, pad_l, upsample, splits, x.dtype, _hip.stream()))
 
 
 def gemm(a_ptr, a_ld, a_bs, a_trans, b_ptr, b_ld, b_bs, b_trans, c_ptr, c_ld, c_bs, M, N, K, dtype, batch=1, alpha=1.0,
          bias=0, res_ptr=0, res_ld=0, res_bs=0, accumulate=0, out_mode=0, splits=1):
-    _hip.call("ddpm_gemm", a_ptr, a_ld, a_bs, a_trans, b_ptr, b_ld, b_bs, b_trans, c_ptr, c_ld, c_bs, bias, res_ptr, res_ld, res_bs,
-         M, N, K, batch, alpha, accumulate, out_mode, splits, dtype, _hip.stream())
+    _timed("gemm_" + "nt"[a_trans] + "nt"[b_trans], 2.0 * batch * M * N * K, lambda: _hip.call(
+        "ddpm_gemm", a_ptr, a_ld, a_bs, a_trans, b_ptr, b_ld, b_bs, b_trans, c_ptr, c_ld, c_bs, bias, res_ptr, res_ld, res_bs,
+        M, N, K, batch, alpha, accumulate, out_mode, splits, dtype, _hip.stream()))
 
 
 def gn_workspace_floats(B, HW, C, dtype):

@@ -100,13 +100,13 @@ def test_backward_with_dropout_vs_oracle(dtype, bar):
     (ref * gy).sum().backward()
     rel = float((y.detach().cpu() - ref.detach()).abs().max() / ref.detach().abs().max())
     assert rel < bar, rel
-    worst = 0.0
-    for k, prm in m.named_parameters():
-        gref = p[k].grad
-        scale = max(float(gref.abs().max()), 1e-3)
-        worst = max(worst, float((prm.grad.cpu() - gref).abs().max()) / scale)
-    print(f"bwd {dtype}: fwd rel {rel:.3e}, worst grad rel {worst:.3e}")
-    assert worst < bar * 3
+    # per-tensor error relative to that tensor's max |grad|, floored at 2% of the typical (median) tensor scale:
+    # with 1 channel per group (hid=32) the conv1 / fc biases have analytically ZERO gradient, pure rounding noise.
+    scales = {k: float(q.grad.abs().max()) for k, q in p.items()}
+    floor = 0.02 * sorted(scales.values())[len(scales) // 2]
+    rows = sorted(((float((prm.grad.cpu() - p[k].grad).abs().max()) / max(scales[k], floor), k) for k, prm in m.named_parameters()), reverse=True)
+    print(f"bwd {dtype}: fwd rel {rel:.3e}; worst grads: " + ", ".join(f"{k}={e:.2e}(scale {scales[k]:.1e})" for e, k in rows[:4]))
+    assert rows[0][0] < bar * 3
 
 
 def _noise_stream(seed, shape, steps):
@@ -136,7 +136,7 @@ def test_sampling_loops_vs_reference_fixture(golden):
     # public API smoke: seeded generator path, right shape/device, finite, deterministic
     a = dd.p_sample(m, shape=(2, 3, 8, 8), device=DEV, seed=11)
     b = dd.p_sample(m, shape=(2, 3, 8, 8), device=DEV, seed=11)
-    assert a.is_cuda and a.shape == (2, 3, 8, 8) and torch.isfinite(a).all() and torch.equal(a, b)
+    assert a.is_cuda and a.shape == (2, 3, 8, 8) and torch.isfinite(a).all() and torch.equal(a, b)   # inference is bit-deterministic
 
 
 def test_trainer_steps_vs_reference_fixture(golden):
