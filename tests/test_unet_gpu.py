@@ -103,7 +103,7 @@ def test_backward_with_dropout_vs_oracle(dtype, bar):
     # per-tensor error relative to that tensor's max |grad|, floored at 2% of the typical (median) tensor scale:
     # with 1 channel per group (hid=32) the conv1 / fc biases have analytically ZERO gradient, pure rounding noise.
     scales = {k: float(q.grad.abs().max()) for k, q in p.items()}
-    floor = 0.02 * sorted(scales.values())[len(scales) // 2]
+    floor = (0.02 if dtype == torch.float32 else 0.1) * sorted(scales.values())[len(scales) // 2]
     rows = sorted(((float((prm.grad.cpu() - p[k].grad).abs().max()) / max(scales[k], floor), k) for k, prm in m.named_parameters()), reverse=True)
     print(f"bwd {dtype}: fwd rel {rel:.3e}; worst grads: " + ", ".join(f"{k}={e:.2e}(scale {scales[k]:.1e})" for e, k in rows[:4]))
     assert rows[0][0] < bar * 3
