@@ -89,6 +89,28 @@ extern "C" int ddpm_pack_weight(const float* w, void* wf, void* wd, int N, int C
     return check_launch();
 }
 
+// packed conv weight gradients [N][R*S][C] -> parameter layout [N][C][R*S], all layers in one launch.
+// descs[i] = {src offset (floats) in gpack, dst offset in gflat, N, C, R*S}; grid = (blocks, n_tensors).
+__global__ void wgrad_unpack_kernel(const float* __restrict__ gpack, float* __restrict__ gflat, const long long* __restrict__ descs) {
+    const long long* d = descs + 5 * (long long)blockIdx.y;
+    const long long src = d[0], dst = d[1];
+    const int C = (int)d[3], RS = (int)d[4];
+    const long long total = d[2] * C * RS;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int tap = (int)(i % RS);
+        const long long nc = i / RS;
+        const int c = (int)(nc % C);
+        const long long n = nc / C;
+        gflat[dst + i] = gpack[src + (n * RS + tap) * C + c];
+    }
+}
+extern "C" int ddpm_wgrad_unpack(const float* gpack, float* gflat, const long long* descs, int n_tensors, void* stream) {
+    if (!gpack || !gflat || !descs) return DDPM_ERR_NULL;
+    if (n_tensors <= 0) return DDPM_OK;
+    hipLaunchKernelGGL(wgrad_unpack_kernel, dim3(64, n_tensors), dim3(256), 0, (hipStream_t)stream, gpack, gflat, descs);
+    return check_launch();
+}
+
 // ------------------------------------------------------------------ diffusion algebra (fp32, per-sample coefficients gathered by t)
 // q_sample: x_t = a[t]*x0 + b[t]*noise   (diffusion.py:92-97); separate roundings like the reference's op chain
 __global__ void q_sample_kernel(const float* __restrict__ x0, const float* __restrict__ noise, const long long* __restrict__ t,

@@ -37,7 +37,7 @@ struct MatDesc {
 struct Epilogue {
     void* out;
     long long out_batch_stride, ldc;
-    int mode;                 // 0 store T | 1 store f32 | 2 atomic-add f32 | 3 store f32 NCHW | 4 wgrad scatter atomic f32
+    int mode;                 // 0 store T | 1 store f32 | 2 atomic-add f32 | 3 store f32 NCHW | 4 packed wgrad (atomic when accumulate)
     float alpha;
     const float* bias;        // [N] or null
     const float* rowbias;     // [M / rows_per_group][rowbias_ld] or null (time bias per sample)
@@ -46,10 +46,11 @@ struct Epilogue {
     const void* residual;     // T, [M][res_ld] or null
     long long res_ld, res_batch_stride;
     int accumulate;           // modes 0/1: out += result
-    int Cpad, Creal, RS;      // mode 4: col = tap*Cpad + c -> dst[(row*Creal + c)*RS + tap]
+    int Cpad, Creal, RS;      // mode 4: col = tap*Cpad + c -> packed gradient dst[(row*RS + tap)*Creal + c]
     FastDiv dCpad;
     FastDiv dHW;              // mode 3: row -> (b, pixel)
     int HW;
+    int vec_ok;               // out / residual pointers and pitches allow 16-byte vector access
 };
 
 template <int I> struct IC { static constexpr int v = I; };
@@ -81,20 +82,24 @@ constexpr int NTHREADS = 256;
 constexpr int ROW_BYTES = 144; // LDS row pitch: 128 B of K data + 16 B pad
 constexpr int NVEC = 4;        // 16-byte vectors per thread per operand per K-step
 
-// Per-thread loader state for one operand tile (TILE rows x BK k).
+// Per-thread loader state for one operand tile (TILE rows x BK k), staged global -> VGPR -> LDS.
+//  !TRANS (memory is k-contiguous): vector i covers row tid/8 + 32 i, 16-byte k-slot tid%8; written to LDS as is.
+//   TRANS (memory has the M/N index contiguous, k is the slow index): each thread owns a 4(k) x VEC(m) block —
+//          k-quad kq = tid % (BK/4) (fastest over lanes), m-group ng = tid / (BK/4) — loads its 4 k-rows as 16-byte
+//          vectors, transposes the block in registers and writes VEC k-contiguous 4-element runs
+//          (ds_write_b64 for bf16, ds_write_b128 for fp32; a 16-lane group fills one LDS row segment: no conflicts).
 template <typename T, bool TRANS>
 struct Loader {
     static constexpr int VEC = Elem<T>::VEC;
     static constexpr int BK = 8 * VEC;
-    static constexpr int FV = TILE / VEC;            // fast vectors per slow row when TRANS
-    static constexpr int SROWS = NTHREADS / FV;      // slow rows covered per pass when TRANS
+    static constexpr int KQ = BK / 4;
 
     const MatDesc& d;
     const T* base;
-    int tile0;        // first M/N index of the tile
-    // !TRANS: vector i covers (row = tid/8 + 32 i, kv = tid%8).  TRANS: (srow = tid/FV + SROWS i, fv = tid%FV)
-    int kv, row0, fv, srow0;
-    // conv, !TRANS: per-row pixel origin;  conv, TRANS: fixed tap/channel
+    int tile0;
+    int kv, row0;                 // !TRANS
+    int kq, ng;                   // TRANS
+    long long roff[NVEC];         // !TRANS conv (no up/down-scaling): element offset of (b, y0, x0)
     int pb[NVEC], py[NVEC], px[NVEC];
     bool rvalid[NVEC];
     int tr, ts, tc; bool fvalid;
@@ -108,11 +113,14 @@ struct Loader {
             for (int i = 0; i < NVEC; ++i) {
                 int m = tile0 + row0 + 32 * i;
                 rvalid[i] = m < d.n_slow;
-                if (d.conv) decode_pixel(rvalid[i] ? m : 0, pb[i], py[i], px[i]);
+                if (d.conv) {
+                    decode_pixel(rvalid[i] ? m : 0, pb[i], py[i], px[i]);
+                    roff[i] = ((long long)(pb[i] * d.H + py[i]) * d.W + px[i]) * d.ld;
+                }
             }
         } else {
-            fv = tid % FV; srow0 = tid / FV;
-            int f = tile0 + fv * VEC;
+            kq = tid % KQ; ng = tid / KQ;
+            int f = tile0 + ng * VEC;
             fvalid = f < d.n_fast;
             if (d.conv) {
                 unsigned tap = fdiv((unsigned)(fvalid ? f : 0), d.dC);
@@ -149,9 +157,18 @@ struct Loader {
                 unsigned tap = fdiv((unsigned)k, d.dC);
                 int c = k - (int)tap * d.C;
                 int r = (int)fdiv(tap, d.dS), s = (int)tap - r * d.S;
+                if (d.sh == 0) {          // plain / strided conv: offset is linear in the tap
+                    const long long tapoff = (long long)(r * d.W + s) * d.ld + c;
 #pragma unroll
-                for (int i = 0; i < NVEC; ++i)
-                    v[i] = (kok && rvalid[i]) ? gather(pb[i], py[i], px[i], r, s, c) : zero16();
+                    for (int i = 0; i < NVEC; ++i) {
+                        bool ok = kok && rvalid[i] && (unsigned)(py[i] + r) < (unsigned)d.H && (unsigned)(px[i] + s) < (unsigned)d.W;
+                        v[i] = ok ? ldg16(base + roff[i] + tapoff) : zero16();
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < NVEC; ++i)
+                        v[i] = (kok && rvalid[i]) ? gather(pb[i], py[i], px[i], r, s, c) : zero16();
+                }
             } else {
 #pragma unroll
                 for (int i = 0; i < NVEC; ++i) {
@@ -162,7 +179,7 @@ struct Loader {
         } else {
 #pragma unroll
             for (int i = 0; i < NVEC; ++i) {
-                int k = k0 + srow0 + SROWS * i;
+                int k = k0 + kq * 4 + i;
                 bool ok = fvalid && k < k_end;
                 if (!ok) { v[i] = zero16(); continue; }
                 if (d.conv) {
@@ -170,7 +187,7 @@ struct Loader {
                     decode_pixel(k, b, y0, x0);
                     v[i] = gather(b, y0, x0, tr, ts, tc);
                 } else {
-                    v[i] = ldg16(base + (long long)k * d.ld + tile0 + fv * VEC);
+                    v[i] = ldg16(base + (long long)k * d.ld + tile0 + ng * VEC);
                 }
             }
         }
@@ -182,54 +199,123 @@ struct Loader {
 #pragma unroll
             for (int i = 0; i < NVEC; ++i)
                 *reinterpret_cast<u32x4*>(lds + (row0 + 32 * i) * ROW_BYTES + kv * 16) = v[i];
+        } else if (sizeof(T) == 2) {
+            char* dst = lds + (ng * 8) * ROW_BYTES + kq * 8;
+#pragma unroll
+            for (int dd = 0; dd < 4; ++dd) {            // dword dd of each vector holds m = 2dd (low half) and 2dd+1 (high half)
+                const unsigned a0 = v[0][dd], a1 = v[1][dd], a2 = v[2][dd], a3 = v[3][dd];
+                uint2 even, odd;
+                even.x = (a0 & 0xffffu) | (a1 << 16); even.y = (a2 & 0xffffu) | (a3 << 16);
+                odd.x = (a0 >> 16) | (a1 & 0xffff0000u); odd.y = (a2 >> 16) | (a3 & 0xffff0000u);
+                *reinterpret_cast<uint2*>(dst + (2 * dd) * ROW_BYTES) = even;
+                *reinterpret_cast<uint2*>(dst + (2 * dd + 1) * ROW_BYTES) = odd;
+            }
         } else {
+            char* dst = lds + (ng * 4) * ROW_BYTES + kq * 16;
 #pragma unroll
-            for (int i = 0; i < NVEC; ++i) {
-                int kk = srow0 + SROWS * i;
-                const T* e = reinterpret_cast<const T*>(&v[i]);
-#pragma unroll
-                for (int j = 0; j < VEC; ++j)
-                    *reinterpret_cast<T*>(lds + (fv * VEC + j) * ROW_BYTES + kk * (int)sizeof(T)) = e[j];
+            for (int j = 0; j < 4; ++j) {
+                u32x4 w; w.x = v[0][j]; w.y = v[1][j]; w.z = v[2][j]; w.w = v[3][j];
+                *reinterpret_cast<u32x4*>(dst + j * ROW_BYTES) = w;
             }
         }
     }
 };
 
-template <typename T>
-__device__ __forceinline__ void epilogue_store(const Epilogue& ep, int batch, int row, int col, int M, int N, float v) {
-    if (row >= M || col >= N) return;
-    v *= ep.alpha;
-    if (ep.bias) v += ep.bias[col];
-    if (ep.rowbias) v += ep.rowbias[(long long)fdiv((unsigned)row, ep.dgroup) * ep.rowbias_ld + col];
-    if (ep.residual)
-        v += Elem<T>::ld(reinterpret_cast<const T*>(ep.residual) + (long long)batch * ep.res_batch_stride + (long long)row * ep.res_ld + col);
-    switch (ep.mode) {
-    case 0: {
-        T* o = reinterpret_cast<T*>(ep.out) + (long long)batch * ep.out_batch_stride + (long long)row * ep.ldc + col;
-        if (ep.accumulate) v += Elem<T>::ld(o);
-        Elem<T>::st(o, v);
-    } break;
-    case 1: {
-        float* o = reinterpret_cast<float*>(ep.out) + (long long)batch * ep.out_batch_stride + (long long)row * ep.ldc + col;
-        if (ep.accumulate) v += *o;
-        *o = v;
-    } break;
-    case 2:
-        atomicAdd(reinterpret_cast<float*>(ep.out) + (long long)batch * ep.out_batch_stride + (long long)row * ep.ldc + col, v);
-        break;
-    case 3: {   // NCHW fp32: row = b*HW + p  ->  out[(b*N + col)*HW + p]
-        unsigned b = fdiv((unsigned)row, ep.dHW);
-        unsigned p = (unsigned)row - b * (unsigned)ep.HW;
-        float* o = reinterpret_cast<float*>(ep.out) + ((long long)b * N + col) * ep.HW + p;
-        if (ep.accumulate) v += *o;
-        *o = v;
-    } break;
-    case 4: {   // wgrad: row = cout, col = tap*Cpad + c
-        unsigned tap = fdiv((unsigned)col, ep.dCpad);
-        int c = col - (int)tap * ep.Cpad;
-        if (c < ep.Creal)
-            atomicAdd(reinterpret_cast<float*>(ep.out) + ((long long)row * ep.Creal + c) * ep.RS + tap, v);
-    } break;
+// ---------------------------------------------------------------------------------------------- epilogue
+// The accumulators are staged through LDS as fp32 [128][CS_LD] so that every global access of the epilogue is a
+// 16-byte vector along n (bias / time-bias / residual reads and the output write are fully coalesced).
+constexpr int CS_LD = TILE + 4;
+
+template <typename T, typename OutT>
+__device__ __forceinline__ void epilogue_rows(const Epilogue& ep, const float* cs, int batch, int row0g, int col0g, int M, int N, int tid) {
+    constexpr int VO = 16 / (int)sizeof(OutT);            // output elements per 16-byte vector
+    constexpr int VPR = TILE / VO;                         // vectors per tile row
+    constexpr int PER_THREAD = TILE * VPR / NTHREADS;
+    constexpr int ROWS_PER_PASS = NTHREADS / VPR;
+    const int cv = tid % VPR, r0 = tid / VPR;
+    const int col = col0g + cv * VO;
+    if (col >= N) return;
+    const bool full = col + VO <= N;
+    float bias[VO];
+#pragma unroll
+    for (int j = 0; j < VO; ++j) bias[j] = (ep.bias && col + j < N) ? ep.bias[col + j] : 0.f;
+    OutT* outb = reinterpret_cast<OutT*>(ep.out) + (long long)batch * ep.out_batch_stride;
+    const T* resb = ep.residual ? reinterpret_cast<const T*>(ep.residual) + (long long)batch * ep.res_batch_stride : nullptr;
+#pragma unroll 2
+    for (int i = 0; i < PER_THREAD; ++i) {
+        const int rl = r0 + i * ROWS_PER_PASS;
+        const int row = row0g + rl;
+        if (row >= M) break;
+        float v[VO];
+#pragma unroll
+        for (int j = 0; j < VO; j += 4) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(cs + rl * CS_LD + cv * VO + j);
+            v[j] = t.x; v[j + 1] = t.y; v[j + 2] = t.z; v[j + 3] = t.w;
+        }
+#pragma unroll
+        for (int j = 0; j < VO; ++j) v[j] = v[j] * ep.alpha + bias[j];
+        if (ep.rowbias) {
+            const float* rb = ep.rowbias + (long long)fdiv((unsigned)row, ep.dgroup) * ep.rowbias_ld + col;
+#pragma unroll
+            for (int j = 0; j < VO; ++j) if (col + j < N) v[j] += rb[j];
+        }
+        OutT* o = outb + (long long)row * ep.ldc + col;
+        if (full && ep.vec_ok) {
+            if (resb) {
+                if (sizeof(T) == sizeof(OutT)) {
+                    float f[VO];
+                    Elem<T>::unpack(ldg16(resb + (long long)row * ep.res_ld + col), f);
+#pragma unroll
+                    for (int j = 0; j < VO; ++j) v[j] += f[j];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < VO; ++j) v[j] += Elem<T>::ld(resb + (long long)row * ep.res_ld + col + j);
+                }
+            }
+            if (ep.accumulate) {
+                float f[VO];
+                Elem<OutT>::unpack(ldg16(o), f);
+#pragma unroll
+                for (int j = 0; j < VO; ++j) v[j] += f[j];
+            }
+            stg16(o, Elem<OutT>::pack(v));
+        } else {
+#pragma unroll
+            for (int j = 0; j < VO; ++j) {
+                if (col + j >= N) break;
+                float x = v[j];
+                if (resb) x += Elem<T>::ld(resb + (long long)row * ep.res_ld + col + j);
+                if (ep.accumulate) x += Elem<OutT>::ld(o + j);
+                Elem<OutT>::st(o + j, x);
+            }
+        }
+    }
+}
+
+// element-wise tail for the scatter / atomic output modes (2: fp32 atomic add, 3: NCHW fp32, 4: packed wgrad)
+__device__ __forceinline__ void epilogue_scatter(const Epilogue& ep, const float* cs, int batch, int row0g, int col0g, int M, int N, int tid) {
+    // lanes run along n (coalesced atomics for modes 2 / 4); NCHW (mode 3) has N <= a few channels
+    for (int idx = tid; idx < TILE * TILE; idx += NTHREADS) {
+        const int rl = idx >> 7, cl = idx & (TILE - 1);
+        const int row = row0g + rl, col = col0g + cl;
+        if (row >= M || col >= N) continue;
+        float v = cs[rl * CS_LD + cl] * ep.alpha;
+        if (ep.bias) v += ep.bias[col];
+        if (ep.mode == 2) {
+            atomicAdd(reinterpret_cast<float*>(ep.out) + (long long)batch * ep.out_batch_stride + (long long)row * ep.ldc + col, v);
+        } else if (ep.mode == 3) {      // row = b*HW + p  ->  out[(b*N + col)*HW + p]
+            const unsigned b = fdiv((unsigned)row, ep.dHW);
+            const unsigned p = (unsigned)row - b * (unsigned)ep.HW;
+            float* o = reinterpret_cast<float*>(ep.out) + ((long long)b * N + col) * ep.HW + p;
+            *o = ep.accumulate ? *o + v : v;
+        } else {                         // packed weight gradient [n][tap][Creal]; col = tap*Cpad + c
+            const unsigned tap = fdiv((unsigned)col, ep.dCpad);
+            const int c = col - (int)tap * ep.Cpad;
+            if (c < ep.Creal) {
+                float* o = reinterpret_cast<float*>(ep.out) + ((long long)row * ep.RS + tap) * ep.Creal + c;
+                if (ep.accumulate) atomicAdd(o, v); else *o = v;
+            }
+        }
     }
 }
 
@@ -240,8 +326,7 @@ void gemm_kernel(MatDesc A, MatDesc B, Epilogue ep, int M, int N, int K, int k_p
     constexpr int BK = 8 * VEC;
     constexpr int KF = Mma<T>::KF;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int TILE_BYTES = TILE * ROW_BYTES;          // one operand tile
-    // layout: [buf][A | B]
+    constexpr int TILE_BYTES = TILE * ROW_BYTES;          // one operand tile; layout: [buf][A | B]
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -268,8 +353,7 @@ void gemm_kernel(MatDesc A, MatDesc B, Epilogue ep, int M, int N, int K, int k_p
     __syncthreads();
 
     const int nsteps = (k_end - k_begin + BK - 1) / BK;
-    // fragment read offsets: row (lane&31), 16-byte k-slot (lane>>5)
-    const int frag_off = (lane & 31) * ROW_BYTES + (lane >> 5) * 16;
+    const int frag_off = (lane & 31) * ROW_BYTES + (lane >> 5) * 16;   // row (lane&31), 16-byte k-slot (lane>>5)
     for (int s = 0; s < nsteps; ++s) {
         const char* cur = smem + (s & 1) * 2 * TILE_BYTES;
         char* nxt = smem + ((s + 1) & 1) * 2 * TILE_BYTES;
@@ -300,15 +384,20 @@ void gemm_kernel(MatDesc A, MatDesc B, Epilogue ep, int M, int N, int K, int k_p
         __syncthreads();
     }
 
-    // accumulator (reg r, lane l) -> row (r&3) + 8*(r>>2) + 4*(l>>5), col l&31 of its 32x32 tile.
-    // static_for keeps every accumulator index a compile-time constant (no scratch).
-    const int row_base = tm * TILE + wm * 64 + 4 * (lane >> 5);
-    const int col_base = tn * TILE + wn * 64 + (lane & 31);
-    static_for<64>([&](auto ic) {
-        constexpr int idx = decltype(ic)::v;
-        constexpr int i = idx >> 5, j = (idx >> 4) & 1, r = idx & 15;
-        epilogue_store<T>(ep, batch, row_base + i * 32 + (r & 3) + 8 * (r >> 2), col_base + j * 32, M, N, acc[i][j][r]);
-    });
+    // accumulator (reg r, lane l) -> row (r&3) + 8*(r>>2) + 4*(l>>5), col l&31 of its 32x32 tile; stage as fp32 in LDS.
+    float* cs = reinterpret_cast<float*>(smem);
+    {
+        const int rb = wm * 64 + 4 * (lane >> 5), cb = wn * 64 + (lane & 31);
+        static_for<64>([&](auto ic) {
+            constexpr int idx = decltype(ic)::v;
+            constexpr int i = idx >> 5, j = (idx >> 4) & 1, r = idx & 15;
+            cs[(rb + i * 32 + (r & 3) + 8 * (r >> 2)) * CS_LD + cb + j * 32] = acc[i][j][r];
+        });
+    }
+    __syncthreads();
+    if (ep.mode == 0) epilogue_rows<T, T>(ep, cs, batch, tm * TILE, tn * TILE, M, N, tid);
+    else if (ep.mode == 1) epilogue_rows<T, float>(ep, cs, batch, tm * TILE, tn * TILE, M, N, tid);
+    else epilogue_scatter(ep, cs, batch, tm * TILE, tn * TILE, M, N, tid);
 }
 
 // ---------------------------------------------------------------------------------------------- host side
@@ -380,6 +469,12 @@ int ddpm_gemm_launch(GemmArgs& g, hipStream_t st) {
     if ((rc = validate(g.B, es)) != DDPM_OK) return rc;
     if (!g.ep.out) return DDPM_ERR_NULL;
     finish_desc(g.A); finish_desc(g.B);
+    {
+        const int vo = g.ep.mode == 0 ? 16 / es : 4;        // elements per 16-byte output vector
+        bool ok = aligned16(g.ep.out) && g.ep.ldc % vo == 0 && g.ep.out_batch_stride % vo == 0;
+        if (g.ep.residual) ok = ok && aligned16(g.ep.residual) && g.ep.res_ld % (16 / es) == 0 && g.ep.res_batch_stride % (16 / es) == 0;
+        g.ep.vec_ok = ok ? 1 : 0;
+    }
     return g.dtype == DDPM_BF16 ? launch_t<bf16_t>(g, st) : launch_t<float>(g, st);
 }
 
@@ -420,7 +515,9 @@ extern "C" int ddpm_conv2d_nhwc(const void* x, long long x_ld, const void* w, vo
     return ddpm_gemm_launch(g, (hipStream_t)stream);
 }
 
-// Weight gradient: dw[n][c][r][s] += sum_{b,oy,ox} dy[b,oy,ox,n] * x[b, f(..), f(..), c]   (fp32 atomics, n < Nreal, c < Creal)
+// Weight gradient in PACKED layout: dw[n][r][s][c] += sum_{b,oy,ox} dy[b,oy,ox,n] * x[b, f(..), f(..), c]
+// (fp32 atomics, n < Nreal, c < Creal; rows of Creal contiguous floats -> coalesced).  ddpm_wgrad_unpack converts
+// every layer's packed gradient to the parameter layout [n][c][r][s] in one launch.
 extern "C" int ddpm_conv2d_wgrad_nhwc(const void* dy, long long dy_ld, const void* x, long long x_ld, float* dw,
                                       int B, int H, int W, int C, int Creal, int Ho, int Wo, int N, int Nreal, int R, int S,
                                       int stride, int pad_t, int pad_l, int upsample, int splits, int dtype, void* stream) {
@@ -435,6 +532,7 @@ extern "C" int ddpm_conv2d_wgrad_nhwc(const void* dy, long long dy_ld, const voi
     conv_desc(g.B, x, x_ld, g.K, H, W, C, Ho, Wo, R, S, stride, pad_t, pad_l, upsample, 0);
     g.B.trans = 1;
     g.ep.out = dw; g.ep.mode = 4; g.ep.Cpad = C; g.ep.Creal = Creal; g.ep.RS = R * S; g.ep.dCpad = make_fastdiv((unsigned)C);
+    g.ep.accumulate = 1;      // always "+=" (atomics): the caller zero-fills once and may add several contributions
     return ddpm_gemm_launch(g, (hipStream_t)stream);
 }
 

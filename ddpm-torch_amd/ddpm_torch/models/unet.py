@@ -233,6 +233,7 @@ class _Engine:
             self.goff[id(p)] = off
             off += (p.numel() + 3) // 4 * 4        # keep every slice 16-byte aligned
         self.gtotal = off
+        self.wdesc = None                          # device table for ddpm_wgrad_unpack (built on first backward)
         m = model
         self.hid, self.E, self.L, self.n = m.hid_channels, m.time_embedding_dim, m.levels, m.num_res_blocks
         self.chs = [m.hid_channels * k for k in m.ch_multipliers]
@@ -341,6 +342,22 @@ class _Engine:
 
     def _gptr(self, gflat, p):
         return gflat.data_ptr() + 4 * self.goff[id(p)]
+
+    def _wgrad_table(self):
+        """Offsets of every conv weight in the packed gradient buffer [N][R*S][C] + the unpack descriptor table."""
+        if self.wdesc is None:
+            self.poff, rows, off = {}, [], 0
+            for cw in self.convs.values():
+                w = cw.mod.weight
+                self.poff[id(w)] = off
+                rows.append([off, self.goff[id(w)], cw.N, cw.C, cw.R * cw.R])
+                off += (w.numel() + 3) // 4 * 4
+            self.ptotal = off
+            self.wdesc = torch.tensor(rows, dtype=torch.int64, device=self.device)
+        return self.wdesc
+
+    def _pptr(self, ctx, p):
+        return ctx["gpack"].data_ptr() + 4 * self.poff[id(p)]
 
     def _grad_target(self, v):
         """(view to write d/dv into, accumulate flag); the first writer stores, later writers accumulate."""
@@ -559,7 +576,9 @@ class _Engine:
         gout = gout.contiguous().float()
         H, W = gout.shape[2], gout.shape[3]
         dtb = torch.zeros((B, self.tb_total), dtype=torch.float32, device=self.device)
-        ctx = dict(gflat=gflat, ws=ws, B=B, dtb=dtb)
+        wdesc = self._wgrad_table()
+        gpack = torch.zeros(self.ptotal, dtype=torch.float32, device=self.device)    # conv weight grads, packed [N][RS][C]
+        ctx = dict(gflat=gflat, gpack=gpack, ws=ws, B=B, dtb=dtb)
         # ---- head
         _, cur, act, stats, _ = head
         norm, conv = m.out_conv[0], m.out_conv[2]
@@ -568,7 +587,7 @@ class _Engine:
         _hip.call("ddpm_nchw_to_nhwc", gout.data_ptr(), dy.ptr, B, m.out_channels, H * W, cw.Np, self.dcode, _hip.stream())
         dact = self._new(B, H, W, self.hid)
         ops.conv2d(dy, cw.wd.data_ptr(), dact.ptr, dact.ld, self.hid, 3, 3, H, W, pad_t=1, pad_l=1)
-        ops.conv2d_wgrad(dy, act, self._gptr(gflat, conv.weight), self.hid, cw.N, 3, 3, pad_t=1, pad_l=1, splits=self._splits(cw.N, 9 * self.hid, B * H * W))
+        ops.conv2d_wgrad(dy, act, self._pptr(ctx, conv.weight), self.hid, cw.N, 3, 3, pad_t=1, pad_l=1, splits=self._splits(cw.N, 9 * self.hid, B * H * W))
         self._bias_grad(ctx, dy, [conv.bias], cw.N)
         g, acc = self._grad_target(cur)
         ops.gn_bwd(cur, dact, g, norm.weight, norm.bias, stats, self._gptr(gflat, norm.weight), self._gptr(gflat, norm.bias), ws, silu=True, accumulate=acc)
@@ -582,6 +601,7 @@ class _Engine:
             else:
                 self._conv_bwd(ctx, rec)
         self._temb_bwd(ctx, st)
+        _hip.call("ddpm_wgrad_unpack", gpack.data_ptr(), gflat.data_ptr(), wdesc.data_ptr(), wdesc.shape[0], _hip.stream())
         grads = []
         for p in self.params:
             o = self.goff[id(p)]
@@ -613,7 +633,7 @@ class _Engine:
         dy = out.grad
         assert dy is not None and out.ginit
         first = conv is self.m.in_conv
-        ops.conv2d_wgrad(dy, x, self._gptr(gflat, conv.weight), cw.C, cw.N, k, k, stride=stride, pad_t=pt, pad_l=pl, upsample=upsample,
+        ops.conv2d_wgrad(dy, x, self._pptr(ctx, conv.weight), cw.C, cw.N, k, k, stride=stride, pad_t=pt, pad_l=pl, upsample=upsample,
                          splits=self._splits(cw.N, k * k * cw.Cp, dy.rows))
         self._bias_grad(ctx, dy, [conv.bias], cw.N)
         if first:
@@ -639,7 +659,7 @@ class _Engine:
         # conv2
         da2 = self._new(B, x.H, x.W, Cout)
         ops.conv2d(dout, c2.wd.data_ptr(), da2.ptr, da2.ld, Cout, 3, 3, x.H, x.W, pad_t=1, pad_l=1)
-        ops.conv2d_wgrad(dout, a2, self._gptr(gflat, rb.conv2.weight), Cout, Cout, 3, 3, pad_t=1, pad_l=1, splits=self._splits(Cout, 9 * Cout, dout.rows))
+        ops.conv2d_wgrad(dout, a2, self._pptr(ctx, rb.conv2.weight), Cout, Cout, 3, 3, pad_t=1, pad_l=1, splits=self._splits(Cout, 9 * Cout, dout.rows))
         self._bias_grad(ctx, dout, [rb.conv2.bias, rb.skip.bias] if rb.has_skip else [rb.conv2.bias], Cout)
         # GN2 + SiLU + dropout
         dh1 = self._new(B, x.H, x.W, Cout)
@@ -650,7 +670,7 @@ class _Engine:
         # conv1
         da1 = self._new(B, x.H, x.W, Cin)
         ops.conv2d(dh1, c1.wd.data_ptr(), da1.ptr, da1.ld, Cin, 3, 3, x.H, x.W, pad_t=1, pad_l=1)
-        ops.conv2d_wgrad(dh1, a1, self._gptr(gflat, rb.conv1.weight), Cin, Cout, 3, 3, pad_t=1, pad_l=1, splits=self._splits(Cout, 9 * Cin, dh1.rows))
+        ops.conv2d_wgrad(dh1, a1, self._pptr(ctx, rb.conv1.weight), Cin, Cout, 3, 3, pad_t=1, pad_l=1, splits=self._splits(Cout, 9 * Cin, dh1.rows))
         # GN1 + SiLU, then the skip path, into d(x)
         g, acc = self._grad_target(x)
         ops.gn_bwd(x, da1, g, rb.norm1.weight, rb.norm1.bias, stats1, self._gptr(gflat, rb.norm1.weight), self._gptr(gflat, rb.norm1.bias),
@@ -658,7 +678,7 @@ class _Engine:
         if rb.has_skip:
             cs = self.convs[id(rb.skip)]
             ops.conv2d(dout, cs.wd.data_ptr(), g.ptr, g.ld, Cin, 1, 1, x.H, x.W, accumulate=1)
-            ops.conv2d_wgrad(dout, x, self._gptr(gflat, rb.skip.weight), Cin, Cout, 1, 1, splits=self._splits(Cout, Cin, dout.rows))
+            ops.conv2d_wgrad(dout, x, self._pptr(ctx, rb.skip.weight), Cin, Cout, 1, 1, splits=self._splits(Cout, Cin, dout.rows))
         else:
             ops.add_rows(dout, g, 1)
         if parts is not None:                                 # x was a concat buffer: hand each producer its slice
@@ -677,7 +697,7 @@ class _Engine:
         # project_out
         do = self._new(B, x.H, x.W, C)
         ops.conv2d(dout, co.wd.data_ptr(), do.ptr, do.ld, C, 1, 1, x.H, x.W)
-        ops.conv2d_wgrad(dout, o, self._gptr(gflat, ab.project_out.weight), C, C, 1, 1, splits=self._splits(C, C, dout.rows))
+        ops.conv2d_wgrad(dout, o, self._pptr(ctx, ab.project_out.weight), C, C, 1, 1, splits=self._splits(C, C, dout.rows))
         self._bias_grad(ctx, dout, [ab.project_out.bias], C)
         # attention core
         q, kk, v = qkv.ptr, qkv.ptr + C * es, qkv.ptr + 2 * C * es
@@ -695,7 +715,7 @@ class _Engine:
         # project_in
         dhn = self._new(B, x.H, x.W, C)
         ops.conv2d(dqkv, ci.wd.data_ptr(), dhn.ptr, dhn.ld, C, 1, 1, x.H, x.W)
-        ops.conv2d_wgrad(dqkv, hn, self._gptr(gflat, ab.project_in.weight), C, 3 * C, 1, 1, splits=self._splits(3 * C, C, dqkv.rows))
+        ops.conv2d_wgrad(dqkv, hn, self._pptr(ctx, ab.project_in.weight), C, 3 * C, 1, 1, splits=self._splits(3 * C, C, dqkv.rows))
         self._bias_grad(ctx, dqkv, [ab.project_in.bias], 3 * C)
         # GN (no SiLU) + identity residual
         g, acc = self._grad_target(x)

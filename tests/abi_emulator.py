@@ -144,8 +144,14 @@ class Emulator:
         g = torch.from_numpy(Mat(dy, B * Ho * Wo, N, dy_ld, dt).get()).reshape(B, Ho, Wo, N).permute(0, 3, 1, 2)[:, :Nreal]
         can = _canvas(xin, Ho, Wo, R, S, stride, pad_t, pad_l, ups, 0)
         gw = torch.nn.grad.conv2d_weight(can.contiguous(), (Nreal, C, R, S), g.contiguous(), stride=stride)
-        arr = f32(dw, Nreal * Creal * R * S).reshape(Nreal, Creal, R, S)
-        arr += gw[:, :Creal].numpy()
+        arr = f32(dw, Nreal * Creal * R * S).reshape(Nreal, R, S, Creal)          # packed layout [n][r][s][c]
+        arr += gw[:, :Creal].permute(0, 2, 3, 1).numpy()
+
+    def ddpm_wgrad_unpack(self, gpack, gflat, descs, n, st):
+        d = i64(descs, 5 * n).reshape(n, 5)
+        for src, dst, N, C, RS in d:
+            v = f32(gpack + 4 * int(src), int(N * C * RS)).reshape(N, RS, C).transpose(0, 2, 1)
+            f32(gflat + 4 * int(dst), int(N * C * RS)).reshape(N, C, RS)[...] = v
 
     def _operand(self, p, ld, bs, trans, rows, K, batch, dt):
         es = 2 if dt == BF16 else 4
