@@ -130,6 +130,8 @@ def main():
         net.eval()
         S = args.sample_steps
         with torch.inference_mode():
+            if S <= 0:
+                raise SystemExit(json.dumps({"train_only_ms_per_step": ms_per_step, "roofline": roofline}))
             xt = torch.randn(B_PER_GPU, 3, 32, 32, device=dev)
             tt = torch.full((B_PER_GPU,), 999, dtype=torch.int64, device=dev)
             for _ in range(3):

@@ -17,7 +17,9 @@
 //   bf16: v_mfma_f32_32x32x16_bf16 (8 bf16 per lane per operand, fp32 accumulate)
 //   fp32: v_mfma_f32_32x32x2_f32   (exact fp32 — the 1e-3 parity path; lanes hold 4 consecutive k, the
 //         k-permutation is the same for A and B so the contraction is unchanged)
-// LDS rows are 144 bytes (BK*sizeof(T) + 16): the 16-lane groups of ds_read_b128 hit distinct 16-B slots.
+// k-contiguous operands go HBM/L2 -> LDS directly (global_load_lds_dwordx4, no VGPR staging); LDS rows are 128 bytes,
+// unpadded, with the 16-byte chunks XOR-swizzled by (row & 7) via the per-lane SOURCE address, so the LDS image
+// stays lane-linear for the DMA and the 16-lane groups of ds_read_b128 hit distinct 16-B slots.
 #include "common.h"
 #include <string.h>
 
@@ -79,15 +81,25 @@ template <> struct Mma<float> {
 
 constexpr int TILE = 128;      // BM == BN
 constexpr int NTHREADS = 256;
-constexpr int ROW_BYTES = 144; // LDS row pitch: 128 B of K data + 16 B pad
+constexpr int ROW_BYTES = 128; // LDS row pitch: 128 B of K data, unpadded (XOR-swizzled chunks)
 constexpr int NVEC = 4;        // 16-byte vectors per thread per operand per K-step
 
-// Per-thread loader state for one operand tile (TILE rows x BK k), staged global -> VGPR -> LDS.
-//  !TRANS (memory is k-contiguous): vector i covers row tid/8 + 32 i, 16-byte k-slot tid%8; written to LDS as is.
-//   TRANS (memory has the M/N index contiguous, k is the slow index): each thread owns a 4(k) x VEC(m) block —
-//          k-quad kq = tid % (BK/4) (fastest over lanes), m-group ng = tid / (BK/4) — loads its 4 k-rows as 16-byte
-//          vectors, transposes the block in registers and writes VEC k-contiguous 4-element runs
-//          (ds_write_b64 for bf16, ds_write_b128 for fp32; a 16-lane group fills one LDS row segment: no conflicts).
+// 16 zero bytes that padded taps, K-tails and rows beyond the matrix are fetched from (direct-to-LDS loads cannot
+// produce zeros by themselves).  Static device memory: nothing is allocated at run time.
+__device__ __attribute__((aligned(16))) unsigned g_zero_page[4];
+
+// LDS operand tile: 128 rows x 128 bytes (64 bf16 / 32 fp32 of K), UNPADDED, with the 16-byte chunk index XOR-swizzled
+// by (row & 7): element (row, chunk c) lives at row*128 + ((c ^ (row&7)) * 16).  The 16-lane groups of ds_read_b128
+// then hit 16 distinct 16-B slots (conflict-free) and rows stay contiguous, which the LDS-DMA loads require.
+__device__ __forceinline__ int lds_off(int row, int chunk) { return row * ROW_BYTES + ((chunk ^ (row & 7)) << 4); }
+
+// Per-thread loader state for one operand tile (TILE rows x BK k).
+//  !TRANS (memory is k-contiguous): `global_load_lds_dwordx4` — data goes HBM/L2 -> LDS without touching VGPRs.  Lane l of
+//          wave w fetches, for i = 0..3, row w*8 + l/8 + 32 i, PHYSICAL chunk l%8, i.e. logical k-chunk (l%8) ^ (row&7):
+//          the swizzle is applied on the per-lane SOURCE address, the LDS image stays lane-linear.
+//   TRANS (k is the slow memory index): each thread owns a 4(k) x VEC(m) block — k-quad kq = tid % (BK/4) fastest over
+//          lanes, m-group ng = tid / (BK/4) — loads its 4 k-rows as 16-byte vectors, transposes in registers and writes
+//          VEC k-contiguous 4-element runs (ds_write_b64 bf16 / ds_write_b128 fp32) into the swizzled image.
 template <typename T, bool TRANS>
 struct Loader {
     static constexpr int VEC = Elem<T>::VEC;
@@ -97,9 +109,10 @@ struct Loader {
     const MatDesc& d;
     const T* base;
     int tile0;
-    int kv, row0;                 // !TRANS
+    int kv, row0, wave;           // !TRANS: logical k-chunk, first tile row, wave id
     int kq, ng;                   // TRANS
-    long long roff[NVEC];         // !TRANS conv (no up/down-scaling): element offset of (b, y0, x0)
+    long long roff[NVEC];         // !TRANS: element offset of the row (plain) or of pixel (b, y0, x0) (conv)
+    unsigned tapmask[NVEC];       // !TRANS conv without up/down-scaling: bit (r*S+s) set when the tap is inside the image
     int pb[NVEC], py[NVEC], px[NVEC];
     bool rvalid[NVEC];
     int tr, ts, tc; bool fvalid;
@@ -108,7 +121,8 @@ struct Loader {
         base = reinterpret_cast<const T*>(d.p) + (long long)batch * d.batch_stride;
         tile0 = tile0_;
         if (!TRANS) {
-            kv = tid & 7; row0 = tid >> 3;
+            row0 = tid >> 3; wave = tid >> 6;
+            kv = (tid & 7) ^ (row0 & 7);
 #pragma unroll
             for (int i = 0; i < NVEC; ++i) {
                 int m = tile0 + row0 + 32 * i;
@@ -116,6 +130,13 @@ struct Loader {
                 if (d.conv) {
                     decode_pixel(rvalid[i] ? m : 0, pb[i], py[i], px[i]);
                     roff[i] = ((long long)(pb[i] * d.H + py[i]) * d.W + px[i]) * d.ld;
+                    unsigned mk = 0;
+                    for (int r = 0; r < d.R; ++r)
+                        for (int s2 = 0; s2 < d.S; ++s2)
+                            if ((unsigned)(py[i] + r) < (unsigned)d.H && (unsigned)(px[i] + s2) < (unsigned)d.W) mk |= 1u << (r * d.S + s2);
+                    tapmask[i] = rvalid[i] ? mk : 0u;
+                } else {
+                    roff[i] = (long long)m * d.ld;
                 }
             }
         } else {
@@ -138,84 +159,79 @@ struct Loader {
         b = (int)bb; y0 = (int)oy * d.stride - d.pad_t; x0 = (int)ox * d.stride - d.pad_l;
     }
 
-    __device__ __forceinline__ u32x4 gather(int b, int y0, int x0, int r, int s, int c) const {
+    // address of the 16-byte vector at virtual pixel (y0+r, x0+s), channel c — or the zero page
+    __device__ __forceinline__ const T* gather_ptr(int b, int y0, int x0, int r, int s, int c) const {
         unsigned uy = (unsigned)(y0 + r), ux = (unsigned)(x0 + s);
         bool ok = ((uy | ux) & (unsigned)d.dmask) == 0;
         uy >>= d.sh; ux >>= d.sh;
         ok = ok && uy < (unsigned)d.H && ux < (unsigned)d.W;
-        if (!ok) return zero16();
         long long off = ((long long)(b * d.H + (int)uy) * d.W + (int)ux) * d.ld + c;
-        return ldg16(base + off);
+        return ok ? base + off : reinterpret_cast<const T*>(g_zero_page);
     }
 
-    // fetch this thread's vectors of the K-step starting at k0 (global loads only)
-    __device__ __forceinline__ void load(int k0, int k_end, u32x4 (&v)[NVEC]) const {
-        if (!TRANS) {
-            int k = k0 + kv * VEC;
-            bool kok = k < k_end;
-            if (d.conv) {
-                unsigned tap = fdiv((unsigned)k, d.dC);
-                int c = k - (int)tap * d.C;
+    // !TRANS: enqueue the direct-to-LDS loads of the K-step starting at k0 into `tile`
+    __device__ __forceinline__ void issue(int k0, int k_end, char* tile) const {
+        const T* zp = reinterpret_cast<const T*>(g_zero_page);
+        const int k = k0 + kv * VEC;
+        const bool kok = k < k_end;
+        const T* src[NVEC];
+        if (d.conv) {
+            unsigned tap = fdiv((unsigned)k, d.dC);
+            int c = k - (int)tap * d.C;
+            if (d.sh == 0) {
                 int r = (int)fdiv(tap, d.dS), s = (int)tap - r * d.S;
-                if (d.sh == 0) {          // plain / strided conv: offset is linear in the tap
-                    const long long tapoff = (long long)(r * d.W + s) * d.ld + c;
+                const long long tapoff = (long long)(r * d.W + s) * d.ld + c;
 #pragma unroll
-                    for (int i = 0; i < NVEC; ++i) {
-                        bool ok = kok && rvalid[i] && (unsigned)(py[i] + r) < (unsigned)d.H && (unsigned)(px[i] + s) < (unsigned)d.W;
-                        v[i] = ok ? ldg16(base + roff[i] + tapoff) : zero16();
-                    }
-                } else {
-#pragma unroll
-                    for (int i = 0; i < NVEC; ++i)
-                        v[i] = (kok && rvalid[i]) ? gather(pb[i], py[i], px[i], r, s, c) : zero16();
-                }
+                for (int i = 0; i < NVEC; ++i) src[i] = (kok && ((tapmask[i] >> tap) & 1u)) ? base + roff[i] + tapoff : zp;
             } else {
+                int r = (int)fdiv(tap, d.dS), s = (int)tap - r * d.S;
 #pragma unroll
-                for (int i = 0; i < NVEC; ++i) {
-                    long long off = (long long)(tile0 + row0 + 32 * i) * d.ld + k;
-                    v[i] = (kok && rvalid[i]) ? ldg16(base + off) : zero16();
-                }
+                for (int i = 0; i < NVEC; ++i) src[i] = (kok && rvalid[i]) ? gather_ptr(pb[i], py[i], px[i], r, s, c) : zp;
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < NVEC; ++i) {
-                int k = k0 + kq * 4 + i;
-                bool ok = fvalid && k < k_end;
-                if (!ok) { v[i] = zero16(); continue; }
-                if (d.conv) {
-                    int b, y0, x0;
-                    decode_pixel(k, b, y0, x0);
-                    v[i] = gather(b, y0, x0, tr, ts, tc);
-                } else {
-                    v[i] = ldg16(base + (long long)k * d.ld + tile0 + ng * VEC);
-                }
+            for (int i = 0; i < NVEC; ++i) src[i] = (kok && rvalid[i]) ? base + roff[i] + k : zp;
+        }
+#pragma unroll
+        for (int i = 0; i < NVEC; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src[i],
+                                             (__attribute__((address_space(3))) void*)(tile + (wave * 8 + 32 * i) * ROW_BYTES), 16, 0, 0);
+    }
+
+    // TRANS: fetch this thread's 4 k-rows of the K-step starting at k0
+    __device__ __forceinline__ void load(int k0, int k_end, u32x4 (&v)[NVEC]) const {
+#pragma unroll
+        for (int i = 0; i < NVEC; ++i) {
+            int k = k0 + kq * 4 + i;
+            bool ok = fvalid && k < k_end;
+            if (!ok) { v[i] = zero16(); continue; }
+            if (d.conv) {
+                int b, y0, x0;
+                decode_pixel(k, b, y0, x0);
+                v[i] = ldg16(gather_ptr(b, y0, x0, tr, ts, tc));
+            } else {
+                v[i] = ldg16(base + (long long)k * d.ld + tile0 + ng * VEC);
             }
         }
     }
 
-    // write the staged vectors into the K-contiguous LDS tile
-    __device__ __forceinline__ void store(char* lds, const u32x4 (&v)[NVEC]) const {
-        if (!TRANS) {
-#pragma unroll
-            for (int i = 0; i < NVEC; ++i)
-                *reinterpret_cast<u32x4*>(lds + (row0 + 32 * i) * ROW_BYTES + kv * 16) = v[i];
-        } else if (sizeof(T) == 2) {
-            char* dst = lds + (ng * 8) * ROW_BYTES + kq * 8;
+    // TRANS: register-transpose the 4 x VEC block and write it into the swizzled K-contiguous tile
+    __device__ __forceinline__ void store(char* tile, const u32x4 (&v)[NVEC]) const {
+        if (sizeof(T) == 2) {
 #pragma unroll
             for (int dd = 0; dd < 4; ++dd) {            // dword dd of each vector holds m = 2dd (low half) and 2dd+1 (high half)
                 const unsigned a0 = v[0][dd], a1 = v[1][dd], a2 = v[2][dd], a3 = v[3][dd];
                 uint2 even, odd;
                 even.x = (a0 & 0xffffu) | (a1 << 16); even.y = (a2 & 0xffffu) | (a3 << 16);
                 odd.x = (a0 >> 16) | (a1 & 0xffff0000u); odd.y = (a2 >> 16) | (a3 & 0xffff0000u);
-                *reinterpret_cast<uint2*>(dst + (2 * dd) * ROW_BYTES) = even;
-                *reinterpret_cast<uint2*>(dst + (2 * dd + 1) * ROW_BYTES) = odd;
+                *reinterpret_cast<uint2*>(tile + lds_off(ng * 8 + 2 * dd, kq >> 1) + (kq & 1) * 8) = even;
+                *reinterpret_cast<uint2*>(tile + lds_off(ng * 8 + 2 * dd + 1, kq >> 1) + (kq & 1) * 8) = odd;
             }
         } else {
-            char* dst = lds + (ng * 4) * ROW_BYTES + kq * 16;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 u32x4 w; w.x = v[0][j]; w.y = v[1][j]; w.z = v[2][j]; w.w = v[3][j];
-                *reinterpret_cast<u32x4*>(dst + j * ROW_BYTES) = w;
+                *reinterpret_cast<u32x4*>(tile + lds_off(ng * 4 + j, kq)) = w;
             }
         }
     }
@@ -346,31 +362,35 @@ void gemm_kernel(MatDesc A, MatDesc B, Epilogue ep, int M, int N, int K, int k_p
         for (int j = 0; j < 2; ++j) acc[i][j] = (f32x16)(0.f);
 
     u32x4 va[NVEC], vb[NVEC];
-    la.load(k_begin, k_end, va);
-    lb.load(k_begin, k_end, vb);
-    la.store(smem, va);
-    lb.store(smem + TILE_BYTES, vb);
+    // stage K-step 0
+    if (!TA) la.issue(k_begin, k_end, smem); else { la.load(k_begin, k_end, va); la.store(smem, va); }
+    if (!TB) lb.issue(k_begin, k_end, smem + TILE_BYTES); else { lb.load(k_begin, k_end, vb); lb.store(smem + TILE_BYTES, vb); }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     const int nsteps = (k_end - k_begin + BK - 1) / BK;
-    const int frag_off = (lane & 31) * ROW_BYTES + (lane >> 5) * 16;   // row (lane&31), 16-byte k-slot (lane>>5)
+    // fragment reads: row (lane&31) of the wave's 32-row block, logical 16-byte chunk 2*kc + (lane>>5), swizzled by row&7 == lane&7
+    const int frag_row = (lane & 31) * ROW_BYTES;
+    const int sw = (lane >> 5) ^ (lane & 7);
     for (int s = 0; s < nsteps; ++s) {
         const char* cur = smem + (s & 1) * 2 * TILE_BYTES;
         char* nxt = smem + ((s + 1) & 1) * 2 * TILE_BYTES;
         const bool more = s + 1 < nsteps;
-        if (more) {
-            la.load(k_begin + (s + 1) * BK, k_end, va);
-            lb.load(k_begin + (s + 1) * BK, k_end, vb);
+        if (more) {       // the other buffer was last read in step s-1: every wave is past that barrier
+            const int kn = k_begin + (s + 1) * BK;
+            if (!TA) la.issue(kn, k_end, nxt); else la.load(kn, k_end, va);
+            if (!TB) lb.issue(kn, k_end, nxt + TILE_BYTES); else lb.load(kn, k_end, vb);
         }
-        const char* pa = cur + (wm * 64) * ROW_BYTES + frag_off;
-        const char* pb = cur + TILE_BYTES + (wn * 64) * ROW_BYTES + frag_off;
+        const char* pa = cur + (wm * 64) * ROW_BYTES + frag_row;
+        const char* pb = cur + TILE_BYTES + (wn * 64) * ROW_BYTES + frag_row;
 #pragma unroll
         for (int kc = 0; kc < BK / KF; ++kc) {
+            const int co = ((2 * kc) ^ sw) << 4;
             u32x4 fa[2], fb[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                fa[i] = *reinterpret_cast<const u32x4*>(pa + i * 32 * ROW_BYTES + kc * 32);
-                fb[i] = *reinterpret_cast<const u32x4*>(pb + i * 32 * ROW_BYTES + kc * 32);
+                fa[i] = *reinterpret_cast<const u32x4*>(pa + i * 32 * ROW_BYTES + co);
+                fb[i] = *reinterpret_cast<const u32x4*>(pb + i * 32 * ROW_BYTES + co);
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -378,9 +398,10 @@ void gemm_kernel(MatDesc A, MatDesc B, Epilogue ep, int M, int N, int K, int k_p
                 for (int j = 0; j < 2; ++j) Mma<T>::run(fa[i], fb[j], acc[i][j]);
         }
         if (more) {
-            la.store(nxt, va);
-            lb.store(nxt + TILE_BYTES, vb);
+            if (TA) la.store(nxt, va);
+            if (TB) lb.store(nxt + TILE_BYTES, vb);
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the LDS-DMA of the next tile has landed
         __syncthreads();
     }
 
@@ -427,7 +448,7 @@ static int launch_t(GemmArgs& g, hipStream_t st) {
     splits = (ksteps + steps_per - 1) / steps_per;
     if (splits > 1 && g.ep.mode != 2 && g.ep.mode != 4) return DDPM_ERR_SHAPE;
     dim3 grid(tiles_m * tiles_n, splits, g.batch);
-    size_t lds = 4 * TILE * ROW_BYTES;
+    size_t lds = TILE * CS_LD * sizeof(float);            // 4 operand tiles (64 KiB) <= fp32 epilogue staging (66 KiB)
     const int kps = steps_per * BK;
 #define LAUNCH(TA, TB)                                                                                                   \
     do {                                                                                                                 \
