@@ -89,13 +89,15 @@ constexpr int NVEC = 4;        // 16-byte vectors per thread per operand per K-s
 __device__ __attribute__((aligned(16))) unsigned g_zero_page[4];
 
 // LDS operand tile: 128 rows x 128 bytes (64 bf16 / 32 fp32 of K), UNPADDED, with the 16-byte chunk index XOR-swizzled
-// by (row & 7): element (row, chunk c) lives at row*128 + ((c ^ (row&7)) * 16).  The 16-lane groups of ds_read_b128
-// then hit 16 distinct 16-B slots (conflict-free) and rows stay contiguous, which the LDS-DMA loads require.
-__device__ __forceinline__ int lds_off(int row, int chunk) { return row * ROW_BYTES + ((chunk ^ (row & 7)) << 4); }
+// by ((row>>1) & 7): element (row, chunk c) lives at row*128 + ((c ^ ((row>>1)&7)) * 16).  Two consecutive rows span one
+// 256-byte bank row, so the key must be distinct over the 8 even (odd) rows of each ds_read_b128 16-lane group
+// ({0-3,12-15,20-27} / {4-11,16-19,28-31}): (row>>1)&7 is, row&7 is not (rows 12 and 20 would collide).  Rows stay
+// contiguous, which the LDS-DMA loads require.
+__device__ __forceinline__ int lds_off(int row, int chunk) { return row * ROW_BYTES + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
 // Per-thread loader state for one operand tile (TILE rows x BK k).
 //  !TRANS (memory is k-contiguous): `global_load_lds_dwordx4` — data goes HBM/L2 -> LDS without touching VGPRs.  Lane l of
-//          wave w fetches, for i = 0..3, row w*8 + l/8 + 32 i, PHYSICAL chunk l%8, i.e. logical k-chunk (l%8) ^ (row&7):
+//          wave w fetches, for i = 0..3, row w*8 + l/8 + 32 i, PHYSICAL chunk l%8, i.e. logical k-chunk (l%8) ^ ((row>>1)&7):
 //          the swizzle is applied on the per-lane SOURCE address, the LDS image stays lane-linear.
 //   TRANS (k is the slow memory index): each thread owns a 4(k) x VEC(m) block — k-quad kq = tid % (BK/4) fastest over
 //          lanes, m-group ng = tid / (BK/4) — loads its 4 k-rows as 16-byte vectors, transposes in registers and writes
@@ -122,7 +124,7 @@ struct Loader {
         tile0 = tile0_;
         if (!TRANS) {
             row0 = tid >> 3; wave = tid >> 6;
-            kv = (tid & 7) ^ (row0 & 7);
+            kv = (tid & 7) ^ ((row0 >> 1) & 7);
 #pragma unroll
             for (int i = 0; i < NVEC; ++i) {
                 int m = tile0 + row0 + 32 * i;
@@ -369,9 +371,9 @@ void gemm_kernel(MatDesc A, MatDesc B, Epilogue ep, int M, int N, int K, int k_p
     __syncthreads();
 
     const int nsteps = (k_end - k_begin + BK - 1) / BK;
-    // fragment reads: row (lane&31) of the wave's 32-row block, logical 16-byte chunk 2*kc + (lane>>5), swizzled by row&7 == lane&7
+    // fragment reads: row (lane&31) of the wave's 32-row block, logical 16-byte chunk 2*kc + (lane>>5), swizzle key (row>>1)&7
     const int frag_row = (lane & 31) * ROW_BYTES;
-    const int sw = (lane >> 5) ^ (lane & 7);
+    const int sw = (lane >> 5) ^ ((lane >> 1) & 7);
     for (int s = 0; s < nsteps; ++s) {
         const char* cur = smem + (s & 1) * 2 * TILE_BYTES;
         char* nxt = smem + ((s + 1) & 1) * 2 * TILE_BYTES;

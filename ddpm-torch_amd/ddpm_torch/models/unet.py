@@ -609,11 +609,11 @@ class _Engine:
         return grads
 
     def _splits(self, M, N, K):
-        """Split the wgrad reduction so that tiles x splits fills the chip (256 CUs, 2 blocks each)."""
+        """Split the wgrad reduction so that tiles x splits is about one full wave of blocks (256 CUs x 2 resident blocks)
+        while every split keeps >= 8 K-steps: more splits only add fp32 atomics (measured: scripts/wgrad_splits.sh)."""
         tiles = -(-M // 128) * -(-N // 128)
         ksteps = -(-K // (8 * self.vec))
-        s = max(1, min(ksteps // 4, -(-1024 // tiles)))
-        return s
+        return max(1, min(512 // tiles, ksteps // 8))
 
     def _bias_grad(self, ctx, dy, biases, creal):
         """db[c] = sum over pixels and batch of dy (first `creal` channels); same vector for every listed bias."""
