@@ -57,7 +57,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--sample-steps", type=int, default=30, help="timed p_sample steps for the sampling figure")
+    ap.add_argument("--sample-steps", type=int, default=1000, help="length of the timed p_sample chain (1000 = the real thing)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -116,9 +116,17 @@ def main():
         torch.cuda.synchronize()
         prof, _ops.PROFILE = _ops.PROFILE, None
         agg = {}
-        for kind, flops, a, b in prof:
+        shapes = {}
+        for kind, flops, a, b, shape in prof:
+            dt_s = a.elapsed_time(b) * 1e-3
             e = agg.setdefault(kind, [0, 0.0, 0.0])
-            e[0] += 1; e[1] += flops; e[2] += a.elapsed_time(b) * 1e-3
+            e[0] += 1; e[1] += flops; e[2] += dt_s
+            e2 = shapes.setdefault(kind + " " + shape, [0, 0.0, 0.0])
+            e2[0] += 1; e2[1] += flops; e2[2] += dt_s
+        if os.environ.get("BENCH_SHAPES"):
+            with open(os.environ["BENCH_SHAPES"], "w") as f:
+                for k, v in sorted(shapes.items(), key=lambda kv: -kv[1][2]):
+                    f.write(f"{v[2] * 1e3:8.3f} ms  n={v[0]:3d}  {v[1] / v[2] / 1e12:7.1f} TF  {k}\n")
         dom = agg["gemm_nn"]
         achieved = dom[1] / dom[2] / 1e12
         kernels = {k: {"launches": v[0], "gflop": round(v[1] / 1e9, 1), "ms": round(v[2] * 1e3, 3), "tflops": round(v[1] / v[2] / 1e12, 1)} for k, v in agg.items()}
@@ -126,26 +134,25 @@ def main():
                     "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3, "unit": "TFLOP/s",
                     "frac": round(achieved / (PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3), 4), "traffic": None,
                     "launches_per_step": dom[0], "avg_launch_us": round(dom[2] / dom[0] * 1e6, 2), "per_kernel": kernels}
-        # ---- sampling: eval-mode ancestral steps at B=128 (EMA weights are what generate.py samples with; same cost)
+        # ---- sampling: the reference's p_sample (EMA weights are what generate.py samples with; same cost), B=128,
+        # eval mode, fixed-large, seed 131071.  --sample-steps 1000 (default) runs the real 1000-step chain end to end;
+        # a smaller S times an S-step chain (identical per-step work) and scales to 1000 steps.
         net.eval()
         S = args.sample_steps
-        with torch.inference_mode():
-            if S <= 0:
-                raise SystemExit(json.dumps({"train_only_ms_per_step": ms_per_step, "roofline": roofline}))
-            xt = torch.randn(B_PER_GPU, 3, 32, 32, device=dev)
-            tt = torch.full((B_PER_GPU,), 999, dtype=torch.int64, device=dev)
-            for _ in range(3):
-                xt = dif.p_sample_step(model, xt, tt)
-            torch.cuda.synchronize()
-            s0 = time.perf_counter()
-            for i in range(S):
-                tt.fill_(999 - i)
-                xt = dif.p_sample_step(model, xt, tt)
-            torch.cuda.synchronize()
-            s_el = time.perf_counter() - s0
-        samp = {"batch": B_PER_GPU, "steps_timed": S, "ms_per_step": round(s_el / S * 1e3, 3),
+        if S <= 0:
+            raise SystemExit(json.dumps({"train_only_ms_per_step": ms_per_step, "roofline": roofline}))
+        sdif = dif if S == 1000 else ddpm_torch.GaussianDiffusion(ddpm_torch.get_beta_schedule("linear", 1e-4, 0.02, S), "eps", "fixed-large", "mse")
+        sdif.p_sample(model, shape=(8, 3, 32, 32), device=dev, seed=1)          # warm-up (small batch, same kernels)
+        torch.cuda.synchronize()
+        s0 = time.perf_counter()
+        xs = sdif.p_sample(model, shape=(B_PER_GPU, 3, 32, 32), device=dev, seed=131071)
+        torch.cuda.synchronize()
+        s_el = time.perf_counter() - s0
+        assert xs.shape == (B_PER_GPU, 3, 32, 32) and bool(torch.isfinite(xs).all())
+        samp = {"batch": B_PER_GPU, "steps_timed": S, "seconds": round(s_el, 3), "ms_per_step": round(s_el / S * 1e3, 3),
                 "samples_per_s_1000_steps": round(B_PER_GPU / (s_el / S * 1000), 4),
-                "model_tflops": round(B_PER_GPU * FWD_GFLOP_PER_SAMPLE / (s_el / S) / 1e3, 1)}
+                "model_tflops": round(B_PER_GPU * FWD_GFLOP_PER_SAMPLE / (s_el / S) / 1e3, 1),
+                "mode": "hipGraph replay of the captured step" if os.environ.get("DDPM_TORCH_AMD_GRAPH", "1") != "0" else "eager"}
         out = {"metric": "training imgs/s/GPU + 1000-step DDPM samples/s, CIFAR-10 UNet @1/2/4/8 MI355X",
                "value": round(imgs_per_s, 2), "unit": "imgs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,

@@ -53,6 +53,8 @@ struct Epilogue {
     FastDiv dHW;              // mode 3: row -> (b, pixel)
     int HW;
     int vec_ok;               // out / residual pointers and pitches allow 16-byte vector access
+    float* splitk_ws;         // split-K slabs [tile][split][128*128] fp32 (modes 0/1/3 with gridDim.y > 1), else null
+    unsigned* splitk_cnt;     // per-tile arrival counters, zero on entry, reset to zero by the last arriver
 };
 
 template <int I> struct IC { static constexpr int v = I; };
@@ -418,6 +420,47 @@ void gemm_kernel(MatDesc A, MatDesc B, Epilogue ep, int M, int N, int K, int k_p
         });
     }
     __syncthreads();
+    if (gridDim.y > 1 && ep.splitk_ws) {
+        // In-launch split-K reduction (placement-independent: agent-scope release / acquire around one arrival ticket).
+        // Every split publishes its fp32 partial tile as a slab; the LAST arriver adds the other slabs to its own
+        // LDS-resident partial and runs the fused epilogue.  Counters return to zero, so no memset between launches.
+        const int nsplit = gridDim.y;
+        const long long tile_id = (long long)batch * gridDim.x + blockIdx.x;
+        float* slabs = ep.splitk_ws + tile_id * nsplit * (TILE * TILE);
+        float* mine = slabs + (long long)blockIdx.y * (TILE * TILE);
+        for (int v = tid; v < TILE * TILE / 4; v += NTHREADS) {
+            const int r = v >> 5, c4 = (v & 31) << 2;
+            *reinterpret_cast<f32x4*>(mine + r * TILE + c4) = *reinterpret_cast<const f32x4*>(cs + r * CS_LD + c4);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        float* flag = cs + TILE;                     // row 0, first padding column: the one shared array holds the flag too
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned ticket = __hip_atomic_fetch_add(ep.splitk_cnt + tile_id, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *flag = (ticket == (unsigned)(nsplit - 1)) ? 1.f : 0.f;
+        }
+        __syncthreads();
+        if (*flag == 0.f) return;
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            __hip_atomic_store(ep.splitk_cnt + tile_id, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        // fixed summation order (slab 0, 1, 2, ...) whichever block happens to arrive last: bit-deterministic results
+        for (int v = tid; v < TILE * TILE / 4; v += NTHREADS) {
+            const int r = v >> 5, c4 = (v & 31) << 2;
+            const f32x4 own = *reinterpret_cast<const f32x4*>(cs + r * CS_LD + c4);
+            f32x4 a = (blockIdx.y == 0) ? own : *reinterpret_cast<const f32x4*>(slabs + r * TILE + c4);
+            for (int sp = 1; sp < nsplit; ++sp) {
+                const f32x4 b = (sp == (int)blockIdx.y) ? own : *reinterpret_cast<const f32x4*>(slabs + (long long)sp * (TILE * TILE) + r * TILE + c4);
+                a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+            }
+            *reinterpret_cast<f32x4*>(cs + r * CS_LD + c4) = a;
+        }
+        __syncthreads();
+    }
     if (ep.mode == 0) epilogue_rows<T, T>(ep, cs, batch, tm * TILE, tn * TILE, M, N, tid);
     else if (ep.mode == 1) epilogue_rows<T, float>(ep, cs, batch, tm * TILE, tn * TILE, M, N, tid);
     else epilogue_scatter(ep, cs, batch, tm * TILE, tn * TILE, M, N, tid);
@@ -448,7 +491,8 @@ static int launch_t(GemmArgs& g, hipStream_t st) {
     int ksteps = (g.K + BK - 1) / BK;
     int steps_per = (ksteps + splits - 1) / splits;
     splits = (ksteps + steps_per - 1) / steps_per;
-    if (splits > 1 && g.ep.mode != 2 && g.ep.mode != 4) return DDPM_ERR_SHAPE;
+    if (splits > 1 && g.ep.mode != 2 && g.ep.mode != 4 && !(g.ep.splitk_ws && g.ep.splitk_cnt)) return DDPM_ERR_SHAPE;
+    if (g.ep.mode == 2 || g.ep.mode == 4) { g.ep.splitk_ws = nullptr; g.ep.splitk_cnt = nullptr; }
     dim3 grid(tiles_m * tiles_n, splits, g.batch);
     size_t lds = TILE * CS_LD * sizeof(float);            // 4 operand tiles (64 KiB) <= fp32 epilogue staging (66 KiB)
     const int kps = steps_per * BK;
@@ -515,12 +559,15 @@ static void conv_desc(MatDesc& d, const void* x, long long x_ld, int npix_out, i
 // Convolution over NHWC activations as implicit GEMM (forward and, with flipped weights, dgrad).
 //   y[b,oy,ox,n] = sum_{r,s,c} x[b, f(oy*stride + r - pad_t), f(ox*stride + s - pad_l), c] * w[n][r][s][c]  (+ epilogue)
 // f = identity, >>1 (nearest-2x upsample fused: upsample=1) or /2-if-even (transposed conv: dilate=1).
+// splits > 1 (small-M layers): the K range is split over gridDim.y and reduced inside the launch through
+// splitk_ws (>= tiles*splits*16384 floats) and splitk_cnt (>= tiles counters, zero on entry and on exit).
 extern "C" int ddpm_conv2d_nhwc(const void* x, long long x_ld, const void* w, void* y, long long y_ld,
                                 const float* bias, const float* rowbias, long long rowbias_ld,
                                 const void* residual, long long res_ld,
                                 int B, int H, int W, int C, int Ho, int Wo, int N, int R, int S,
                                 int stride, int pad_t, int pad_l, int upsample, int dilate,
-                                int accumulate, int out_mode, int dtype, void* stream) {
+                                int accumulate, int out_mode, int splits, float* splitk_ws, unsigned* splitk_cnt,
+                                int dtype, void* stream) {
     if (!x || !w || !y) return DDPM_ERR_NULL;
     if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || Ho <= 0 || Wo <= 0 || N <= 0 || R <= 0 || S <= 0 || stride <= 0) return DDPM_ERR_SHAPE;
     if (upsample && dilate) return DDPM_ERR_SHAPE;
@@ -535,6 +582,7 @@ extern "C" int ddpm_conv2d_nhwc(const void* x, long long x_ld, const void* w, vo
     g.ep.rowbias = rowbias; g.ep.rowbias_ld = rowbias_ld; g.ep.dgroup = make_fastdiv((unsigned)(Ho * Wo));
     g.ep.residual = residual; g.ep.res_ld = res_ld; g.ep.accumulate = accumulate;
     g.ep.HW = Ho * Wo; g.ep.dHW = make_fastdiv((unsigned)(Ho * Wo));
+    g.splits = splits; g.ep.splitk_ws = splitk_ws; g.ep.splitk_cnt = splitk_cnt;
     return ddpm_gemm_launch(g, (hipStream_t)stream);
 }
 

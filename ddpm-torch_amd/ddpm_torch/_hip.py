@@ -21,7 +21,7 @@ P, I, L, F, U = c_void_p, c_int, c_longlong, c_float, c_ulonglong
 
 # name -> argtypes; every function returns int status (0 = OK) except ddpm_gn_workspace_floats.
 PROTOTYPES = {
-    "ddpm_conv2d_nhwc": [P, L, P, P, L, P, P, L, P, L] + [I] * 14 + [I, I, I, P],
+    "ddpm_conv2d_nhwc": [P, L, P, P, L, P, P, L, P, L] + [I] * 14 + [I, I, I, P, P, I, P],
     "ddpm_conv2d_wgrad_nhwc": [P, L, P, L, P] + [I] * 17 + [P],
     "ddpm_wgrad_unpack": [P, P, P, I, P],
     "ddpm_gemm": [P, L, L, I, P, L, L, I, P, L, L, P, P, L, L, I, I, I, I, F, I, I, I, I, P],

@@ -16,7 +16,7 @@ GN_EPS = 1e-6
 PROFILE = None
 
 
-def _timed(kind, flops, fn):
+def _timed(kind, flops, fn, shape=""):
     if PROFILE is None:
         fn()
         return
@@ -24,7 +24,7 @@ def _timed(kind, flops, fn):
     a.record()
     fn()
     b.record()
-    PROFILE.append((kind, flops, a, b))
+    PROFILE.append((kind, flops, a, b, shape))
 
 
 class View:
@@ -66,24 +66,51 @@ class View:
 
 
 def conv2d(x, w_ptr, y_ptr, y_ld, N, R, S, Ho, Wo, stride=1, pad_t=0, pad_l=0, upsample=0, dilate=0,
-           bias=0, rowbias=0, rowbias_ld=0, res_ptr=0, res_ld=0, accumulate=0, out_mode=0):
-    """x: View (its H, W are the STORED input dims)."""
+           bias=0, rowbias=0, rowbias_ld=0, res_ptr=0, res_ld=0, accumulate=0, out_mode=0, splitk=None):
+    """x: View (its H, W are the STORED input dims).  splitk: SplitK workspace (small-M layers get an in-launch split-K)."""
+    splits, ws, cnt = splitk.plan(x.B * Ho * Wo, N, R * S * x.C, x.dtype) if splitk is not None else (1, 0, 0)
     _timed("gemm_nn", 2.0 * x.B * Ho * Wo * N * R * S * x.C, lambda: _hip.call(
         "ddpm_conv2d_nhwc", x.ptr, x.ld, w_ptr, y_ptr, y_ld, bias, rowbias, rowbias_ld, res_ptr, res_ld,
-        x.B, x.H, x.W, x.C, Ho, Wo, N, R, S, stride, pad_t, pad_l, upsample, dilate, accumulate, out_mode, x.dtype, _hip.stream()))
+        x.B, x.H, x.W, x.C, Ho, Wo, N, R, S, stride, pad_t, pad_l, upsample, dilate, accumulate, out_mode, splits, ws, cnt,
+        x.dtype, _hip.stream()),
+        f"conv M={x.B * Ho * Wo} N={N} K={R * S * x.C} {R}x{S} s{stride} u{upsample} d{dilate}")
+
+
+class SplitK:
+    """Workspace for the in-launch split-K of layers with few output tiles (the 8x8 / 4x4 levels): fp32 slabs + per-tile
+    arrival counters (zero between launches: the last arriver of every tile resets its counter)."""
+    TARGET_BLOCKS = 256          # one block per CU
+
+    def __init__(self, device):
+        self.device = device
+        self.ws = None
+        self.cnt = None
+
+    def plan(self, M, N, K, dtype):
+        tiles = -(-M // 128) * -(-N // 128)
+        ksteps = -(-K // (64 if dtype == _hip.BF16 else 32))
+        splits = min(self.TARGET_BLOCKS // tiles, ksteps // 4)
+        if splits < 2:
+            return 1, 0, 0
+        need = tiles * splits * 16384
+        if self.ws is None or self.ws.numel() < need:
+            self.ws = torch.empty(need, dtype=torch.float32, device=self.device)
+        if self.cnt is None or self.cnt.numel() < tiles:
+            self.cnt = torch.zeros(max(tiles, 1024), dtype=torch.int32, device=self.device)
+        return splits, self.ws.data_ptr(), self.cnt.data_ptr()
 
 
 def conv2d_wgrad(dy, x, dw_ptr, Creal, Nreal, R, S, stride=1, pad_t=0, pad_l=0, upsample=0, splits=1):
     _timed("gemm_tt", 2.0 * dy.rows * Nreal * R * S * x.C, lambda: _hip.call(
         "ddpm_conv2d_wgrad_nhwc", dy.ptr, dy.ld, x.ptr, x.ld, dw_ptr, x.B, x.H, x.W, x.C, Creal, dy.H, dy.W, dy.C, Nreal, R, S,
-        stride, pad_t, pad_l, upsample, splits, x.dtype, _hip.stream()))
+        stride, pad_t, pad_l, upsample, splits, x.dtype, _hip.stream()), f"wgrad M={Nreal} N={R * S * x.C} K={dy.rows} splits={splits}")
 
 
 def gemm(a_ptr, a_ld, a_bs, a_trans, b_ptr, b_ld, b_bs, b_trans, c_ptr, c_ld, c_bs, M, N, K, dtype, batch=1, alpha=1.0,
          bias=0, res_ptr=0, res_ld=0, res_bs=0, accumulate=0, out_mode=0, splits=1):
     _timed("gemm_" + "nt"[a_trans] + "nt"[b_trans], 2.0 * batch * M * N * K, lambda: _hip.call(
         "ddpm_gemm", a_ptr, a_ld, a_bs, a_trans, b_ptr, b_ld, b_bs, b_trans, c_ptr, c_ld, c_bs, bias, res_ptr, res_ld, res_bs,
-        M, N, K, batch, alpha, accumulate, out_mode, splits, dtype, _hip.stream()))
+        M, N, K, batch, alpha, accumulate, out_mode, splits, dtype, _hip.stream()), f"gemm b={batch} M={M} N={N} K={K} dt={dtype}")
 
 
 def gn_workspace_floats(B, HW, C, dtype):

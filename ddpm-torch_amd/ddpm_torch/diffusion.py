@@ -14,6 +14,8 @@ per-sample coefficients by ``t`` on the device:
 Arithmetic is fp32 with the reference's operation order (no fused multiply-add contraction) so identical
 (x_t, t, noise) give matching results.  No CPU path: CPU tensors raise.
 """
+import os
+
 import torch
 
 from . import _hip
@@ -208,7 +210,12 @@ class GaussianDiffusion:
 
     def _sample_loop(self, denoise_fn, shape, device, noise, seed, on_step=None, z_stream=None):
         """The T-step (or S-step) loop.  ``z_stream`` (parity tests only) is an iterator of per-step noise tensors
-        that replaces the generator draws, so an identical (x_T, z_1..z_T) stream can be injected."""
+        that replaces the generator draws, so an identical (x_T, z_1..z_T) stream can be injected.
+
+        The step body (model call, noise draw, fused update, t -= 1) has static shapes, so it is captured ONCE into a
+        hipGraph and replayed: at 32x32 the eager loop is bound by ~250 kernel launches per step, not by the GPU.
+        RNG consumption (x_T first, then one z per step incl. t = 0) and results are identical to the eager loop;
+        set DDPM_TORCH_AMD_GRAPH=0 to force eager."""
         device = torch.device(device)
         _hip.require_cuda(torch.empty(0, device=device))        # no CPU fallback: sampling runs on the GPU only
         B = (shape or noise.shape)[0]
@@ -217,8 +224,15 @@ class GaussianDiffusion:
             x_t = torch.empty(shape, device=device).normal_(generator=rng)                  # x_T first, then one z per step
         else:
             x_t = noise.to(device)
-        t = torch.empty((B,), dtype=torch.int64, device=device)
-        for ti in range(self._num_steps() - 1, -1, -1):
+        steps = self._num_steps()
+        t = torch.full((B,), steps - 1, dtype=torch.int64, device=device)
+        x_t = x_t.contiguous().float().clone()
+        if (on_step is None and z_stream is None and steps >= 4 and device.type == "cuda"
+                and os.environ.get("DDPM_TORCH_AMD_GRAPH", "1") != "0" and not torch.cuda.is_current_stream_capturing()):
+            done = self._graph_loop(denoise_fn, x_t, t, rng, steps)
+            if done is not None:
+                return done
+        for ti in range(steps - 1, -1, -1):
             t.fill_(ti)
             out = denoise_fn(x_t, self._model_t(t))
             z = torch.empty_like(x_t).normal_(generator=rng) if z_stream is None else next(z_stream).to(x_t)
@@ -226,6 +240,51 @@ class GaussianDiffusion:
             if on_step is not None:
                 on_step(ti, pred)
         return x_t
+
+    def _graph_loop(self, denoise_fn, x_t, t, rng, steps):
+        """Capture one sampling step as a hipGraph and replay it ``steps`` times; returns None if capture is not possible
+        (the caller then runs the eager loop from the untouched state)."""
+        dev = x_t.device
+        z = torch.empty_like(x_t)
+        tabs = [self._tab(n, dev) for n in _STEP_TABLES]
+        mean_code = _MEAN_CODE[self.model_mean_type]
+        B, n = x_t.shape[0], x_t[0].numel()
+
+        def body():
+            out = denoise_fn(x_t, self._model_t(t)).contiguous().float()
+            z.normal_(generator=rng)
+            _hip.call("ddpm_p_sample_step", x_t.data_ptr(), out.data_ptr(), z.data_ptr(), t.data_ptr(), *[tb.data_ptr() for tb in tabs],
+                      x_t.data_ptr(), 0, B, n, mean_code, 1, _hip.stream())            # in place: each element is read once, then written
+            _hip.call("ddpm_add_i64", t.data_ptr(), B, -1, _hip.stream())
+
+        # warm-up on a side stream (lazy kernel / cache initialisation), from a snapshot so that no state is consumed
+        snap_x, snap_t = x_t.clone(), t.clone()
+        gen = rng if rng is not None else torch.cuda.default_generators[dev.index if dev.index is not None else torch.cuda.current_device()]
+        snap_rng = gen.get_state()
+        graph = None
+        try:
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                body()
+            torch.cuda.current_stream(dev).wait_stream(side)
+            x_t.copy_(snap_x); t.copy_(snap_t); gen.set_state(snap_rng)
+            graph = torch.cuda.CUDAGraph()
+            if rng is not None:
+                graph.register_generator_state(rng)
+            with torch.cuda.graph(graph):
+                body()
+        except Exception as e:                                   # capture not possible for this denoise_fn: eager loop instead
+            import warnings
+            warnings.warn(f"hipGraph capture of the sampling step failed ({type(e).__name__}: {e}); running the eager loop")
+            torch.cuda.synchronize(dev)
+            x_t.copy_(snap_x); t.copy_(snap_t); gen.set_state(snap_rng)
+            return None
+        # capture does not execute: state is still the snapshot.  Replay the step `steps` times.
+        x_t.copy_(snap_x); t.copy_(snap_t)
+        for _ in range(steps):
+            graph.replay()
+        return x_t.clone()
 
     def _num_steps(self):
         return self.timesteps

@@ -255,6 +255,7 @@ class _Engine:
         self._ws_key = None
         self.drop_calls = 0
         self.last_tape = None
+        self.splitk = ops.SplitK(self.device)
         _hip.lib()
 
     # ---------------------------------------------------------------- topology helpers
@@ -485,7 +486,7 @@ class _Engine:
         norm, conv = m.out_conv[0], m.out_conv[2]
         ops.gn_fwd(cur, act, norm.weight, norm.bias, stats, ws, silu=True)
         cw = self._packed(conv, save)
-        ops.conv2d(act, cw.wf.data_ptr(), out.data_ptr(), 0, cw.N, 3, 3, H, W, pad_t=1, pad_l=1, bias=conv.bias.data_ptr(), out_mode=3)
+        ops.conv2d(act, cw.wf.data_ptr(), out.data_ptr(), 0, cw.N, 3, 3, H, W, pad_t=1, pad_l=1, bias=conv.bias.data_ptr(), out_mode=3, splitk=self.splitk)
         if save:
             tape.append(("head", cur, act, stats, st))
         return out
@@ -502,7 +503,7 @@ class _Engine:
         if cw.Cp != x.C:
             raise RuntimeError("channel padding mismatch")
         ops.conv2d(xin, cw.wf.data_ptr(), out.ptr, out.ld, cw.N, k, k, out.H, out.W, stride=stride, pad_t=pt, pad_l=pl,
-                   upsample=upsample, bias=conv.bias.data_ptr())
+                   upsample=upsample, bias=conv.bias.data_ptr(), splitk=self.splitk)
         if st["save"]:
             st["tape"].append(("conv", conv, x, out, k, stride, pt, pl, upsample))
 
@@ -525,7 +526,7 @@ class _Engine:
         c1 = self._packed(rb.conv1, save)
         tb = st["tb"]
         ops.conv2d(a1, c1.wf.data_ptr(), h1.ptr, h1.ld, Cout, 3, 3, x.H, x.W, pad_t=1, pad_l=1,
-                   rowbias=tb.data_ptr() + 4 * self.tb_off[id(rb)], rowbias_ld=self.tb_total)
+                   rowbias=tb.data_ptr() + 4 * self.tb_off[id(rb)], rowbias_ld=self.tb_total, splitk=self.splitk)
         a2 = self._new(B, x.H, x.W, Cout)
         stats2 = self._f32(B, ops.GN_GROUPS, 2) if save else None
         seed = (st["seed"] + 0x51ED27 * (self.tb_off[id(rb)] + 1)) & ((1 << 63) - 1) if st["drop_p"] > 0 else 0
@@ -533,12 +534,12 @@ class _Engine:
         c2 = self._packed(rb.conv2, save)
         if rb.has_skip:
             cs = self._packed(rb.skip, save)
-            ops.conv2d(x, cs.wf.data_ptr(), out.ptr, out.ld, Cout, 1, 1, x.H, x.W, bias=rb.skip.bias.data_ptr())
+            ops.conv2d(x, cs.wf.data_ptr(), out.ptr, out.ld, Cout, 1, 1, x.H, x.W, bias=rb.skip.bias.data_ptr(), splitk=self.splitk)
             res_ptr, res_ld = out.ptr, out.ld          # conv2's epilogue adds the skip projection it finds in `out`
         else:
             res_ptr, res_ld = x.ptr, x.ld
         ops.conv2d(a2, c2.wf.data_ptr(), out.ptr, out.ld, Cout, 3, 3, x.H, x.W, pad_t=1, pad_l=1,
-                   bias=rb.conv2.bias.data_ptr(), res_ptr=res_ptr, res_ld=res_ld)
+                   bias=rb.conv2.bias.data_ptr(), res_ptr=res_ptr, res_ld=res_ld, splitk=self.splitk)
         if save:
             st["tape"].append(("res", rb, x, out, a1, stats1, h1, a2, stats2, seed, parts))
 
@@ -550,7 +551,7 @@ class _Engine:
         ops.gn_fwd(x, hn, ab.norm.weight, ab.norm.bias, stats, ws, silu=False)
         qkv = self._new(B, x.H, x.W, 3 * C)
         ci = self._packed(ab.project_in, save)
-        ops.conv2d(hn, ci.wf.data_ptr(), qkv.ptr, qkv.ld, 3 * C, 1, 1, x.H, x.W, bias=ab.project_in.bias.data_ptr())
+        ops.conv2d(hn, ci.wf.data_ptr(), qkv.ptr, qkv.ld, 3 * C, 1, 1, x.H, x.W, bias=ab.project_in.bias.data_ptr(), splitk=self.splitk)
         es, bs = self.es, Lk * 3 * C
         q, kk, v = qkv.ptr, qkv.ptr + C * es, qkv.ptr + 2 * C * es
         logits = self._f32(B, Lk, Lk)                       # S = Q K^T / sqrt(C)   (unet.py:46-48)
@@ -562,7 +563,7 @@ class _Engine:
         ops.gemm(prob.data_ptr(), Lk, Lk * Lk, 0, v, 3 * C, bs, 1, o.ptr, C, Lk * C, Lk, C, Lk, self.dcode, batch=B)
         co = self._packed(ab.project_out, save)
         ops.conv2d(o, co.wf.data_ptr(), out.ptr, out.ld, C, 1, 1, x.H, x.W, bias=ab.project_out.bias.data_ptr(),
-                   res_ptr=x.ptr, res_ld=x.ld)
+                   res_ptr=x.ptr, res_ld=x.ld, splitk=self.splitk)
         if save:
             st["tape"].append(("attn", ab, x, out, hn, stats, qkv, prob, o))
 
@@ -586,7 +587,7 @@ class _Engine:
         dy = self._new(B, H, W, cw.Np)                          # NCHW fp32 grad -> channel-padded NHWC
         _hip.call("ddpm_nchw_to_nhwc", gout.data_ptr(), dy.ptr, B, m.out_channels, H * W, cw.Np, self.dcode, _hip.stream())
         dact = self._new(B, H, W, self.hid)
-        ops.conv2d(dy, cw.wd.data_ptr(), dact.ptr, dact.ld, self.hid, 3, 3, H, W, pad_t=1, pad_l=1)
+        ops.conv2d(dy, cw.wd.data_ptr(), dact.ptr, dact.ld, self.hid, 3, 3, H, W, pad_t=1, pad_l=1, splitk=self.splitk)
         ops.conv2d_wgrad(dy, act, self._pptr(ctx, conv.weight), self.hid, cw.N, 3, 3, pad_t=1, pad_l=1, splits=self._splits(cw.N, 9 * self.hid, B * H * W))
         self._bias_grad(ctx, dy, [conv.bias], cw.N)
         g, acc = self._grad_target(cur)
@@ -640,13 +641,13 @@ class _Engine:
             return                                          # no gradient w.r.t. the input image
         if upsample:
             tmp = self._new(B, dy.H, dy.W, cw.C)            # dgrad at the upsampled resolution, then 2x2 sum
-            ops.conv2d(dy, cw.wd.data_ptr(), tmp.ptr, tmp.ld, cw.C, k, k, dy.H, dy.W, pad_t=k - 1 - pt, pad_l=k - 1 - pl)
+            ops.conv2d(dy, cw.wd.data_ptr(), tmp.ptr, tmp.ld, cw.C, k, k, dy.H, dy.W, pad_t=k - 1 - pt, pad_l=k - 1 - pl, splitk=self.splitk)
             g, acc = self._grad_target(x)
             _hip.call("ddpm_upsample2x_bwd", tmp.ptr, g.ptr, g.ld, B, x.H, x.W, cw.C, acc, self.dcode, _hip.stream())
         else:
             g, acc = self._grad_target(x)
             ops.conv2d(dy, cw.wd.data_ptr(), g.ptr, g.ld, cw.C, k, k, x.H, x.W, pad_t=k - 1 - pt, pad_l=k - 1 - pl,
-                       dilate=1 if stride == 2 else 0, accumulate=acc)
+                       dilate=1 if stride == 2 else 0, accumulate=acc, splitk=self.splitk)
 
     def _res_bwd(self, ctx, rec):
         _, rb, x, out, a1, stats1, h1, a2, stats2, seed, parts = rec
@@ -658,7 +659,7 @@ class _Engine:
         c1, c2 = self.convs[id(rb.conv1)], self.convs[id(rb.conv2)]
         # conv2
         da2 = self._new(B, x.H, x.W, Cout)
-        ops.conv2d(dout, c2.wd.data_ptr(), da2.ptr, da2.ld, Cout, 3, 3, x.H, x.W, pad_t=1, pad_l=1)
+        ops.conv2d(dout, c2.wd.data_ptr(), da2.ptr, da2.ld, Cout, 3, 3, x.H, x.W, pad_t=1, pad_l=1, splitk=self.splitk)
         ops.conv2d_wgrad(dout, a2, self._pptr(ctx, rb.conv2.weight), Cout, Cout, 3, 3, pad_t=1, pad_l=1, splits=self._splits(Cout, 9 * Cout, dout.rows))
         self._bias_grad(ctx, dout, [rb.conv2.bias, rb.skip.bias] if rb.has_skip else [rb.conv2.bias], Cout)
         # GN2 + SiLU + dropout
@@ -669,7 +670,7 @@ class _Engine:
         ops.colsum(dh1, ctx["dtb"].data_ptr() + 4 * self.tb_off[id(rb)], self.tb_total, 0)
         # conv1
         da1 = self._new(B, x.H, x.W, Cin)
-        ops.conv2d(dh1, c1.wd.data_ptr(), da1.ptr, da1.ld, Cin, 3, 3, x.H, x.W, pad_t=1, pad_l=1)
+        ops.conv2d(dh1, c1.wd.data_ptr(), da1.ptr, da1.ld, Cin, 3, 3, x.H, x.W, pad_t=1, pad_l=1, splitk=self.splitk)
         ops.conv2d_wgrad(dh1, a1, self._pptr(ctx, rb.conv1.weight), Cin, Cout, 3, 3, pad_t=1, pad_l=1, splits=self._splits(Cout, 9 * Cin, dh1.rows))
         # GN1 + SiLU, then the skip path, into d(x)
         g, acc = self._grad_target(x)
@@ -677,7 +678,7 @@ class _Engine:
                    ws, silu=True, accumulate=acc)
         if rb.has_skip:
             cs = self.convs[id(rb.skip)]
-            ops.conv2d(dout, cs.wd.data_ptr(), g.ptr, g.ld, Cin, 1, 1, x.H, x.W, accumulate=1)
+            ops.conv2d(dout, cs.wd.data_ptr(), g.ptr, g.ld, Cin, 1, 1, x.H, x.W, accumulate=1, splitk=self.splitk)
             ops.conv2d_wgrad(dout, x, self._pptr(ctx, rb.skip.weight), Cin, Cout, 1, 1, splits=self._splits(Cout, Cin, dout.rows))
         else:
             ops.add_rows(dout, g, 1)
@@ -696,7 +697,7 @@ class _Engine:
         es, bs = self.es, Lk * 3 * C
         # project_out
         do = self._new(B, x.H, x.W, C)
-        ops.conv2d(dout, co.wd.data_ptr(), do.ptr, do.ld, C, 1, 1, x.H, x.W)
+        ops.conv2d(dout, co.wd.data_ptr(), do.ptr, do.ld, C, 1, 1, x.H, x.W, splitk=self.splitk)
         ops.conv2d_wgrad(dout, o, self._pptr(ctx, ab.project_out.weight), C, C, 1, 1, splits=self._splits(C, C, dout.rows))
         self._bias_grad(ctx, dout, [ab.project_out.bias], C)
         # attention core
@@ -714,7 +715,7 @@ class _Engine:
         ops.gemm(ds.data_ptr(), Lk, Lk * Lk, 1, q, 3 * C, bs, 1, dk, 3 * C, bs, Lk, C, Lk, self.dcode, batch=B, alpha=scale)    # dK = dS^T Q
         # project_in
         dhn = self._new(B, x.H, x.W, C)
-        ops.conv2d(dqkv, ci.wd.data_ptr(), dhn.ptr, dhn.ld, C, 1, 1, x.H, x.W)
+        ops.conv2d(dqkv, ci.wd.data_ptr(), dhn.ptr, dhn.ld, C, 1, 1, x.H, x.W, splitk=self.splitk)
         ops.conv2d_wgrad(dqkv, hn, self._pptr(ctx, ab.project_in.weight), C, 3 * C, 1, 1, splits=self._splits(3 * C, C, dqkv.rows))
         self._bias_grad(ctx, dqkv, [ab.project_in.bias], 3 * C)
         # GN (no SiLU) + identity residual
@@ -732,8 +733,8 @@ class _Engine:
         dW = self._f32(Ct, E)
         ops.gemm(dtb.data_ptr(), Ct, 0, 1, s_t.data_ptr(), E, 0, 1, dW.data_ptr(), E, 0, Ct, E, B, F, out_mode=1)
         db = dtb.sum(0)
-        ds_t = self._f32(B, E)
-        ops.gemm(dtb.data_ptr(), Ct, 0, 0, fc_w.data_ptr(), E, 0, 1, ds_t.data_ptr(), E, 0, B, E, Ct, F, out_mode=1)
+        ds_t = torch.zeros((B, E), dtype=torch.float32, device=self.device)     # K = sum Cout (~5000): split-K with fp32 atomics
+        ops.gemm(dtb.data_ptr(), Ct, 0, 0, fc_w.data_ptr(), E, 0, 1, ds_t.data_ptr(), E, 0, B, E, Ct, F, out_mode=2, splits=max(1, Ct // 256))
         for rb in self.res_blocks:
             o, c = self.tb_off[id(rb)], rb.out_channels
             gw, gb, gc = self.goff[id(rb.fc.weight)], self.goff[id(rb.fc.bias)], self.goff[id(rb.conv1.bias)]

@@ -27,13 +27,16 @@ extern "C" {
  *                  + bias[n] + rowbias[b*rowbias_ld + n] + residual[b,oy,ox,n]      (+ y when accumulate)
  * f = identity | v>>1 (upsample=1, H/W are the stored low-res dims) | v/2 for even v only (dilate=1: the dgrad
  * of a stride-2 conv).  w is packed [N][R][S][C] in dtype (ddpm_pack_weight).  dgrad = same call on dy with the
- * flipped/transposed pack and pad = R-1-pad.  out_mode: 0 NHWC dtype (pitch y_ld) | 1 NHWC fp32 | 3 NCHW fp32. */
+ * flipped/transposed pack and pad = R-1-pad.  out_mode: 0 NHWC dtype (pitch y_ld) | 1 NHWC fp32 | 3 NCHW fp32.
+ * splits > 1 splits K over blocks and reduces in-launch (for layers with few output tiles): splitk_ws holds
+ * ceil(M/128)*ceil(N/128)*splits*16384 floats, splitk_cnt one zero-initialised counter per tile (left zero). */
 int ddpm_conv2d_nhwc(const void* x, long long x_ld, const void* w, void* y, long long y_ld,
                      const float* bias, const float* rowbias, long long rowbias_ld,
                      const void* residual, long long res_ld,
                      int B, int H, int W, int C, int Ho, int Wo, int N, int R, int S,
                      int stride, int pad_t, int pad_l, int upsample, int dilate,
-                     int accumulate, int out_mode, int dtype, void* stream);
+                     int accumulate, int out_mode, int splits, float* splitk_ws, unsigned* splitk_cnt,
+                     int dtype, void* stream);
 
 /* convolution_backward w.r.t. the weight (autograd of the sites above), into a PACKED gradient [Nreal][R][S][Creal]:
  *   dw[n][r][s][c] += sum_{b,oy,ox} dy[b,oy,ox,n] * x[b, f(..), f(..), c]      n < Nreal, c < Creal (fp32 atomics)

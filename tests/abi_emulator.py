@@ -113,7 +113,7 @@ class Emulator:
 
     # ------------------------------------------------------------------ conv / gemm
     def ddpm_conv2d_nhwc(self, x, x_ld, w, y, y_ld, bias, rowbias, rb_ld, res, res_ld, B, H, W, C, Ho, Wo, N, R, S,
-                         stride, pad_t, pad_l, ups, dil, acc, mode, dt, st):
+                         stride, pad_t, pad_l, ups, dil, acc, mode, splits, skws, skcnt, dt, st):
         xin = torch.from_numpy(Mat(x, B * H * W, C, x_ld, dt).get()).reshape(B, H, W, C).permute(0, 3, 1, 2)
         wt = torch.from_numpy(Mat(w, N, R * S * C, R * S * C, dt).get()).reshape(N, R, S, C).permute(0, 3, 1, 2)
         can = _canvas(xin, Ho, Wo, R, S, stride, pad_t, pad_l, ups, dil)

@@ -83,14 +83,33 @@ def test_conv_fwd(case, dt):
     y = r(B * Ho * Wo, yld, seed=6, dt=dt)
     for acc in (0, 1):
         both("ddpm_conv2d_nhwc", A(x), ld, A(w), A(y.clone(), out=True, name="y"), yld, A(bias), A(rowb), N + 8, A(res), yld,
-             B, H, W, C, Ho, Wo, N, R, R, stride, pt, pl, ups, dil, acc, 0, dt, tol=TOL[dt])
+             B, H, W, C, Ho, Wo, N, R, R, stride, pt, pl, ups, dil, acc, 0, 1, None, None, dt, tol=TOL[dt])
     # fp32 output modes (NHWC fp32, NCHW fp32) without the optional operands
     y32 = torch.zeros(B * Ho * Wo, N)
     both("ddpm_conv2d_nhwc", A(x), ld, A(w), A(y32, out=True, name="y32"), N, None, None, 0, None, 0,
-         B, H, W, C, Ho, Wo, N, R, R, stride, pt, pl, ups, dil, 0, 1, dt, tol=TOL[0] if dt == 0 else 4e-3)
+         B, H, W, C, Ho, Wo, N, R, R, stride, pt, pl, ups, dil, 0, 1, 1, None, None, dt, tol=TOL[0] if dt == 0 else 4e-3)
     ynchw = torch.zeros(B, N, Ho, Wo)
     both("ddpm_conv2d_nhwc", A(x), ld, A(w), A(ynchw, out=True, name="nchw"), 0, A(bias), None, 0, None, 0,
-         B, H, W, C, Ho, Wo, N, R, R, stride, pt, pl, ups, dil, 0, 3, dt, tol=TOL[0] if dt == 0 else 4e-3)
+         B, H, W, C, Ho, Wo, N, R, R, stride, pt, pl, ups, dil, 0, 3, 1, None, None, dt, tol=TOL[0] if dt == 0 else 4e-3)
+
+
+@pytest.mark.parametrize("dt", [0, 1])
+@pytest.mark.parametrize("splits", [2, 5, 9])
+def test_conv_fwd_inlaunch_splitk(dt, splits):
+    """Small-M layers: K split over blocks, partial tiles reduced inside the launch by the last arriver (all epilogue
+    fusions still applied once); counters must be back at zero so the next launch needs no memset."""
+    B, H, C, N, R = 16, 4, 256, 256, 3
+    M = B * H * H
+    x, w = r(M, C, seed=1, dt=dt), r(N, 9 * C, seed=2, dt=dt, scale=0.02)
+    bias, rowb, res = r(N, seed=3), r(B, N, seed=4), r(M, N, seed=5, dt=dt)
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    ws, cnt = torch.zeros(tiles * splits * 16384), torch.zeros(tiles, dtype=torch.int32)
+    for rep in range(2):
+        y = r(M, N, seed=6, dt=dt)
+        wsd, cntd = ws.cuda(), cnt.cuda()
+        for acc in (0, 1):
+            both("ddpm_conv2d_nhwc", A(x), C, A(w), A(y.clone(), out=True, name="y"), N, A(bias), A(rowb), N, A(res), N,
+                 B, H, H, C, H, H, N, R, R, 1, 1, 1, 0, 0, acc, 0, splits, A(ws), A(cnt, out=True, name="cnt"), dt, tol=TOL[dt])
 
 
 @pytest.mark.parametrize("dt", [0, 1])
@@ -99,7 +118,7 @@ def test_conv_out3_channels_nchw(dt):
     x, w = r(B * H * H, C, seed=1, dt=dt), r(N, 9 * C, seed=2, dt=dt, scale=0.03)
     y = torch.zeros(B, N, H, H)
     both("ddpm_conv2d_nhwc", A(x), C, A(w), A(y, out=True, name="y"), 0, A(r(N, seed=3)), None, 0, None, 0,
-         B, H, H, C, H, H, N, 3, 3, 1, 1, 1, 0, 0, 0, 3, dt, tol=TOL[0] if dt == 0 else 4e-3)
+         B, H, H, C, H, H, N, 3, 3, 1, 1, 1, 0, 0, 0, 3, 1, None, None, dt, tol=TOL[0] if dt == 0 else 4e-3)
 
 
 WGRAD_CASES = [

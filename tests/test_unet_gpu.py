@@ -139,6 +139,25 @@ def test_sampling_loops_vs_reference_fixture(golden):
     assert a.is_cuda and a.shape == (2, 3, 8, 8) and torch.isfinite(a).all() and torch.equal(a, b)   # inference is bit-deterministic
 
 
+def test_graph_replayed_sampler_equals_eager_loop(golden, monkeypatch):
+    """The hipGraph-replayed loop must consume the RNG stream and produce results exactly like the eager loop."""
+    m, _ = tiny_from_golden(golden("g3_model.pt"))
+    m.eval()
+    betas = ddpm_torch.get_beta_schedule("linear", 1e-4, 0.02, 200)
+    dif = ddpm_torch.GaussianDiffusion(betas, "eps", "fixed-large", "mse")
+    dd = ddim_mod.DDIM(ddpm_torch.get_beta_schedule("linear", 1e-4, 0.02, 1000), "eps", "fixed-small", "mse", eta=1.0,
+                       subsequence=ddim_mod.get_selection_schedule("quadratic", 40, 1000))
+    for sampler in (dif, dd):
+        outs = {}
+        for mode in ("1", "0"):
+            monkeypatch.setenv("DDPM_TORCH_AMD_GRAPH", mode)
+            outs[mode] = sampler.p_sample(m, shape=(3, 3, 8, 8), device=DEV, seed=77)
+            torch.manual_seed(5)
+            outs[mode + "d"] = sampler.p_sample(m, shape=(3, 3, 8, 8), device=DEV)          # default generator path
+        assert torch.equal(outs["1"], outs["0"]), float((outs["1"] - outs["0"]).abs().max())
+        assert torch.equal(outs["1d"], outs["0d"]), float((outs["1d"] - outs["0d"]).abs().max())
+
+
 def test_trainer_steps_vs_reference_fixture(golden):
     g = golden("g7_train.pt")
     torch.manual_seed(g["init_seed"])
