@@ -30,7 +30,9 @@ struct MatDesc {
     int trans;                // 0: slow index = M/N index, fast (contiguous) = K.  1: slow = K, fast = M/N
     int conv;                 // 1: slow = output pixel, fast = (r*S+s)*C + c gathered from NHWC (pixel pitch ld)
     int n_slow, n_fast;       // logical extents (rows beyond are zero)
+    unsigned extent_bytes;    // bytes addressable from (p + batch*batch_stride): bound of the buffer descriptor (< 2 GiB)
     int H, W, C, Ho, Wo, R, S, stride, pad_t, pad_l;
+    int conv_batches;         // conv: images in the NHWC tensor (extent = conv_batches*H*W pixels)
     int sh;                   // 1 when the virtual input grid is 2x the stored one (upsample or dilation)
     int dmask;                // 1 for dilation-2 (only even virtual coordinates exist), else 0
     FastDiv dHoWo, dWo, dC, dS;
@@ -86,10 +88,6 @@ constexpr int NTHREADS = 256;
 constexpr int ROW_BYTES = 128; // LDS row pitch: 128 B of K data, unpadded (XOR-swizzled chunks)
 constexpr int NVEC = 4;        // 16-byte vectors per thread per operand per K-step
 
-// 16 zero bytes that padded taps, K-tails and rows beyond the matrix are fetched from (direct-to-LDS loads cannot
-// produce zeros by themselves).  Static device memory: nothing is allocated at run time.
-__device__ __attribute__((aligned(16))) unsigned g_zero_page[4];
-
 // LDS operand tile: 128 rows x 128 bytes (64 bf16 / 32 fp32 of K), UNPADDED, with the 16-byte chunk index XOR-swizzled
 // by ((row>>1) & 7): element (row, chunk c) lives at row*128 + ((c ^ ((row>>1)&7)) * 16).  Two consecutive rows span one
 // 256-byte bank row, so the key must be distinct over the 8 even (odd) rows of each ds_read_b128 16-lane group
@@ -97,59 +95,69 @@ __device__ __attribute__((aligned(16))) unsigned g_zero_page[4];
 // contiguous, which the LDS-DMA loads require.
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * ROW_BYTES + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
-// Per-thread loader state for one operand tile (TILE rows x BK k).
-//  !TRANS (memory is k-contiguous): `global_load_lds_dwordx4` — data goes HBM/L2 -> LDS without touching VGPRs.  Lane l of
-//          wave w fetches, for i = 0..3, row w*8 + l/8 + 32 i, PHYSICAL chunk l%8, i.e. logical k-chunk (l%8) ^ ((row>>1)&7):
-//          the swizzle is applied on the per-lane SOURCE address, the LDS image stays lane-linear.
+// Per-thread loader state for one operand tile (TILE rows x BK k).  All global reads go through a raw buffer descriptor
+// (base = operand pointer of this batch, num_records = its extent): addressing is one 32-bit byte offset per vector and
+// the hardware range check returns ZEROS for any offset >= num_records — padded taps, K-tails and rows beyond the matrix
+// simply use the offset OOB (verified on gfx950 also for the direct-to-LDS form: scripts/probes/buffer_lds_oob.hip).
+//  !TRANS (memory is k-contiguous): `buffer_load_dwordx4 ... lds` — HBM/L2 -> LDS without touching VGPRs.  Lane l of wave w
+//          fetches, for i = 0..3, row w*8 + l/8 + 32 i, PHYSICAL chunk l%8, i.e. logical k-chunk (l%8) ^ ((row>>1)&7):
+//          the swizzle is applied on the per-lane SOURCE offset, the LDS image stays lane-linear.
 //   TRANS (k is the slow memory index): each thread owns a 4(k) x VEC(m) block — k-quad kq = tid % (BK/4) fastest over
 //          lanes, m-group ng = tid / (BK/4) — loads its 4 k-rows as 16-byte vectors, transposes in registers and writes
 //          VEC k-contiguous 4-element runs (ds_write_b64 bf16 / ds_write_b128 fp32) into the swizzled image.
+constexpr unsigned OOB = 0x7ffffff0u;
+
 template <typename T, bool TRANS>
 struct Loader {
     static constexpr int VEC = Elem<T>::VEC;
     static constexpr int BK = 8 * VEC;
     static constexpr int KQ = BK / 4;
+    static constexpr int ES = (int)sizeof(T);
 
     const MatDesc& d;
-    const T* base;
+    __amdgpu_buffer_rsrc_t rsrc;
     int tile0;
-    int kv, row0, wave;           // !TRANS: logical k-chunk, first tile row, wave id
+    int kv, wave, row0;           // !TRANS: logical k-chunk, wave id, first tile row
     int kq, ng;                   // TRANS
-    long long roff[NVEC];         // !TRANS: element offset of the row (plain) or of pixel (b, y0, x0) (conv)
+    int roff[NVEC];               // !TRANS: byte offset of the row (plain; OOB when the row is outside) or of pixel (b, y0, x0) (conv)
     unsigned tapmask[NVEC];       // !TRANS conv without up/down-scaling: bit (r*S+s) set when the tap is inside the image
-    int pb[NVEC], py[NVEC], px[NVEC];
-    bool rvalid[NVEC];
-    int tr, ts, tc; bool fvalid;
+    int tr, ts, tc; unsigned foff;   // TRANS: fixed tap/channel (conv) or fixed byte offset along the fast index (plain, OOB if outside)
 
     __device__ __forceinline__ Loader(const MatDesc& d_, int batch, int tile0_, int tid) : d(d_) {
-        base = reinterpret_cast<const T*>(d.p) + (long long)batch * d.batch_stride;
+        const T* base = reinterpret_cast<const T*>(d.p) + (long long)batch * d.batch_stride;
+        rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(base), 0, (int)d.extent_bytes, 0x00020000);
         tile0 = tile0_;
         if (!TRANS) {
-            row0 = tid >> 3; wave = tid >> 6;
+            row0 = tid >> 3;
+            wave = __builtin_amdgcn_readfirstlane(tid >> 6);
             kv = (tid & 7) ^ ((row0 >> 1) & 7);
 #pragma unroll
             for (int i = 0; i < NVEC; ++i) {
-                int m = tile0 + row0 + 32 * i;
-                rvalid[i] = m < d.n_slow;
-                if (d.conv) {
-                    decode_pixel(rvalid[i] ? m : 0, pb[i], py[i], px[i]);
-                    roff[i] = ((long long)(pb[i] * d.H + py[i]) * d.W + px[i]) * d.ld;
-                    unsigned mk = 0;
-                    for (int r = 0; r < d.R; ++r)
-                        for (int s2 = 0; s2 < d.S; ++s2)
-                            if ((unsigned)(py[i] + r) < (unsigned)d.H && (unsigned)(px[i] + s2) < (unsigned)d.W) mk |= 1u << (r * d.S + s2);
-                    tapmask[i] = rvalid[i] ? mk : 0u;
-                } else {
-                    roff[i] = (long long)m * d.ld;
-                }
+                const int m = tile0 + row0 + 32 * i;
+                const bool valid = m < d.n_slow;
+                // both addressing forms are computed and SELECTED (no divergent stores into the state arrays -> registers)
+                int b, y0, x0;
+                decode_pixel(valid ? m : 0, b, y0, x0);
+                const int conv_off = (int)((((long long)(b * d.H + y0) * d.W + x0) * d.ld) * ES);
+                const int plain_off = valid ? (int)((long long)m * d.ld * ES) : (int)OOB;
+                // taps inside the image: rows r in [max(0,-y0), min(R, H-y0)), columns likewise (closed form, R,S <= 5)
+                const int rlo = min(max(-y0, 0), d.R), rhi = min(max(d.H - y0, 0), d.R);
+                const int slo = min(max(-x0, 0), d.S), shi = min(max(d.W - x0, 0), d.S);
+                const unsigned vy = ((1u << rhi) - 1u) & ~((1u << rlo) - 1u), vx = ((1u << shi) - 1u) & ~((1u << slo) - 1u);
+                unsigned mk = 0;
+#pragma unroll
+                for (int r = 0; r < 5; ++r) mk |= ((vy >> r) & 1u) ? vx << (r * d.S) : 0u;
+                roff[i] = d.conv ? conv_off : plain_off;
+                tapmask[i] = (d.conv && valid) ? mk : 0u;
             }
         } else {
             kq = tid % KQ; ng = tid / KQ;
-            int f = tile0 + ng * VEC;
-            fvalid = f < d.n_fast;
+            const int f = tile0 + ng * VEC;
+            const bool fvalid = f < d.n_fast;
+            foff = fvalid ? (unsigned)(f * ES) : OOB;
             if (d.conv) {
                 unsigned tap = fdiv((unsigned)(fvalid ? f : 0), d.dC);
-                tc = (fvalid ? f : 0) - (int)tap * d.C;
+                tc = fvalid ? f - (int)tap * d.C : -1;      // tc < 0 marks "outside"
                 tr = (int)fdiv(tap, d.dS); ts = (int)tap - tr * d.S;
             }
         }
@@ -163,58 +171,71 @@ struct Loader {
         b = (int)bb; y0 = (int)oy * d.stride - d.pad_t; x0 = (int)ox * d.stride - d.pad_l;
     }
 
-    // address of the 16-byte vector at virtual pixel (y0+r, x0+s), channel c — or the zero page
-    __device__ __forceinline__ const T* gather_ptr(int b, int y0, int x0, int r, int s, int c) const {
+    // byte offset of the 16-byte vector at virtual pixel (y0+r, x0+s), channel c — or OOB
+    __device__ __forceinline__ unsigned gather_off(int b, int y0, int x0, int r, int s, int c) const {
         unsigned uy = (unsigned)(y0 + r), ux = (unsigned)(x0 + s);
         bool ok = ((uy | ux) & (unsigned)d.dmask) == 0;
         uy >>= d.sh; ux >>= d.sh;
         ok = ok && uy < (unsigned)d.H && ux < (unsigned)d.W;
-        long long off = ((long long)(b * d.H + (int)uy) * d.W + (int)ux) * d.ld + c;
-        return ok ? base + off : reinterpret_cast<const T*>(g_zero_page);
+        const unsigned off = (unsigned)(((b * d.H + (int)uy) * d.W + (int)ux) * (int)d.ld + c) * ES;
+        return ok ? off : OOB;
     }
 
     // !TRANS: enqueue the direct-to-LDS loads of the K-step starting at k0 into `tile`
     __device__ __forceinline__ void issue(int k0, int k_end, char* tile) const {
-        const T* zp = reinterpret_cast<const T*>(g_zero_page);
         const int k = k0 + kv * VEC;
         const bool kok = k < k_end;
-        const T* src[NVEC];
+        unsigned off[NVEC];
         if (d.conv) {
             unsigned tap = fdiv((unsigned)k, d.dC);
-            int c = k - (int)tap * d.C;
+            const int c = k - (int)tap * d.C;
+            const int r = (int)fdiv(tap, d.dS), s = (int)tap - r * d.S;
             if (d.sh == 0) {
-                int r = (int)fdiv(tap, d.dS), s = (int)tap - r * d.S;
-                const long long tapoff = (long long)(r * d.W + s) * d.ld + c;
+                const int tapoff = ((r * d.W + s) * (int)d.ld + c) * ES;
+                tap = kok ? tap : 31u;                          // bit 31 is never set: K-tail reads zeros
 #pragma unroll
-                for (int i = 0; i < NVEC; ++i) src[i] = (kok && ((tapmask[i] >> tap) & 1u)) ? base + roff[i] + tapoff : zp;
+                for (int i = 0; i < NVEC; ++i) off[i] = ((tapmask[i] >> tap) & 1u) ? (unsigned)(roff[i] + tapoff) : OOB;
             } else {
-                int r = (int)fdiv(tap, d.dS), s = (int)tap - r * d.S;
 #pragma unroll
-                for (int i = 0; i < NVEC; ++i) src[i] = (kok && rvalid[i]) ? gather_ptr(pb[i], py[i], px[i], r, s, c) : zp;
+                for (int i = 0; i < NVEC; ++i) {        // up/down-scaled maps (6 convs per pass): decode on the fly
+                    const int m = tile0 + row0 + 32 * i;
+                    int b, y0, x0;
+                    decode_pixel(m < d.n_slow ? m : 0, b, y0, x0);
+                    off[i] = (kok && m < d.n_slow) ? gather_off(b, y0, x0, r, s, c) : OOB;
+                }
             }
         } else {
+            const unsigned koff = kok ? (unsigned)(k * ES) : OOB;
 #pragma unroll
-            for (int i = 0; i < NVEC; ++i) src[i] = (kok && rvalid[i]) ? base + roff[i] + k : zp;
+            for (int i = 0; i < NVEC; ++i) off[i] = (unsigned)roff[i] + koff;     // OOB + small stays out of range
         }
 #pragma unroll
         for (int i = 0; i < NVEC; ++i)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src[i],
-                                             (__attribute__((address_space(3))) void*)(tile + (wave * 8 + 32 * i) * ROW_BYTES), 16, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(tile + (wave * 8 + 32 * i) * ROW_BYTES),
+                                                     16, off[i], 0, 0, 0);
     }
 
     // TRANS: fetch this thread's 4 k-rows of the K-step starting at k0
     __device__ __forceinline__ void load(int k0, int k_end, u32x4 (&v)[NVEC]) const {
+        const int kb = k0 + kq * 4;
+        if (d.conv) {
+            int b, y0, x0;
+            decode_pixel(kb < k_end ? kb : 0, b, y0, x0);
+            const int xend = d.Wo * d.stride - d.pad_l, yend = d.Ho * d.stride - d.pad_t;
 #pragma unroll
-        for (int i = 0; i < NVEC; ++i) {
-            int k = k0 + kq * 4 + i;
-            bool ok = fvalid && k < k_end;
-            if (!ok) { v[i] = zero16(); continue; }
-            if (d.conv) {
-                int b, y0, x0;
-                decode_pixel(k, b, y0, x0);
-                v[i] = ldg16(gather_ptr(b, y0, x0, tr, ts, tc));
-            } else {
-                v[i] = ldg16(base + (long long)k * d.ld + tile0 + ng * VEC);
+            for (int i = 0; i < NVEC; ++i) {
+                const bool ok = tc >= 0 && kb + i < k_end;
+                const unsigned o = ok ? gather_off(b, y0, x0, tr, ts, tc) : OOB;
+                v[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o, 0, 0));
+                x0 += d.stride;                                   // next output pixel (row-major over b, oy, ox)
+                if (x0 == xend) { x0 = -d.pad_l; y0 += d.stride; if (y0 == yend) { y0 = -d.pad_t; ++b; } }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NVEC; ++i) {
+                const int k = kb + i;
+                const unsigned o = k < k_end ? (unsigned)((long long)k * d.ld * ES) + foff : OOB;
+                v[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o, 0, 0));
             }
         }
     }
@@ -339,9 +360,15 @@ __device__ __forceinline__ void epilogue_scatter(const Epilogue& ep, const float
     }
 }
 
-template <typename T, bool TA, bool TB>
+// NBUF = 2: classic double buffer, 64 KiB of operand LDS -> two blocks per CU overlap each other's memory latency.
+// NBUF = 3 (both operands k-contiguous only): a 3-deep LDS-DMA ring — the tile two steps ahead is already in flight and
+//           each step waits with a COUNTED s_waitcnt vmcnt(8) (the newest tile's 8 DMA instructions stay outstanding)
+//           behind a raw s_barrier.  Used when the grid cannot put two blocks on every CU (small-M layers), where a
+//           single block would otherwise expose one full memory latency per K-step.
+template <typename T, bool TA, bool TB, int NBUF>
 __global__ __launch_bounds__(NTHREADS, 2)
 void gemm_kernel(MatDesc A, MatDesc B, Epilogue ep, int M, int N, int K, int k_per_split, int tiles_n) {
+    static_assert(NBUF == 2 || (!TA && !TB), "the deep ring needs direct-to-LDS loads on both operands");
     constexpr int VEC = Elem<T>::VEC;
     constexpr int BK = 8 * VEC;
     constexpr int KF = Mma<T>::KF;
@@ -366,24 +393,52 @@ void gemm_kernel(MatDesc A, MatDesc B, Epilogue ep, int M, int N, int K, int k_p
         for (int j = 0; j < 2; ++j) acc[i][j] = (f32x16)(0.f);
 
     u32x4 va[NVEC], vb[NVEC];
-    // stage K-step 0
-    if (!TA) la.issue(k_begin, k_end, smem); else { la.load(k_begin, k_end, va); la.store(smem, va); }
-    if (!TB) lb.issue(k_begin, k_end, smem + TILE_BYTES); else { lb.load(k_begin, k_end, vb); lb.store(smem + TILE_BYTES, vb); }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
     const int nsteps = (k_end - k_begin + BK - 1) / BK;
+    // stage the first NBUF-1 K-steps
+    if (NBUF == 2) {
+        if (!TA) la.issue(k_begin, k_end, smem); else { la.load(k_begin, k_end, va); la.store(smem, va); }
+        if (!TB) lb.issue(k_begin, k_end, smem + TILE_BYTES); else { lb.load(k_begin, k_end, vb); lb.store(smem + TILE_BYTES, vb); }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    } else {
+        if constexpr (!TA && !TB) {
+            la.issue(k_begin, k_end, smem);
+            lb.issue(k_begin, k_end, smem + TILE_BYTES);
+            if (nsteps > 1) {
+                la.issue(k_begin + BK, k_end, smem + 2 * TILE_BYTES);
+                lb.issue(k_begin + BK, k_end, smem + 3 * TILE_BYTES);
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");       // tile 0 landed, tile 1 (8 DMA instructions) in flight
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+        }
+    }
+
     // fragment reads: row (lane&31) of the wave's 32-row block, logical 16-byte chunk 2*kc + (lane>>5), swizzle key (row>>1)&7
     const int frag_row = (lane & 31) * ROW_BYTES;
     const int sw = (lane >> 5) ^ ((lane >> 1) & 7);
+    int cur_i = 0;                                            // ring slot of K-step s
     for (int s = 0; s < nsteps; ++s) {
-        const char* cur = smem + (s & 1) * 2 * TILE_BYTES;
-        char* nxt = smem + ((s + 1) & 1) * 2 * TILE_BYTES;
+        const char* cur = smem + cur_i * 2 * TILE_BYTES;
+        const int nxt_i = cur_i + 1 == NBUF ? 0 : cur_i + 1;
+        char* nxt = smem + nxt_i * 2 * TILE_BYTES;
         const bool more = s + 1 < nsteps;
-        if (more) {       // the other buffer was last read in step s-1: every wave is past that barrier
-            const int kn = k_begin + (s + 1) * BK;
-            if (!TA) la.issue(kn, k_end, nxt); else la.load(kn, k_end, va);
-            if (!TB) lb.issue(kn, k_end, nxt + TILE_BYTES); else lb.load(kn, k_end, vb);
+        if (NBUF == 2) {
+            if (more) {       // the other buffer was last read in step s-1: every wave is past that barrier
+                const int kn = k_begin + (s + 1) * BK;
+                if (!TA) la.issue(kn, k_end, nxt); else la.load(kn, k_end, va);
+                if (!TB) lb.issue(kn, k_end, nxt + TILE_BYTES); else lb.load(kn, k_end, vb);
+            }
+        } else {
+            if constexpr (!TA && !TB) {
+                if (s + 2 < nsteps) {   // slot of step s+2 == slot of step s-1: free since the barrier that ended step s-1
+                    const int far_i = nxt_i + 1 == NBUF ? 0 : nxt_i + 1;
+                    const int kn = k_begin + (s + 2) * BK;
+                    la.issue(kn, k_end, smem + far_i * 2 * TILE_BYTES);
+                    lb.issue(kn, k_end, smem + far_i * 2 * TILE_BYTES + TILE_BYTES);
+                }
+            }
         }
         const char* pa = cur + (wm * 64) * ROW_BYTES + frag_row;
         const char* pb = cur + TILE_BYTES + (wn * 64) * ROW_BYTES + frag_row;
@@ -401,13 +456,23 @@ void gemm_kernel(MatDesc A, MatDesc B, Epilogue ep, int M, int N, int K, int k_p
 #pragma unroll
                 for (int j = 0; j < 2; ++j) Mma<T>::run(fa[i], fb[j], acc[i][j]);
         }
-        if (more) {
-            if (TA) la.store(nxt, va);
-            if (TB) lb.store(nxt + TILE_BYTES, vb);
+        if (NBUF == 2) {
+            if (more) {
+                if (TA) la.store(nxt, va);
+                if (TB) lb.store(nxt + TILE_BYTES, vb);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the LDS-DMA of the next tile has landed
+            __syncthreads();
+        } else {
+            // tile s+1 must have landed; tile s+2 (just issued) may stay in flight across the barrier
+            if (s + 2 < nsteps) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the LDS-DMA of the next tile has landed
-        __syncthreads();
+        cur_i = nxt_i;
     }
+    if (NBUF != 2) __syncthreads();     // the epilogue staging below reuses the ring
 
     // accumulator (reg r, lane l) -> row (r&3) + 8*(r>>2) + 4*(l>>5), col l&31 of its 32x32 tile; stage as fp32 in LDS.
     float* cs = reinterpret_cast<float*>(smem);
@@ -474,13 +539,20 @@ struct GemmArgs {          // plain-C mirror filled by the extern "C" entry poin
     int M, N, K, batch, splits, dtype;
 };
 
-static void finish_desc(MatDesc& d) {
+static int finish_desc(MatDesc& d, int esize) {
+    // extent of the region one batch of the operand can touch (the buffer descriptor's num_records)
+    const long long elems = d.conv ? (long long)d.conv_batches * d.H * d.W * d.ld - (d.ld - d.C)
+                                   : (long long)(d.n_slow - 1) * d.ld + d.n_fast;
+    const long long bytes = elems * esize;
+    if (bytes <= 0 || bytes > 0x7ffffff0ll) return DDPM_ERR_SHAPE;      // 32-bit buffer offsets: operands < 2 GiB
+    d.extent_bytes = (unsigned)bytes;
     if (d.conv) {
         d.dHoWo = make_fastdiv((unsigned)(d.Ho * d.Wo));
         d.dWo = make_fastdiv((unsigned)d.Wo);
         d.dC = make_fastdiv((unsigned)d.C);
         d.dS = make_fastdiv((unsigned)d.S);
     }
+    return DDPM_OK;
 }
 
 template <typename T>
@@ -494,26 +566,27 @@ static int launch_t(GemmArgs& g, hipStream_t st) {
     if (splits > 1 && g.ep.mode != 2 && g.ep.mode != 4 && !(g.ep.splitk_ws && g.ep.splitk_cnt)) return DDPM_ERR_SHAPE;
     if (g.ep.mode == 2 || g.ep.mode == 4) { g.ep.splitk_ws = nullptr; g.ep.splitk_cnt = nullptr; }
     dim3 grid(tiles_m * tiles_n, splits, g.batch);
-    size_t lds = TILE * CS_LD * sizeof(float);            // 4 operand tiles (64 KiB) <= fp32 epilogue staging (66 KiB)
+    const size_t lds2 = TILE * CS_LD * sizeof(float);     // 4 operand tiles (64 KiB) <= fp32 epilogue staging (66 KiB)
+    const size_t lds3 = 6 * TILE * ROW_BYTES;             // 3-deep ring: 96 KiB, one block per CU
     const int kps = steps_per * BK;
-#define LAUNCH(TA, TB)                                                                                                   \
+    // deep ring when the grid cannot keep two blocks on each of the 256 CUs anyway
+    const bool deep = !g.A.trans && !g.B.trans && (long long)grid.x * grid.y * grid.z <= 384 && steps_per >= 3;
+#define LAUNCH(TA, TB, NB, LDS)                                                                                          \
     do {                                                                                                                 \
-        static bool attr_set = false;   /* 72 KiB of dynamic LDS needs the opt-in once per instantiation */             \
+        static bool attr_set = false;   /* > 64 KiB of dynamic LDS needs the opt-in once per instantiation */            \
         if (!attr_set) {                                                                                                 \
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, TA, TB>),                              \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)                \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, TA, TB, NB>),                          \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS)) != hipSuccess)              \
                 return DDPM_ERR_LAUNCH;                                                                                  \
             attr_set = true;                                                                                             \
         }                                                                                                                \
-        LAUNCH_(TA, TB);                                                                                                 \
+        hipLaunchKernelGGL((gemm_kernel<T, TA, TB, NB>), grid, dim3(NTHREADS), (LDS), st, g.A, g.B, g.ep, g.M, g.N, g.K, kps, tiles_n); \
     } while (0)
-#define LAUNCH_(TA, TB) hipLaunchKernelGGL((gemm_kernel<T, TA, TB>), grid, dim3(NTHREADS), lds, st, g.A, g.B, g.ep, g.M, g.N, g.K, kps, tiles_n)
-    if (!g.A.trans && !g.B.trans) LAUNCH(false, false);
-    else if (!g.A.trans && g.B.trans) LAUNCH(false, true);
-    else if (g.A.trans && !g.B.trans) LAUNCH(true, false);
-    else LAUNCH(true, true);
+    if (!g.A.trans && !g.B.trans) { if (deep) LAUNCH(false, false, 3, lds3); else LAUNCH(false, false, 2, lds2); }
+    else if (!g.A.trans && g.B.trans) LAUNCH(false, true, 2, lds2);
+    else if (g.A.trans && !g.B.trans) LAUNCH(true, false, 2, lds2);
+    else LAUNCH(true, true, 2, lds2);
 #undef LAUNCH
-#undef LAUNCH_
     return check_launch();
 }
 
@@ -535,7 +608,8 @@ int ddpm_gemm_launch(GemmArgs& g, hipStream_t st) {
     if ((rc = validate(g.A, es)) != DDPM_OK) return rc;
     if ((rc = validate(g.B, es)) != DDPM_OK) return rc;
     if (!g.ep.out) return DDPM_ERR_NULL;
-    finish_desc(g.A); finish_desc(g.B);
+    if ((rc = finish_desc(g.A, es)) != DDPM_OK) return rc;
+    if ((rc = finish_desc(g.B, es)) != DDPM_OK) return rc;
     {
         const int vo = g.ep.mode == 0 ? 16 / es : 4;        // elements per 16-byte output vector
         bool ok = aligned16(g.ep.out) && g.ep.ldc % vo == 0 && g.ep.out_batch_stride % vo == 0;
@@ -552,6 +626,7 @@ static void conv_desc(MatDesc& d, const void* x, long long x_ld, int npix_out, i
                       int stride, int pad_t, int pad_l, int upsample, int dilate) {
     d.p = x; d.ld = x_ld; d.batch_stride = 0; d.conv = 1;
     d.n_slow = npix_out; d.n_fast = R * S * C;
+    d.conv_batches = npix_out / (Ho * Wo);
     d.H = H; d.W = W; d.C = C; d.Ho = Ho; d.Wo = Wo; d.R = R; d.S = S; d.stride = stride; d.pad_t = pad_t; d.pad_l = pad_l;
     d.sh = (upsample || dilate) ? 1 : 0; d.dmask = dilate ? 1 : 0;
 }
