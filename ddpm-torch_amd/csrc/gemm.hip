@@ -113,6 +113,8 @@ struct Loader {
     static constexpr int BK = 8 * VEC;
     static constexpr int KQ = BK / 4;
     static constexpr int ES = (int)sizeof(T);
+    static constexpr bool TR16 = TRANS && sizeof(T) == 2;    // k-strided bf16 operand: LDS-DMA + ds_read_b64_tr_b16
+    static constexpr bool DMA = !TRANS || TR16;              // operand staged HBM/L2 -> LDS without VGPRs
 
     const MatDesc& d;
     __amdgpu_buffer_rsrc_t rsrc;
@@ -122,10 +124,15 @@ struct Loader {
     int roff[NVEC];               // !TRANS: byte offset of the row (plain; OOB when the row is outside) or of pixel (b, y0, x0) (conv)
     unsigned tapmask[NVEC];       // !TRANS conv without up/down-scaling: bit (r*S+s) set when the tap is inside the image
     int tr, ts, tc; unsigned foff;   // TRANS: fixed tap/channel (conv) or fixed byte offset along the fast index (plain, OOB if outside)
+    int krow0;                    // TRANS bf16 (LDS-DMA of the m-major image): first k-row of this thread (tid>>4), +16 per vector
 
     __device__ __forceinline__ Loader(const MatDesc& d_, int batch, int tile0_, int tid) : d(d_) {
-        const T* base = reinterpret_cast<const T*>(d.p) + (long long)batch * d.batch_stride;
-        rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(base), 0, (int)d.extent_bytes, 0x00020000);
+        // The descriptor must be PROVABLY wave-uniform or hipcc wraps every buffer op in a waterfall loop
+        // (v_readfirstlane x4 + s_and_saveexec per load): readfirstlane its inputs once.
+        const unsigned long long baddr = (unsigned long long)(reinterpret_cast<const T*>(d.p) + (long long)batch * d.batch_stride);
+        const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)baddr), bhi = __builtin_amdgcn_readfirstlane((unsigned)(baddr >> 32));
+        rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)bhi << 32) | blo), 0,
+                                                 __builtin_amdgcn_readfirstlane((int)d.extent_bytes), 0x00020000);
         tile0 = tile0_;
         if (!TRANS) {
             row0 = tid >> 3;
@@ -152,7 +159,10 @@ struct Loader {
             }
         } else {
             kq = tid % KQ; ng = tid / KQ;
-            const int f = tile0 + ng * VEC;
+            wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+            krow0 = tid >> 4;
+            // bf16: thread owns PHYSICAL 16-byte chunk tid&15 of k-rows krow0 + 16 i, i.e. logical chunk (tid&15) ^ ((krow&3)<<2)
+            const int f = TR16 ? tile0 + (((tid & 15) ^ ((krow0 & 3) << 2)) * VEC) : tile0 + ng * VEC;
             const bool fvalid = f < d.n_fast;
             foff = fvalid ? (unsigned)(f * ES) : OOB;
             if (d.conv) {
@@ -212,6 +222,28 @@ struct Loader {
 #pragma unroll
         for (int i = 0; i < NVEC; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(tile + (wave * 8 + 32 * i) * ROW_BYTES),
+                                                     16, off[i], 0, 0, 0);
+    }
+
+    // TRANS bf16: LDS-DMA of the operand AS STORED (k-rows of 128 m-elements = 256 bytes, 64 rows per K-step) with the
+    // 16-byte chunks XOR-swizzled by (krow & 3) << 2 on the source side; fragments are then formed by the hardware
+    // transpose read (ds_read_b64_tr_b16: in each 16-lane group lanes 4r..4r+3 supply row r, lane c receives column c).
+    __device__ __forceinline__ void issue_tr(int k0, int k_end, char* tile) const {
+        unsigned off[NVEC];
+#pragma unroll
+        for (int i = 0; i < NVEC; ++i) {
+            const int k = k0 + krow0 + 16 * i;
+            if (d.conv) {
+                int b, y0, x0;
+                decode_pixel(k < k_end ? k : 0, b, y0, x0);
+                off[i] = (tc >= 0 && k < k_end) ? gather_off(b, y0, x0, tr, ts, tc) : OOB;
+            } else {
+                off[i] = k < k_end ? (unsigned)((long long)k * d.ld * ES) + foff : OOB;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NVEC; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(tile + (wave * 64 + 256 * i) * 16),
                                                      16, off[i], 0, 0, 0);
     }
 
@@ -360,6 +392,30 @@ __device__ __forceinline__ void epilogue_scatter(const Epilogue& ep, const float
     }
 }
 
+// One MFMA operand fragment (8 bf16 / 4 fp32 of K per lane) for the 32-row block starting at tile row `rb`, K sub-step kc.
+template <typename T, bool TRANS>
+__device__ __forceinline__ u32x4 read_frag(const char* tile, int rb, int kc, int lane) {
+    if constexpr (TRANS && sizeof(T) == 2) {
+        // m-major image (k-rows of 256 bytes): hardware transpose read, two 4-k halves
+        typedef short s16x4 __attribute__((ext_vector_type(4)));
+        const int i16 = lane & 15;
+        const int mcol = rb + ((lane >> 4) & 1) * 16 + (i16 & 3) * 4;
+        const int krow = kc * 16 + (lane >> 5) * 8 + (i16 >> 2);
+        const int pch = (mcol >> 3) ^ (((i16 >> 2) & 3) << 2);
+        const char* p = tile + krow * 256 + pch * 16 + (mcol & 7) * 2;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p + 4 * 256));
+        u32x4 r;
+        r.x = __builtin_bit_cast(uint2, lo).x; r.y = __builtin_bit_cast(uint2, lo).y;
+        r.z = __builtin_bit_cast(uint2, hi).x; r.w = __builtin_bit_cast(uint2, hi).y;
+        return r;
+    } else {
+        // k-contiguous image: row (lane&31), logical 16-byte chunk 2*kc + (lane>>5), swizzle key (row>>1)&7
+        const int sw = (lane >> 5) ^ ((lane >> 1) & 7);
+        return *reinterpret_cast<const u32x4*>(tile + (rb + (lane & 31)) * ROW_BYTES + (((2 * kc) ^ sw) << 4));
+    }
+}
+
 // NBUF = 2: classic double buffer, 64 KiB of operand LDS -> two blocks per CU overlap each other's memory latency.
 // NBUF = 3 (both operands k-contiguous only): a 3-deep LDS-DMA ring — the tile two steps ahead is already in flight and
 //           each step waits with a COUNTED s_waitcnt vmcnt(8) (the newest tile's 8 DMA instructions stay outstanding)
@@ -393,11 +449,14 @@ void gemm_kernel(MatDesc A, MatDesc B, Epilogue ep, int M, int N, int K, int k_p
         for (int j = 0; j < 2; ++j) acc[i][j] = (f32x16)(0.f);
 
     u32x4 va[NVEC], vb[NVEC];
+    constexpr bool DMA_A = Loader<T, TA>::DMA, DMA_B = Loader<T, TB>::DMA;
+    auto stage_a = [&](int k0, char* tile) { if constexpr (TA) la.issue_tr(k0, k_end, tile); else la.issue(k0, k_end, tile); };
+    auto stage_b = [&](int k0, char* tile) { if constexpr (TB) lb.issue_tr(k0, k_end, tile); else lb.issue(k0, k_end, tile); };
     const int nsteps = (k_end - k_begin + BK - 1) / BK;
     // stage the first NBUF-1 K-steps
     if (NBUF == 2) {
-        if (!TA) la.issue(k_begin, k_end, smem); else { la.load(k_begin, k_end, va); la.store(smem, va); }
-        if (!TB) lb.issue(k_begin, k_end, smem + TILE_BYTES); else { lb.load(k_begin, k_end, vb); lb.store(smem + TILE_BYTES, vb); }
+        if constexpr (DMA_A) stage_a(k_begin, smem); else { la.load(k_begin, k_end, va); la.store(smem, va); }
+        if constexpr (DMA_B) stage_b(k_begin, smem + TILE_BYTES); else { lb.load(k_begin, k_end, vb); lb.store(smem + TILE_BYTES, vb); }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     } else {
@@ -415,9 +474,6 @@ void gemm_kernel(MatDesc A, MatDesc B, Epilogue ep, int M, int N, int K, int k_p
         }
     }
 
-    // fragment reads: row (lane&31) of the wave's 32-row block, logical 16-byte chunk 2*kc + (lane>>5), swizzle key (row>>1)&7
-    const int frag_row = (lane & 31) * ROW_BYTES;
-    const int sw = (lane >> 5) ^ ((lane >> 1) & 7);
     int cur_i = 0;                                            // ring slot of K-step s
     for (int s = 0; s < nsteps; ++s) {
         const char* cur = smem + cur_i * 2 * TILE_BYTES;
@@ -427,8 +483,8 @@ void gemm_kernel(MatDesc A, MatDesc B, Epilogue ep, int M, int N, int K, int k_p
         if (NBUF == 2) {
             if (more) {       // the other buffer was last read in step s-1: every wave is past that barrier
                 const int kn = k_begin + (s + 1) * BK;
-                if (!TA) la.issue(kn, k_end, nxt); else la.load(kn, k_end, va);
-                if (!TB) lb.issue(kn, k_end, nxt + TILE_BYTES); else lb.load(kn, k_end, vb);
+                if constexpr (DMA_A) stage_a(kn, nxt); else la.load(kn, k_end, va);
+                if constexpr (DMA_B) stage_b(kn, nxt + TILE_BYTES); else lb.load(kn, k_end, vb);
             }
         } else {
             if constexpr (!TA && !TB) {
@@ -440,16 +496,15 @@ void gemm_kernel(MatDesc A, MatDesc B, Epilogue ep, int M, int N, int K, int k_p
                 }
             }
         }
-        const char* pa = cur + (wm * 64) * ROW_BYTES + frag_row;
-        const char* pb = cur + TILE_BYTES + (wn * 64) * ROW_BYTES + frag_row;
+        const char* ta = cur;
+        const char* tb = cur + TILE_BYTES;
 #pragma unroll
         for (int kc = 0; kc < BK / KF; ++kc) {
-            const int co = ((2 * kc) ^ sw) << 4;
             u32x4 fa[2], fb[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                fa[i] = *reinterpret_cast<const u32x4*>(pa + i * 32 * ROW_BYTES + co);
-                fb[i] = *reinterpret_cast<const u32x4*>(pb + i * 32 * ROW_BYTES + co);
+                fa[i] = read_frag<T, TA>(ta, wm * 64 + i * 32, kc, lane);
+                fb[i] = read_frag<T, TB>(tb, wn * 64 + i * 32, kc, lane);
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -458,8 +513,8 @@ void gemm_kernel(MatDesc A, MatDesc B, Epilogue ep, int M, int N, int K, int k_p
         }
         if (NBUF == 2) {
             if (more) {
-                if (TA) la.store(nxt, va);
-                if (TB) lb.store(nxt + TILE_BYTES, vb);
+                if constexpr (!DMA_A) la.store(nxt, va);
+                if constexpr (!DMA_B) lb.store(nxt + TILE_BYTES, vb);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the LDS-DMA of the next tile has landed
             __syncthreads();
