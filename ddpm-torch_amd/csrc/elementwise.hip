@@ -89,6 +89,41 @@ extern "C" int ddpm_pack_weight(const float* w, void* wf, void* wd, int N, int C
     return check_launch();
 }
 
+// all layers in ONE launch: descs[i] = {w, wf, wd, N, C, R, Cp, Np} (8 x int64; R == S); grid = (blocks, n_tensors)
+template <typename T>
+__global__ void pack_weight_multi_kernel(const long long* __restrict__ descs) {
+    const long long* d = descs + 8 * (long long)blockIdx.y;
+    const float* w = reinterpret_cast<const float*>(d[0]);
+    T* wf = reinterpret_cast<T*>(d[1]);
+    T* wd = reinterpret_cast<T*>(d[2]);
+    const int N = (int)d[3], C = (int)d[4], R = (int)d[5], Cp = (int)d[6], Np = (int)d[7];
+    const int RS = R * R;
+    if (wf) {
+        const long long n = (long long)N * RS * Cp;
+        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+            const int c = (int)(i % Cp); const long long r1 = i / Cp;
+            const int tap = (int)(r1 % RS); const int nn = (int)(r1 / RS);
+            Elem<T>::st(wf + i, c < C ? w[((long long)nn * C + c) * RS + tap] : 0.f);
+        }
+    }
+    if (wd) {
+        const long long n = (long long)C * RS * Np;
+        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+            const int nn = (int)(i % Np); const long long r1 = i / Np;
+            const int tap = (int)(r1 % RS); const int c = (int)(r1 / RS);
+            Elem<T>::st(wd + i, nn < N ? w[((long long)nn * C + c) * RS + (RS - 1 - tap)] : 0.f);
+        }
+    }
+}
+extern "C" int ddpm_pack_weight_multi(const long long* descs, int n_tensors, int dtype, void* stream) {
+    if (!descs) return DDPM_ERR_NULL;
+    if (n_tensors <= 0) return DDPM_OK;
+    if (dtype == DDPM_BF16) hipLaunchKernelGGL(pack_weight_multi_kernel<bf16_t>, dim3(48, n_tensors), dim3(256), 0, (hipStream_t)stream, descs);
+    else if (dtype == DDPM_F32) hipLaunchKernelGGL(pack_weight_multi_kernel<float>, dim3(48, n_tensors), dim3(256), 0, (hipStream_t)stream, descs);
+    else return DDPM_ERR_DTYPE;
+    return check_launch();
+}
+
 // packed conv weight gradients [N][R*S][C] -> parameter layout [N][C][R*S], all layers in one launch.
 // descs[i] = {src offset (floats) in gpack, dst offset in gflat, N, C, R*S}; grid = (blocks, n_tensors).
 __global__ void wgrad_unpack_kernel(const float* __restrict__ gpack, float* __restrict__ gflat, const long long* __restrict__ descs) {

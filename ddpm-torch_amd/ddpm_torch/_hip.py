@@ -31,6 +31,7 @@ PROTOTYPES = {
     "ddpm_timestep_embedding": [P, P, P, I, I, P],
     "ddpm_nchw_to_nhwc": [P, P, I, I, I, I, I, P],
     "ddpm_pack_weight": [P, P, P, I, I, I, I, I, I, I, P],
+    "ddpm_pack_weight_multi": [P, I, I, P],
     "ddpm_q_sample": [P, P, P, P, P, P, I, I, P],
     "ddpm_mse_fwd": [P, P, P, I, I, P],
     "ddpm_mse_bwd": [P, P, P, P, I, I, P],

@@ -79,7 +79,7 @@ def conv2d(x, w_ptr, y_ptr, y_ld, N, R, S, Ho, Wo, stride=1, pad_t=0, pad_l=0, u
 class SplitK:
     """Workspace for the in-launch split-K of layers with few output tiles (the 8x8 / 4x4 levels): fp32 slabs + per-tile
     arrival counters (zero between launches: the last arriver of every tile resets its counter)."""
-    TARGET_BLOCKS = 256          # one block per CU
+    TARGET_BLOCKS = 128          # measured (scripts/splitk_probe.py): beyond ~128 blocks the slab reduction costs more than it buys
 
     def __init__(self, device):
         self.device = device
@@ -89,7 +89,7 @@ class SplitK:
     def plan(self, M, N, K, dtype):
         tiles = -(-M // 128) * -(-N // 128)
         ksteps = -(-K // (64 if dtype == _hip.BF16 else 32))
-        splits = min(self.TARGET_BLOCKS // tiles, ksteps // 4)
+        splits = min(self.TARGET_BLOCKS // tiles, ksteps // 8)
         if splits < 2:
             return 1, 0, 0
         need = tiles * splits * 16384
@@ -133,8 +133,9 @@ def gn_bwd(x, dy, dx, gamma, beta, stats, dgamma_ptr, dbeta_ptr, ws, silu, drop_
 def colsum(dy, per_sample_ptr, ps_ld, total_ptr):
     """per_sample[b][c] = sum_pixels dy (store);  total[c] += sum_{b,pixels} dy (atomic).  <= 2048 channels per launch."""
     es = 2 if dy.dtype == _hip.BF16 else 4
-    for c0 in range(0, dy.C, 2048):
-        c1 = min(dy.C, c0 + 2048)
+    step = 256 * (16 // es)                      # one launch covers <= 256 16-byte channel vectors
+    for c0 in range(0, dy.C, step):
+        c1 = min(dy.C, c0 + step)
         _hip.call("ddpm_colsum", dy.ptr + c0 * es, dy.ld, per_sample_ptr + c0 * 4 if per_sample_ptr else 0, ps_ld,
              total_ptr + c0 * 4 if total_ptr else 0, dy.B, dy.H * dy.W, c1 - c0, dy.dtype, _hip.stream())
 

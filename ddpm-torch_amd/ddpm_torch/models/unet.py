@@ -256,6 +256,8 @@ class _Engine:
         self.drop_calls = 0
         self.last_tape = None
         self.splitk = ops.SplitK(self.device)
+        self.pack_table = self.pack_ptrs = self.pack_key = None
+        self.pack_has_dgrad = False
         _hip.lib()
 
     # ---------------------------------------------------------------- topology helpers
@@ -296,18 +298,27 @@ class _Engine:
         reg(m.out_conv[2])
 
     # ---------------------------------------------------------------- derived weight caches
+    def _refresh_packs(self, need_dgrad):
+        """Re-derive every conv's packed copies in ONE launch when any master weight changed (optimizer step,
+        load_state_dict, EMA swap: all bump ``_version``) or the dgrad copies are needed for the first time."""
+        key = tuple(cw.mod.weight._version for cw in self.convs.values())
+        ptrs = tuple(cw.mod.weight.data_ptr() for cw in self.convs.values())
+        if self.pack_table is None or ptrs != self.pack_ptrs or (need_dgrad and not self.pack_has_dgrad):
+            rows = []
+            for cw in self.convs.values():
+                if cw.wf is None:
+                    cw.wf = torch.empty(cw.N * cw.R * cw.R * cw.Cp, dtype=self.T, device=self.device)
+                if need_dgrad and cw.wd is None:
+                    cw.wd = torch.empty(cw.C * cw.R * cw.R * cw.Np, dtype=self.T, device=self.device)
+                rows.append([cw.mod.weight.data_ptr(), cw.wf.data_ptr(), _hip.ptr(cw.wd), cw.N, cw.C, cw.R, cw.Cp, cw.Np])
+            self.pack_table = torch.tensor(rows, dtype=torch.int64, device=self.device)
+            self.pack_ptrs, self.pack_has_dgrad, self.pack_key = ptrs, self.pack_has_dgrad or need_dgrad, None
+        if key != self.pack_key:
+            _hip.call("ddpm_pack_weight_multi", self.pack_table.data_ptr(), self.pack_table.shape[0], self.dcode, _hip.stream())
+            self.pack_key = key
+
     def _packed(self, conv, need_dgrad):
-        cw = self.convs[id(conv)]
-        w = conv.weight
-        key = (w._version, w.data_ptr())
-        if cw.ver != key or cw.wf is None or (need_dgrad and cw.wd is None):
-            if cw.wf is None:
-                cw.wf = torch.empty(cw.N * cw.R * cw.R * cw.Cp, dtype=self.T, device=self.device)
-            if need_dgrad and cw.wd is None:
-                cw.wd = torch.empty(cw.C * cw.R * cw.R * cw.Np, dtype=self.T, device=self.device)
-            _hip.call("ddpm_pack_weight", w.data_ptr(), cw.wf.data_ptr(), _hip.ptr(cw.wd), cw.N, cw.C, cw.R, cw.R, cw.Cp, cw.Np, self.dcode, _hip.stream())
-            cw.ver = key
-        return cw
+        return self.convs[id(conv)]
 
     def _fc_all(self):
         """Concatenated time-bias projection: rows = all ResidualBlock.fc weights; bias = fc.bias + conv1.bias
@@ -345,20 +356,41 @@ class _Engine:
         return gflat.data_ptr() + 4 * self.goff[id(p)]
 
     def _wgrad_table(self):
-        """Offsets of every conv weight in the packed gradient buffer [N][R*S][C] + the unpack descriptor table."""
+        """Layout of the packed gradient scratch ``gpack`` and the descriptor table that ddpm_wgrad_unpack scatters from
+        it into the flat parameter-order gradient: conv weights ([N][R*S][C] -> [N][C][R*S]) plus plain segment copies
+        (R*S = 1) for everything that is produced once and owed to several parameters: the concatenated fc weight / bias
+        gradients (fc.bias and conv1.bias share one vector) and the bias shared by conv2 and the 1x1 skip."""
         if self.wdesc is None:
             self.poff, rows, off = {}, [], 0
+
+            def slot(key, n):
+                nonlocal off
+                self.poff[key] = off
+                off += (n + 3) // 4 * 4
+                return self.poff[key]
+
             for cw in self.convs.values():
                 w = cw.mod.weight
-                self.poff[id(w)] = off
-                rows.append([off, self.goff[id(w)], cw.N, cw.C, cw.R * cw.R])
-                off += (w.numel() + 3) // 4 * 4
+                rows.append([slot(id(w), w.numel()), self.goff[id(w)], cw.N, cw.C, cw.R * cw.R])
+            E = self.E
+            fw, fb = slot("fc_w", self.tb_total * E), slot("fc_b", self.tb_total)
+            for rb in self.res_blocks:
+                o, c = self.tb_off[id(rb)], rb.out_channels
+                rows.append([fw + o * E, self.goff[id(rb.fc.weight)], 1, c * E, 1])
+                rows.append([fb + o, self.goff[id(rb.fc.bias)], 1, c, 1])
+                rows.append([fb + o, self.goff[id(rb.conv1.bias)], 1, c, 1])
+                if rb.has_skip:
+                    t = slot(("b2", id(rb)), c)
+                    rows.append([t, self.goff[id(rb.conv2.bias)], 1, c, 1])
+                    rows.append([t, self.goff[id(rb.skip.bias)], 1, c, 1])
+            oc = self.m.out_conv[2]
+            rows.append([slot("out_b", self.convs[id(oc)].Np), self.goff[id(oc.bias)], 1, self.m.out_channels, 1])
             self.ptotal = off
             self.wdesc = torch.tensor(rows, dtype=torch.int64, device=self.device)
         return self.wdesc
 
     def _pptr(self, ctx, p):
-        return ctx["gpack"].data_ptr() + 4 * self.poff[id(p)]
+        return ctx["gpack"].data_ptr() + 4 * self.poff[p if isinstance(p, (str, tuple)) else id(p)]
 
     def _grad_target(self, v):
         """(view to write d/dv into, accumulate flag); the first writer stores, later writers accumulate."""
@@ -386,6 +418,7 @@ class _Engine:
         x = x.contiguous().float()
         t = t.contiguous().to(torch.int64)
         save = tape is not None
+        self._refresh_packs(save)
         ws = self._workspace(B, H, W)
         st = dict(B=B, ws=ws, save=save, training=training, tape=tape)
         drop_p = float(m.drop_rate) if training else 0.0
@@ -589,7 +622,7 @@ class _Engine:
         dact = self._new(B, H, W, self.hid)
         ops.conv2d(dy, cw.wd.data_ptr(), dact.ptr, dact.ld, self.hid, 3, 3, H, W, pad_t=1, pad_l=1, splitk=self.splitk)
         ops.conv2d_wgrad(dy, act, self._pptr(ctx, conv.weight), self.hid, cw.N, 3, 3, pad_t=1, pad_l=1, splits=self._splits(cw.N, 9 * self.hid, B * H * W))
-        self._bias_grad(ctx, dy, [conv.bias], cw.N)
+        self._bias_grad(ctx, dy, [conv.bias], cw.N, slot="out_b")
         g, acc = self._grad_target(cur)
         ops.gn_bwd(cur, dact, g, norm.weight, norm.bias, stats, self._gptr(gflat, norm.weight), self._gptr(gflat, norm.bias), ws, silu=True, accumulate=acc)
         # ---- the rest of the tape in reverse
@@ -616,16 +649,14 @@ class _Engine:
         ksteps = -(-K // (8 * self.vec))
         return max(1, min(512 // tiles, ksteps // 8))
 
-    def _bias_grad(self, ctx, dy, biases, creal):
-        """db[c] = sum over pixels and batch of dy (first `creal` channels); same vector for every listed bias."""
-        if dy.C == creal and len(biases) == 1:
+    def _bias_grad(self, ctx, dy, biases, creal, slot=None):
+        """db[c] = sum over pixels and batch of dy.  One owner: atomics straight into its gradient.  Several owners or a
+        channel-padded dy: reduce into a gpack slot that the unpack table fans out."""
+        if slot is None:
+            assert dy.C == creal and len(biases) == 1
             ops.colsum(dy, 0, 0, self._gptr(ctx["gflat"], biases[0]))
-            return
-        tmp = torch.zeros(dy.C, dtype=torch.float32, device=self.device)
-        ops.colsum(dy, 0, 0, tmp.data_ptr())
-        for b in biases:
-            o = self.goff[id(b)]
-            ctx["gflat"][o:o + creal].copy_(tmp[:creal])
+        else:
+            ops.colsum(dy, 0, 0, self._pptr(ctx, slot))
 
     def _conv_bwd(self, ctx, rec):
         _, conv, x, out, k, stride, pt, pl, upsample = rec
@@ -661,7 +692,7 @@ class _Engine:
         da2 = self._new(B, x.H, x.W, Cout)
         ops.conv2d(dout, c2.wd.data_ptr(), da2.ptr, da2.ld, Cout, 3, 3, x.H, x.W, pad_t=1, pad_l=1, splitk=self.splitk)
         ops.conv2d_wgrad(dout, a2, self._pptr(ctx, rb.conv2.weight), Cout, Cout, 3, 3, pad_t=1, pad_l=1, splits=self._splits(Cout, 9 * Cout, dout.rows))
-        self._bias_grad(ctx, dout, [rb.conv2.bias, rb.skip.bias] if rb.has_skip else [rb.conv2.bias], Cout)
+        self._bias_grad(ctx, dout, [rb.conv2.bias], Cout, slot=("b2", id(rb)) if rb.has_skip else None)
         # GN2 + SiLU + dropout
         dh1 = self._new(B, x.H, x.W, Cout)
         ops.gn_bwd(h1, da2, dh1, rb.norm2.weight, rb.norm2.bias, stats2, self._gptr(gflat, rb.norm2.weight), self._gptr(gflat, rb.norm2.bias),
@@ -729,28 +760,20 @@ class _Engine:
         temb, e1, s1, t_emb, s_t, fc_w = st["temb_saved"]
         Ct = self.tb_total
         F = _hip.F32
-        # fc (all blocks at once): dW = dtb^T s_t ; db = colsum(dtb) ; d(s_t) = dtb W
-        dW = self._f32(Ct, E)
-        ops.gemm(dtb.data_ptr(), Ct, 0, 1, s_t.data_ptr(), E, 0, 1, dW.data_ptr(), E, 0, Ct, E, B, F, out_mode=1)
-        db = dtb.sum(0)
+        # fc (all blocks at once): dW = dtb^T s_t ; db = colsum(dtb) ; d(s_t) = dtb W.  dW / db land in gpack slots that the
+        # unpack table fans out to every fc.weight / fc.bias / conv1.bias.
+        ops.gemm(dtb.data_ptr(), Ct, 0, 1, s_t.data_ptr(), E, 0, 1, self._pptr(ctx, "fc_w"), E, 0, Ct, E, B, F, out_mode=1)
+        ops.colsum(View(dtb, 1, B, 1, Ct), 0, 0, self._pptr(ctx, "fc_b"))
         ds_t = torch.zeros((B, E), dtype=torch.float32, device=self.device)     # K = sum Cout (~5000): split-K with fp32 atomics
         ops.gemm(dtb.data_ptr(), Ct, 0, 0, fc_w.data_ptr(), E, 0, 1, ds_t.data_ptr(), E, 0, B, E, Ct, F, out_mode=2, splits=max(1, Ct // 256))
-        for rb in self.res_blocks:
-            o, c = self.tb_off[id(rb)], rb.out_channels
-            gw, gb, gc = self.goff[id(rb.fc.weight)], self.goff[id(rb.fc.bias)], self.goff[id(rb.conv1.bias)]
-            gflat[gw:gw + c * E].copy_(dW[o:o + c].reshape(-1))
-            gflat[gb:gb + c].copy_(db[o:o + c])
-            gflat[gc:gc + c].copy_(db[o:o + c])
         dt_emb = self._f32(B, E)
         _hip.call("ddpm_silu_bwd", t_emb.data_ptr(), ds_t.data_ptr(), dt_emb.data_ptr(), B * E, 0, _hip.stream())
         lin2, lin1 = m.embed[2], m.embed[0]
         ops.gemm(dt_emb.data_ptr(), E, 0, 1, s1.data_ptr(), E, 0, 1, self._gptr(gflat, lin2.weight), E, 0, E, E, B, F, out_mode=1)
-        gb = self.goff[id(lin2.bias)]
-        gflat[gb:gb + E].copy_(dt_emb.sum(0))
+        ops.colsum(View(dt_emb, 1, B, 1, E), 0, 0, self._gptr(gflat, lin2.bias))
         ds1 = self._f32(B, E)
         ops.gemm(dt_emb.data_ptr(), E, 0, 0, lin2.weight.data_ptr(), E, 0, 1, ds1.data_ptr(), E, 0, B, E, E, F, out_mode=1)
         de1 = self._f32(B, E)
         _hip.call("ddpm_silu_bwd", e1.data_ptr(), ds1.data_ptr(), de1.data_ptr(), B * E, 0, _hip.stream())
         ops.gemm(de1.data_ptr(), E, 0, 1, temb.data_ptr(), self.hid, 0, 1, self._gptr(gflat, lin1.weight), self.hid, 0, E, self.hid, B, F, out_mode=1)
-        gb = self.goff[id(lin1.bias)]
-        gflat[gb:gb + E].copy_(de1.sum(0))
+        ops.colsum(View(de1, 1, B, 1, E), 0, 0, self._gptr(gflat, lin1.bias))

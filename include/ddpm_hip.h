@@ -82,6 +82,9 @@ int ddpm_nchw_to_nhwc(const float* x, void* y, int B, int C, int HW, int Cp, int
 int ddpm_pack_weight(const float* w, void* w_fwd /*[N][R][S][Cp]*/, void* w_dgrad /*[C][R][S][Np], taps flipped*/,
                      int N, int C, int R, int S, int Cp, int Np, int dtype, void* stream);
 
+/* every layer's pack in one launch: descs[i] = {w, w_fwd, w_dgrad (or 0), N, C, R (== S), Cp, Np} as int64 */
+int ddpm_pack_weight_multi(const long long* descs, int n_tensors, int dtype, void* stream);
+
 /* GaussianDiffusion.q_sample (ddpm_torch/diffusion.py:92-97): xt = sqrt_ab[t]*x0 + sqrt_1mab[t]*noise  (fp32, [B][n]) */
 int ddpm_q_sample(const float* x0, const float* noise, const long long* t, const float* sqrt_ab, const float* sqrt_1mab,
                   float* xt, int B, int n, void* stream);

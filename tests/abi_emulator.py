@@ -243,6 +243,10 @@ class Emulator:
             out[..., :N] = src[:, :, ::-1, ::-1].transpose(1, 2, 3, 0)
             Mat(wd, C, R * S * Np, R * S * Np, dt).set(out.reshape(C, -1))
 
+    def ddpm_pack_weight_multi(self, descs, n, dt, st):
+        for w, wf, wd, N, C, R, Cp, Np in i64(descs, 8 * n).reshape(n, 8):
+            self.ddpm_pack_weight(int(w), int(wf), int(wd), int(N), int(C), int(R), int(R), int(Cp), int(Np), dt, st)
+
     def ddpm_q_sample(self, x0, noise, t, ca, cb, xt, B, n, st):
         tt = i64(t, B)
         T = int(tt.max()) + 1
