@@ -118,8 +118,8 @@ __global__ void pack_weight_multi_kernel(const long long* __restrict__ descs) {
 extern "C" int ddpm_pack_weight_multi(const long long* descs, int n_tensors, int dtype, void* stream) {
     if (!descs) return DDPM_ERR_NULL;
     if (n_tensors <= 0) return DDPM_OK;
-    if (dtype == DDPM_BF16) hipLaunchKernelGGL(pack_weight_multi_kernel<bf16_t>, dim3(48, n_tensors), dim3(256), 0, (hipStream_t)stream, descs);
-    else if (dtype == DDPM_F32) hipLaunchKernelGGL(pack_weight_multi_kernel<float>, dim3(48, n_tensors), dim3(256), 0, (hipStream_t)stream, descs);
+    if (dtype == DDPM_BF16) hipLaunchKernelGGL(pack_weight_multi_kernel<bf16_t>, dim3(256, n_tensors), dim3(256), 0, (hipStream_t)stream, descs);
+    else if (dtype == DDPM_F32) hipLaunchKernelGGL(pack_weight_multi_kernel<float>, dim3(256, n_tensors), dim3(256), 0, (hipStream_t)stream, descs);
     else return DDPM_ERR_DTYPE;
     return check_launch();
 }
@@ -283,20 +283,22 @@ extern "C" int ddpm_silu_bwd(const float* x, const float* dy, float* dx, long lo
 }
 
 // ------------------------------------------------------------------ column sums of an NHWC gradient (bias / time-bias grads)
-// per_sample[b][c] = sum_p dy[b][p][c]  (store, pitch ps_ld)   and/or   total[c] += sum_{b,p} dy (atomic)
+// per_sample[b][c] += sum_p dy[b][p][c]   and/or   total[c] += sum_{b,p} dy   (both fp32 atomics into zero-initialised
+// buffers; grid = (pixel slabs, B) so that large activations use every CU)
 template <typename T>
 __global__ void colsum_kernel(const T* __restrict__ dy, long long ld, float* __restrict__ per_sample, long long ps_ld,
-                              float* __restrict__ total, int HW, int C) {
+                              float* __restrict__ total, int HW, int C, int pix_per_slab) {
     constexpr int VEC = Elem<T>::VEC;
     __shared__ float sh[2048];
-    const int b = blockIdx.x;
+    const int b = blockIdx.y;
     const int cx = threadIdx.x, py = threadIdx.y;
     const int t = threadIdx.y * blockDim.x + threadIdx.x, nt = blockDim.x * blockDim.y;
+    const int p0 = blockIdx.x * pix_per_slab, p1 = min(HW, p0 + pix_per_slab);
     float acc[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
     const T* base = dy + (long long)b * HW * ld + cx * VEC;
-    for (int p = py; p < HW; p += blockDim.y) {
+    for (int p = p0 + py; p < p1; p += blockDim.y) {
         float f[VEC];
         Elem<T>::unpack(ldg16(base + (long long)p * ld), f);
 #pragma unroll
@@ -308,12 +310,8 @@ __global__ void colsum_kernel(const T* __restrict__ dy, long long ld, float* __r
     for (int c = t; c < C; c += nt) {
         float a = 0.f;
         for (int r = 0; r < (int)blockDim.y; ++r) a += sh[r * C + c];
-        sh[c] = a;
-    }
-    __syncthreads();
-    for (int c = t; c < C; c += nt) {
-        if (per_sample) per_sample[(long long)b * ps_ld + c] = sh[c];
-        if (total) atomicAdd(total + c, sh[c]);
+        if (per_sample) atomicAdd(per_sample + (long long)b * ps_ld + c, a);
+        if (total) atomicAdd(total + c, a);
     }
 }
 extern "C" int ddpm_colsum(const void* dy, long long ld, float* per_sample, long long ps_ld, float* total, int B, int HW, int C, int dtype, void* stream) {
@@ -323,8 +321,14 @@ extern "C" int ddpm_colsum(const void* dy, long long ld, float* per_sample, long
     if (!aligned16(dy)) return DDPM_ERR_ALIGN;
     const int cv = C / vec;
     int py = 256 / cv; if (py > HW) py = HW; if (py < 1) py = 1;
-    if (dtype == DDPM_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3(B), dim3(cv, py), 0, (hipStream_t)stream, (const bf16_t*)dy, ld, per_sample, ps_ld, total, HW, C);
-    else if (dtype == DDPM_F32) hipLaunchKernelGGL(colsum_kernel<float>, dim3(B), dim3(cv, py), 0, (hipStream_t)stream, (const float*)dy, ld, per_sample, ps_ld, total, HW, C);
+    int S = (1024 + B - 1) / B;                       // ~1024 blocks in total, >= 4 pixel iterations each
+    const int maxS = (HW + 4 * py - 1) / (4 * py);
+    if (S > maxS) S = maxS;
+    if (S < 1) S = 1;
+    const int pps = (HW + S - 1) / S;
+    S = (HW + pps - 1) / pps;
+    if (dtype == DDPM_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3(S, B), dim3(cv, py), 0, (hipStream_t)stream, (const bf16_t*)dy, ld, per_sample, ps_ld, total, HW, C, pps);
+    else if (dtype == DDPM_F32) hipLaunchKernelGGL(colsum_kernel<float>, dim3(S, B), dim3(cv, py), 0, (hipStream_t)stream, (const float*)dy, ld, per_sample, ps_ld, total, HW, C, pps);
     else return DDPM_ERR_DTYPE;
     return check_launch();
 }

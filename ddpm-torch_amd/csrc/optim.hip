@@ -46,13 +46,13 @@ __global__ void adam_ema_kernel(float* __restrict__ p, const float* __restrict__
         clip = c < 1.f ? c : 1.f;
     }
     const float step = lr / bc1;
-    const float inv_sqrt_bc2 = rsqrtf(bc2);
+    const float sqrt_bc2 = sqrtf(bc2);
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const float gi = g[i] * clip;
         const float mi = beta1 * m[i] + (1.f - beta1) * gi;
         const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
         m[i] = mi; v[i] = vi;
-        const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
+        const float denom = sqrtf(vi) / sqrt_bc2 + eps;
         const float pi = p[i] - step * (mi / denom);
         p[i] = pi;
         if (shadow) shadow[i] += ema_w * (pi - shadow[i]);
@@ -67,5 +67,63 @@ extern "C" int ddpm_adam_ema_step(float* p, const float* g, float* m, float* v, 
     const int nblk = (int)(want > 4096 ? 4096 : want);
     hipLaunchKernelGGL(adam_ema_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, p, g, m, v, shadow, n, total_sq, max_norm, lr, beta1, beta2,
                        eps, bias_corr1, bias_corr2, ema_w);
+    return check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------- multi-tensor forms
+// One launch over ALL parameter tensors (304 for the CIFAR UNet).  table[i] = {p, g, m, v, shadow (or 0), numel} as int64;
+// grid = (blocks per tensor, n_tensors), grid-stride inside a tensor.
+__global__ void mt_sumsq_kernel(const long long* __restrict__ table, float* __restrict__ total_sq) {
+    __shared__ float sh[4];
+    const long long* row = table + 6 * (long long)blockIdx.y;
+    const float* g = reinterpret_cast<const float*>(row[1]);
+    const long long n = row[5];
+    float acc = 0.f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) acc += g[i] * g[i];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) { const float s = sh[0] + sh[1] + sh[2] + sh[3]; if (s != 0.f) atomicAdd(total_sq, s); }
+}
+__global__ void mt_adam_ema_kernel(const long long* __restrict__ table, const float* __restrict__ total_sq, float max_norm, float lr,
+                                   float beta1, float beta2, float eps, float bc1, float bc2, float ema_w) {
+    const long long* row = table + 6 * (long long)blockIdx.y;
+    float* p = reinterpret_cast<float*>(row[0]);
+    const float* g = reinterpret_cast<const float*>(row[1]);
+    float* m = reinterpret_cast<float*>(row[2]);
+    float* v = reinterpret_cast<float*>(row[3]);
+    float* shadow = reinterpret_cast<float*>(row[4]);
+    const long long n = row[5];
+    float clip = 1.f;
+    if (total_sq && max_norm > 0.f) {
+        const float c = max_norm / (sqrtf(total_sq[0]) + 1e-6f);
+        clip = c < 1.f ? c : 1.f;
+    }
+    const float step = lr / bc1;
+    const float sqrt_bc2 = sqrtf(bc2);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float gi = g[i] * clip;
+        const float mi = beta1 * m[i] + (1.f - beta1) * gi;
+        const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        const float denom = sqrtf(vi) / sqrt_bc2 + eps;             // torch.optim.Adam: (sqrt(v) / sqrt(bias_correction2)) + eps
+        const float pi = p[i] - step * (mi / denom);
+        p[i] = pi;
+        if (shadow) shadow[i] += ema_w * (pi - shadow[i]);
+    }
+}
+// total_sq[0] must be zero on entry to the norm pass.
+extern "C" int ddpm_mt_grad_sumsq(const long long* table, int n_tensors, float* total_sq, void* stream) {
+    if (!table || !total_sq) return DDPM_ERR_NULL;
+    if (n_tensors <= 0) return DDPM_OK;
+    hipLaunchKernelGGL(mt_sumsq_kernel, dim3(16, n_tensors), dim3(256), 0, (hipStream_t)stream, table, total_sq);
+    return check_launch();
+}
+extern "C" int ddpm_mt_adam_ema(const long long* table, int n_tensors, const float* total_sq, float max_norm, float lr, float beta1,
+                                float beta2, float eps, float bias_corr1, float bias_corr2, float ema_w, void* stream) {
+    if (!table) return DDPM_ERR_NULL;
+    if (n_tensors <= 0) return DDPM_OK;
+    hipLaunchKernelGGL(mt_adam_ema_kernel, dim3(32, n_tensors), dim3(256), 0, (hipStream_t)stream, table, total_sq, max_norm, lr, beta1, beta2, eps,
+                       bias_corr1, bias_corr2, ema_w);
     return check_launch();
 }

@@ -46,6 +46,8 @@ PROTOTYPES = {
     "ddpm_softmax_fwd": [P, P, L, I, I, P],
     "ddpm_softmax_bwd": [P, P, P, L, I, I, P],
     "ddpm_dropout_mask": [P, L, F, U, P],
+    "ddpm_mt_grad_sumsq": [P, I, P, P],
+    "ddpm_mt_adam_ema": [P, I, P, F, F, F, F, F, F, F, F, P],
     "ddpm_sumsq_accumulate": [P, L, P, P, P],
     "ddpm_adam_ema_step": [P, P, P, P, P, L, P, F, F, F, F, F, F, F, F, P],
 }

@@ -131,7 +131,7 @@ def gn_bwd(x, dy, dx, gamma, beta, stats, dgamma_ptr, dbeta_ptr, ws, silu, drop_
 
 
 def colsum(dy, per_sample_ptr, ps_ld, total_ptr):
-    """per_sample[b][c] = sum_pixels dy (store);  total[c] += sum_{b,pixels} dy (atomic).  <= 2048 channels per launch."""
+    """per_sample[b][c] += sum_pixels dy;  total[c] += sum_{b,pixels} dy  (atomics into zero-initialised buffers)."""
     es = 2 if dy.dtype == _hip.BF16 else 4
     step = 256 * (16 // es)                      # one launch covers <= 256 16-byte channel vectors
     for c0 in range(0, dy.C, step):

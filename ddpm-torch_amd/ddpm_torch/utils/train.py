@@ -19,7 +19,78 @@ import torch.distributed as dist
 import torch.nn as nn
 from torch.nn.parallel import DistributedDataParallel as DDP
 
+from .. import _hip
+
 __all__ = ["Trainer", "EMA", "ModelWrapper", "DummyScheduler", "RunningStatistics"]
+
+
+class _FusedUpdate:
+    """clip_grad_norm_ -> Adam.step -> EMA.update as TWO launches over all parameters (utils/train.py:159-165,300-305).
+
+    Transparent fast path for the reference's own objects: it keeps torch.optim.Adam's state layout (``state[p]`` =
+    {step, exp_avg, exp_avg_sq}) and the EMA shadow dict, so ``state_dict()`` / checkpoints are unchanged.  Anything it
+    does not recognise (other optimizer, weight decay, amsgrad, several param groups, CPU params) falls back to the
+    generic torch calls.  The clip coefficient is computed on the device from the accumulated squared norm: there is no
+    host synchronisation between backward and the update.
+    """
+
+    def __init__(self, optimizer, ema):
+        self.opt, self.ema = optimizer, ema
+        self.ok = (type(optimizer) is torch.optim.Adam and len(optimizer.param_groups) == 1)
+        if self.ok:
+            g = optimizer.param_groups[0]
+            self.ok = (not g.get("amsgrad") and not g.get("maximize") and g.get("weight_decay", 0) == 0
+                       and not g.get("capturable") and not g.get("differentiable") and not g.get("fused")
+                       and all(p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() for p in g["params"]))
+        self.table = None
+        self.steps = 0
+
+    def _build(self):
+        g = self.opt.param_groups[0]
+        self.params = [p for p in g["params"] if p.requires_grad]
+        dev = self.params[0].device
+        shadow = {}
+        if isinstance(self.ema, EMA):
+            by_param = {id(r()): k for k, r in self.ema._refs.items()}
+            shadow = {id(p): self.ema.shadow[by_param[id(p)]] for p in self.params if id(p) in by_param}
+        rows = []
+        for p in self.params:
+            st = self.opt.state[p]
+            if "exp_avg" not in st:                   # torch's lazy state initialisation (adam.py _init_group)
+                st["step"] = torch.tensor(0.0, dtype=torch.float32)
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            sh = shadow.get(id(p))
+            rows.append([p.data_ptr(), 0, st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), 0 if sh is None else sh.data_ptr(), p.numel()])
+        self.host = torch.tensor(rows, dtype=torch.int64).pin_memory()
+        self.table = torch.empty_like(self.host, device=dev)
+        self.total = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.key = [p.data_ptr() for p in self.params]
+        self.steps = int(self.opt.state[self.params[0]]["step"].item())
+
+    def __call__(self, max_norm, ema_w):
+        """Returns False (nothing done) when the fast path does not apply."""
+        if not self.ok:
+            return False
+        if self.table is None or any(p.data_ptr() != k for p, k in zip(self.params, self.key)):
+            self._build()
+        if any(p.grad is None or not p.grad.is_contiguous() or p.grad.dtype != torch.float32 for p in self.params):
+            return False
+        self.host[:, 1] = torch.tensor([p.grad.data_ptr() for p in self.params], dtype=torch.int64)
+        self.table.copy_(self.host, non_blocking=True)
+        g = self.opt.param_groups[0]
+        self.steps += 1
+        b1, b2 = g["betas"]
+        n = len(self.params)
+        s = _hip.stream()
+        if max_norm and max_norm > 0:
+            self.total.zero_()
+            _hip.call("ddpm_mt_grad_sumsq", self.table.data_ptr(), n, self.total.data_ptr(), s)
+        _hip.call("ddpm_mt_adam_ema", self.table.data_ptr(), n, self.total.data_ptr() if max_norm and max_norm > 0 else 0, float(max_norm or 0.0),
+                  float(g["lr"]), b1, b2, g["eps"], 1 - b1 ** self.steps, 1 - b2 ** self.steps, float(ema_w), s)
+        torch._foreach_add_([self.opt.state[p]["step"] for p in self.params], 1)
+        self.opt._opt_called = True                    # what LR schedulers check before their own step()
+        return True
 
 
 class DummyScheduler:
@@ -158,6 +229,7 @@ class Trainer:
         self.use_ema = use_ema
         self.ema = EMA(model.module if isinstance(model, DDP) else model, decay=ema_decay) if use_ema else nullcontext()
         self.stats = RunningStatistics(loss=None)
+        self._fused = _FusedUpdate(optimizer, self.ema)
 
     @property
     def timesteps(self):
@@ -179,12 +251,18 @@ class Trainer:
         loss = self.loss(x).mean()
         loss.div(self.num_accum).backward()
         if global_steps % self.num_accum == 0:
-            nn.utils.clip_grad_norm_(self.model.parameters(), max_norm=self.grad_norm)   # after DDP averaging
-            self.optimizer.step()
+            ema_on = self.use_ema and hasattr(self.ema, "update")
+            ema_w = 1 - min(self.ema.decay, (2 + self.ema.num_updates) / (11 + self.ema.num_updates)) if ema_on else 0.0
+            if self._fused(self.grad_norm, ema_w):          # clip + Adam + EMA in two launches (after DDP averaging)
+                if ema_on:
+                    self.ema.num_updates += 1
+            else:
+                nn.utils.clip_grad_norm_(self.model.parameters(), max_norm=self.grad_norm)
+                self.optimizer.step()
+                if ema_on:
+                    self.ema.update()
             self.optimizer.zero_grad(set_to_none=True)
             self.scheduler.step()
-            if self.use_ema and hasattr(self.ema, "update"):
-                self.ema.update()
         loss = loss.detach()
         if self.distributed:
             dist.reduce(loss, dst=0, op=dist.ReduceOp.SUM)

@@ -105,7 +105,8 @@ int ddpm_add_i64(long long* t, int B, long long delta, void* stream);
 int ddpm_silu_fwd(const float* x, float* y, long long n, void* stream);
 int ddpm_silu_bwd(const float* x, const float* dy, float* dx, long long n, int accumulate, void* stream);
 
-/* bias / time-bias gradients: per_sample[b][c] = sum_pixels dy (store), total[c] += sum_{b,pixels} dy (atomic); C <= 2048 */
+/* bias / time-bias gradients: per_sample[b][c] += sum_pixels dy, total[c] += sum_{b,pixels} dy (fp32 atomics into
+ * zero-initialised buffers); C <= 256 16-byte vectors per launch */
 int ddpm_colsum(const void* dy, long long ld, float* per_sample, long long ps_ld, float* total, int B, int HW, int C, int dtype, void* stream);
 /* backward of nn.Upsample(2,"nearest"): dx[b,y,x,c] (+)= sum of the 2x2 block of dy_up */
 int ddpm_upsample2x_bwd(const void* dy_up, void* dx, long long dx_ld, int B, int H, int W, int C, int accumulate, int dtype, void* stream);
@@ -124,6 +125,12 @@ int ddpm_sumsq_accumulate(const float* g, long long n, float* total_sq, float* w
 int ddpm_adam_ema_step(float* p, const float* g, float* m, float* v, float* shadow, long long n, const float* total_sq,
                        float max_norm, float lr, float beta1, float beta2, float eps, float bias_corr1, float bias_corr2,
                        float ema_w, void* stream);
+
+/* multi-tensor forms: ONE launch over every parameter tensor.  table[i] = {p, g, m, v, shadow (0 = none), numel} (int64).
+ * ddpm_mt_grad_sumsq: total_sq[0] (zero on entry) += sum ||g_i||^2.  ddpm_mt_adam_ema: the fused update above for all i. */
+int ddpm_mt_grad_sumsq(const long long* table, int n_tensors, float* total_sq, void* stream);
+int ddpm_mt_adam_ema(const long long* table, int n_tensors, const float* total_sq, float max_norm, float lr, float beta1,
+                     float beta2, float eps, float bias_corr1, float bias_corr2, float ema_w, void* stream);
 
 /* test hook: the keep-mask (1/0) the GroupNorm kernels regenerate for element indices 0..n-1 */
 int ddpm_dropout_mask(float* mask, long long n, float p, unsigned long long seed, void* stream);

@@ -301,7 +301,8 @@ class Emulator:
     def ddpm_colsum(self, dy, ld, per_sample, ps_ld, total, B, HW, C, dt, st):
         v = Mat(dy, B * HW, C, ld, dt).get().reshape(B, HW, C).sum(1)
         if per_sample:
-            Mat(per_sample, B, C, ps_ld, F32).set(v)
+            dst = Mat(per_sample, B, C, ps_ld, F32)
+            dst.set(dst.get() + v)
         if total:
             f32(total, C)[...] += v.sum(0)
 

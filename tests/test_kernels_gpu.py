@@ -252,7 +252,7 @@ def test_diffusion_algebra_kernels():
 def test_reductions_and_fanin(dt):
     B, HW, C, ld = 3, 64, 256, 272
     dy = r(B * HW, ld, seed=1, dt=dt)
-    ps, tot = torch.zeros(B, C + 4), r(C, seed=2)
+    ps, tot = r(B, C + 4, seed=12), r(C, seed=2)
     both("ddpm_colsum", A(dy), ld, A(ps, out=True, name="per_sample"), C + 4, A(tot, out=True, name="total"), B, HW, C, dt, tol=2e-5 if dt == 0 else 1e-4)
     up = r(B * 4 * 16, 64, seed=3, dt=dt)
     for acc in (0, 1):
