@@ -22,6 +22,7 @@
 // stays lane-linear for the DMA and the 16-lane groups of ds_read_b128 hit distinct 16-B slots.
 #include "common.h"
 #include <string.h>
+#include <stdlib.h>
 
 struct MatDesc {
     const void* p;
@@ -84,7 +85,7 @@ template <> struct Mma<float> {
 };
 
 constexpr int TILE = 128;      // BM == BN
-constexpr int NTHREADS = 256;
+constexpr int NTHREADS = 256;  // 4-wave blocks; the 8-wave variant (NW = 8) uses 512
 constexpr int ROW_BYTES = 128; // LDS row pitch: 128 B of K data, unpadded (XOR-swizzled chunks)
 constexpr int NVEC = 4;        // 16-byte vectors per thread per operand per K-step
 
@@ -107,22 +108,25 @@ __device__ __forceinline__ int lds_off(int row, int chunk) { return row * ROW_BY
 //          VEC k-contiguous 4-element runs (ds_write_b64 bf16 / ds_write_b128 fp32) into the swizzled image.
 constexpr unsigned OOB = 0x7ffffff0u;
 
-template <typename T, bool TRANS>
+template <typename T, bool TRANS, int NW = 4>
 struct Loader {
+    static constexpr int NT = NW * 64;                       // threads per block
+    static constexpr int NV = 1024 / NT;                     // 16-byte vectors per thread per operand per K-step
     static constexpr int VEC = Elem<T>::VEC;
     static constexpr int BK = 8 * VEC;
     static constexpr int KQ = BK / 4;
     static constexpr int ES = (int)sizeof(T);
     static constexpr bool TR16 = TRANS && sizeof(T) == 2;    // k-strided bf16 operand: LDS-DMA + ds_read_b64_tr_b16
     static constexpr bool DMA = !TRANS || TR16;              // operand staged HBM/L2 -> LDS without VGPRs
+    static_assert(NW == 4 || DMA, "the register-transposed path is laid out for 256 threads");
 
     const MatDesc& d;
     __amdgpu_buffer_rsrc_t rsrc;
     int tile0;
     int kv, wave, row0;           // !TRANS: logical k-chunk, wave id, first tile row
     int kq, ng;                   // TRANS
-    int roff[NVEC];               // !TRANS: byte offset of the row (plain; OOB when the row is outside) or of pixel (b, y0, x0) (conv)
-    unsigned tapmask[NVEC];       // !TRANS conv without up/down-scaling: bit (r*S+s) set when the tap is inside the image
+    int roff[NV];               // !TRANS: byte offset of the row (plain; OOB when the row is outside) or of pixel (b, y0, x0) (conv)
+    unsigned tapmask[NV];       // !TRANS conv without up/down-scaling: bit (r*S+s) set when the tap is inside the image
     int tr, ts, tc; unsigned foff;   // TRANS: fixed tap/channel (conv) or fixed byte offset along the fast index (plain, OOB if outside)
     int krow0;                    // TRANS bf16 (LDS-DMA of the m-major image): first k-row of this thread (tid>>4), +16 per vector
 
@@ -139,8 +143,8 @@ struct Loader {
             wave = __builtin_amdgcn_readfirstlane(tid >> 6);
             kv = (tid & 7) ^ ((row0 >> 1) & 7);
 #pragma unroll
-            for (int i = 0; i < NVEC; ++i) {
-                const int m = tile0 + row0 + 32 * i;
+            for (int i = 0; i < NV; ++i) {
+                const int m = tile0 + row0 + (NT / 8) * i;
                 const bool valid = m < d.n_slow;
                 // both addressing forms are computed and SELECTED (no divergent stores into the state arrays -> registers)
                 int b, y0, x0;
@@ -195,7 +199,7 @@ struct Loader {
     __device__ __forceinline__ void issue(int k0, int k_end, char* tile) const {
         const int k = k0 + kv * VEC;
         const bool kok = k < k_end;
-        unsigned off[NVEC];
+        unsigned off[NV];
         if (d.conv) {
             unsigned tap = fdiv((unsigned)k, d.dC);
             const int c = k - (int)tap * d.C;
@@ -204,11 +208,11 @@ struct Loader {
                 const int tapoff = ((r * d.W + s) * (int)d.ld + c) * ES;
                 tap = kok ? tap : 31u;                          // bit 31 is never set: K-tail reads zeros
 #pragma unroll
-                for (int i = 0; i < NVEC; ++i) off[i] = ((tapmask[i] >> tap) & 1u) ? (unsigned)(roff[i] + tapoff) : OOB;
+                for (int i = 0; i < NV; ++i) off[i] = ((tapmask[i] >> tap) & 1u) ? (unsigned)(roff[i] + tapoff) : OOB;
             } else {
 #pragma unroll
-                for (int i = 0; i < NVEC; ++i) {        // up/down-scaled maps (6 convs per pass): decode on the fly
-                    const int m = tile0 + row0 + 32 * i;
+                for (int i = 0; i < NV; ++i) {        // up/down-scaled maps (6 convs per pass): decode on the fly
+                    const int m = tile0 + row0 + (NT / 8) * i;
                     int b, y0, x0;
                     decode_pixel(m < d.n_slow ? m : 0, b, y0, x0);
                     off[i] = (kok && m < d.n_slow) ? gather_off(b, y0, x0, r, s, c) : OOB;
@@ -217,11 +221,11 @@ struct Loader {
         } else {
             const unsigned koff = kok ? (unsigned)(k * ES) : OOB;
 #pragma unroll
-            for (int i = 0; i < NVEC; ++i) off[i] = (unsigned)roff[i] + koff;     // OOB + small stays out of range
+            for (int i = 0; i < NV; ++i) off[i] = (unsigned)roff[i] + koff;     // OOB + small stays out of range
         }
 #pragma unroll
-        for (int i = 0; i < NVEC; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(tile + (wave * 8 + 32 * i) * ROW_BYTES),
+        for (int i = 0; i < NV; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(tile + (wave * 8 + (NT / 8) * i) * ROW_BYTES),
                                                      16, off[i], 0, 0, 0);
     }
 
@@ -229,10 +233,10 @@ struct Loader {
     // 16-byte chunks XOR-swizzled by (krow & 3) << 2 on the source side; fragments are then formed by the hardware
     // transpose read (ds_read_b64_tr_b16: in each 16-lane group lanes 4r..4r+3 supply row r, lane c receives column c).
     __device__ __forceinline__ void issue_tr(int k0, int k_end, char* tile) const {
-        unsigned off[NVEC];
+        unsigned off[NV];
 #pragma unroll
-        for (int i = 0; i < NVEC; ++i) {
-            const int k = k0 + krow0 + 16 * i;
+        for (int i = 0; i < NV; ++i) {
+            const int k = k0 + krow0 + (NT / 16) * i;
             if (d.conv) {
                 int b, y0, x0;
                 decode_pixel(k < k_end ? k : 0, b, y0, x0);
@@ -242,20 +246,20 @@ struct Loader {
             }
         }
 #pragma unroll
-        for (int i = 0; i < NVEC; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(tile + (wave * 64 + 256 * i) * 16),
+        for (int i = 0; i < NV; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(tile + (wave * 64 + NT * i) * 16),
                                                      16, off[i], 0, 0, 0);
     }
 
     // TRANS: fetch this thread's 4 k-rows of the K-step starting at k0
-    __device__ __forceinline__ void load(int k0, int k_end, u32x4 (&v)[NVEC]) const {
+    __device__ __forceinline__ void load(int k0, int k_end, u32x4 (&v)[NV]) const {
         const int kb = k0 + kq * 4;
         if (d.conv) {
             int b, y0, x0;
             decode_pixel(kb < k_end ? kb : 0, b, y0, x0);
             const int xend = d.Wo * d.stride - d.pad_l, yend = d.Ho * d.stride - d.pad_t;
 #pragma unroll
-            for (int i = 0; i < NVEC; ++i) {
+            for (int i = 0; i < NV; ++i) {
                 const bool ok = tc >= 0 && kb + i < k_end;
                 const unsigned o = ok ? gather_off(b, y0, x0, tr, ts, tc) : OOB;
                 v[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o, 0, 0));
@@ -264,7 +268,7 @@ struct Loader {
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < NVEC; ++i) {
+            for (int i = 0; i < NV; ++i) {
                 const int k = kb + i;
                 const unsigned o = k < k_end ? (unsigned)((long long)k * d.ld * ES) + foff : OOB;
                 v[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, o, 0, 0));
@@ -273,7 +277,7 @@ struct Loader {
     }
 
     // TRANS: register-transpose the 4 x VEC block and write it into the swizzled K-contiguous tile
-    __device__ __forceinline__ void store(char* tile, const u32x4 (&v)[NVEC]) const {
+    __device__ __forceinline__ void store(char* tile, const u32x4 (&v)[NV]) const {
         if (sizeof(T) == 2) {
 #pragma unroll
             for (int dd = 0; dd < 4; ++dd) {            // dword dd of each vector holds m = 2dd (low half) and 2dd+1 (high half)
@@ -299,12 +303,12 @@ struct Loader {
 // 16-byte vector along n (bias / time-bias / residual reads and the output write are fully coalesced).
 constexpr int CS_LD = TILE + 4;
 
-template <typename T, typename OutT>
+template <typename T, typename OutT, int NT>
 __device__ __forceinline__ void epilogue_rows(const Epilogue& ep, const float* cs, int batch, int row0g, int col0g, int M, int N, int tid) {
     constexpr int VO = 16 / (int)sizeof(OutT);            // output elements per 16-byte vector
     constexpr int VPR = TILE / VO;                         // vectors per tile row
-    constexpr int PER_THREAD = TILE * VPR / NTHREADS;
-    constexpr int ROWS_PER_PASS = NTHREADS / VPR;
+    constexpr int PER_THREAD = TILE * VPR / NT;
+    constexpr int ROWS_PER_PASS = NT / VPR;
     const int cv = tid % VPR, r0 = tid / VPR;
     const int col = col0g + cv * VO;
     if (col >= N) return;
@@ -366,9 +370,10 @@ __device__ __forceinline__ void epilogue_rows(const Epilogue& ep, const float* c
 }
 
 // element-wise tail for the scatter / atomic output modes (2: fp32 atomic add, 3: NCHW fp32, 4: packed wgrad)
+template <int NT>
 __device__ __forceinline__ void epilogue_scatter(const Epilogue& ep, const float* cs, int batch, int row0g, int col0g, int M, int N, int tid) {
     // lanes run along n (coalesced atomics for modes 2 / 4); NCHW (mode 3) has N <= a few channels
-    for (int idx = tid; idx < TILE * TILE; idx += NTHREADS) {
+    for (int idx = tid; idx < TILE * TILE; idx += NT) {
         const int rl = idx >> 7, cl = idx & (TILE - 1);
         const int row = row0g + rl, col = col0g + cl;
         if (row >= M || col >= N) continue;
@@ -421,10 +426,15 @@ __device__ __forceinline__ u32x4 read_frag(const char* tile, int rb, int kc, int
 //           each step waits with a COUNTED s_waitcnt vmcnt(8) (the newest tile's 8 DMA instructions stay outstanding)
 //           behind a raw s_barrier.  Used when the grid cannot put two blocks on every CU (small-M layers), where a
 //           single block would otherwise expose one full memory latency per K-step.
-template <typename T, bool TA, bool TB, int NBUF>
-__global__ __launch_bounds__(NTHREADS, 2)
+// NW = 4: 4 waves as 2(M) x 2(N), 64x64 per wave.  NW = 8: 8 waves as 4(M) x 2(N), 32x64 per wave — twice the waves per CU
+//         (two 512-thread blocks) to hide LDS-DMA latency and barrier skew; needs both operands on the DMA path.
+template <typename T, bool TA, bool TB, int NBUF, int NW>
+__global__ __launch_bounds__(NW * 64, NW / 2)
 void gemm_kernel(MatDesc A, MatDesc B, Epilogue ep, int M, int N, int K, int k_per_split, int tiles_n) {
     static_assert(NBUF == 2 || (!TA && !TB), "the deep ring needs direct-to-LDS loads on both operands");
+    constexpr int NT = NW * 64;
+    constexpr int MI = 8 / NW;                              // 32-row accumulator blocks per wave along M
+    constexpr int NVEC = 1024 / NT;
     constexpr int VEC = Elem<T>::VEC;
     constexpr int BK = 8 * VEC;
     constexpr int KF = Mma<T>::KF;
@@ -432,24 +442,24 @@ void gemm_kernel(MatDesc A, MatDesc B, Epilogue ep, int M, int N, int K, int k_p
     constexpr int TILE_BYTES = TILE * ROW_BYTES;          // one operand tile; layout: [buf][A | B]
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave >> 1, wn = wave & 1;               // wave row block (of 32*MI rows) and column block (of 64)
     const int tm = blockIdx.x / tiles_n, tn = blockIdx.x - tm * tiles_n;
     const int batch = blockIdx.z;
     const int k_begin = blockIdx.y * k_per_split;
     const int k_end = min(K, k_begin + k_per_split);
     if (k_begin >= k_end) return;
 
-    Loader<T, TA> la(A, batch, tm * TILE, tid);
-    Loader<T, TB> lb(B, batch, tn * TILE, tid);
+    Loader<T, TA, NW> la(A, batch, tm * TILE, tid);
+    Loader<T, TB, NW> lb(B, batch, tn * TILE, tid);
 
-    f32x16 acc[2][2];
+    f32x16 acc[MI][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = (f32x16)(0.f);
 
     u32x4 va[NVEC], vb[NVEC];
-    constexpr bool DMA_A = Loader<T, TA>::DMA, DMA_B = Loader<T, TB>::DMA;
+    constexpr bool DMA_A = Loader<T, TA, NW>::DMA, DMA_B = Loader<T, TB, NW>::DMA;
     auto stage_a = [&](int k0, char* tile) { if constexpr (TA) la.issue_tr(k0, k_end, tile); else la.issue(k0, k_end, tile); };
     auto stage_b = [&](int k0, char* tile) { if constexpr (TB) lb.issue_tr(k0, k_end, tile); else lb.issue(k0, k_end, tile); };
     const int nsteps = (k_end - k_begin + BK - 1) / BK;
@@ -500,14 +510,13 @@ void gemm_kernel(MatDesc A, MatDesc B, Epilogue ep, int M, int N, int K, int k_p
         const char* tb = cur + TILE_BYTES;
 #pragma unroll
         for (int kc = 0; kc < BK / KF; ++kc) {
-            u32x4 fa[2], fb[2];
+            u32x4 fa[MI], fb[2];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                fa[i] = read_frag<T, TA>(ta, wm * 64 + i * 32, kc, lane);
-                fb[i] = read_frag<T, TB>(tb, wn * 64 + i * 32, kc, lane);
-            }
+            for (int i = 0; i < MI; ++i) fa[i] = read_frag<T, TA>(ta, wm * (32 * MI) + i * 32, kc, lane);
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int j = 0; j < 2; ++j) fb[j] = read_frag<T, TB>(tb, wn * 64 + j * 32, kc, lane);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) Mma<T>::run(fa[i], fb[j], acc[i][j]);
         }
@@ -532,8 +541,8 @@ void gemm_kernel(MatDesc A, MatDesc B, Epilogue ep, int M, int N, int K, int k_p
     // accumulator (reg r, lane l) -> row (r&3) + 8*(r>>2) + 4*(l>>5), col l&31 of its 32x32 tile; stage as fp32 in LDS.
     float* cs = reinterpret_cast<float*>(smem);
     {
-        const int rb = wm * 64 + 4 * (lane >> 5), cb = wn * 64 + (lane & 31);
-        static_for<64>([&](auto ic) {
+        const int rb = wm * (32 * MI) + 4 * (lane >> 5), cb = wn * 64 + (lane & 31);
+        static_for<MI * 32>([&](auto ic) {
             constexpr int idx = decltype(ic)::v;
             constexpr int i = idx >> 5, j = (idx >> 4) & 1, r = idx & 15;
             cs[(rb + i * 32 + (r & 3) + 8 * (r >> 2)) * CS_LD + cb + j * 32] = acc[i][j][r];
@@ -548,7 +557,7 @@ void gemm_kernel(MatDesc A, MatDesc B, Epilogue ep, int M, int N, int K, int k_p
         const long long tile_id = (long long)batch * gridDim.x + blockIdx.x;
         float* slabs = ep.splitk_ws + tile_id * nsplit * (TILE * TILE);
         float* mine = slabs + (long long)blockIdx.y * (TILE * TILE);
-        for (int v = tid; v < TILE * TILE / 4; v += NTHREADS) {
+        for (int v = tid; v < TILE * TILE / 4; v += NT) {
             const int r = v >> 5, c4 = (v & 31) << 2;
             *reinterpret_cast<f32x4*>(mine + r * TILE + c4) = *reinterpret_cast<const f32x4*>(cs + r * CS_LD + c4);
         }
@@ -569,7 +578,7 @@ void gemm_kernel(MatDesc A, MatDesc B, Epilogue ep, int M, int N, int K, int k_p
         }
         __syncthreads();
         // fixed summation order (slab 0, 1, 2, ...) whichever block happens to arrive last: bit-deterministic results
-        for (int v = tid; v < TILE * TILE / 4; v += NTHREADS) {
+        for (int v = tid; v < TILE * TILE / 4; v += NT) {
             const int r = v >> 5, c4 = (v & 31) << 2;
             const f32x4 own = *reinterpret_cast<const f32x4*>(cs + r * CS_LD + c4);
             f32x4 a = (blockIdx.y == 0) ? own : *reinterpret_cast<const f32x4*>(slabs + r * TILE + c4);
@@ -581,10 +590,20 @@ void gemm_kernel(MatDesc A, MatDesc B, Epilogue ep, int M, int N, int K, int k_p
         }
         __syncthreads();
     }
-    if (ep.mode == 0) epilogue_rows<T, T>(ep, cs, batch, tm * TILE, tn * TILE, M, N, tid);
-    else if (ep.mode == 1) epilogue_rows<T, float>(ep, cs, batch, tm * TILE, tn * TILE, M, N, tid);
-    else epilogue_scatter(ep, cs, batch, tm * TILE, tn * TILE, M, N, tid);
+    if (ep.mode == 0) epilogue_rows<T, T, NT>(ep, cs, batch, tm * TILE, tn * TILE, M, N, tid);
+    else if (ep.mode == 1) epilogue_rows<T, float, NT>(ep, cs, batch, tm * TILE, tn * TILE, M, N, tid);
+    else epilogue_scatter<NT>(ep, cs, batch, tm * TILE, tn * TILE, M, N, tid);
 }
+
+// Explicit instantiations: every (dtype, operand layout, ring depth, wave count) the launcher can pick.
+#define INST(T, TA, TB, NB, NWV) template __global__ void gemm_kernel<T, TA, TB, NB, NWV>(MatDesc, MatDesc, Epilogue, int, int, int, int, int);
+INST(bf16_t, false, false, 2, 4) INST(bf16_t, false, false, 2, 8) INST(bf16_t, false, false, 3, 4)
+INST(bf16_t, false, true, 2, 4) INST(bf16_t, false, true, 2, 8)
+INST(bf16_t, true, false, 2, 4) INST(bf16_t, true, false, 2, 8)
+INST(bf16_t, true, true, 2, 4) INST(bf16_t, true, true, 2, 8)
+INST(float, false, false, 2, 4) INST(float, false, false, 2, 8) INST(float, false, false, 3, 4)
+INST(float, false, true, 2, 4) INST(float, true, false, 2, 4) INST(float, true, true, 2, 4)
+#undef INST
 
 // ---------------------------------------------------------------------------------------------- host side
 
@@ -610,6 +629,8 @@ static int finish_desc(MatDesc& d, int esize) {
     return DDPM_OK;
 }
 
+static bool g_use_w8 = getenv("DDPM_GEMM_W4") == nullptr;      // A/B switch for experiments: DDPM_GEMM_W4=1 forces 4-wave blocks
+
 template <typename T>
 static int launch_t(GemmArgs& g, hipStream_t st) {
     constexpr int BK = 8 * Elem<T>::VEC;
@@ -626,21 +647,31 @@ static int launch_t(GemmArgs& g, hipStream_t st) {
     const int kps = steps_per * BK;
     // deep ring when the grid cannot keep two blocks on each of the 256 CUs anyway
     const bool deep = !g.A.trans && !g.B.trans && (long long)grid.x * grid.y * grid.z <= 384 && steps_per >= 3;
-#define LAUNCH(TA, TB, NB, LDS)                                                                                          \
+#define LAUNCH(TA, TB, NB, NWV, LDS)                                                                                     \
     do {                                                                                                                 \
         static bool attr_set = false;   /* > 64 KiB of dynamic LDS needs the opt-in once per instantiation */            \
         if (!attr_set) {                                                                                                 \
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, TA, TB, NB>),                          \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, TA, TB, NB, NWV>),                     \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS)) != hipSuccess)              \
                 return DDPM_ERR_LAUNCH;                                                                                  \
             attr_set = true;                                                                                             \
         }                                                                                                                \
-        hipLaunchKernelGGL((gemm_kernel<T, TA, TB, NB>), grid, dim3(NTHREADS), (LDS), st, g.A, g.B, g.ep, g.M, g.N, g.K, kps, tiles_n); \
+        hipLaunchKernelGGL((gemm_kernel<T, TA, TB, NB, NWV>), grid, dim3(NWV * 64), (LDS), st, g.A, g.B, g.ep, g.M, g.N, g.K, kps, tiles_n); \
     } while (0)
-    if (!g.A.trans && !g.B.trans) { if (deep) LAUNCH(false, false, 3, lds3); else LAUNCH(false, false, 2, lds2); }
-    else if (!g.A.trans && g.B.trans) LAUNCH(false, true, 2, lds2);
-    else if (g.A.trans && !g.B.trans) LAUNCH(true, false, 2, lds2);
-    else LAUNCH(true, true, 2, lds2);
+    // 8-wave blocks whenever both operands take the DMA path (all bf16 products, fp32 with k-contiguous operands)
+    constexpr bool BF = sizeof(T) == 2;
+    const bool w8 = g_use_w8;
+    if (!g.A.trans && !g.B.trans) {
+        if (deep) LAUNCH(false, false, 3, 4, lds3);
+        else if (w8) LAUNCH(false, false, 2, 8, lds2);
+        else LAUNCH(false, false, 2, 4, lds2);
+    } else if (!g.A.trans && g.B.trans) {
+        if constexpr (BF) { if (w8) LAUNCH(false, true, 2, 8, lds2); else LAUNCH(false, true, 2, 4, lds2); } else LAUNCH(false, true, 2, 4, lds2);
+    } else if (g.A.trans && !g.B.trans) {
+        if constexpr (BF) { if (w8) LAUNCH(true, false, 2, 8, lds2); else LAUNCH(true, false, 2, 4, lds2); } else LAUNCH(true, false, 2, 4, lds2);
+    } else {
+        if constexpr (BF) { if (w8) LAUNCH(true, true, 2, 8, lds2); else LAUNCH(true, true, 2, 4, lds2); } else LAUNCH(true, true, 2, 4, lds2);
+    }
 #undef LAUNCH
     return check_launch();
 }
