@@ -76,7 +76,15 @@ def main():
     from ddpm_torch import _ops
     ddpm_torch.seed_all(1234)
     model = ddpm_torch.UNet(**CIFAR).to(dev).set_compute_dtype(args.dtype)
-    net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local]) if distributed else model
+    # Data parallelism: the engine's own reducer (parameters broadcast from rank 0; gradient staging buffer all-reduced over
+    # RCCL in chunks from inside the hand-written backward, overlapped with the rest of it).  BENCH_DDP=torch falls back to
+    # the reference's DistributedDataParallel wrapper (train.py:110), which also works but only starts reducing after backward.
+    net = model
+    if distributed:
+        if os.environ.get("BENCH_DDP", "native") == "torch":
+            net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local])
+        else:
+            model.set_process_group()
     dif = ddpm_torch.GaussianDiffusion(ddpm_torch.get_beta_schedule("linear", 1e-4, 0.02, 1000), "eps", "fixed-large", "mse")
     opt = torch.optim.Adam(net.parameters(), lr=2e-4, betas=(0.9, 0.999))
     sched = torch.optim.lr_scheduler.LambdaLR(opt, lr_lambda=lambda s: min((s + 1) / 5000, 1.0))
@@ -158,7 +166,7 @@ def main():
                "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": args.dtype, "data": "synthetic",
                "config": {"workload": "configs/cifar10.json UNet (35.7M params), full Trainer.step, B=128 per GPU, 32x32, T=1000, dropout 0.1, Adam+clip+EMA",
-                          "global_batch": B_PER_GPU * world, "parallelism": f"dp{world}", "imgs_per_s_per_gpu": round(imgs_per_s / world, 2),
+                          "global_batch": B_PER_GPU * world, "parallelism": f"dp{world}" + ("" if world == 1 else (" (torch DDP)" if os.environ.get("BENCH_DDP") == "torch" else " (native chunked RCCL all-reduce inside backward)")), "imgs_per_s_per_gpu": round(imgs_per_s / world, 2),
                           "train_model_tflops_per_gpu": round(imgs_per_s / world * 3 * FWD_GFLOP_PER_SAMPLE / 1e3, 1), "final_loss": round(loss, 4)},
                "roofline": roofline, "sampling": samp}
         if not args.no_cpu_baseline:

@@ -126,7 +126,7 @@ extern "C" int ddpm_pack_weight_multi(const long long* descs, int n_tensors, int
 
 // packed conv weight gradients [N][R*S][C] -> parameter layout [N][C][R*S], all layers in one launch.
 // descs[i] = {src offset (floats) in gpack, dst offset in gflat, N, C, R*S}; grid = (blocks, n_tensors).
-__global__ void wgrad_unpack_kernel(const float* __restrict__ gpack, float* __restrict__ gflat, const long long* __restrict__ descs) {
+__global__ void wgrad_unpack_kernel(const float* __restrict__ gpack, float* __restrict__ gflat, const long long* __restrict__ descs, float scale) {
     const long long* d = descs + 5 * (long long)blockIdx.y;
     const long long src = d[0], dst = d[1];
     const int C = (int)d[3], RS = (int)d[4];
@@ -136,13 +136,13 @@ __global__ void wgrad_unpack_kernel(const float* __restrict__ gpack, float* __re
         const long long nc = i / RS;
         const int c = (int)(nc % C);
         const long long n = nc / C;
-        gflat[dst + i] = gpack[src + (n * RS + tap) * C + c];
+        gflat[dst + i] = gpack[src + (n * RS + tap) * C + c] * scale;
     }
 }
-extern "C" int ddpm_wgrad_unpack(const float* gpack, float* gflat, const long long* descs, int n_tensors, void* stream) {
+extern "C" int ddpm_wgrad_unpack(const float* gpack, float* gflat, const long long* descs, int n_tensors, float scale, void* stream) {
     if (!gpack || !gflat || !descs) return DDPM_ERR_NULL;
     if (n_tensors <= 0) return DDPM_OK;
-    hipLaunchKernelGGL(wgrad_unpack_kernel, dim3(64, n_tensors), dim3(256), 0, (hipStream_t)stream, gpack, gflat, descs);
+    hipLaunchKernelGGL(wgrad_unpack_kernel, dim3(64, n_tensors), dim3(256), 0, (hipStream_t)stream, gpack, gflat, descs, scale);
     return check_launch();
 }
 

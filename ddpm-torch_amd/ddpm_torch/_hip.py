@@ -23,7 +23,7 @@ P, I, L, F, U = c_void_p, c_int, c_longlong, c_float, c_ulonglong
 PROTOTYPES = {
     "ddpm_conv2d_nhwc": [P, L, P, P, L, P, P, L, P, L] + [I] * 14 + [I, I, I, P, P, I, P],
     "ddpm_conv2d_wgrad_nhwc": [P, L, P, L, P] + [I] * 17 + [P],
-    "ddpm_wgrad_unpack": [P, P, P, I, P],
+    "ddpm_wgrad_unpack": [P, P, P, I, F, P],
     "ddpm_gemm": [P, L, L, I, P, L, L, I, P, L, L, P, P, L, L, I, I, I, I, F, I, I, I, I, P],
     "ddpm_groupnorm_silu_fwd": [P, L, P, L, P, P, P, P, I, I, I, I, F, I, F, U, I, P],
     "ddpm_groupnorm_silu_bwd": [P, L, P, L, P, L, P, P, P, P, P, P, I, I, I, I, I, F, U, I, I, P],

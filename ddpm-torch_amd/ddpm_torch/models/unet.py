@@ -166,6 +166,22 @@ class UNet(nn.Module):
         self._eng = None
         return self
 
+    def set_process_group(self, group="default", broadcast=True):
+        """Native data parallelism (instead of wrapping the model in DistributedDataParallel): the hand-written backward
+        all-reduces its gradient staging buffer over ``group`` in a few large chunks, issued from inside the backward as
+        soon as each chunk is final (RCCL runs them on its own stream under the remaining backward kernels), and divides
+        by the world size in the unpack — the result equals DDP's averaged gradients.  ``broadcast`` copies rank 0's
+        parameters to every rank first, as DDP's constructor does.  Pass ``None`` to switch it off."""
+        import torch.distributed as dist
+        self._pg = None if group is None else (dist.group.WORLD if group == "default" else group)
+        if self._pg is not None and broadcast:
+            with torch.no_grad():
+                for p in self.parameters():
+                    dist.broadcast(p.data, src=dist.get_global_rank(self._pg, 0), group=self._pg)
+        if self._eng is not None:
+            self._eng.pg = self._pg
+        return self
+
     def _apply(self, fn, *a, **k):
         self._eng = None                       # .to()/.cuda() re-create parameter storage: drop pointer caches
         return super()._apply(fn, *a, **k)
@@ -173,6 +189,7 @@ class UNet(nn.Module):
     def engine(self):
         if self._eng is None:
             self._eng = _Engine(self)
+            self._eng.pg = getattr(self, "_pg", None)
         return self._eng
 
     def forward(self, x, t):
@@ -256,6 +273,7 @@ class _Engine:
         self.drop_calls = 0
         self.last_tape = None
         self.splitk = ops.SplitK(self.device)
+        self.pg = None                              # process group of the native data-parallel path (set_process_group)
         self.pack_table = self.pack_ptrs = self.pack_key = None
         self.pack_has_dgrad = False
         _hip.lib()
@@ -385,9 +403,42 @@ class _Engine:
                     rows.append([t, self.goff[id(rb.skip.bias)], 1, c, 1])
             oc = self.m.out_conv[2]
             rows.append([slot("out_b", self.convs[id(oc)].Np), self.goff[id(oc.bias)], 1, self.m.out_channels, 1])
+            # every remaining parameter (GroupNorm affine, biases with a single owner, the embed MLP) gets a plain slot:
+            # the staging buffer is then the ONLY thing gradients are written to (and the only thing all-reduced).
+            covered = {r[1] for r in rows}
+            for prm in self.params:
+                if self.goff[id(prm)] not in covered:
+                    rows.append([slot(id(prm), prm.numel()), self.goff[id(prm)], 1, prm.numel(), 1])
             self.ptotal = off
             self.wdesc = torch.tensor(rows, dtype=torch.int64, device=self.device)
+            # all-reduce plan for the native data-parallel path: the conv-weight region (execution order) in chunks that
+            # become final one after another as the backward walks the network in reverse; the small tail goes last.
+            convs = list(self.convs.values())
+            conv_end = self.poff[id(convs[-1].mod.weight)] + (convs[-1].mod.weight.numel() + 3) // 4 * 4
+            target = max(conv_end // 6, 1 << 20)
+            self.chunks, start, members = [], 0, []
+            for i, cw in enumerate(convs):
+                members.append(id(cw.mod.weight))
+                end = self.poff[id(convs[i + 1].mod.weight)] if i + 1 < len(convs) else conv_end
+                if end - start >= target or i + 1 == len(convs):
+                    self.chunks.append((start, end, members))
+                    start, members = end, []
+            self.tail = (conv_end, self.ptotal)
         return self.wdesc
+
+    def _wgrad(self, ctx, weight, dy, x, *args, **kw):
+        """Weight gradient into the staging buffer; then hand finished all-reduce chunks to the communicator."""
+        ops.conv2d_wgrad(dy, x, self._pptr(ctx, weight), *args, **kw)
+        if ctx.get("pending") is not None:
+            for ch in ctx["pending"]:
+                ch[2].discard(id(weight))
+            while ctx["pending"] and not ctx["pending"][-1][2]:
+                a, b, _ = ctx["pending"].pop()
+                ctx["works"].append(self._all_reduce(ctx["gpack"][a:b]))
+
+    def _all_reduce(self, t):
+        import torch.distributed as dist
+        return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
 
     def _pptr(self, ctx, p):
         return ctx["gpack"].data_ptr() + 4 * self.poff[p if isinstance(p, (str, tuple)) else id(p)]
@@ -603,7 +654,7 @@ class _Engine:
     # ================================================================ backward
     def backward(self, tape, gout):
         m = self.m
-        gflat = torch.zeros(self.gtotal, dtype=torch.float32, device=self.device)
+        gflat = torch.empty(self.gtotal, dtype=torch.float32, device=self.device)   # written only by the final unpack
         head = tape[-1]
         st = head[4]
         B, ws = st["B"], st["ws"]
@@ -612,7 +663,13 @@ class _Engine:
         dtb = torch.zeros((B, self.tb_total), dtype=torch.float32, device=self.device)
         wdesc = self._wgrad_table()
         gpack = torch.zeros(self.ptotal, dtype=torch.float32, device=self.device)    # conv weight grads, packed [N][RS][C]
-        ctx = dict(gflat=gflat, gpack=gpack, ws=ws, B=B, dtb=dtb)
+        ctx = dict(gflat=gflat, gpack=gpack, ws=ws, B=B, dtb=dtb, pending=None, works=[])
+        world = 1
+        if self.pg is not None:
+            import torch.distributed as dist
+            world = dist.get_world_size(self.pg)
+            # chunks in execution order; the backward finishes them from the last one backwards
+            ctx["pending"] = [(a, b, set(mem)) for a, b, mem in self.chunks]
         # ---- head
         _, cur, act, stats, _ = head
         norm, conv = m.out_conv[0], m.out_conv[2]
@@ -621,10 +678,10 @@ class _Engine:
         _hip.call("ddpm_nchw_to_nhwc", gout.data_ptr(), dy.ptr, B, m.out_channels, H * W, cw.Np, self.dcode, _hip.stream())
         dact = self._new(B, H, W, self.hid)
         ops.conv2d(dy, cw.wd.data_ptr(), dact.ptr, dact.ld, self.hid, 3, 3, H, W, pad_t=1, pad_l=1, splitk=self.splitk)
-        ops.conv2d_wgrad(dy, act, self._pptr(ctx, conv.weight), self.hid, cw.N, 3, 3, pad_t=1, pad_l=1, splits=self._splits(cw.N, 9 * self.hid, B * H * W))
+        self._wgrad(ctx, conv.weight, dy, act, self.hid, cw.N, 3, 3, pad_t=1, pad_l=1, splits=self._splits(cw.N, 9 * self.hid, B * H * W))
         self._bias_grad(ctx, dy, [conv.bias], cw.N, slot="out_b")
         g, acc = self._grad_target(cur)
-        ops.gn_bwd(cur, dact, g, norm.weight, norm.bias, stats, self._gptr(gflat, norm.weight), self._gptr(gflat, norm.bias), ws, silu=True, accumulate=acc)
+        ops.gn_bwd(cur, dact, g, norm.weight, norm.bias, stats, self._pptr(ctx, norm.weight), self._pptr(ctx, norm.bias), ws, silu=True, accumulate=acc)
         # ---- the rest of the tape in reverse
         for rec in reversed(tape[:-1]):
             kind = rec[0]
@@ -635,7 +692,12 @@ class _Engine:
             else:
                 self._conv_bwd(ctx, rec)
         self._temb_bwd(ctx, st)
-        _hip.call("ddpm_wgrad_unpack", gpack.data_ptr(), gflat.data_ptr(), wdesc.data_ptr(), wdesc.shape[0], _hip.stream())
+        if self.pg is not None:
+            assert not ctx["pending"], "a conv weight gradient was never produced"
+            ctx["works"].append(self._all_reduce(gpack[self.tail[0]:self.tail[1]]))
+            for w in ctx["works"]:
+                w.wait()                                   # the compute stream waits for the communicator; no host sync
+        _hip.call("ddpm_wgrad_unpack", gpack.data_ptr(), gflat.data_ptr(), wdesc.data_ptr(), wdesc.shape[0], 1.0 / world, _hip.stream())
         grads = []
         for p in self.params:
             o = self.goff[id(p)]
@@ -654,7 +716,7 @@ class _Engine:
         channel-padded dy: reduce into a gpack slot that the unpack table fans out."""
         if slot is None:
             assert dy.C == creal and len(biases) == 1
-            ops.colsum(dy, 0, 0, self._gptr(ctx["gflat"], biases[0]))
+            ops.colsum(dy, 0, 0, self._pptr(ctx, biases[0]))
         else:
             ops.colsum(dy, 0, 0, self._pptr(ctx, slot))
 
@@ -665,7 +727,7 @@ class _Engine:
         dy = out.grad
         assert dy is not None and out.ginit
         first = conv is self.m.in_conv
-        ops.conv2d_wgrad(dy, x, self._pptr(ctx, conv.weight), cw.C, cw.N, k, k, stride=stride, pad_t=pt, pad_l=pl, upsample=upsample,
+        self._wgrad(ctx, conv.weight, dy, x, cw.C, cw.N, k, k, stride=stride, pad_t=pt, pad_l=pl, upsample=upsample,
                          splits=self._splits(cw.N, k * k * cw.Cp, dy.rows))
         self._bias_grad(ctx, dy, [conv.bias], cw.N)
         if first:
@@ -691,26 +753,26 @@ class _Engine:
         # conv2
         da2 = self._new(B, x.H, x.W, Cout)
         ops.conv2d(dout, c2.wd.data_ptr(), da2.ptr, da2.ld, Cout, 3, 3, x.H, x.W, pad_t=1, pad_l=1, splitk=self.splitk)
-        ops.conv2d_wgrad(dout, a2, self._pptr(ctx, rb.conv2.weight), Cout, Cout, 3, 3, pad_t=1, pad_l=1, splits=self._splits(Cout, 9 * Cout, dout.rows))
+        self._wgrad(ctx, rb.conv2.weight, dout, a2, Cout, Cout, 3, 3, pad_t=1, pad_l=1, splits=self._splits(Cout, 9 * Cout, dout.rows))
         self._bias_grad(ctx, dout, [rb.conv2.bias], Cout, slot=("b2", id(rb)) if rb.has_skip else None)
         # GN2 + SiLU + dropout
         dh1 = self._new(B, x.H, x.W, Cout)
-        ops.gn_bwd(h1, da2, dh1, rb.norm2.weight, rb.norm2.bias, stats2, self._gptr(gflat, rb.norm2.weight), self._gptr(gflat, rb.norm2.bias),
+        ops.gn_bwd(h1, da2, dh1, rb.norm2.weight, rb.norm2.bias, stats2, self._pptr(ctx, rb.norm2.weight), self._pptr(ctx, rb.norm2.bias),
                    ws, silu=True, drop_p=drop_p, seed=seed)
         # time bias (+conv1 bias): per-sample column sums into the concatenated dtb
         ops.colsum(dh1, ctx["dtb"].data_ptr() + 4 * self.tb_off[id(rb)], self.tb_total, 0)
         # conv1
         da1 = self._new(B, x.H, x.W, Cin)
         ops.conv2d(dh1, c1.wd.data_ptr(), da1.ptr, da1.ld, Cin, 3, 3, x.H, x.W, pad_t=1, pad_l=1, splitk=self.splitk)
-        ops.conv2d_wgrad(dh1, a1, self._pptr(ctx, rb.conv1.weight), Cin, Cout, 3, 3, pad_t=1, pad_l=1, splits=self._splits(Cout, 9 * Cin, dh1.rows))
+        self._wgrad(ctx, rb.conv1.weight, dh1, a1, Cin, Cout, 3, 3, pad_t=1, pad_l=1, splits=self._splits(Cout, 9 * Cin, dh1.rows))
         # GN1 + SiLU, then the skip path, into d(x)
         g, acc = self._grad_target(x)
-        ops.gn_bwd(x, da1, g, rb.norm1.weight, rb.norm1.bias, stats1, self._gptr(gflat, rb.norm1.weight), self._gptr(gflat, rb.norm1.bias),
+        ops.gn_bwd(x, da1, g, rb.norm1.weight, rb.norm1.bias, stats1, self._pptr(ctx, rb.norm1.weight), self._pptr(ctx, rb.norm1.bias),
                    ws, silu=True, accumulate=acc)
         if rb.has_skip:
             cs = self.convs[id(rb.skip)]
             ops.conv2d(dout, cs.wd.data_ptr(), g.ptr, g.ld, Cin, 1, 1, x.H, x.W, accumulate=1, splitk=self.splitk)
-            ops.conv2d_wgrad(dout, x, self._pptr(ctx, rb.skip.weight), Cin, Cout, 1, 1, splits=self._splits(Cout, Cin, dout.rows))
+            self._wgrad(ctx, rb.skip.weight, dout, x, Cin, Cout, 1, 1, splits=self._splits(Cout, Cin, dout.rows))
         else:
             ops.add_rows(dout, g, 1)
         if parts is not None:                                 # x was a concat buffer: hand each producer its slice
@@ -729,7 +791,7 @@ class _Engine:
         # project_out
         do = self._new(B, x.H, x.W, C)
         ops.conv2d(dout, co.wd.data_ptr(), do.ptr, do.ld, C, 1, 1, x.H, x.W, splitk=self.splitk)
-        ops.conv2d_wgrad(dout, o, self._pptr(ctx, ab.project_out.weight), C, C, 1, 1, splits=self._splits(C, C, dout.rows))
+        self._wgrad(ctx, ab.project_out.weight, dout, o, C, C, 1, 1, splits=self._splits(C, C, dout.rows))
         self._bias_grad(ctx, dout, [ab.project_out.bias], C)
         # attention core
         q, kk, v = qkv.ptr, qkv.ptr + C * es, qkv.ptr + 2 * C * es
@@ -747,11 +809,11 @@ class _Engine:
         # project_in
         dhn = self._new(B, x.H, x.W, C)
         ops.conv2d(dqkv, ci.wd.data_ptr(), dhn.ptr, dhn.ld, C, 1, 1, x.H, x.W, splitk=self.splitk)
-        ops.conv2d_wgrad(dqkv, hn, self._pptr(ctx, ab.project_in.weight), C, 3 * C, 1, 1, splits=self._splits(3 * C, C, dqkv.rows))
+        self._wgrad(ctx, ab.project_in.weight, dqkv, hn, C, 3 * C, 1, 1, splits=self._splits(3 * C, C, dqkv.rows))
         self._bias_grad(ctx, dqkv, [ab.project_in.bias], 3 * C)
         # GN (no SiLU) + identity residual
         g, acc = self._grad_target(x)
-        ops.gn_bwd(x, dhn, g, ab.norm.weight, ab.norm.bias, stats, self._gptr(gflat, ab.norm.weight), self._gptr(gflat, ab.norm.bias),
+        ops.gn_bwd(x, dhn, g, ab.norm.weight, ab.norm.bias, stats, self._pptr(ctx, ab.norm.weight), self._pptr(ctx, ab.norm.bias),
                    ws, silu=False, accumulate=acc)
         ops.add_rows(dout, g, 1)
 
@@ -769,11 +831,11 @@ class _Engine:
         dt_emb = self._f32(B, E)
         _hip.call("ddpm_silu_bwd", t_emb.data_ptr(), ds_t.data_ptr(), dt_emb.data_ptr(), B * E, 0, _hip.stream())
         lin2, lin1 = m.embed[2], m.embed[0]
-        ops.gemm(dt_emb.data_ptr(), E, 0, 1, s1.data_ptr(), E, 0, 1, self._gptr(gflat, lin2.weight), E, 0, E, E, B, F, out_mode=1)
-        ops.colsum(View(dt_emb, 1, B, 1, E), 0, 0, self._gptr(gflat, lin2.bias))
+        ops.gemm(dt_emb.data_ptr(), E, 0, 1, s1.data_ptr(), E, 0, 1, self._pptr(ctx, lin2.weight), E, 0, E, E, B, F, out_mode=1)
+        ops.colsum(View(dt_emb, 1, B, 1, E), 0, 0, self._pptr(ctx, lin2.bias))
         ds1 = self._f32(B, E)
         ops.gemm(dt_emb.data_ptr(), E, 0, 0, lin2.weight.data_ptr(), E, 0, 1, ds1.data_ptr(), E, 0, B, E, E, F, out_mode=1)
         de1 = self._f32(B, E)
         _hip.call("ddpm_silu_bwd", e1.data_ptr(), ds1.data_ptr(), de1.data_ptr(), B * E, 0, _hip.stream())
-        ops.gemm(de1.data_ptr(), E, 0, 1, temb.data_ptr(), self.hid, 0, 1, self._gptr(gflat, lin1.weight), self.hid, 0, E, self.hid, B, F, out_mode=1)
-        ops.colsum(View(de1, 1, B, 1, E), 0, 0, self._gptr(gflat, lin1.bias))
+        ops.gemm(de1.data_ptr(), E, 0, 1, temb.data_ptr(), self.hid, 0, 1, self._pptr(ctx, lin1.weight), self.hid, 0, E, self.hid, B, F, out_mode=1)
+        ops.colsum(View(de1, 1, B, 1, E), 0, 0, self._pptr(ctx, lin1.bias))

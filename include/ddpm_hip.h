@@ -42,12 +42,13 @@ int ddpm_conv2d_nhwc(const void* x, long long x_ld, const void* w, void* y, long
  *   dw[n][r][s][c] += sum_{b,oy,ox} dy[b,oy,ox,n] * x[b, f(..), f(..), c]      n < Nreal, c < Creal (fp32 atomics)
  * dy has N (>= Nreal) channels, x has C (>= Creal) channels (zero padding beyond the real counts).
  * ddpm_wgrad_unpack rewrites all layers' packed gradients into the parameter layout [n][c][r][s] in one launch:
- * descs[i] = {src offset in gpack, dst offset in gflat (floats), N, C, R*S} as int64. */
+ * descs[i] = {src offset in gpack, dst offset in gflat (floats), N, C, R*S} as int64 (R*S = 1: plain segment copy);
+ * every value is multiplied by `scale` (1/world_size after the data-parallel sum all-reduce of gpack). */
 int ddpm_conv2d_wgrad_nhwc(const void* dy, long long dy_ld, const void* x, long long x_ld, float* dw,
                            int B, int H, int W, int C, int Creal, int Ho, int Wo, int N, int Nreal, int R, int S,
                            int stride, int pad_t, int pad_l, int upsample, int splits, int dtype, void* stream);
 
-int ddpm_wgrad_unpack(const float* gpack, float* gflat, const long long* descs, int n_tensors, void* stream);
+int ddpm_wgrad_unpack(const float* gpack, float* gflat, const long long* descs, int n_tensors, float scale, void* stream);
 
 /* F.linear (modules.py:58-59; unet.py:77,123,125) and torch.einsum in AttentionBlock.qkv (unet.py:46,50):
  *   C[b][m][n] = alpha * sum_k A[b][m][k] * B[b][n][k] + bias[n] + residual[b][m][n]   (+ C when accumulate)

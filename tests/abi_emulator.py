@@ -147,11 +147,11 @@ class Emulator:
         arr = f32(dw, Nreal * Creal * R * S).reshape(Nreal, R, S, Creal)          # packed layout [n][r][s][c]
         arr += gw[:, :Creal].permute(0, 2, 3, 1).numpy()
 
-    def ddpm_wgrad_unpack(self, gpack, gflat, descs, n, st):
+    def ddpm_wgrad_unpack(self, gpack, gflat, descs, n, scale, st):
         d = i64(descs, 5 * n).reshape(n, 5)
         for src, dst, N, C, RS in d:
             v = f32(gpack + 4 * int(src), int(N * C * RS)).reshape(N, RS, C).transpose(0, 2, 1)
-            f32(gflat + 4 * int(dst), int(N * C * RS)).reshape(N, C, RS)[...] = v
+            f32(gflat + 4 * int(dst), int(N * C * RS)).reshape(N, C, RS)[...] = v * np.float32(scale)
 
     def _operand(self, p, ld, bs, trans, rows, K, batch, dt):
         es = 2 if dt == BF16 else 4

@@ -239,3 +239,32 @@ def test_toy_config_plumbing_on_device(golden):
     assert losses[-1] < losses[0]
     x = dif.p_sample(fn, shape=(1000, 2), device=DEV, seed=1)
     assert x.shape == (1000, 2) and torch.isfinite(x).all()
+
+
+def test_native_data_parallel_path_on_rccl_single_rank():
+    """world_size 1 over the "nccl" (= RCCL) backend: exercises the in-backward async all-reduce / wait / scaled unpack on the
+    real device and streams (the 2-rank arithmetic is covered on CPU by tests/test_ddp_gloo.py)."""
+    import socket
+    import torch.distributed as dist
+    with socket.socket() as sck:
+        sck.bind(("127.0.0.1", 0))
+        port = sck.getsockname()[1]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    try:
+        m, sd = make(TINY3, dtype=torch.float32)
+        m.train()
+        x, t, gy = rnd(2, 3, 16, 16, seed=3).to(DEV), torch.tensor([7, 912], device=DEV), rnd(2, 3, 16, 16, seed=4).to(DEV)
+        torch.manual_seed(0)
+        (m(x, t) * gy).sum().backward()
+        ref = {k: p.grad.clone() for k, p in m.named_parameters()}
+        m.zero_grad(set_to_none=True)
+        m.set_process_group()
+        m.engine().drop_calls = 0
+        torch.manual_seed(0)
+        (m(x, t) * gy).sum().backward()
+        torch.cuda.synchronize()
+        for k, p in m.named_parameters():
+            scale = max(float(ref[k].abs().max()), 1e-4)
+            assert float((p.grad - ref[k]).abs().max()) <= 1e-4 * scale + 1e-6, k
+    finally:
+        dist.destroy_process_group()
