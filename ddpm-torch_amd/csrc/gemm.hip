@@ -303,11 +303,12 @@ struct Loader {
 // 16-byte vector along n (bias / time-bias / residual reads and the output write are fully coalesced).
 constexpr int CS_LD = TILE + 4;
 
-template <typename T, typename OutT, int NT>
-__device__ __forceinline__ void epilogue_rows(const Epilogue& ep, const float* cs, int batch, int row0g, int col0g, int M, int N, int tid) {
+// `rowmap(rl)` gives the global output row of staged row rl (or -1 to skip it); NROWS rows are staged in `cs`.
+template <typename T, typename OutT, int NT, int NROWS, typename RowMap>
+__device__ __forceinline__ void epilogue_rows(const Epilogue& ep, const float* cs, int batch, RowMap rowmap, int col0g, int N, int tid) {
     constexpr int VO = 16 / (int)sizeof(OutT);            // output elements per 16-byte vector
     constexpr int VPR = TILE / VO;                         // vectors per tile row
-    constexpr int PER_THREAD = TILE * VPR / NT;
+    constexpr int PER_THREAD = (NROWS * VPR + NT - 1) / NT;
     constexpr int ROWS_PER_PASS = NT / VPR;
     const int cv = tid % VPR, r0 = tid / VPR;
     const int col = col0g + cv * VO;
@@ -321,8 +322,9 @@ __device__ __forceinline__ void epilogue_rows(const Epilogue& ep, const float* c
 #pragma unroll 2
     for (int i = 0; i < PER_THREAD; ++i) {
         const int rl = r0 + i * ROWS_PER_PASS;
-        const int row = row0g + rl;
-        if (row >= M) break;
+        if (rl >= NROWS) break;
+        const int row = rowmap(rl);
+        if (row < 0) continue;
         float v[VO];
 #pragma unroll
         for (int j = 0; j < VO; j += 4) {
@@ -590,9 +592,191 @@ void gemm_kernel(MatDesc A, MatDesc B, Epilogue ep, int M, int N, int K, int k_p
         }
         __syncthreads();
     }
-    if (ep.mode == 0) epilogue_rows<T, T, NT>(ep, cs, batch, tm * TILE, tn * TILE, M, N, tid);
-    else if (ep.mode == 1) epilogue_rows<T, float, NT>(ep, cs, batch, tm * TILE, tn * TILE, M, N, tid);
+    auto rowmap = [&](int rl) { const int row = tm * TILE + rl; return row < M ? row : -1; };
+    if (ep.mode == 0) epilogue_rows<T, T, NT, TILE>(ep, cs, batch, rowmap, tn * TILE, N, tid);
+    else if (ep.mode == 1) epilogue_rows<T, float, NT, TILE>(ep, cs, batch, rowmap, tn * TILE, N, tid);
     else epilogue_scatter<NT>(ep, cs, batch, tm * TILE, tn * TILE, M, N, tid);
+}
+
+
+// =====================================================================================================================
+// 3x3 / stride 1 / pad 1 convolution with a STATIONARY INPUT HALO (bf16): the hot conv of the UNet (forward and dgrad).
+//
+// The generic implicit GEMM re-fetches every input pixel 9x (once per tap) and every weight tile once per 128 pixels;
+// at ~30 % MFMA utilisation its L2 -> LDS stream (TCC_BUSY 75 %) is the limiter.  Here a block owns 256 output pixels
+// (NB images x PH x PW patch, e.g. one 16x16 patch) x 128 output channels and walks K as (64-channel chunk, tap):
+//   * the input halo of the patch ((PH+2) x (PW+2) pixels x 64 channels, zero-padded by out-of-range buffer offsets) is
+//     DMA'd to LDS ONCE per chunk and serves all 9 taps — the A fragment of tap (r,s) is the same LDS tile read at pixel
+//     offset r*(PW+2)+s;
+//   * only the 128 x 64 weight tile streams per tap (double-buffered LDS-DMA), shared by twice as many pixels as before.
+// L2 -> LDS bytes per FLOP drop to ~1/3 of the generic kernel's.  8 waves as 4(M) x 2(N), 64x64 per wave; one block per CU.
+struct Conv3Args {
+    const void* x; long long x_ld; unsigned x_extent;
+    const void* w; unsigned w_extent;
+    int B, H, W, C, N, K;
+    int PH, PW, NB, lPW, lPP;         // patch geometry: PW and PH*PW are powers of two (log2 in lPW, lPP); NB*PH*PW == 256
+    int tiles_y, tiles_x;             // patches per image
+    Epilogue ep;
+};
+constexpr int C3_NI = 7;              // halo DMA parts of 512 vectors: up to 448 halo pixels x 8 chunks
+
+// RING = depth of the weight-tile ring (RING-1 tiles in flight, counted s_waitcnt + raw s_barrier); HROWS = LDS rows
+// reserved per halo buffer.  LDS = 2*HROWS*128 + RING*16 KiB = 160 KiB in both instantiated configurations.
+template <int RING, int HROWS>
+__global__ __launch_bounds__(512, 2)
+void conv3x3_halo_kernel(Conv3Args a, int tiles_n) {
+    typedef bf16_t T;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // LDS: [halo 0 | halo 1 | weight ring]; the fp32 epilogue staging (64 rows) aliases the halo region afterwards
+    constexpr int HALO_BYTES = HROWS * ROW_BYTES, BT_BYTES = TILE * ROW_BYTES;
+    char* halo = smem;
+    char* btile = smem + 2 * HALO_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tmi = blockIdx.x / tiles_n, tn = blockIdx.x - tmi * tiles_n;
+    const int tpi = a.tiles_y * a.tiles_x;
+    const int grp = tmi / tpi, pt = tmi - grp * tpi;
+    const int ty = pt / a.tiles_x, tx = pt - ty * a.tiles_x;
+    const int py0 = ty * a.PH, px0 = tx * a.PW, img0 = grp * a.NB;
+    const int HH = a.PH + 2, HWd = a.PW + 2, HP = a.NB * HH * HWd;
+    const int ES = 2;
+
+    auto rsrc_of = [&](const void* p, unsigned extent) {
+        const unsigned long long ad = (unsigned long long)p;
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)ad), hi = __builtin_amdgcn_readfirstlane((unsigned)(ad >> 32));
+        return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0,
+                                                 __builtin_amdgcn_readfirstlane((int)extent), 0x00020000);
+    };
+    const __amdgpu_buffer_rsrc_t rx = rsrc_of(a.x, a.x_extent), rw = rsrc_of(a.w, a.w_extent);
+
+    // halo DMA plan: vector v = tid + 512 i -> halo pixel hp = v>>3, physical chunk v&7 (logical chunk ^ key(hp))
+    unsigned hoff[C3_NI];
+#pragma unroll
+    for (int i = 0; i < C3_NI; ++i) {
+        const int v = tid + 512 * i, hp = v >> 3;
+        const int img = hp / (HH * HWd), rem = hp - img * (HH * HWd);
+        const int hy = rem / HWd, hx = rem - hy * HWd;
+        const int iy = py0 + hy - 1, ix = px0 + hx - 1, gi = img0 + img;
+        const bool ok = hp < HP && gi < a.B && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+        const int lc = (v & 7) ^ ((hp >> 1) & 7);
+        hoff[i] = ok ? (unsigned)((((long long)(gi * a.H + iy) * a.W + ix) * a.x_ld + lc * 8) * ES) : OOB;
+    }
+    // weight DMA plan: vector v = tid + 512 i -> row n = v>>3 of the 128-row tile, physical chunk v&7
+    unsigned woff[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int v = tid + 512 * i, row = v >> 3, n = tn * TILE + row;
+        const int lc = (v & 7) ^ ((row >> 1) & 7);
+        woff[i] = n < a.N ? (unsigned)(((long long)n * a.K + lc * 8) * ES) : OOB;
+    }
+    auto issue_halo_part = [&](unsigned ho, int i, int cc, char* dst) {     // part i of the halo of channel chunk cc
+        const unsigned o = ho == OOB ? OOB : ho + (unsigned)(cc * 64 * ES);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(dst + (wave * 64 + 512 * i) * 16), 16, o, 0, 0, 0);
+    };
+    const int nchunks = a.C / 64;
+    const int total = nchunks * 9;                        // K-steps: (channel chunk, tap)
+    auto issue_w = [&](int step) {                          // weight tile of K-step `step` into its ring slot
+        const int cc = step / 9, tap = step - 9 * cc;
+        char* dst = btile + (step % RING) * BT_BYTES;
+        const unsigned koff = (unsigned)((tap * a.C + cc * 64) * ES);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const unsigned o = woff[i] == OOB ? OOB : woff[i] + koff;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(dst + (wave * 64 + 512 * i) * 16), 16, o, 0, 0, 0);
+        }
+    };
+
+    // this lane's output pixels (rows of its two 32-row accumulator blocks) -> halo index of tap (0,0)
+    int hp0[2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+        const int p = wm * 64 + mi * 32 + (lane & 31);
+        const int il = p >> a.lPP, q = p & ((1 << a.lPP) - 1);
+        const int py = q >> a.lPW, px = q & (a.PW - 1);
+        hp0[mi] = il * HH * HWd + py * HWd + px;
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x16)(0.f);
+
+    const int ni = (HP * 8 + 511) / 512;                 // halo DMA parts actually needed
+    // prologue: halo of chunk 0, then the first RING-1 weight tiles; wait for halo + tile 0 only
+#pragma unroll
+    for (int i = 0; i < C3_NI; ++i)
+        if (i < ni) issue_halo_part(hoff[i], i, 0, halo);
+#pragma unroll
+    for (int t = 0; t < RING - 1; ++t)
+        if (t < total) issue_w(t);
+    if (total >= RING - 1) { if (RING == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    const int hi = lane >> 5;
+    int step = 0;
+    for (int cc = 0; cc < nchunks; ++cc) {
+        const char* hcur = halo + (cc & 1) * HALO_BYTES;
+        char* hnxt = halo + ((cc + 1) & 1) * HALO_BYTES;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap, ++step) {     // fully unrolled: the halo-part index must be a constant
+            const char* bcur = btile + (step % RING) * BT_BYTES;
+            // in program order: next chunk's halo part first, then the weight tile RING-1 steps ahead (its slot was read
+            // in step-1; every wave is past that barrier).  Loads retire in order, so once tile (cc+1, 0) has landed the
+            // whole next halo has too.
+            if (tap < C3_NI && tap < ni && cc + 1 < nchunks) issue_halo_part(hoff[tap < C3_NI ? tap : 0], tap, cc + 1, hnxt);
+            if (step + RING - 1 < total) issue_w(step + RING - 1);
+            const int r = tap / 3, s = tap - 3 * r;
+            const int shift = r * HWd + s;
+#pragma unroll
+            for (int kc = 0; kc < 4; ++kc) {
+                u32x4 fa[2], fb[2];
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) {
+                    const int hp = hp0[mi] + shift;
+                    fa[mi] = *reinterpret_cast<const u32x4*>(hcur + hp * ROW_BYTES + ((((2 * kc) | hi) ^ ((hp >> 1) & 7)) << 4));
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) fb[j] = read_frag<T, false>(bcur, wn * 64 + j * 32, kc, lane);
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) Mma<T>::run(fa[mi], fb[j], acc[mi][j]);
+            }
+            // tile step+1 must have landed; the RING-2 newer tiles (2 DMA instructions each) may stay in flight
+            const int newer = total - 2 - step;         // tiles issued after tile step+1
+            if (RING == 4 && newer >= 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else if (newer >= 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+    }
+    __syncthreads();
+
+    // epilogue: four passes of 64 output pixels (the two waves with wm == q) through an fp32 LDS stage
+    float* cs = reinterpret_cast<float*>(smem);
+    for (int q = 0; q < 4; ++q) {
+        if (wm == q) {
+            const int rb = 4 * (lane >> 5), cb = wn * 64 + (lane & 31);
+            static_for<64>([&](auto ic) {
+                constexpr int idx = decltype(ic)::v;
+                constexpr int i = idx >> 5, j = (idx >> 4) & 1, rr = idx & 15;
+                cs[(rb + i * 32 + (rr & 3) + 8 * (rr >> 2)) * CS_LD + cb + j * 32] = acc[i][j][rr];
+            });
+        }
+        __syncthreads();
+        auto rowmap = [&](int rl) {
+            const int p = q * 64 + rl;
+            const int il = p >> a.lPP, qq = p & ((1 << a.lPP) - 1);
+            const int gi = img0 + il;
+            return gi < a.B ? (gi * a.H + py0 + (qq >> a.lPW)) * a.W + px0 + (qq & (a.PW - 1)) : -1;
+        };
+        epilogue_rows<T, T, 512, 64>(a.ep, cs, 0, rowmap, tn * TILE, a.N, tid);
+        __syncthreads();
+    }
 }
 
 // Explicit instantiations: every (dtype, operand layout, ring depth, wave count) the launcher can pick.
@@ -612,6 +796,44 @@ struct GemmArgs {          // plain-C mirror filled by the extern "C" entry poin
     Epilogue ep;
     int M, N, K, batch, splits, dtype;
 };
+
+static int conv3x3_halo_launch(GemmArgs& g, const void* x, long long x_ld, const void* w, int B, int H, int W, int C, int N, hipStream_t st) {
+    // patch geometry: 256 output pixels per block
+    int PW = W >= 16 ? 16 : W, PH = H >= 16 ? 16 : H;
+    while (PH * PW > 256) PH >>= 1;
+    const int NB = 256 / (PH * PW);
+    auto ilog2 = [](int v) { int l = 0; while ((1 << l) < v) ++l; return l; };
+    if ((PW & (PW - 1)) || ((PH * PW) & (PH * PW - 1)) || H % PH || W % PW || NB * PH * PW != 256) return -1;
+    const int HP = NB * (PH + 2) * (PW + 2);
+    if (HP > 448) return -1;
+    Conv3Args a;
+    memset(&a, 0, sizeof(a));
+    a.x = x; a.x_ld = x_ld; a.w = w;
+    a.B = B; a.H = H; a.W = W; a.C = C; a.N = N; a.K = 9 * C;
+    const long long xbytes = ((long long)B * H * W * x_ld - (x_ld - C)) * 2, wbytes = (long long)N * 9 * C * 2;
+    if (xbytes > 0x7ffffff0ll || wbytes > 0x7ffffff0ll) return -1;
+    a.x_extent = (unsigned)xbytes; a.w_extent = (unsigned)wbytes;
+    a.PH = PH; a.PW = PW; a.NB = NB; a.lPW = ilog2(PW); a.lPP = ilog2(PH * PW);
+    a.tiles_y = H / PH; a.tiles_x = W / PW;
+    a.ep = g.ep;
+    const int groups = (B + NB - 1) / NB, tiles_n = (N + TILE - 1) / TILE;
+    const dim3 grid(groups * a.tiles_y * a.tiles_x * tiles_n);
+    constexpr int LDS = 160 * 1024;                       // both configurations fill the CU's LDS
+#define C3_LAUNCH(RING, HROWS)                                                                                          \
+    do {                                                                                                                 \
+        static bool attr_set = false;                                                                                    \
+        if (!attr_set) {                                                                                                 \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<RING, HROWS>),                    \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return DDPM_ERR_LAUNCH; \
+            attr_set = true;                                                                                             \
+        }                                                                                                                \
+        hipLaunchKernelGGL((conv3x3_halo_kernel<RING, HROWS>), grid, dim3(512), LDS, st, a, tiles_n);                    \
+    } while (0)
+    if (HP <= 384) C3_LAUNCH(4, 384);      // one 16x16 patch: 2 x 48 KiB halo + 4 x 16 KiB weight ring
+    else C3_LAUNCH(3, 448);                // four 8x8 patches: 2 x 56 KiB halo + 3 x 16 KiB weight ring
+#undef C3_LAUNCH
+    return check_launch();
+}
 
 static int finish_desc(MatDesc& d, int esize) {
     // extent of the region one batch of the operand can touch (the buffer descriptor's num_records)
@@ -686,6 +908,13 @@ static int validate(const MatDesc& d, int esize) {
     return DDPM_OK;
 }
 
+static void set_vec_ok(GemmArgs& g, int es) {
+    const int vo = g.ep.mode == 0 ? 16 / es : 4;        // elements per 16-byte output vector
+    bool ok = aligned16(g.ep.out) && g.ep.ldc % vo == 0 && g.ep.out_batch_stride % vo == 0;
+    if (g.ep.residual) ok = ok && aligned16(g.ep.residual) && g.ep.res_ld % (16 / es) == 0 && g.ep.res_batch_stride % (16 / es) == 0;
+    g.ep.vec_ok = ok ? 1 : 0;
+}
+
 int ddpm_gemm_launch(GemmArgs& g, hipStream_t st) {
     if (g.M <= 0 || g.N <= 0 || g.K <= 0 || g.batch <= 0) return DDPM_ERR_SHAPE;
     if (g.dtype != DDPM_F32 && g.dtype != DDPM_BF16) return DDPM_ERR_DTYPE;
@@ -696,12 +925,7 @@ int ddpm_gemm_launch(GemmArgs& g, hipStream_t st) {
     if (!g.ep.out) return DDPM_ERR_NULL;
     if ((rc = finish_desc(g.A, es)) != DDPM_OK) return rc;
     if ((rc = finish_desc(g.B, es)) != DDPM_OK) return rc;
-    {
-        const int vo = g.ep.mode == 0 ? 16 / es : 4;        // elements per 16-byte output vector
-        bool ok = aligned16(g.ep.out) && g.ep.ldc % vo == 0 && g.ep.out_batch_stride % vo == 0;
-        if (g.ep.residual) ok = ok && aligned16(g.ep.residual) && g.ep.res_ld % (16 / es) == 0 && g.ep.res_batch_stride % (16 / es) == 0;
-        g.ep.vec_ok = ok ? 1 : 0;
-    }
+    set_vec_ok(g, es);
     return g.dtype == DDPM_BF16 ? launch_t<bf16_t>(g, st) : launch_t<float>(g, st);
 }
 
@@ -744,6 +968,15 @@ extern "C" int ddpm_conv2d_nhwc(const void* x, long long x_ld, const void* w, vo
     g.ep.residual = residual; g.ep.res_ld = res_ld; g.ep.accumulate = accumulate;
     g.ep.HW = Ho * Wo; g.ep.dHW = make_fastdiv((unsigned)(Ho * Wo));
     g.splits = splits; g.ep.splitk_ws = splitk_ws; g.ep.splitk_cnt = splitk_cnt;
+    // hot case: 3x3 / stride 1 / pad 1 on bf16 with enough pixels to fill the chip -> stationary-halo kernel
+    static const bool no_halo = getenv("DDPM_CONV_NO_HALO") != nullptr;
+    static const int halo_min_c = getenv("DDPM_CONV_HALO_MINC") ? atoi(getenv("DDPM_CONV_HALO_MINC")) : 256;
+    if (!no_halo && C >= halo_min_c && dtype == DDPM_BF16 && R == 3 && S == 3 && stride == 1 && pad_t == 1 && pad_l == 1 && !upsample && !dilate &&
+        out_mode == 0 && splits <= 1 && C % 64 == 0 && Ho == H && Wo == W && g.M >= 16384 && aligned16(x) && aligned16(w) && x_ld % 8 == 0) {
+        set_vec_ok(g, 2);
+        const int rc = conv3x3_halo_launch(g, x, x_ld, w, B, H, W, C, N, (hipStream_t)stream);
+        if (rc >= 0) return rc;              // -1: geometry not covered, fall through to the generic kernel
+    }
     return ddpm_gemm_launch(g, (hipStream_t)stream);
 }
 

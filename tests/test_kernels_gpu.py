@@ -93,6 +93,26 @@ def test_conv_fwd(case, dt):
          B, H, W, C, Ho, Wo, N, R, R, stride, pt, pl, ups, dil, 0, 3, 1, None, None, dt, tol=TOL[0] if dt == 0 else 4e-3)
 
 
+@pytest.mark.parametrize("B,H,C,N", [(16, 32, 64, 128), (65, 16, 128, 192), (258, 8, 64, 128), (17, 32, 192, 256)])
+def test_conv3x3_stationary_halo_path(B, H, C, N):
+    """bf16 3x3/s1/p1 with >= 16384 output pixels takes the stationary-halo kernel: ragged image groups (B % NB != 0),
+    N not a multiple of the tile, pitched operands and every epilogue fusion."""
+    dt = 1
+    M = B * H * H
+    assert M >= 16384
+    ld, yld = C + 16, N + 32
+    x = r(M, ld, seed=1, dt=dt)
+    w = r(N, 9 * C, seed=2, dt=dt, scale=1.0 / math.sqrt(9 * C))
+    bias, rowb = r(N, seed=3), r(B, N + 8, seed=4)
+    res, y = r(M, yld, seed=5, dt=dt), r(M, yld, seed=6, dt=dt)
+    for acc in (0, 1):
+        both("ddpm_conv2d_nhwc", A(x), ld, A(w), A(y.clone(), out=True, name="y"), yld, A(bias), A(rowb), N + 8, A(res), yld,
+             B, H, H, C, H, H, N, 3, 3, 1, 1, 1, 0, 0, acc, 0, 1, None, None, dt, tol=TOL[dt])
+    y2 = torch.zeros(M, N, dtype=DT[dt])
+    both("ddpm_conv2d_nhwc", A(x), ld, A(w), A(y2, out=True, name="y_plain"), N, None, None, 0, None, 0,
+         B, H, H, C, H, H, N, 3, 3, 1, 1, 1, 0, 0, 0, 0, 1, None, None, dt, tol=TOL[dt])
+
+
 @pytest.mark.parametrize("dt", [0, 1])
 @pytest.mark.parametrize("splits", [2, 5, 9])
 def test_conv_fwd_inlaunch_splitk(dt, splits):
