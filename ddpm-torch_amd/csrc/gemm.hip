@@ -319,53 +319,81 @@ __device__ __forceinline__ void epilogue_rows(const Epilogue& ep, const float* c
     for (int j = 0; j < VO; ++j) bias[j] = (ep.bias && col + j < N) ? ep.bias[col + j] : 0.f;
     OutT* outb = reinterpret_cast<OutT*>(ep.out) + (long long)batch * ep.out_batch_stride;
     const T* resb = ep.residual ? reinterpret_cast<const T*>(ep.residual) + (long long)batch * ep.res_batch_stride : nullptr;
-#pragma unroll 2
-    for (int i = 0; i < PER_THREAD; ++i) {
-        const int rl = r0 + i * ROWS_PER_PASS;
-        if (rl >= NROWS) break;
-        const int row = rowmap(rl);
-        if (row < 0) continue;
-        float v[VO];
+    // Rows are handled in batches of U: every global read of the batch (time bias, residual, accumulate target) is issued
+    // before the first one is consumed, so a thread pays one memory latency per batch instead of one per row.
+    constexpr int U = PER_THREAD < 4 ? PER_THREAD : 4;
+    const bool fast = full && ep.vec_ok;
+    const bool same = sizeof(T) == sizeof(OutT);
+    for (int i0 = 0; i0 < PER_THREAD; i0 += U) {
+        int rows[U];
+        float rbv[U][VO];
+        u32x4 resv[U], accv[U];
 #pragma unroll
-        for (int j = 0; j < VO; j += 4) {
-            const f32x4 t = *reinterpret_cast<const f32x4*>(cs + rl * CS_LD + cv * VO + j);
-            v[j] = t.x; v[j + 1] = t.y; v[j + 2] = t.z; v[j + 3] = t.w;
+        for (int u = 0; u < U; ++u) {
+            const int rl = r0 + (i0 + u) * ROWS_PER_PASS;
+            const int row = (i0 + u < PER_THREAD && rl < NROWS) ? rowmap(rl) : -1;
+            rows[u] = row;
+            if (row < 0) continue;
+            if (ep.rowbias) {
+                const float* rb = ep.rowbias + (long long)fdiv((unsigned)row, ep.dgroup) * ep.rowbias_ld + col;
+#pragma unroll
+                for (int j = 0; j < VO; ++j) rbv[u][j] = (col + j < N) ? rb[j] : 0.f;
+            }
+            if (fast) {
+                if (resb && same) resv[u] = ldg16(resb + (long long)row * ep.res_ld + col);
+                if (ep.accumulate) accv[u] = ldg16(outb + (long long)row * ep.ldc + col);
+            }
         }
 #pragma unroll
-        for (int j = 0; j < VO; ++j) v[j] = v[j] * ep.alpha + bias[j];
-        if (ep.rowbias) {
-            const float* rb = ep.rowbias + (long long)fdiv((unsigned)row, ep.dgroup) * ep.rowbias_ld + col;
+        for (int u = 0; u < U; ++u) {
+            const int row = rows[u];
+            if (row < 0) continue;
+            const int rl = r0 + (i0 + u) * ROWS_PER_PASS;
+            float v[VO];
 #pragma unroll
-            for (int j = 0; j < VO; ++j) if (col + j < N) v[j] += rb[j];
-        }
-        OutT* o = outb + (long long)row * ep.ldc + col;
-        if (full && ep.vec_ok) {
-            if (resb) {
-                if (sizeof(T) == sizeof(OutT)) {
+            for (int j = 0; j < VO; j += 4) {
+                const f32x4 t = *reinterpret_cast<const f32x4*>(cs + rl * CS_LD + cv * VO + j);
+                v[j] = t.x; v[j + 1] = t.y; v[j + 2] = t.z; v[j + 3] = t.w;
+            }
+#pragma unroll
+            for (int j = 0; j < VO; ++j) v[j] = v[j] * ep.alpha + bias[j];
+            if (ep.rowbias) {
+#pragma unroll
+                for (int j = 0; j < VO; ++j) v[j] += rbv[u][j];
+            }
+            OutT* o = outb + (long long)row * ep.ldc + col;
+            if (fast) {
+                if (resb) {
+                    if (same) {
+                        float f[VO];
+                        Elem<T>::unpack(resv[u], f);
+#pragma unroll
+                        for (int j = 0; j < VO; ++j) v[j] += f[j];
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < VO; ++j) v[j] += Elem<T>::ld(resb + (long long)row * ep.res_ld + col + j);
+                    }
+                }
+                if (ep.accumulate) {
                     float f[VO];
-                    Elem<T>::unpack(ldg16(resb + (long long)row * ep.res_ld + col), f);
+                    Elem<OutT>::unpack(accv[u], f);
 #pragma unroll
                     for (int j = 0; j < VO; ++j) v[j] += f[j];
-                } else {
-#pragma unroll
-                    for (int j = 0; j < VO; ++j) v[j] += Elem<T>::ld(resb + (long long)row * ep.res_ld + col + j);
                 }
-            }
-            if (ep.accumulate) {
-                float f[VO];
-                Elem<OutT>::unpack(ldg16(o), f);
+#ifndef EABL_NOSTORE
+                stg16(o, Elem<OutT>::pack(v));
+#else
+                if (v[0] == 1234.5f) stg16(o, Elem<OutT>::pack(v));
+#endif
+            } else {
 #pragma unroll
-                for (int j = 0; j < VO; ++j) v[j] += f[j];
-            }
-            stg16(o, Elem<OutT>::pack(v));
-        } else {
-#pragma unroll
-            for (int j = 0; j < VO; ++j) {
-                if (col + j >= N) break;
-                float x = v[j];
-                if (resb) x += Elem<T>::ld(resb + (long long)row * ep.res_ld + col + j);
-                if (ep.accumulate) x += Elem<OutT>::ld(o + j);
-                Elem<OutT>::st(o + j, x);
+                for (int j = 0; j < VO; ++j) {
+                    if (col + j >= N) break;
+                    float x = v[j];
+                    if (resb) x += Elem<T>::ld(resb + (long long)row * ep.res_ld + col + j);
+                    if (ep.accumulate) x += Elem<OutT>::ld(o + j);
+                    Elem<OutT>::st(o + j, x);
+                }
             }
         }
     }
@@ -423,11 +451,20 @@ __device__ __forceinline__ u32x4 read_frag(const char* tile, int rb, int kc, int
     }
 }
 
+// s_waitcnt vmcnt(PER * tiles): allow `tiles` operand-tile pairs (PER LDS-DMA instructions per wave each) to stay in flight
+template <int PER>
+__device__ __forceinline__ void wait_tiles_in_flight(int tiles) {
+    if (tiles >= 3) { if (PER == 8) asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); }
+    else if (tiles == 2) { if (PER == 8) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+    else if (tiles == 1) { if (PER == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 // NBUF = 2: classic double buffer, 64 KiB of operand LDS -> two blocks per CU overlap each other's memory latency.
-// NBUF = 3 (both operands k-contiguous only): a 3-deep LDS-DMA ring — the tile two steps ahead is already in flight and
-//           each step waits with a COUNTED s_waitcnt vmcnt(8) (the newest tile's 8 DMA instructions stay outstanding)
-//           behind a raw s_barrier.  Used when the grid cannot put two blocks on every CU (small-M layers), where a
-//           single block would otherwise expose one full memory latency per K-step.
+// NBUF = 5 (both operands k-contiguous only): a 5-deep LDS-DMA ring (160 KiB) — four tile pairs are in flight and each step
+//           waits with a COUNTED s_waitcnt vmcnt(8 * newer tiles) behind a raw s_barrier.  Used when the grid cannot put
+//           two blocks on every CU (small-M layers): one block alone is memory-LATENCY bound per K-step (measured
+//           ~0.65 us/step with two tiles in flight), so more tiles in flight is what shortens the step.
 // NW = 4: 4 waves as 2(M) x 2(N), 64x64 per wave.  NW = 8: 8 waves as 4(M) x 2(N), 32x64 per wave — twice the waves per CU
 //         (two 512-thread blocks) to hide LDS-DMA latency and barrier skew; needs both operands on the DMA path.
 template <typename T, bool TA, bool TB, int NBUF, int NW>
@@ -473,15 +510,15 @@ void gemm_kernel(MatDesc A, MatDesc B, Epilogue ep, int M, int N, int K, int k_p
         __syncthreads();
     } else {
         if constexpr (!TA && !TB) {
-            la.issue(k_begin, k_end, smem);
-            lb.issue(k_begin, k_end, smem + TILE_BYTES);
-            if (nsteps > 1) {
-                la.issue(k_begin + BK, k_end, smem + 2 * TILE_BYTES);
-                lb.issue(k_begin + BK, k_end, smem + 3 * TILE_BYTES);
-                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");       // tile 0 landed, tile 1 (8 DMA instructions) in flight
-            } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
+            // deep ring: NBUF-1 tiles go out before anything is consumed; wait for tile 0 only (counted vmcnt: DMA
+            // instructions retire in order, 8 per tile pair)
+#pragma unroll
+            for (int t = 0; t < NBUF - 1; ++t)
+                if (t < nsteps) {
+                    la.issue(k_begin + t * BK, k_end, smem + t * 2 * TILE_BYTES);
+                    lb.issue(k_begin + t * BK, k_end, smem + t * 2 * TILE_BYTES + TILE_BYTES);
+                }
+            wait_tiles_in_flight<32 / NW>(min(NBUF - 2, nsteps - 1));
             __builtin_amdgcn_s_barrier();
         }
     }
@@ -500,11 +537,15 @@ void gemm_kernel(MatDesc A, MatDesc B, Epilogue ep, int M, int N, int K, int k_p
             }
         } else {
             if constexpr (!TA && !TB) {
-                if (s + 2 < nsteps) {   // slot of step s+2 == slot of step s-1: free since the barrier that ended step s-1
-                    const int far_i = nxt_i + 1 == NBUF ? 0 : nxt_i + 1;
-                    const int kn = k_begin + (s + 2) * BK;
+                if (s + NBUF - 1 < nsteps) {   // slot of step s+NBUF-1 == slot of step s-1: free since the barrier that ended it
+                    const int far_i = cur_i == 0 ? NBUF - 1 : cur_i - 1;
+                    const int kn = k_begin + (s + NBUF - 1) * BK;
+#ifndef GABL_NOISSUE_A
                     la.issue(kn, k_end, smem + far_i * 2 * TILE_BYTES);
+#endif
+#ifndef GABL_NOISSUE_B
                     lb.issue(kn, k_end, smem + far_i * 2 * TILE_BYTES + TILE_BYTES);
+#endif
                 }
             }
         }
@@ -513,14 +554,28 @@ void gemm_kernel(MatDesc A, MatDesc B, Epilogue ep, int M, int N, int K, int k_p
 #pragma unroll
         for (int kc = 0; kc < BK / KF; ++kc) {
             u32x4 fa[MI], fb[2];
+#ifndef GABL_NOREAD
 #pragma unroll
             for (int i = 0; i < MI; ++i) fa[i] = read_frag<T, TA>(ta, wm * (32 * MI) + i * 32, kc, lane);
 #pragma unroll
             for (int j = 0; j < 2; ++j) fb[j] = read_frag<T, TB>(tb, wn * 64 + j * 32, kc, lane);
+#else
+#pragma unroll
+            for (int i = 0; i < MI; ++i) fa[i] = u32x4{(unsigned)s, (unsigned)kc, (unsigned)i, (unsigned)lane};
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fb[j] = u32x4{(unsigned)s, (unsigned)kc, (unsigned)j, (unsigned)lane};
+#endif
+#ifndef GABL_NOMFMA
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) Mma<T>::run(fa[i], fb[j], acc[i][j]);
+#else
+#pragma unroll
+            for (int i = 0; i < MI; ++i) asm volatile("" :: "v"(fa[i]));
+#pragma unroll
+            for (int j = 0; j < 2; ++j) asm volatile("" :: "v"(fb[j]));
+#endif
         }
         if (NBUF == 2) {
             if (more) {
@@ -530,9 +585,8 @@ void gemm_kernel(MatDesc A, MatDesc B, Epilogue ep, int M, int N, int K, int k_p
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the LDS-DMA of the next tile has landed
             __syncthreads();
         } else {
-            // tile s+1 must have landed; tile s+2 (just issued) may stay in flight across the barrier
-            if (s + 2 < nsteps) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // tile s+1 must have landed; the (up to NBUF-2) tiles issued after it may stay in flight across the barrier
+            wait_tiles_in_flight<32 / NW>(min(NBUF - 2, max(nsteps - 2 - s, 0)));
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
         }
@@ -622,9 +676,19 @@ constexpr int C3_NI = 7;              // halo DMA parts of 512 vectors: up to 44
 
 // RING = depth of the weight-tile ring (RING-1 tiles in flight, counted s_waitcnt + raw s_barrier); HROWS = LDS rows
 // reserved per halo buffer.  LDS = 2*HROWS*128 + RING*16 KiB = 160 KiB in both instantiated configurations.
+#ifdef HALO_TIMING
+__device__ unsigned long long* g_halo_timing = nullptr;      // debug builds only: [block][8] = {wall0, clk0, clk_prologue, clk_loop, clk_end, wall_end}
+#define HALO_STAMP(slot) do { if (g_halo_timing && threadIdx.x == 0) g_halo_timing[blockIdx.x * 8 + (slot)] = clock64(); } while (0)
+#define HALO_WALL(slot) do { if (g_halo_timing && threadIdx.x == 0) g_halo_timing[blockIdx.x * 8 + (slot)] = wall_clock64(); } while (0)
+#else
+#define HALO_STAMP(slot)
+#define HALO_WALL(slot)
+#endif
+
 template <int RING, int HROWS>
 __global__ __launch_bounds__(512, 2)
 void conv3x3_halo_kernel(Conv3Args a, int tiles_n) {
+    HALO_WALL(0); HALO_STAMP(1);
     typedef bf16_t T;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // LDS: [halo 0 | halo 1 | weight ring]; the fp32 epilogue staging (64 rows) aliases the halo region afterwards
@@ -714,6 +778,7 @@ void conv3x3_halo_kernel(Conv3Args a, int tiles_n) {
     if (total >= RING - 1) { if (RING == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    HALO_STAMP(2);
 
     const int hi = lane >> 5;
     int step = 0;
@@ -755,37 +820,44 @@ void conv3x3_halo_kernel(Conv3Args a, int tiles_n) {
         }
     }
     __syncthreads();
+    HALO_STAMP(3);
 
-    // epilogue: four passes of 64 output pixels (the two waves with wm == q) through an fp32 LDS stage
+    // epilogue: the whole 256 x 128 fp32 tile is staged at once (132 KiB of the now idle LDS) — one barrier, then every
+    // thread streams 16-byte vectors out; nothing waits for the stores to be acknowledged.
     float* cs = reinterpret_cast<float*>(smem);
-    for (int q = 0; q < 4; ++q) {
-        if (wm == q) {
-            const int rb = 4 * (lane >> 5), cb = wn * 64 + (lane & 31);
-            static_for<64>([&](auto ic) {
-                constexpr int idx = decltype(ic)::v;
-                constexpr int i = idx >> 5, j = (idx >> 4) & 1, rr = idx & 15;
-                cs[(rb + i * 32 + (rr & 3) + 8 * (rr >> 2)) * CS_LD + cb + j * 32] = acc[i][j][rr];
-            });
-        }
-        __syncthreads();
-        auto rowmap = [&](int rl) {
-            const int p = q * 64 + rl;
-            const int il = p >> a.lPP, qq = p & ((1 << a.lPP) - 1);
-            const int gi = img0 + il;
-            return gi < a.B ? (gi * a.H + py0 + (qq >> a.lPW)) * a.W + px0 + (qq & (a.PW - 1)) : -1;
-        };
-        epilogue_rows<T, T, 512, 64>(a.ep, cs, 0, rowmap, tn * TILE, a.N, tid);
-        __syncthreads();
+    {
+        const int rb = wm * 64 + 4 * (lane >> 5), cb = wn * 64 + (lane & 31);
+        static_for<64>([&](auto ic) {
+            constexpr int idx = decltype(ic)::v;
+            constexpr int i = idx >> 5, j = (idx >> 4) & 1, rr = idx & 15;
+            cs[(rb + i * 32 + (rr & 3) + 8 * (rr >> 2)) * CS_LD + cb + j * 32] = acc[i][j][rr];
+        });
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    HALO_STAMP(6);
+    auto rowmap = [&](int p) {
+        const int il = p >> a.lPP, qq = p & ((1 << a.lPP) - 1);
+        const int gi = img0 + il;
+        return gi < a.B ? (gi * a.H + py0 + (qq >> a.lPW)) * a.W + px0 + (qq & (a.PW - 1)) : -1;
+    };
+    epilogue_rows<T, T, 512, 256>(a.ep, cs, 0, rowmap, tn * TILE, a.N, tid);
+    HALO_STAMP(4); HALO_WALL(5);
 }
+
+#ifdef HALO_TIMING
+extern "C" int ddpm_debug_set_halo_timing(void* p) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_halo_timing), &p, sizeof(p)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 // Explicit instantiations: every (dtype, operand layout, ring depth, wave count) the launcher can pick.
 #define INST(T, TA, TB, NB, NWV) template __global__ void gemm_kernel<T, TA, TB, NB, NWV>(MatDesc, MatDesc, Epilogue, int, int, int, int, int);
-INST(bf16_t, false, false, 2, 4) INST(bf16_t, false, false, 2, 8) INST(bf16_t, false, false, 3, 4)
+INST(bf16_t, false, false, 2, 4) INST(bf16_t, false, false, 2, 8) INST(bf16_t, false, false, 5, 4) INST(bf16_t, false, false, 5, 8)
 INST(bf16_t, false, true, 2, 4) INST(bf16_t, false, true, 2, 8)
 INST(bf16_t, true, false, 2, 4) INST(bf16_t, true, false, 2, 8)
 INST(bf16_t, true, true, 2, 4) INST(bf16_t, true, true, 2, 8)
-INST(float, false, false, 2, 4) INST(float, false, false, 2, 8) INST(float, false, false, 3, 4)
+INST(float, false, false, 2, 4) INST(float, false, false, 2, 8) INST(float, false, false, 5, 4) INST(float, false, false, 5, 8)
 INST(float, false, true, 2, 4) INST(float, true, false, 2, 4) INST(float, true, true, 2, 4)
 #undef INST
 
@@ -865,10 +937,10 @@ static int launch_t(GemmArgs& g, hipStream_t st) {
     if (g.ep.mode == 2 || g.ep.mode == 4) { g.ep.splitk_ws = nullptr; g.ep.splitk_cnt = nullptr; }
     dim3 grid(tiles_m * tiles_n, splits, g.batch);
     const size_t lds2 = TILE * CS_LD * sizeof(float);     // 4 operand tiles (64 KiB) <= fp32 epilogue staging (66 KiB)
-    const size_t lds3 = 6 * TILE * ROW_BYTES;             // 3-deep ring: 96 KiB, one block per CU
+    const size_t lds3 = 10 * TILE * ROW_BYTES;            // 5-deep ring: 160 KiB, one block per CU
     const int kps = steps_per * BK;
     // deep ring when the grid cannot keep two blocks on each of the 256 CUs anyway
-    const bool deep = !g.A.trans && !g.B.trans && (long long)grid.x * grid.y * grid.z <= 384 && steps_per >= 3;
+    const bool deep = !g.A.trans && !g.B.trans && (long long)grid.x * grid.y * grid.z <= 256 && steps_per >= 3;
 #define LAUNCH(TA, TB, NB, NWV, LDS)                                                                                     \
     do {                                                                                                                 \
         static bool attr_set = false;   /* > 64 KiB of dynamic LDS needs the opt-in once per instantiation */            \
@@ -884,7 +956,8 @@ static int launch_t(GemmArgs& g, hipStream_t st) {
     constexpr bool BF = sizeof(T) == 2;
     const bool w8 = g_use_w8;
     if (!g.A.trans && !g.B.trans) {
-        if (deep) LAUNCH(false, false, 3, 4, lds3);
+        if (deep && w8) LAUNCH(false, false, 5, 8, lds3);
+        else if (deep) LAUNCH(false, false, 5, 4, lds3);
         else if (w8) LAUNCH(false, false, 2, 8, lds2);
         else LAUNCH(false, false, 2, 4, lds2);
     } else if (!g.A.trans && g.B.trans) {
@@ -970,7 +1043,7 @@ extern "C" int ddpm_conv2d_nhwc(const void* x, long long x_ld, const void* w, vo
     g.splits = splits; g.ep.splitk_ws = splitk_ws; g.ep.splitk_cnt = splitk_cnt;
     // hot case: 3x3 / stride 1 / pad 1 on bf16 with enough pixels to fill the chip -> stationary-halo kernel
     static const bool no_halo = getenv("DDPM_CONV_NO_HALO") != nullptr;
-    static const int halo_min_c = getenv("DDPM_CONV_HALO_MINC") ? atoi(getenv("DDPM_CONV_HALO_MINC")) : 256;
+    static const int halo_min_c = getenv("DDPM_CONV_HALO_MINC") ? atoi(getenv("DDPM_CONV_HALO_MINC")) : 64;
     if (!no_halo && C >= halo_min_c && dtype == DDPM_BF16 && R == 3 && S == 3 && stride == 1 && pad_t == 1 && pad_l == 1 && !upsample && !dilate &&
         out_mode == 0 && splits <= 1 && C % 64 == 0 && Ho == H && Wo == W && g.M >= 16384 && aligned16(x) && aligned16(w) && x_ld % 8 == 0) {
         set_vec_ok(g, 2);
