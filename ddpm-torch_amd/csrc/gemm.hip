@@ -304,8 +304,19 @@ struct Loader {
 constexpr int CS_LD = TILE + 4;
 
 // `rowmap(rl)` gives the global output row of staged row rl (or -1 to skip it); NROWS rows are staged in `cs`.
+// per-thread bias vector of the row epilogue (thread tid owns output columns col0g + (tid % VPR) * VO ...): loaded early
+// by the kernels so that its latency hides under the accumulator staging
+template <typename OutT, int NT>
+__device__ __forceinline__ void epilogue_bias(const Epilogue& ep, int col0g, int N, int tid, float (&bias)[16 / (int)sizeof(OutT)]) {
+    constexpr int VO = 16 / (int)sizeof(OutT), VPR = TILE / VO;
+    const int col = col0g + (tid % VPR) * VO;
+#pragma unroll
+    for (int j = 0; j < VO; ++j) bias[j] = (ep.bias && col + j < N) ? ep.bias[col + j] : 0.f;
+}
+
 template <typename T, typename OutT, int NT, int NROWS, typename RowMap>
-__device__ __forceinline__ void epilogue_rows(const Epilogue& ep, const float* cs, int batch, RowMap rowmap, int col0g, int N, int tid) {
+__device__ __forceinline__ void epilogue_rows(const Epilogue& ep, const float* cs, int batch, RowMap rowmap, int col0g, int N, int tid,
+                                              const float (&bias)[16 / (int)sizeof(OutT)]) {
     constexpr int VO = 16 / (int)sizeof(OutT);            // output elements per 16-byte vector
     constexpr int VPR = TILE / VO;                         // vectors per tile row
     constexpr int PER_THREAD = (NROWS * VPR + NT - 1) / NT;
@@ -314,9 +325,6 @@ __device__ __forceinline__ void epilogue_rows(const Epilogue& ep, const float* c
     const int col = col0g + cv * VO;
     if (col >= N) return;
     const bool full = col + VO <= N;
-    float bias[VO];
-#pragma unroll
-    for (int j = 0; j < VO; ++j) bias[j] = (ep.bias && col + j < N) ? ep.bias[col + j] : 0.f;
     OutT* outb = reinterpret_cast<OutT*>(ep.out) + (long long)batch * ep.out_batch_stride;
     const T* resb = ep.residual ? reinterpret_cast<const T*>(ep.residual) + (long long)batch * ep.res_batch_stride : nullptr;
     // Rows are handled in batches of U: every global read of the batch (time bias, residual, accumulate target) is issued
@@ -451,6 +459,15 @@ __device__ __forceinline__ u32x4 read_frag(const char* tile, int rb, int kc, int
     }
 }
 
+#ifdef HALO_TIMING
+__device__ unsigned long long* g_halo_timing = nullptr;      // debug builds only: [block][8] = {wall0, clk0, clk_prologue, clk_loop, clk_end, wall_end}
+#define HALO_STAMP(slot) do { if (g_halo_timing && threadIdx.x == 0) g_halo_timing[((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + (slot)] = clock64(); } while (0)
+#define HALO_WALL(slot) do { if (g_halo_timing && threadIdx.x == 0) g_halo_timing[((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + (slot)] = wall_clock64(); } while (0)
+#else
+#define HALO_STAMP(slot)
+#define HALO_WALL(slot)
+#endif
+
 // s_waitcnt vmcnt(PER * tiles): allow `tiles` operand-tile pairs (PER LDS-DMA instructions per wave each) to stay in flight
 template <int PER>
 __device__ __forceinline__ void wait_tiles_in_flight(int tiles) {
@@ -470,6 +487,7 @@ __device__ __forceinline__ void wait_tiles_in_flight(int tiles) {
 template <typename T, bool TA, bool TB, int NBUF, int NW>
 __global__ __launch_bounds__(NW * 64, NW / 2)
 void gemm_kernel(MatDesc A, MatDesc B, Epilogue ep, int M, int N, int K, int k_per_split, int tiles_n) {
+    HALO_WALL(0); HALO_STAMP(1);
     static_assert(NBUF == 2 || (!TA && !TB), "the deep ring needs direct-to-LDS loads on both operands");
     constexpr int NT = NW * 64;
     constexpr int MI = 8 / NW;                              // 32-row accumulator blocks per wave along M
@@ -482,9 +500,10 @@ void gemm_kernel(MatDesc A, MatDesc B, Epilogue ep, int M, int N, int K, int k_p
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;               // wave row block (of 32*MI rows) and column block (of 64)
-    const int tm = blockIdx.x / tiles_n, tn = blockIdx.x - tm * tiles_n;
+    const int bx = blockIdx.x, by = blockIdx.y, nsplit = gridDim.y, ntiles = gridDim.x;
+    const int tm = bx / tiles_n, tn = bx - tm * tiles_n;
     const int batch = blockIdx.z;
-    const int k_begin = blockIdx.y * k_per_split;
+    const int k_begin = by * k_per_split;
     const int k_end = min(K, k_begin + k_per_split);
     if (k_begin >= k_end) return;
 
@@ -523,6 +542,7 @@ void gemm_kernel(MatDesc A, MatDesc B, Epilogue ep, int M, int N, int K, int k_p
         }
     }
 
+    HALO_STAMP(2);
     int cur_i = 0;                                            // ring slot of K-step s
     for (int s = 0; s < nsteps; ++s) {
         const char* cur = smem + cur_i * 2 * TILE_BYTES;
@@ -593,9 +613,13 @@ void gemm_kernel(MatDesc A, MatDesc B, Epilogue ep, int M, int N, int K, int k_p
         cur_i = nxt_i;
     }
     if (NBUF != 2) __syncthreads();     // the epilogue staging below reuses the ring
+    HALO_STAMP(3);
 
     // accumulator (reg r, lane l) -> row (r&3) + 8*(r>>2) + 4*(l>>5), col l&31 of its 32x32 tile; stage as fp32 in LDS.
     float* cs = reinterpret_cast<float*>(smem);
+    float bias_t[Elem<T>::VEC], bias_f[4];
+    if (ep.mode == 0) epilogue_bias<T, NT>(ep, tn * TILE, N, tid, bias_t);
+    else if (ep.mode == 1) epilogue_bias<float, NT>(ep, tn * TILE, N, tid, bias_f);
     {
         const int rb = wm * (32 * MI) + 4 * (lane >> 5), cb = wn * 64 + (lane & 31);
         static_for<MI * 32>([&](auto ic) {
@@ -605,14 +629,14 @@ void gemm_kernel(MatDesc A, MatDesc B, Epilogue ep, int M, int N, int K, int k_p
         });
     }
     __syncthreads();
-    if (gridDim.y > 1 && ep.splitk_ws) {
+    HALO_STAMP(6);
+    if (nsplit > 1 && ep.splitk_ws) {
         // In-launch split-K reduction (placement-independent: agent-scope release / acquire around one arrival ticket).
         // Every split publishes its fp32 partial tile as a slab; the LAST arriver adds the other slabs to its own
         // LDS-resident partial and runs the fused epilogue.  Counters return to zero, so no memset between launches.
-        const int nsplit = gridDim.y;
-        const long long tile_id = (long long)batch * gridDim.x + blockIdx.x;
+                const long long tile_id = (long long)batch * ntiles + bx;
         float* slabs = ep.splitk_ws + tile_id * nsplit * (TILE * TILE);
-        float* mine = slabs + (long long)blockIdx.y * (TILE * TILE);
+        float* mine = slabs + (long long)by * (TILE * TILE);
         for (int v = tid; v < TILE * TILE / 4; v += NT) {
             const int r = v >> 5, c4 = (v & 31) << 2;
             *reinterpret_cast<f32x4*>(mine + r * TILE + c4) = *reinterpret_cast<const f32x4*>(cs + r * CS_LD + c4);
@@ -637,9 +661,9 @@ void gemm_kernel(MatDesc A, MatDesc B, Epilogue ep, int M, int N, int K, int k_p
         for (int v = tid; v < TILE * TILE / 4; v += NT) {
             const int r = v >> 5, c4 = (v & 31) << 2;
             const f32x4 own = *reinterpret_cast<const f32x4*>(cs + r * CS_LD + c4);
-            f32x4 a = (blockIdx.y == 0) ? own : *reinterpret_cast<const f32x4*>(slabs + r * TILE + c4);
+            f32x4 a = (by == 0) ? own : *reinterpret_cast<const f32x4*>(slabs + r * TILE + c4);
             for (int sp = 1; sp < nsplit; ++sp) {
-                const f32x4 b = (sp == (int)blockIdx.y) ? own : *reinterpret_cast<const f32x4*>(slabs + (long long)sp * (TILE * TILE) + r * TILE + c4);
+                const f32x4 b = (sp == (int)by) ? own : *reinterpret_cast<const f32x4*>(slabs + (long long)sp * (TILE * TILE) + r * TILE + c4);
                 a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
             }
             *reinterpret_cast<f32x4*>(cs + r * CS_LD + c4) = a;
@@ -647,9 +671,10 @@ void gemm_kernel(MatDesc A, MatDesc B, Epilogue ep, int M, int N, int K, int k_p
         __syncthreads();
     }
     auto rowmap = [&](int rl) { const int row = tm * TILE + rl; return row < M ? row : -1; };
-    if (ep.mode == 0) epilogue_rows<T, T, NT, TILE>(ep, cs, batch, rowmap, tn * TILE, N, tid);
-    else if (ep.mode == 1) epilogue_rows<T, float, NT, TILE>(ep, cs, batch, rowmap, tn * TILE, N, tid);
+    if (ep.mode == 0) epilogue_rows<T, T, NT, TILE>(ep, cs, batch, rowmap, tn * TILE, N, tid, bias_t);
+    else if (ep.mode == 1) epilogue_rows<T, float, NT, TILE>(ep, cs, batch, rowmap, tn * TILE, N, tid, bias_f);
     else epilogue_scatter<NT>(ep, cs, batch, tm * TILE, tn * TILE, M, N, tid);
+    HALO_STAMP(4); HALO_WALL(5);
 }
 
 
@@ -669,6 +694,7 @@ struct Conv3Args {
     const void* w; unsigned w_extent;
     int B, H, W, C, N, K;
     int PH, PW, NB, lPW, lPP;         // patch geometry: PW and PH*PW are powers of two (log2 in lPW, lPP); NB*PH*PW == 256
+    int ky;                           // 1 when the halo row parity takes part in the LDS swizzle key (8-wide patches)
     int tiles_y, tiles_x;             // patches per image
     Epilogue ep;
 };
@@ -676,15 +702,6 @@ constexpr int C3_NI = 7;              // halo DMA parts of 512 vectors: up to 44
 
 // RING = depth of the weight-tile ring (RING-1 tiles in flight, counted s_waitcnt + raw s_barrier); HROWS = LDS rows
 // reserved per halo buffer.  LDS = 2*HROWS*128 + RING*16 KiB = 160 KiB in both instantiated configurations.
-#ifdef HALO_TIMING
-__device__ unsigned long long* g_halo_timing = nullptr;      // debug builds only: [block][8] = {wall0, clk0, clk_prologue, clk_loop, clk_end, wall_end}
-#define HALO_STAMP(slot) do { if (g_halo_timing && threadIdx.x == 0) g_halo_timing[blockIdx.x * 8 + (slot)] = clock64(); } while (0)
-#define HALO_WALL(slot) do { if (g_halo_timing && threadIdx.x == 0) g_halo_timing[blockIdx.x * 8 + (slot)] = wall_clock64(); } while (0)
-#else
-#define HALO_STAMP(slot)
-#define HALO_WALL(slot)
-#endif
-
 template <int RING, int HROWS>
 __global__ __launch_bounds__(512, 2)
 void conv3x3_halo_kernel(Conv3Args a, int tiles_n) {
@@ -714,7 +731,11 @@ void conv3x3_halo_kernel(Conv3Args a, int tiles_n) {
     };
     const __amdgpu_buffer_rsrc_t rx = rsrc_of(a.x, a.x_extent), rw = rsrc_of(a.w, a.w_extent);
 
-    // halo DMA plan: vector v = tid + 512 i -> halo pixel hp = v>>3, physical chunk v&7 (logical chunk ^ key(hp))
+    // LDS swizzle of the halo rows (128 B each, bank half = hp & 1 = hx & 1 since the halo pitch is even): the 16-byte
+    // chunk c of halo pixel (hy, hx) sits at physical chunk c ^ key, key = (hx >> 1) ^ ((hy & ky) << 2).  With it the 16
+    // pixels one ds_read_b128 lane group touches (two half patch rows, or four quarter rows of an 8-wide patch) land on
+    // 16 distinct (bank half, chunk) pairs for every tap shift — the address-derived key (hp >> 1) was 2-3 way conflicted.
+    // halo DMA plan: vector v = tid + 512 i -> halo pixel hp = v>>3, physical chunk v&7 (logical chunk ^ key)
     unsigned hoff[C3_NI];
 #pragma unroll
     for (int i = 0; i < C3_NI; ++i) {
@@ -723,7 +744,7 @@ void conv3x3_halo_kernel(Conv3Args a, int tiles_n) {
         const int hy = rem / HWd, hx = rem - hy * HWd;
         const int iy = py0 + hy - 1, ix = px0 + hx - 1, gi = img0 + img;
         const bool ok = hp < HP && gi < a.B && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-        const int lc = (v & 7) ^ ((hp >> 1) & 7);
+        const int lc = (v & 7) ^ (((hx >> 1) ^ ((hy & a.ky) << 2)) & 7);
         hoff[i] = ok ? (unsigned)((((long long)(gi * a.H + iy) * a.W + ix) * a.x_ld + lc * 8) * ES) : OOB;
     }
     // weight DMA plan: vector v = tid + 512 i -> row n = v>>3 of the 128-row tile, physical chunk v&7
@@ -752,13 +773,14 @@ void conv3x3_halo_kernel(Conv3Args a, int tiles_n) {
     };
 
     // this lane's output pixels (rows of its two 32-row accumulator blocks) -> halo index of tap (0,0)
-    int hp0[2];
+    int hp0[2], pxl[2], pyl[2];
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
         const int p = wm * 64 + mi * 32 + (lane & 31);
         const int il = p >> a.lPP, q = p & ((1 << a.lPP) - 1);
         const int py = q >> a.lPW, px = q & (a.PW - 1);
         hp0[mi] = il * HH * HWd + py * HWd + px;
+        pxl[mi] = px; pyl[mi] = py & a.ky;
     }
 
     f32x16 acc[2][2];
@@ -801,7 +823,8 @@ void conv3x3_halo_kernel(Conv3Args a, int tiles_n) {
 #pragma unroll
                 for (int mi = 0; mi < 2; ++mi) {
                     const int hp = hp0[mi] + shift;
-                    fa[mi] = *reinterpret_cast<const u32x4*>(hcur + hp * ROW_BYTES + ((((2 * kc) | hi) ^ ((hp >> 1) & 7)) << 4));
+                    const int key = (((pxl[mi] + s) >> 1) ^ (((pyl[mi] + r) & a.ky) << 2)) & 7;
+                    fa[mi] = *reinterpret_cast<const u32x4*>(hcur + hp * ROW_BYTES + ((((2 * kc) | hi) ^ key) << 4));
                 }
 #pragma unroll
                 for (int j = 0; j < 2; ++j) fb[j] = read_frag<T, false>(bcur, wn * 64 + j * 32, kc, lane);
@@ -825,6 +848,8 @@ void conv3x3_halo_kernel(Conv3Args a, int tiles_n) {
     // epilogue: the whole 256 x 128 fp32 tile is staged at once (132 KiB of the now idle LDS) — one barrier, then every
     // thread streams 16-byte vectors out; nothing waits for the stores to be acknowledged.
     float* cs = reinterpret_cast<float*>(smem);
+    float bias[8];
+    epilogue_bias<T, 512>(a.ep, tn * TILE, a.N, tid, bias);
     {
         const int rb = wm * 64 + 4 * (lane >> 5), cb = wn * 64 + (lane & 31);
         static_for<64>([&](auto ic) {
@@ -841,7 +866,7 @@ void conv3x3_halo_kernel(Conv3Args a, int tiles_n) {
         const int gi = img0 + il;
         return gi < a.B ? (gi * a.H + py0 + (qq >> a.lPW)) * a.W + px0 + (qq & (a.PW - 1)) : -1;
     };
-    epilogue_rows<T, T, 512, 256>(a.ep, cs, 0, rowmap, tn * TILE, a.N, tid);
+    epilogue_rows<T, T, 512, 256>(a.ep, cs, 0, rowmap, tn * TILE, a.N, tid, bias);
     HALO_STAMP(4); HALO_WALL(5);
 }
 
@@ -886,6 +911,7 @@ static int conv3x3_halo_launch(GemmArgs& g, const void* x, long long x_ld, const
     if (xbytes > 0x7ffffff0ll || wbytes > 0x7ffffff0ll) return -1;
     a.x_extent = (unsigned)xbytes; a.w_extent = (unsigned)wbytes;
     a.PH = PH; a.PW = PW; a.NB = NB; a.lPW = ilog2(PW); a.lPP = ilog2(PH * PW);
+    a.ky = PW == 8 ? 1 : 0;
     a.tiles_y = H / PH; a.tiles_x = W / PW;
     a.ep = g.ep;
     const int groups = (B + NB - 1) / NB, tiles_n = (N + TILE - 1) / TILE;

@@ -118,6 +118,161 @@ __global__ void gn_apply_kernel(const T* __restrict__ x, T* __restrict__ y, GnSh
     }
 }
 
+// ---- single-launch forward: one block owns (sample b, a chunk of GPB groups) = all HW pixels x seg_ch = GPB*cpg channels.
+// The slice (<= 64 KiB) is DMA'd into LDS once, statistics are taken from LDS (two-pass: mean, then centred variance),
+// and y is produced from the LDS copy: exactly one HBM read of x and one write of y, no partial-sum workspace, one launch.
+struct GnFused {
+    int GPB, seg_ch, seg_vecs;     // groups per block, channels / 16-byte vectors per pixel segment
+    int nta;                       // active threads: largest multiple of seg_vecs <= GN_THREADS (a thread keeps one vector column)
+    int rows_per_iter;             // nta / seg_vecs pixels per sweep of the block
+    int tpg;                       // threads cooperating on one group's statistics (GN_THREADS / GPB)
+};
+
+template <typename T>
+__global__ __launch_bounds__(GN_THREADS)
+void gn_fused_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, GnShape s, GnFused f, GnApply a) {
+    constexpr int VEC = Elem<T>::VEC, ES = (int)sizeof(T);
+    extern __shared__ __attribute__((aligned(16))) char gsm[];
+    const int slice_bytes = s.HW * f.seg_ch * ES;
+    float* sh_a = reinterpret_cast<float*>(gsm + slice_bytes);       // [seg_ch] scale
+    float* sh_b = sh_a + f.seg_ch;                                    // [seg_ch] shift
+    float* sh_red = sh_b + f.seg_ch;                                  // [GN_THREADS / 64][GPB] cross-wave partials
+    float* sh_mean = sh_red + (GN_THREADS / 64) * 32;                 // [GPB]
+    float* sh_rstd = sh_mean + 32;                                    // [GPB]
+    const int b = blockIdx.y, c0 = blockIdx.x * f.seg_ch, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nvec = s.HW * f.seg_vecs;
+    const bool active = tid < f.nta;
+    const int j = tid % f.seg_vecs, prow = tid / f.seg_vecs;          // this thread's vector column and first pixel
+
+    // phase 1: slice -> LDS (direct-to-LDS loads, vector v lands at byte 16 v)
+    {
+        const T* xb = x + ((long long)b * s.HW) * s.x_ld + c0;
+        const unsigned long long ad = (unsigned long long)xb;
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)ad), hi = __builtin_amdgcn_readfirstlane((unsigned)(ad >> 32));
+        const long long ext = ((long long)(s.HW - 1) * s.x_ld + f.seg_ch) * ES;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0,
+                                                                           __builtin_amdgcn_readfirstlane((int)ext), 0x00020000);
+        int pp = prow;
+        for (int v0 = 0; v0 < nvec; v0 += f.nta, pp += f.rows_per_iter) {
+            // lanes past the slice (or past the last whole vector column set) stay masked: an LDS-DMA lane always writes
+            if (active && pp < s.HW) {
+                const unsigned off = (unsigned)(((long long)pp * s.x_ld + j * VEC) * ES);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(gsm + (v0 + wave * 64) * 16), 16, off, 0, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+
+    // phase 2: statistics from LDS — tpg threads per group, each strides over the pixels of its group's cpg channels
+    {
+        const int g = tid / f.tpg, t = tid - g * f.tpg;                // tpg * GPB == GN_THREADS
+        const int chunks = s.cpg * ES / 8;                            // 8-byte pieces of one pixel's group segment
+        const char* base = gsm + g * s.cpg * ES;
+        const int pitch = f.seg_ch * ES;
+        auto reduce_group = [&](float v) -> float {
+            // deterministic: xor-butterfly inside the (<= 64 lane) thread set of the group, then fixed-order sum over waves
+            const int span = f.tpg < 64 ? f.tpg : 64;
+            for (int o = span >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+            if (f.tpg <= 64) return v;
+            __syncthreads();
+            if (lane == 0) sh_red[wave] = v;
+            __syncthreads();
+            const int w0 = g * (f.tpg >> 6);
+            float r = 0.f;
+            for (int w = 0; w < (f.tpg >> 6); ++w) r += sh_red[w0 + w];
+            return r;
+        };
+        float sum = 0.f;
+        for (int p = t; p < s.HW; p += f.tpg)
+            for (int q = 0; q < chunks; ++q) {
+                const uint2 u = *reinterpret_cast<const uint2*>(base + p * pitch + q * 8);
+                if (ES == 2) sum += (__uint_as_float(u.x << 16) + __uint_as_float(u.x & 0xffff0000u)) + (__uint_as_float(u.y << 16) + __uint_as_float(u.y & 0xffff0000u));
+                else sum += __uint_as_float(u.x) + __uint_as_float(u.y);
+            }
+        const float n = (float)s.HW * (float)s.cpg;
+        const float mean = reduce_group(sum) / n;
+        float sq = 0.f;
+        for (int p = t; p < s.HW; p += f.tpg)
+            for (int q = 0; q < chunks; ++q) {
+                const uint2 u = *reinterpret_cast<const uint2*>(base + p * pitch + q * 8);
+                if (ES == 2) {
+                    const float e0 = __uint_as_float(u.x << 16) - mean, e1 = __uint_as_float(u.x & 0xffff0000u) - mean;
+                    const float e2 = __uint_as_float(u.y << 16) - mean, e3 = __uint_as_float(u.y & 0xffff0000u) - mean;
+                    sq += (e0 * e0 + e1 * e1) + (e2 * e2 + e3 * e3);
+                } else {
+                    const float e0 = __uint_as_float(u.x) - mean, e1 = __uint_as_float(u.y) - mean;
+                    sq += e0 * e0 + e1 * e1;
+                }
+            }
+        const float var = reduce_group(sq) / n;
+        const float rstd = 1.0f / sqrtf(var + a.eps);
+        if (t == 0) {
+            sh_mean[g] = mean; sh_rstd[g] = rstd;
+            if (a.stats) {
+                const long long gi = (long long)b * s.G + blockIdx.x * f.GPB + g;
+                a.stats[gi * 2] = mean; a.stats[gi * 2 + 1] = rstd;
+            }
+        }
+    }
+    __syncthreads();
+    for (int c = tid; c < f.seg_ch; c += GN_THREADS) {
+        const int g = c / s.cpg;
+        const float sc = sh_rstd[g] * a.gamma[c0 + c];
+        sh_a[c] = sc; sh_b[c] = a.beta[c0 + c] - sh_mean[g] * sc;
+    }
+    __syncthreads();
+
+    // phase 3: y = silu(x * a_c + b_c) [* keep / (1 - p)] from the LDS copy
+    if (active) {
+        float ca[VEC], cb[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) { ca[e] = sh_a[j * VEC + e]; cb[e] = sh_b[j * VEC + e]; }
+        const float keep_scale = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
+        T* yb = y + ((long long)b * s.HW) * s.y_ld + c0 + j * VEC;
+        for (int p = prow; p < s.HW; p += f.rows_per_iter) {
+            float v[VEC];
+            Elem<T>::unpack(*reinterpret_cast<const u32x4*>(gsm + (p * f.seg_vecs + j) * 16), v);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                float z = v[e] * ca[e] + cb[e];
+                if (a.silu) z = siluf_(z);
+                if (a.drop_p > 0.f) {
+                    const unsigned long long idx = ((unsigned long long)b * s.HW + p) * s.C + c0 + j * VEC + e;
+                    z = dropout_keep(a.seed, idx, a.thresh24) ? z * keep_scale : 0.f;
+                }
+                v[e] = z;
+            }
+            stg16(yb + (long long)p * s.y_ld, Elem<T>::pack(v));
+        }
+    }
+}
+
+constexpr int GN_FUSED_SLICE = 64 * 1024;     // LDS bytes of activations per block: two blocks per CU
+
+// picks the group chunk; false when no chunk of this geometry fits (falls back to the two-launch path)
+static bool gn_fused_plan(const GnShape& s, int esize, GnFused& f, size_t& lds_bytes) {
+    const int vec = 16 / esize;
+    if ((s.cpg * esize) % 8) return false;
+    int best = 0;
+    for (int gpb = 1; gpb <= s.G && gpb <= 32; gpb <<= 1) {
+        if (s.G % gpb || GN_THREADS % gpb) continue;
+        const int seg_ch = gpb * s.cpg;
+        if (seg_ch % vec) continue;
+        if ((long long)s.HW * seg_ch * esize > GN_FUSED_SLICE) break;
+        if (seg_ch / vec > GN_THREADS) break;
+        best = gpb;
+    }
+    if (!best) return false;
+    // prefer >= 512 blocks (two per CU) as long as a pixel segment stays >= 128 bytes
+    while (best > 1 && (long long)s.B * (s.G / best) < 512 && (best / 2) * s.cpg * esize >= 128 && ((best / 2) * s.cpg) % vec == 0) best >>= 1;
+    f.GPB = best; f.seg_ch = best * s.cpg; f.seg_vecs = f.seg_ch / vec;
+    f.nta = (GN_THREADS / f.seg_vecs) * f.seg_vecs; f.rows_per_iter = f.nta / f.seg_vecs; f.tpg = GN_THREADS / best;
+    lds_bytes = (size_t)s.HW * f.seg_ch * esize + (2 * f.seg_ch + (GN_THREADS / 64) * 32 + 64) * sizeof(float);
+    return true;
+}
+
 // ---- backward
 // dz = dy * mask/(1-p) * silu'(z), z = gamma*xhat + beta.  Per (b, c): A1 = sum dz*xhat, A2 = sum dz.
 template <typename T>
@@ -283,6 +438,24 @@ extern "C" int ddpm_groupnorm_silu_fwd(const void* x, long long x_ld, void* y, l
     if (rc) return rc;
     GnApply a = make_apply(gamma, beta, eps, silu, drop_p, seed, stats);
     hipStream_t st = (hipStream_t)stream;
+    GnFused f; size_t lds = 0;
+    static const bool no_fused = getenv("DDPM_GN_NO_FUSED") != nullptr;
+    // measured (scripts/microbench.py): the single-launch kernel wins while the tensor is small (launch / latency bound
+    // 8x8 and 4x4 levels); on the big levels the two-launch path streams at the HBM rate and stays ahead
+    const bool small = (long long)B * HW * C * es <= (12ll << 20);
+    if (!no_fused && small && gn_fused_plan(s, es, f, lds)) {
+        const dim3 fgrid(G / f.GPB, B);
+        if (dtype == DDPM_BF16) {
+            static bool attr = false;
+            if (!attr) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_fused_fwd_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, GN_FUSED_SLICE + 4096) != hipSuccess) return DDPM_ERR_LAUNCH; attr = true; }
+            hipLaunchKernelGGL(gn_fused_fwd_kernel<bf16_t>, fgrid, dim3(GN_THREADS), lds, st, (const bf16_t*)x, (bf16_t*)y, s, f, a);
+        } else {
+            static bool attr = false;
+            if (!attr) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_fused_fwd_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, GN_FUSED_SLICE + 4096) != hipSuccess) return DDPM_ERR_LAUNCH; attr = true; }
+            hipLaunchKernelGGL(gn_fused_fwd_kernel<float>, fgrid, dim3(GN_THREADS), lds, st, (const float*)x, (float*)y, s, f, a);
+        }
+        return check_launch();
+    }
     if (dtype == DDPM_BF16) {
         hipLaunchKernelGGL(gn_stats_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)x, s, workspace);
         hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)x, (bf16_t*)y, s, workspace, a);

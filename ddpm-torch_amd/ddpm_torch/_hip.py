@@ -81,7 +81,13 @@ def call(name, *args):
         raise RuntimeError(f"{name} failed: {_ERR.get(rc, rc)}")
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream():
+    """hipStream_t of torch's current stream (the raw getter skips building a torch.cuda.Stream per launch)."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 

@@ -29,3 +29,16 @@ for B in (128, 4):
     for _ in range(10): tr.step(x)
     torch.cuda.synchronize(); t_all = time.perf_counter() - t0
     print(f"B={B:4d} train step  : wall {t_all / 10 * 1e3:6.2f} ms per step")
+
+if os.environ.get("HOST_PROFILE"):
+    import cProfile, pstats
+    x = torch.rand(4, 3, 32, 32, device=dev) * 2 - 1
+    m.train()
+    for _ in range(3): tr.step(x)
+    pr = cProfile.Profile()
+    pr.enable()
+    for _ in range(10): tr.step(x)
+    torch.cuda.synchronize()
+    pr.disable()
+    st = pstats.Stats(pr)
+    st.sort_stats("tottime").print_stats(28)
