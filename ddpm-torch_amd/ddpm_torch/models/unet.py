@@ -234,6 +234,9 @@ class _ConvW:
         self.ver = self.src = None
 
 
+_WGRAD_TARGET_BLOCKS = int(os.environ.get("DDPM_WGRAD_BLOCKS", "512"))
+
+
 class _Engine:
     def __init__(self, model):
         self.m = model
@@ -705,11 +708,12 @@ class _Engine:
         return grads
 
     def _splits(self, M, N, K):
-        """Split the wgrad reduction so that tiles x splits is about one full wave of blocks (256 CUs x 2 resident blocks)
-        while every split keeps >= 8 K-steps: more splits only add fp32 atomics (measured: scripts/wgrad_splits.sh)."""
+        """Split the wgrad reduction so that tiles x splits is about one full wave of blocks (256 CUs x 2 resident blocks).
+        Every split ends in 128x128 fp32 atomics (~20 us per block at the L2's atomic rate), so a split must keep enough
+        K-steps to amortise them: >= 20 when K allows it, >= 8 on the short reductions (scripts/microbench.py sweeps)."""
         tiles = -(-M // 128) * -(-N // 128)
         ksteps = -(-K // (8 * self.vec))
-        return max(1, min(512 // tiles, ksteps // 8))
+        return max(1, min(_WGRAD_TARGET_BLOCKS // tiles, ksteps // (20 if ksteps >= 100 else 8)))
 
     def _bias_grad(self, ctx, dy, biases, creal, slot=None):
         """db[c] = sum over pixels and batch of dy.  One owner: atomics straight into its gradient.  Several owners or a

@@ -41,7 +41,7 @@ def conv_case(B, H, C, N, R, dtype, kind="fwd"):
         dw = torch.zeros(N, C, R, R, device=DEV)
         tiles = -(-N // 128) * -(-(R * R * C) // 128)
         ksteps = B * H * H // (64 if dtype == torch.bfloat16 else 32)
-        splits = max(1, min(512 // tiles, ksteps // 8))
+        splits = max(1, min(512 // tiles, ksteps // (20 if ksteps >= 100 else 8)))      # the engine's rule (_Engine._splits)
         fn = lambda: ops.conv2d_wgrad(y, x, dw.data_ptr(), C, N, R, R, pad_t=R // 2, pad_l=R // 2, splits=splits)
     t = timeit(fn)
     return t, flops / t / 1e12
