@@ -108,10 +108,11 @@ __device__ __forceinline__ int lds_off(int row, int chunk) { return row * ROW_BY
 //          VEC k-contiguous 4-element runs (ds_write_b64 bf16 / ds_write_b128 fp32) into the swizzled image.
 constexpr unsigned OOB = 0x7ffffff0u;
 
-template <typename T, bool TRANS, int NW = 4>
+template <typename T, bool TRANS, int NW = 4, int ROWS = 128>
 struct Loader {
     static constexpr int NT = NW * 64;                       // threads per block
-    static constexpr int NV = 1024 / NT;                     // 16-byte vectors per thread per operand per K-step
+    static constexpr int NV = ROWS * 8 / NT;                 // 16-byte vectors per thread per operand per K-step
+    static_assert(ROWS == 128 || !TRANS, "only the k-contiguous path is built for the 64-row tile");
     static constexpr int VEC = Elem<T>::VEC;
     static constexpr int BK = 8 * VEC;
     static constexpr int KQ = BK / 4;
@@ -306,19 +307,20 @@ constexpr int CS_LD = TILE + 4;
 // `rowmap(rl)` gives the global output row of staged row rl (or -1 to skip it); NROWS rows are staged in `cs`.
 // per-thread bias vector of the row epilogue (thread tid owns output columns col0g + (tid % VPR) * VO ...): loaded early
 // by the kernels so that its latency hides under the accumulator staging
-template <typename OutT, int NT>
+template <typename OutT, int NT, int TN = 128>
 __device__ __forceinline__ void epilogue_bias(const Epilogue& ep, int col0g, int N, int tid, float (&bias)[16 / (int)sizeof(OutT)]) {
-    constexpr int VO = 16 / (int)sizeof(OutT), VPR = TILE / VO;
+    constexpr int VO = 16 / (int)sizeof(OutT), VPR = TN / VO;
     const int col = col0g + (tid % VPR) * VO;
 #pragma unroll
     for (int j = 0; j < VO; ++j) bias[j] = (ep.bias && col + j < N) ? ep.bias[col + j] : 0.f;
 }
 
-template <typename T, typename OutT, int NT, int NROWS, typename RowMap>
+template <typename T, typename OutT, int NT, int NROWS, int TN = 128, typename RowMap>
 __device__ __forceinline__ void epilogue_rows(const Epilogue& ep, const float* cs, int batch, RowMap rowmap, int col0g, int N, int tid,
                                               const float (&bias)[16 / (int)sizeof(OutT)]) {
     constexpr int VO = 16 / (int)sizeof(OutT);            // output elements per 16-byte vector
-    constexpr int VPR = TILE / VO;                         // vectors per tile row
+    constexpr int VPR = TN / VO;                           // vectors per tile row
+    constexpr int CS_LD = TN + 4;                          // staging pitch (shadows the 128-column constant)
     constexpr int PER_THREAD = (NROWS * VPR + NT - 1) / NT;
     constexpr int ROWS_PER_PASS = NT / VPR;
     const int cv = tid % VPR, r0 = tid / VPR;
@@ -484,6 +486,10 @@ __device__ __forceinline__ void wait_tiles_in_flight(int tiles) {
 //           ~0.65 us/step with two tiles in flight), so more tiles in flight is what shortens the step.
 // NW = 4: 4 waves as 2(M) x 2(N), 64x64 per wave.  NW = 8: 8 waves as 4(M) x 2(N), 32x64 per wave — twice the waves per CU
 //         (two 512-thread blocks) to hide LDS-DMA latency and barrier skew; needs both operands on the DMA path.
+#ifndef DEEP_ISSUE_KC
+#define DEEP_ISSUE_KC 1
+#endif
+
 template <typename T, bool TA, bool TB, int NBUF, int NW>
 __global__ __launch_bounds__(NW * 64, NW / 2)
 void gemm_kernel(MatDesc A, MatDesc B, Epilogue ep, int M, int N, int K, int k_per_split, int tiles_n) {
@@ -555,47 +561,31 @@ void gemm_kernel(MatDesc A, MatDesc B, Epilogue ep, int M, int N, int K, int k_p
                 if constexpr (DMA_A) stage_a(kn, nxt); else la.load(kn, k_end, va);
                 if constexpr (DMA_B) stage_b(kn, nxt + TILE_BYTES); else lb.load(kn, k_end, vb);
             }
-        } else {
-            if constexpr (!TA && !TB) {
-                if (s + NBUF - 1 < nsteps) {   // slot of step s+NBUF-1 == slot of step s-1: free since the barrier that ended it
-                    const int far_i = cur_i == 0 ? NBUF - 1 : cur_i - 1;
-                    const int kn = k_begin + (s + NBUF - 1) * BK;
-#ifndef GABL_NOISSUE_A
-                    la.issue(kn, k_end, smem + far_i * 2 * TILE_BYTES);
-#endif
-#ifndef GABL_NOISSUE_B
-                    lb.issue(kn, k_end, smem + far_i * 2 * TILE_BYTES + TILE_BYTES);
-#endif
-                }
-            }
         }
         const char* ta = cur;
         const char* tb = cur + TILE_BYTES;
 #pragma unroll
         for (int kc = 0; kc < BK / KF; ++kc) {
             u32x4 fa[MI], fb[2];
-#ifndef GABL_NOREAD
 #pragma unroll
             for (int i = 0; i < MI; ++i) fa[i] = read_frag<T, TA>(ta, wm * (32 * MI) + i * 32, kc, lane);
 #pragma unroll
             for (int j = 0; j < 2; ++j) fb[j] = read_frag<T, TB>(tb, wn * 64 + j * 32, kc, lane);
-#else
-#pragma unroll
-            for (int i = 0; i < MI; ++i) fa[i] = u32x4{(unsigned)s, (unsigned)kc, (unsigned)i, (unsigned)lane};
-#pragma unroll
-            for (int j = 0; j < 2; ++j) fb[j] = u32x4{(unsigned)s, (unsigned)kc, (unsigned)j, (unsigned)lane};
-#endif
-#ifndef GABL_NOMFMA
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) Mma<T>::run(fa[i], fb[j], acc[i][j]);
-#else
-#pragma unroll
-            for (int i = 0; i < MI; ++i) asm volatile("" :: "v"(fa[i]));
-#pragma unroll
-            for (int j = 0; j < 2; ++j) asm volatile("" :: "v"(fb[j]));
-#endif
+            if constexpr (NBUF != 2 && !TA && !TB) {
+                // deep ring: the tile NBUF-1 steps ahead is requested in the MIDDLE of the step (its slot — the one of step
+                // s-1 — has been free since the last barrier), so the address arithmetic and the LDS-DMA issue overlap
+                // the MFMAs already queued instead of delaying the first one
+                if (kc == (DEEP_ISSUE_KC < BK / KF ? DEEP_ISSUE_KC : 0) && s + NBUF - 1 < nsteps) {
+                    const int far_i = cur_i == 0 ? NBUF - 1 : cur_i - 1;
+                    const int kn = k_begin + (s + NBUF - 1) * BK;
+                    la.issue(kn, k_end, smem + far_i * 2 * TILE_BYTES);
+                    lb.issue(kn, k_end, smem + far_i * 2 * TILE_BYTES + TILE_BYTES);
+                }
+            }
         }
         if (NBUF == 2) {
             if (more) {
@@ -671,12 +661,100 @@ void gemm_kernel(MatDesc A, MatDesc B, Epilogue ep, int M, int N, int K, int k_p
         __syncthreads();
     }
     auto rowmap = [&](int rl) { const int row = tm * TILE + rl; return row < M ? row : -1; };
-    if (ep.mode == 0) epilogue_rows<T, T, NT, TILE>(ep, cs, batch, rowmap, tn * TILE, N, tid, bias_t);
-    else if (ep.mode == 1) epilogue_rows<T, float, NT, TILE>(ep, cs, batch, rowmap, tn * TILE, N, tid, bias_f);
+    if (ep.mode == 0) epilogue_rows<T, T, NT, TILE, TILE>(ep, cs, batch, rowmap, tn * TILE, N, tid, bias_t);
+    else if (ep.mode == 1) epilogue_rows<T, float, NT, TILE, TILE>(ep, cs, batch, rowmap, tn * TILE, N, tid, bias_f);
     else epilogue_scatter<NT>(ep, cs, batch, tm * TILE, tn * TILE, M, N, tid);
     HALO_STAMP(4); HALO_WALL(5);
 }
 
+
+// =====================================================================================================================
+// 64 x 64 tile variant for SMALL grids (the 8x8 / 4x4 levels, 1x1 shortcuts and linears there): with 128x128 tiles those
+// layers put 32-128 blocks on 256 CUs and every block is bound by the rate at which ONE CU can move operand tiles into
+// LDS (~64 B/clk: 32 KiB per K-step ~ the MFMA time of the step, the two barely overlap).  Quarter-size tiles spread the
+// same traffic over 4x the CUs.  k-contiguous operands only (LDS-DMA), 4 waves as 2 x 2 with one 32x32 MFMA block each,
+// R-deep ring of 16 KiB stages with counted waits, row epilogue modes 0 / 1.
+constexpr int T64 = 64;
+constexpr int RING64 = 4;
+
+template <typename T>
+__global__ __launch_bounds__(256, 2)
+void gemm64_kernel(MatDesc A, MatDesc B, Epilogue ep, int M, int N, int K, int tiles_n) {
+    constexpr int BK = 8 * Elem<T>::VEC, KF = Mma<T>::KF, NT = 256;
+    constexpr int OP_BYTES = T64 * ROW_BYTES;             // one operand tile (8 KiB); stage = [A | B]
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tm = blockIdx.x / tiles_n, tn = blockIdx.x - tm * tiles_n;
+    const int batch = blockIdx.z;
+    Loader<T, false, 4, T64> la(A, batch, tm * T64, tid);
+    Loader<T, false, 4, T64> lb(B, batch, tn * T64, tid);
+    f32x16 acc0 = (f32x16)(0.f), acc1 = (f32x16)(0.f);   // two accumulators: consecutive MFMAs do not wait on each other
+    const int nsteps = (K + BK - 1) / BK;
+    // 4 LDS-DMA instructions per wave and stage (2 per operand)
+#pragma unroll
+    for (int t = 0; t < RING64 - 1; ++t)
+        if (t < nsteps) {
+            la.issue(t * BK, K, smem + t * 2 * OP_BYTES);
+            lb.issue(t * BK, K, smem + t * 2 * OP_BYTES + OP_BYTES);
+        }
+    wait_tiles_in_flight<4>(min(RING64 - 2, nsteps - 1));
+    __builtin_amdgcn_s_barrier();
+    int cur_i = 0;
+    for (int s = 0; s < nsteps; ++s) {
+        const char* ta = smem + cur_i * 2 * OP_BYTES;
+        const char* tb = ta + OP_BYTES;
+        // one wave per SIMD: nothing else hides latencies.  All fragments of the step are requested first, the MFMAs are
+        // queued on two independent accumulators, and only then comes the address arithmetic + LDS-DMA issue of the tile
+        // RING64-1 steps ahead (its slot — the one of step s-1 — is free since the last barrier): it runs under the MFMAs.
+        u32x4 fa[BK / KF], fb[BK / KF];
+#pragma unroll
+        for (int kc = 0; kc < BK / KF; ++kc) {
+            fa[kc] = read_frag<T, false>(ta, wm * 32, kc, lane);
+            fb[kc] = read_frag<T, false>(tb, wn * 32, kc, lane);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kc = 0; kc < BK / KF; ++kc) {
+            if (kc & 1) Mma<T>::run(fa[kc], fb[kc], acc1); else Mma<T>::run(fa[kc], fb[kc], acc0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + RING64 - 1 < nsteps) {
+            const int far_i = cur_i == 0 ? RING64 - 1 : cur_i - 1;
+            const int kn = (s + RING64 - 1) * BK;
+            la.issue(kn, K, smem + far_i * 2 * OP_BYTES);
+            lb.issue(kn, K, smem + far_i * 2 * OP_BYTES + OP_BYTES);
+        }
+        wait_tiles_in_flight<4>(min(RING64 - 2, max(nsteps - 2 - s, 0)));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        cur_i = cur_i + 1 == RING64 ? 0 : cur_i + 1;
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = acc0[r] + acc1[r];
+    // epilogue: fp32 staging [64][68]
+    constexpr int LD64 = T64 + 4;
+    float* cs = reinterpret_cast<float*>(smem);
+    float bias_t[Elem<T>::VEC], bias_f[4];
+    if (ep.mode == 0) epilogue_bias<T, NT, T64>(ep, tn * T64, N, tid, bias_t);
+    else epilogue_bias<float, NT, T64>(ep, tn * T64, N, tid, bias_f);
+    {
+        const int rb = wm * 32 + 4 * (lane >> 5), cb = wn * 32 + (lane & 31);
+        static_for<16>([&](auto ic) {
+            constexpr int r = decltype(ic)::v;
+            cs[(rb + (r & 3) + 8 * (r >> 2)) * LD64 + cb] = acc[r];
+        });
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    auto rowmap = [&](int rl) { const int row = tm * T64 + rl; return row < M ? row : -1; };
+    if (ep.mode == 0) epilogue_rows<T, T, NT, T64, T64>(ep, cs, batch, rowmap, tn * T64, N, tid, bias_t);
+    else epilogue_rows<T, float, NT, T64, T64>(ep, cs, batch, rowmap, tn * T64, N, tid, bias_f);
+}
+template __global__ void gemm64_kernel<bf16_t>(MatDesc, MatDesc, Epilogue, int, int, int, int);
+template __global__ void gemm64_kernel<float>(MatDesc, MatDesc, Epilogue, int, int, int, int);
 
 // =====================================================================================================================
 // 3x3 / stride 1 / pad 1 convolution with a STATIONARY INPUT HALO (bf16): the hot conv of the UNet (forward and dgrad).
@@ -866,7 +944,7 @@ void conv3x3_halo_kernel(Conv3Args a, int tiles_n) {
         const int gi = img0 + il;
         return gi < a.B ? (gi * a.H + py0 + (qq >> a.lPW)) * a.W + px0 + (qq & (a.PW - 1)) : -1;
     };
-    epilogue_rows<T, T, 512, 256>(a.ep, cs, 0, rowmap, tn * TILE, a.N, tid, bias);
+    epilogue_rows<T, T, 512, 256, TILE>(a.ep, cs, 0, rowmap, tn * TILE, a.N, tid, bias);
     HALO_STAMP(4); HALO_WALL(5);
 }
 
@@ -962,6 +1040,22 @@ static int launch_t(GemmArgs& g, hipStream_t st) {
     if (splits > 1 && g.ep.mode != 2 && g.ep.mode != 4 && !(g.ep.splitk_ws && g.ep.splitk_cnt)) return DDPM_ERR_SHAPE;
     if (g.ep.mode == 2 || g.ep.mode == 4) { g.ep.splitk_ws = nullptr; g.ep.splitk_cnt = nullptr; }
     dim3 grid(tiles_m * tiles_n, splits, g.batch);
+    // small grids of k-contiguous products: 64x64 tiles put 4x as many CUs to work (see gemm64_kernel)
+    static const bool no_t64 = getenv("DDPM_GEMM_NO_T64") != nullptr;
+    if (!no_t64 && !g.A.trans && !g.B.trans && splits == 1 && (g.ep.mode == 0 || g.ep.mode == 1) &&
+        (long long)tiles_m * tiles_n * g.batch <= 128) {
+        const int t64n = (g.N + T64 - 1) / T64;
+        const dim3 grid64(((g.M + T64 - 1) / T64) * t64n, 1, g.batch);
+        constexpr int LDS64 = RING64 * 2 * T64 * ROW_BYTES;
+        static bool attr_set = false;
+        if (!attr_set) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm64_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS64) != hipSuccess)
+                return DDPM_ERR_LAUNCH;
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((gemm64_kernel<T>), grid64, dim3(256), LDS64, st, g.A, g.B, g.ep, g.M, g.N, g.K, t64n);
+        return check_launch();
+    }
     const size_t lds2 = TILE * CS_LD * sizeof(float);     // 4 operand tiles (64 KiB) <= fp32 epilogue staging (66 KiB)
     const size_t lds3 = 10 * TILE * ROW_BYTES;            // 5-deep ring: 160 KiB, one block per CU
     const int kps = steps_per * BK;

@@ -4,6 +4,8 @@ Activations are NHWC; a ``View`` is (base tensor kept alive, device pointer, pix
 channel slices of a shared buffer (the zero-copy decoder concat, q/k/v inside project_in's output) are
 first-class operands.  Nothing here allocates or synchronises except where noted.
 """
+import os
+
 import torch
 
 from . import _hip
@@ -76,10 +78,15 @@ def conv2d(x, w_ptr, y_ptr, y_ld, N, R, S, Ho, Wo, stride=1, pad_t=0, pad_l=0, u
         f"conv M={x.B * Ho * Wo} N={N} K={R * S * x.C} {R}x{S} s{stride} u{upsample} d{dilate}")
 
 
+_USE_SPLITK = bool(os.environ.get("DDPM_SPLITK"))
+
+
 class SplitK:
-    """Workspace for the in-launch split-K of layers with few output tiles (the 8x8 / 4x4 levels): fp32 slabs + per-tile
-    arrival counters (zero between launches: the last arriver of every tile resets its counter)."""
-    TARGET_BLOCKS = 128          # measured (scripts/splitk_probe.py): beyond ~128 blocks the slab reduction costs more than it buys
+    """Workspace for the in-launch split-K of layers with few output tiles: fp32 slabs + per-tile arrival counters (zero
+    between launches: the last arriver of every tile resets its counter).  Off by default since the 64x64-tile kernel took
+    over the small grids (it beats 128x128 tiles + split-K on every 8x8 / 4x4 layer, scripts/smallm_sweep.py); set
+    DDPM_SPLITK=1 to get the old behaviour for comparisons."""
+    TARGET_BLOCKS = 128
 
     def __init__(self, device):
         self.device = device
@@ -87,6 +94,8 @@ class SplitK:
         self.cnt = None
 
     def plan(self, M, N, K, dtype):
+        if not _USE_SPLITK:
+            return 1, 0, 0
         tiles = -(-M // 128) * -(-N // 128)
         ksteps = -(-K // (64 if dtype == _hip.BF16 else 32))
         splits = min(self.TARGET_BLOCKS // tiles, ksteps // 8)
