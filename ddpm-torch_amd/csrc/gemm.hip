@@ -966,6 +966,10 @@ INST(float, false, true, 2, 4) INST(float, true, false, 2, 4) INST(float, true, 
 
 // ---------------------------------------------------------------------------------------------- host side
 
+// which kernel the most recent conv / GEMM call of this thread dispatched to (bench.py attributes its per-launch timings
+// with it): 1 gemm_kernel 4-wave, 2 gemm_kernel 8-wave, 3 gemm_kernel deep ring, 4 gemm64_kernel, 5 conv3x3_halo_kernel
+static thread_local int g_last_variant = 0;
+
 struct GemmArgs {          // plain-C mirror filled by the extern "C" entry points
     MatDesc A, B;
     Epilogue ep;
@@ -1005,6 +1009,7 @@ static int conv3x3_halo_launch(GemmArgs& g, const void* x, long long x_ld, const
         }                                                                                                                \
         hipLaunchKernelGGL((conv3x3_halo_kernel<RING, HROWS>), grid, dim3(512), LDS, st, a, tiles_n);                    \
     } while (0)
+    g_last_variant = 5;
     if (HP <= 384) C3_LAUNCH(4, 384);      // one 16x16 patch: 2 x 48 KiB halo + 4 x 16 KiB weight ring
     else C3_LAUNCH(3, 448);                // four 8x8 patches: 2 x 56 KiB halo + 3 x 16 KiB weight ring
 #undef C3_LAUNCH
@@ -1054,6 +1059,7 @@ static int launch_t(GemmArgs& g, hipStream_t st) {
             attr_set = true;
         }
         hipLaunchKernelGGL((gemm64_kernel<T>), grid64, dim3(256), LDS64, st, g.A, g.B, g.ep, g.M, g.N, g.K, t64n);
+        g_last_variant = 4;
         return check_launch();
     }
     const size_t lds2 = TILE * CS_LD * sizeof(float);     // 4 operand tiles (64 KiB) <= fp32 epilogue staging (66 KiB)
@@ -1071,6 +1077,7 @@ static int launch_t(GemmArgs& g, hipStream_t st) {
             attr_set = true;                                                                                             \
         }                                                                                                                \
         hipLaunchKernelGGL((gemm_kernel<T, TA, TB, NB, NWV>), grid, dim3(NWV * 64), (LDS), st, g.A, g.B, g.ep, g.M, g.N, g.K, kps, tiles_n); \
+        g_last_variant = NB != 2 ? 3 : (NWV == 8 ? 2 : 1);                                                               \
     } while (0)
     // 8-wave blocks whenever both operands take the DMA path (all bf16 products, fp32 with k-contiguous operands)
     constexpr bool BF = sizeof(T) == 2;
@@ -1215,4 +1222,10 @@ extern "C" int ddpm_gemm(const void* a, long long a_ld, long long a_bs, int a_tr
     g.ep.bias = bias; g.ep.residual = residual; g.ep.res_ld = res_ld; g.ep.res_batch_stride = res_bs;
     g.ep.accumulate = accumulate;
     return ddpm_gemm_launch(g, (hipStream_t)stream);
+}
+
+extern "C" int ddpm_last_gemm_variant(int reset) {
+    const int v = g_last_variant;
+    if (reset) g_last_variant = 0;
+    return v;
 }

@@ -19,7 +19,8 @@ _ERR = {1: "bad shape / divisibility", 2: "unsupported dtype", 3: "misaligned po
 
 P, I, L, F, U = c_void_p, c_int, c_longlong, c_float, c_ulonglong
 
-# name -> argtypes; every function returns int status (0 = OK) except ddpm_gn_workspace_floats.
+# name -> argtypes; every function returns int status (0 = OK) except ddpm_gn_workspace_floats and
+# ddpm_last_gemm_variant (a plain value).
 PROTOTYPES = {
     "ddpm_conv2d_nhwc": [P, L, P, P, L, P, P, L, P, L] + [I] * 14 + [I, I, I, P, P, I, P],
     "ddpm_conv2d_wgrad_nhwc": [P, L, P, L, P] + [I] * 17 + [P],
@@ -28,6 +29,7 @@ PROTOTYPES = {
     "ddpm_groupnorm_silu_fwd": [P, L, P, L, P, P, P, P, I, I, I, I, F, I, F, U, I, P],
     "ddpm_groupnorm_silu_bwd": [P, L, P, L, P, L, P, P, P, P, P, P, I, I, I, I, I, F, U, I, I, P],
     "ddpm_gn_workspace_floats": [I, I, I, I, I],
+    "ddpm_last_gemm_variant": [I],
     "ddpm_timestep_embedding": [P, P, P, I, I, P],
     "ddpm_nchw_to_nhwc": [P, P, I, I, I, I, I, P],
     "ddpm_pack_weight": [P, P, P, I, I, I, I, I, I, I, P],

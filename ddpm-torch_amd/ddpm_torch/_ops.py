@@ -26,7 +26,7 @@ def _timed(kind, flops, fn, shape=""):
     a.record()
     fn()
     b.record()
-    PROFILE.append((kind, flops, a, b, shape))
+    PROFILE.append((kind, flops, a, b, shape, _hip.lib().ddpm_last_gemm_variant(1)))
 
 
 class View:

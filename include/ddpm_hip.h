@@ -60,6 +60,12 @@ int ddpm_gemm(const void* a, long long a_ld, long long a_bs, int a_trans,
               int M, int N, int K, int batch, float alpha, int accumulate, int out_mode, int splits,
               int dtype, void* stream);
 
+/* Instrumentation (no upstream counterpart): which kernel the most recent ddpm_conv2d_nhwc / ddpm_conv2d_wgrad_nhwc /
+ * ddpm_gemm call of the calling thread dispatched to — 1 gemm_kernel (4 waves), 2 gemm_kernel (8 waves), 3 gemm_kernel
+ * (deep LDS ring), 4 gemm64_kernel (64x64 tiles), 5 conv3x3_halo_kernel; 0 = none since the last reset.  bench.py uses it
+ * to attribute its per-launch HIP-event timings to the kernel that actually ran.  Not a status code. */
+int ddpm_last_gemm_variant(int reset);
+
 /* nn.GroupNorm(32, C, eps=1e-6) -> SiLU -> Dropout(p) (unet.py:18-20,15,81,85-87,139-140; :57 without SiLU):
  *   y = drop(silu((x - mean_g) * rstd_g * gamma_c + beta_c)),  biased variance over (C/G)*HW elements.
  * stats (optional) receives [B][G][2] = (mean, rstd) for the backward.  workspace: ddpm_gn_workspace_floats().
