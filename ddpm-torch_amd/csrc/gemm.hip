@@ -964,6 +964,154 @@ INST(float, false, false, 2, 4) INST(float, false, false, 2, 8) INST(float, fals
 INST(float, false, true, 2, 4) INST(float, true, false, 2, 4) INST(float, true, true, 2, 4)
 #undef INST
 
+// =====================================================================================================================
+// Fused single-head attention forward (inference): O = softmax(Q K^T * scale) V for one image per blockIdx.y, 128 queries
+// per block (4 waves x 32 queries), keys / values streamed in chunks of 64 through LDS; the L x L logits never leave the
+// chip.  Reference: AttentionBlock.forward, ddpm_torch/models/unet.py:41-52.
+//
+// Formulated TRANSPOSED so that no operand ever has to be re-laid-out through LDS:
+//   S^T[key, q] = K Q^T      A = K chunk (rows = keys), B = Q tile (rows = queries), both k-contiguous LDS-DMA tiles;
+//   a lane of the 32x32 accumulator owns ONE query (column lane&31) and 16 keys per block -> the softmax over keys is a
+//   per-lane register reduction plus one exchange between the two half-waves (online max / sum across chunks);
+//   O^T[dv, q] += V^T P^T    B = P^T straight from the S^T accumulator registers (the contraction index is the key, so
+//   the MFMA k-slots simply follow the accumulator's key order 16t + 4g + {0..3}, 16t + 8 + 4g + {0..3}); A = V^T read
+//   from the V chunk AS STORED (key-major) with the hardware transpose read in the same key order.
+template <int DB>          // head dimension D = 32 * DB (DB = 4 or 8)
+__global__ __launch_bounds__(256)
+void attn_fwd_kernel(MatDesc Qd, MatDesc Kd, MatDesc Vd, bf16_t* __restrict__ out, long long out_ld, int L, float scale) {
+    typedef bf16_t T;
+    constexpr int D = 32 * DB, DC = D / 64, VT = D / 128;
+    constexpr int Q_BYTES = TILE * ROW_BYTES, K_BYTES = 64 * ROW_BYTES, V_BYTES = 64 * 256;
+    constexpr int NK = 2 * DC, NV_ = 4 * VT;                  // LDS-DMA instructions per thread: one K chunk / one V chunk
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Qs = smem;                                          // [DC][128 q][64 d]
+    char* Ks = Qs + DC * Q_BYTES;                             // [DC][64 keys][64 d]
+    char* Vs = Ks + DC * K_BYTES;                             // [VT][64 keys][128 dv] (key-major image)
+    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.y, q0 = blockIdx.x * TILE;
+    const int nchunks = L / 64;
+
+    auto wait_vm = [&](int n) {                               // n in {0, 4, 8}
+        if (n == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (n == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    Loader<T, true, 4> lv0(Vd, b, 0, tid), lv1(Vd, b, VT > 1 ? 128 : 0, tid);
+    auto issue_k = [&](int chunk) {
+        Loader<T, false, 4, 64> lk(Kd, b, chunk * 64, tid);
+#pragma unroll
+        for (int c = 0; c < DC; ++c) lk.issue(c * 64, D, Ks + c * K_BYTES);
+    };
+    auto issue_v = [&](int chunk) {
+        lv0.issue_tr(chunk * 64, L, Vs);
+        if (VT > 1) lv1.issue_tr(chunk * 64, L, Vs + V_BYTES);
+    };
+    {
+        Loader<T, false, 4, 128> lq(Qd, b, q0, tid);
+#pragma unroll
+        for (int c = 0; c < DC; ++c) lq.issue(c * 64, D, Qs + c * Q_BYTES);
+    }
+    issue_k(0);
+    issue_v(0);
+
+    f32x16 acc_o[DB];
+#pragma unroll
+    for (int j = 0; j < DB; ++j) acc_o[j] = (f32x16)(0.f);
+    float m_run = -3.0e38f, l_run = 0.f;                      // running max (scaled logits) and sum for this lane's query
+
+    for (int ch = 0; ch < nchunks; ++ch) {
+        wait_vm(NV_);                                         // Q and this K chunk have landed; the V chunk may still fly
+        __builtin_amdgcn_s_barrier();
+        // ---- S^T = K Q^T for 64 keys x this wave's 32 queries
+        f32x16 acc_s[2] = {(f32x16)(0.f), (f32x16)(0.f)};
+#pragma unroll
+        for (int c = 0; c < DC; ++c)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const u32x4 fq = read_frag<T, false>(Qs + c * Q_BYTES, wave * 32, kk, lane);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const u32x4 fk = read_frag<T, false>(Ks + c * K_BYTES, i * 32, kk, lane);
+                    Mma<T>::run(fk, fq, acc_s[i]);
+                }
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                         // every wave is done with the K chunk
+        if (ch + 1 < nchunks) issue_k(ch + 1);
+        // ---- online softmax over the keys of this chunk (per lane: one query)
+        float mloc = acc_s[0][0];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, acc_s[i][r]);
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+        const float m_new = fmaxf(m_run, mloc * scale);
+        const float alpha = __expf(m_run - m_new);
+        m_run = m_new;
+        float psum = 0.f;
+        u32x4 pb[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                float e[8];
+#pragma unroll
+                for (int r = 0; r < 8; ++r) { e[r] = __expf(acc_s[i][8 * t + r] * scale - m_new); psum += e[r]; }
+                pb[i][t] = u32x4{pack_bf2(e[0], e[1]), pack_bf2(e[2], e[3]), pack_bf2(e[4], e[5]), pack_bf2(e[6], e[7])};
+            }
+        l_run = l_run * alpha + psum;
+#pragma unroll
+        for (int j = 0; j < DB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc_o[j][r] *= alpha;
+        // ---- O^T += V^T P^T
+        wait_vm(ch + 1 < nchunks ? NK : 0);                   // this V chunk has landed (the next K chunk may still fly)
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int kb = i * 32 + t * 16;
+#pragma unroll
+                for (int j = 0; j < DB; ++j) {
+                    // V^T fragment of dv block j in the accumulator's key order: keys kb + 4g + {0..3}, kb + 8 + 4g + {0..3}
+                    typedef short s16x4 __attribute__((ext_vector_type(4)));
+                    const int i16 = lane & 15;
+                    const int mcol = (j & 3) * 32 + ((lane >> 4) & 1) * 16 + (i16 & 3) * 4;
+                    const int krow = kb + g * 4 + (i16 >> 2);
+                    const int pch = (mcol >> 3) ^ (((i16 >> 2) & 3) << 2);
+                    const char* p = Vs + (j >> 2) * V_BYTES + krow * 256 + pch * 16 + (mcol & 7) * 2;
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p + 8 * 256));
+                    u32x4 fv;
+                    fv.x = __builtin_bit_cast(uint2, lo).x; fv.y = __builtin_bit_cast(uint2, lo).y;
+                    fv.z = __builtin_bit_cast(uint2, hi).x; fv.w = __builtin_bit_cast(uint2, hi).y;
+                    Mma<T>::run(fv, pb[i][t], acc_o[j]);
+                }
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                         // every wave is done with the V chunk
+        if (ch + 1 < nchunks) issue_v(ch + 1);
+    }
+    // ---- normalise and store: this lane owns query q, and per accumulator register quad 4 consecutive channels
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    const int q = q0 + wave * 32 + (lane & 31);
+    T* orow = out + ((long long)b * L + q) * out_ld;
+#pragma unroll
+    for (int j = 0; j < DB; ++j)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+            uint2 w;
+            w.x = pack_bf2(acc_o[j][4 * rq] * inv, acc_o[j][4 * rq + 1] * inv);
+            w.y = pack_bf2(acc_o[j][4 * rq + 2] * inv, acc_o[j][4 * rq + 3] * inv);
+            *reinterpret_cast<uint2*>(orow + j * 32 + 8 * rq + 4 * g) = w;
+        }
+}
+template __global__ void attn_fwd_kernel<4>(MatDesc, MatDesc, MatDesc, bf16_t*, long long, int, float);
+template __global__ void attn_fwd_kernel<8>(MatDesc, MatDesc, MatDesc, bf16_t*, long long, int, float);
+
 // ---------------------------------------------------------------------------------------------- host side
 
 // which kernel the most recent conv / GEMM call of this thread dispatched to (bench.py attributes its per-launch timings
@@ -1222,6 +1370,37 @@ extern "C" int ddpm_gemm(const void* a, long long a_ld, long long a_bs, int a_tr
     g.ep.bias = bias; g.ep.residual = residual; g.ep.res_ld = res_ld; g.ep.res_batch_stride = res_bs;
     g.ep.accumulate = accumulate;
     return ddpm_gemm_launch(g, (hipStream_t)stream);
+}
+
+// Fused attention forward over a packed qkv buffer [B][L][ld] (q at channel 0, k at C, v at 2C): out[B][L][out_ld] =
+// softmax(q k^T * scale) v.  bf16 only; C in {128, 256}; L a multiple of 128.  Other geometries: DDPM_ERR_SHAPE (the
+// caller keeps the three-launch path for them).
+extern "C" int ddpm_attention_fwd(const void* qkv, long long ld, void* out, long long out_ld, int B, int L, int C, float scale,
+                                  int dtype, void* stream) {
+    if (!qkv || !out) return DDPM_ERR_NULL;
+    if (dtype != DDPM_BF16) return DDPM_ERR_DTYPE;
+    if (B <= 0 || L <= 0 || L % 128 || (C != 128 && C != 256) || ld < 3 * C) return DDPM_ERR_SHAPE;
+    if (!aligned16(qkv) || !aligned16(out) || ld % 8 || out_ld % 8) return DDPM_ERR_ALIGN;
+    MatDesc q, k, v;
+    memset(&q, 0, sizeof(q));
+    q.p = qkv; q.ld = ld; q.batch_stride = (long long)L * ld; q.trans = 0; q.n_slow = L; q.n_fast = C;
+    k = q; k.p = (const bf16_t*)qkv + C;
+    v = q; v.p = (const bf16_t*)qkv + 2 * C; v.trans = 1; v.n_slow = L; v.n_fast = C;
+    if (finish_desc(q, 2) || finish_desc(k, 2) || finish_desc(v, 2)) return DDPM_ERR_SHAPE;
+    const int DC = C / 64, VT = C / 128;
+    const int lds = DC * TILE * ROW_BYTES + DC * 64 * ROW_BYTES + VT * 64 * 256;
+    const dim3 grid(L / 128, B);
+    hipStream_t st = (hipStream_t)stream;
+    if (C == 256) {
+        static bool attr = false;
+        if (!attr) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return DDPM_ERR_LAUNCH; attr = true; }
+        hipLaunchKernelGGL(attn_fwd_kernel<8>, grid, dim3(256), lds, st, q, k, v, (bf16_t*)out, out_ld, L, scale);
+    } else {
+        static bool attr = false;
+        if (!attr) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return DDPM_ERR_LAUNCH; attr = true; }
+        hipLaunchKernelGGL(attn_fwd_kernel<4>, grid, dim3(256), lds, st, q, k, v, (bf16_t*)out, out_ld, L, scale);
+    }
+    return check_launch();
 }
 
 extern "C" int ddpm_last_gemm_variant(int reset) {

@@ -30,6 +30,7 @@ PROTOTYPES = {
     "ddpm_groupnorm_silu_bwd": [P, L, P, L, P, L, P, P, P, P, P, P, I, I, I, I, I, F, U, I, I, P],
     "ddpm_gn_workspace_floats": [I, I, I, I, I],
     "ddpm_last_gemm_variant": [I],
+    "ddpm_attention_fwd": [P, L, P, L, I, I, I, F, I, P],
     "ddpm_timestep_embedding": [P, P, P, I, I, P],
     "ddpm_nchw_to_nhwc": [P, P, I, I, I, I, I, P],
     "ddpm_pack_weight": [P, P, P, I, I, I, I, I, I, I, P],

@@ -235,6 +235,7 @@ class _ConvW:
 
 
 _WGRAD_TARGET_BLOCKS = int(os.environ.get("DDPM_WGRAD_BLOCKS", "512"))
+_FUSED_ATTENTION = os.environ.get("DDPM_FUSED_ATTENTION", "1") != "0"
 
 
 class _Engine:
@@ -640,14 +641,19 @@ class _Engine:
         ci = self._packed(ab.project_in, save)
         ops.conv2d(hn, ci.wf.data_ptr(), qkv.ptr, qkv.ld, 3 * C, 1, 1, x.H, x.W, bias=ab.project_in.bias.data_ptr(), splitk=self.splitk)
         es, bs = self.es, Lk * 3 * C
-        q, kk, v = qkv.ptr, qkv.ptr + C * es, qkv.ptr + 2 * C * es
-        logits = self._f32(B, Lk, Lk)                       # S = Q K^T / sqrt(C)   (unet.py:46-48)
-        ops.gemm(q, 3 * C, bs, 0, kk, 3 * C, bs, 0, logits.data_ptr(), Lk, Lk * Lk, Lk, Lk, C, self.dcode, batch=B,
-                 alpha=1.0 / math.sqrt(C), out_mode=1)
-        prob = torch.empty((B, Lk, Lk), dtype=self.T, device=self.device)
-        _hip.call("ddpm_softmax_fwd", logits.data_ptr(), prob.data_ptr(), B * Lk, Lk, self.dcode, _hip.stream())
-        o = self._new(B, x.H, x.W, C)                         # O = P V   (unet.py:50)
-        ops.gemm(prob.data_ptr(), Lk, Lk * Lk, 0, v, 3 * C, bs, 1, o.ptr, C, Lk * C, Lk, C, Lk, self.dcode, batch=B)
+        o = self._new(B, x.H, x.W, C)
+        prob = None
+        if not save and _FUSED_ATTENTION and self.T == torch.bfloat16 and Lk % 128 == 0 and C in (128, 256):
+            # inference: one kernel, the L x L logits / probabilities stay in LDS and registers (unet.py:41-52)
+            _hip.call("ddpm_attention_fwd", qkv.ptr, qkv.ld, o.ptr, o.ld, B, Lk, C, 1.0 / math.sqrt(C), self.dcode, _hip.stream())
+        else:
+            q, kk, v = qkv.ptr, qkv.ptr + C * es, qkv.ptr + 2 * C * es
+            logits = self._f32(B, Lk, Lk)                       # S = Q K^T / sqrt(C)   (unet.py:46-48)
+            ops.gemm(q, 3 * C, bs, 0, kk, 3 * C, bs, 0, logits.data_ptr(), Lk, Lk * Lk, Lk, Lk, C, self.dcode, batch=B,
+                     alpha=1.0 / math.sqrt(C), out_mode=1)
+            prob = torch.empty((B, Lk, Lk), dtype=self.T, device=self.device)
+            _hip.call("ddpm_softmax_fwd", logits.data_ptr(), prob.data_ptr(), B * Lk, Lk, self.dcode, _hip.stream())
+            ops.gemm(prob.data_ptr(), Lk, Lk * Lk, 0, v, 3 * C, bs, 1, o.ptr, C, Lk * C, Lk, C, Lk, self.dcode, batch=B)   # O = P V (unet.py:50)
         co = self._packed(ab.project_out, save)
         ops.conv2d(o, co.wf.data_ptr(), out.ptr, out.ld, C, 1, 1, x.H, x.W, bias=ab.project_out.bias.data_ptr(),
                    res_ptr=x.ptr, res_ld=x.ld, splitk=self.splitk)

@@ -60,6 +60,15 @@ int ddpm_gemm(const void* a, long long a_ld, long long a_bs, int a_trans,
               int M, int N, int K, int batch, float alpha, int accumulate, int out_mode, int splits,
               int dtype, void* stream);
 
+/* Fused single-head attention forward (inference path) — replaces the three products of AttentionBlock.forward
+ * (ddpm_torch/models/unet.py:41-52: einsum("bchw,bcHW->bhwHW") * C**-0.5, softmax over the key positions, einsum with v)
+ * for a packed projection buffer qkv[B][L][ld] with q at channel 0, k at channel C and v at channel 2C:
+ *     out[b][i][:] = sum_j softmax_j(q[b][i] . k[b][j] * scale) v[b][j]        (out pitch out_ld, bf16)
+ * The L x L logits stay on chip (LDS / registers).  bf16 only, C in {128, 256}, L a multiple of 128; anything else returns
+ * DDPM_ERR_SHAPE and the caller keeps ddpm_gemm + ddpm_softmax_fwd + ddpm_gemm. */
+int ddpm_attention_fwd(const void* qkv, long long ld, void* out, long long out_ld, int B, int L, int C, float scale,
+                       int dtype, void* stream);
+
 /* Instrumentation (no upstream counterpart): which kernel the most recent ddpm_conv2d_nhwc / ddpm_conv2d_wgrad_nhwc /
  * ddpm_gemm call of the calling thread dispatched to — 1 gemm_kernel (4 waves), 2 gemm_kernel (8 waves), 3 gemm_kernel
  * (deep LDS ring), 4 gemm64_kernel (64x64 tiles), 5 conv3x3_halo_kernel; 0 = none since the last reset.  bench.py uses it

@@ -47,6 +47,14 @@ def conv_case(B, H, C, N, R, dtype, kind="fwd"):
     return t, flops / t / 1e12
 
 
+def attn_case(B, L, C):
+    qkv = torch.randn(B * L, 3 * C, device=DEV).to(torch.bfloat16)
+    o = torch.empty(B * L, C, device=DEV, dtype=torch.bfloat16)
+    fn = lambda: _hip.call("ddpm_attention_fwd", qkv.data_ptr(), 3 * C, o.data_ptr(), C, B, L, C, 1.0 / math.sqrt(C), 1, _hip.stream())
+    t = timeit(fn)
+    return t, 4.0 * B * L * L * C / t / 1e12
+
+
 def gn_case(B, H, C, dtype):
     x = View(torch.randn(B, H, H, C, device=DEV).to(dtype), B, H, H, C)
     y = View(torch.empty(B, H, H, C, device=DEV, dtype=dtype), B, H, H, C)
@@ -75,6 +83,11 @@ def main():
             key = f"gn_silu_fwd_{str(dtype)[6:]}_B{B}_H{H}_C{C}"
             out[key] = dict(ms=t * 1e3, gbps=gbs)
             print(f"{key:60s} {t * 1e6:9.1f} us  {gbs:8.1f} GB/s (algorithmic)", flush=True)
+    for (B, L, C) in [(128, 256, 256), (128, 256, 128)]:
+        t, tf = attn_case(B, L, C)
+        key = f"attention_fused_fwd_bfloat16_B{B}_L{L}_C{C}"
+        out[key] = dict(ms=t * 1e3, tflops=tf)
+        print(f"{key:60s} {t * 1e6:9.1f} us  {tf:8.1f} TFLOP/s", flush=True)
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     json.dump(out, open(os.path.join(ROOT, "gpurun_out", "microbench.json"), "w"), indent=1)
 

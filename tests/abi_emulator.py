@@ -320,6 +320,14 @@ class Emulator:
         v = torch.softmax(torch.from_numpy(f32(s, rows * L).reshape(rows, L).copy()), -1)
         Mat(p, rows, L, L, dt).set(v.numpy())
 
+    def ddpm_attention_fwd(self, qkv, ld, out, out_ld, B, L, C, scale, dt, st):
+        x = Mat(qkv, B * L, 3 * C, ld, dt).get().reshape(B, L, 3 * C).astype(np.float64)
+        q, k, v = x[..., :C], x[..., C:2 * C], x[..., 2 * C:]
+        s = np.einsum("bic,bjc->bij", q, k) * scale
+        s = np.exp(s - s.max(-1, keepdims=True))
+        p_ = s / s.sum(-1, keepdims=True)
+        Mat(out, B * L, C, out_ld, dt).set(np.einsum("bij,bjc->bic", p_, v).reshape(B * L, C).astype(np.float32))
+
     def ddpm_softmax_bwd(self, p, dp, ds, rows, L, dt, st):
         P = Mat(p, rows, L, L, dt).get()
         d = f32(dp, rows * L).reshape(rows, L)

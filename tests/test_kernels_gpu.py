@@ -219,6 +219,24 @@ def test_groupnorm_fwd_bwd(dt, B, HW, C, silu, drop):
              tol=2e-4 if dt == 0 else 2e-2)
 
 
+@pytest.mark.parametrize("B,L,C", [(3, 256, 256), (2, 128, 128), (2, 384, 256)])
+def test_attention_fwd_fused(B, L, C):
+    ld, old = 3 * C + 16, C + 8                                # exercise pitches
+    qkv = r(B * L, ld, seed=11, dt=1, scale=1.3)
+    out = torch.zeros(B * L, old, dtype=torch.bfloat16)
+    both("ddpm_attention_fwd", A(qkv), ld, A(out, out=True, name="o"), old, B, L, C, 1.0 / math.sqrt(C), 1, tol=TOL[1])
+    # peaked rows (one dominant key): the online max / rescale path
+    qkv2 = qkv.clone().float()
+    qkv2[:, :C] *= 6.0
+    both("ddpm_attention_fwd", A(qkv2.to(torch.bfloat16)), ld, A(out, out=True, name="o_peaked"), old, B, L, C, 1.0 / math.sqrt(C), 1, tol=TOL[1])
+
+
+def test_attention_fwd_rejects_unsupported_geometry():
+    x = torch.zeros(16, 3 * 64, dtype=torch.bfloat16).cuda()
+    o = torch.zeros(16, 64, dtype=torch.bfloat16).cuda()
+    assert _hip.lib().ddpm_attention_fwd(x.data_ptr(), 192, o.data_ptr(), 64, 1, 16, 64, 0.125, 1, _hip.stream()) == 1
+
+
 def test_dropout_mask_bit_exact_and_rate():
     n = 1 << 20
     m = torch.zeros(n)
