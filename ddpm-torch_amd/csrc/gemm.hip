@@ -675,13 +675,16 @@ void gemm_kernel(MatDesc A, MatDesc B, Epilogue ep, int M, int N, int K, int k_p
 // same traffic over 4x the CUs.  k-contiguous operands only (LDS-DMA), 4 waves as 2 x 2 with one 32x32 MFMA block each,
 // R-deep ring of 16 KiB stages with counted waits, row epilogue modes 0 / 1.
 constexpr int T64 = 64;
-constexpr int RING64 = 4;
+constexpr int G64 = 2;            // K-steps per barrier group
 
-template <typename T>
-__global__ __launch_bounds__(256, 2)
+// NG = groups in the LDS ring: 3 (96 KiB, one block per CU, two groups in flight) for grids of <= 256 blocks, 2 (64 KiB, two
+// blocks per CU, one group in flight) for larger ones where the second resident block hides what the shallower ring exposes.
+template <typename T, int NG>
+__global__ __launch_bounds__(256, NG == 2 ? 2 : 1)
 void gemm64_kernel(MatDesc A, MatDesc B, Epilogue ep, int M, int N, int K, int tiles_n) {
     constexpr int BK = 8 * Elem<T>::VEC, KF = Mma<T>::KF, NT = 256;
     constexpr int OP_BYTES = T64 * ROW_BYTES;             // one operand tile (8 KiB); stage = [A | B]
+    constexpr int GROUP_BYTES = G64 * 2 * OP_BYTES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -691,45 +694,47 @@ void gemm64_kernel(MatDesc A, MatDesc B, Epilogue ep, int M, int N, int K, int t
     Loader<T, false, 4, T64> la(A, batch, tm * T64, tid);
     Loader<T, false, 4, T64> lb(B, batch, tn * T64, tid);
     f32x16 acc0 = (f32x16)(0.f), acc1 = (f32x16)(0.f);   // two accumulators: consecutive MFMAs do not wait on each other
-    const int nsteps = (K + BK - 1) / BK;
-    // 4 LDS-DMA instructions per wave and stage (2 per operand)
+    const int ngroups = ((K + BK - 1) / BK + G64 - 1) / G64;
+    // one group = G64 stages = 8 LDS-DMA instructions per wave (K-steps past the end fetch zeros: out-of-range offsets)
+    auto issue_group = [&](int grp, int slot) {
 #pragma unroll
-    for (int t = 0; t < RING64 - 1; ++t)
-        if (t < nsteps) {
-            la.issue(t * BK, K, smem + t * 2 * OP_BYTES);
-            lb.issue(t * BK, K, smem + t * 2 * OP_BYTES + OP_BYTES);
+        for (int u = 0; u < G64; ++u) {
+            la.issue((grp * G64 + u) * BK, K, smem + slot * GROUP_BYTES + u * 2 * OP_BYTES);
+            lb.issue((grp * G64 + u) * BK, K, smem + slot * GROUP_BYTES + u * 2 * OP_BYTES + OP_BYTES);
         }
-    wait_tiles_in_flight<4>(min(RING64 - 2, nsteps - 1));
+    };
+    issue_group(0, 0);
+    if (NG > 2 && ngroups > 1) issue_group(1, 1);
+    wait_tiles_in_flight<8>(NG > 2 && ngroups > 1 ? 1 : 0);
     __builtin_amdgcn_s_barrier();
-    int cur_i = 0;
-    for (int s = 0; s < nsteps; ++s) {
-        const char* ta = smem + cur_i * 2 * OP_BYTES;
-        const char* tb = ta + OP_BYTES;
-        // one wave per SIMD: nothing else hides latencies.  All fragments of the step are requested first, the MFMAs are
-        // queued on two independent accumulators, and only then comes the address arithmetic + LDS-DMA issue of the tile
-        // RING64-1 steps ahead (its slot — the one of step s-1 — is free since the last barrier): it runs under the MFMAs.
-        u32x4 fa[BK / KF], fb[BK / KF];
+    int slot = 0;
+    for (int gi = 0; gi < ngroups; ++gi) {
+        const char* base = smem + slot * GROUP_BYTES;
+        // One wave per SIMD: nothing else hides latencies, and a K-step of this tile is short — so ONE barrier covers two
+        // K-steps.  All fragments of the group are requested first, the MFMAs queue on two independent accumulators, then
+        // comes the address arithmetic + LDS-DMA issue of the group NG-1 ahead (its slot, the one of group gi-1, is free
+        // since the last barrier): it runs under the MFMAs.
+        u32x4 fa[G64][BK / KF], fb[G64][BK / KF];
 #pragma unroll
-        for (int kc = 0; kc < BK / KF; ++kc) {
-            fa[kc] = read_frag<T, false>(ta, wm * 32, kc, lane);
-            fb[kc] = read_frag<T, false>(tb, wn * 32, kc, lane);
-        }
+        for (int u = 0; u < G64; ++u)
+#pragma unroll
+            for (int kc = 0; kc < BK / KF; ++kc) {
+                fa[u][kc] = read_frag<T, false>(base + u * 2 * OP_BYTES, wm * 32, kc, lane);
+                fb[u][kc] = read_frag<T, false>(base + u * 2 * OP_BYTES + OP_BYTES, wn * 32, kc, lane);
+            }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int kc = 0; kc < BK / KF; ++kc) {
-            if (kc & 1) Mma<T>::run(fa[kc], fb[kc], acc1); else Mma<T>::run(fa[kc], fb[kc], acc0);
-        }
+        for (int u = 0; u < G64; ++u)
+#pragma unroll
+            for (int kc = 0; kc < BK / KF; ++kc) {
+                if (kc & 1) Mma<T>::run(fa[u][kc], fb[u][kc], acc1); else Mma<T>::run(fa[u][kc], fb[u][kc], acc0);
+            }
         __builtin_amdgcn_sched_barrier(0);
-        if (s + RING64 - 1 < nsteps) {
-            const int far_i = cur_i == 0 ? RING64 - 1 : cur_i - 1;
-            const int kn = (s + RING64 - 1) * BK;
-            la.issue(kn, K, smem + far_i * 2 * OP_BYTES);
-            lb.issue(kn, K, smem + far_i * 2 * OP_BYTES + OP_BYTES);
-        }
-        wait_tiles_in_flight<4>(min(RING64 - 2, max(nsteps - 2 - s, 0)));
+        if (gi + NG - 1 < ngroups) issue_group(gi + NG - 1, slot == 0 ? NG - 1 : slot - 1);
+        wait_tiles_in_flight<8>(NG > 2 && gi + 2 < ngroups ? 1 : 0);   // group gi+1 has landed; group gi+2 may stay in flight
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        cur_i = cur_i + 1 == RING64 ? 0 : cur_i + 1;
+        slot = slot == NG - 1 ? 0 : slot + 1;
     }
     f32x16 acc;
 #pragma unroll
@@ -753,8 +758,10 @@ void gemm64_kernel(MatDesc A, MatDesc B, Epilogue ep, int M, int N, int K, int t
     if (ep.mode == 0) epilogue_rows<T, T, NT, T64, T64>(ep, cs, batch, rowmap, tn * T64, N, tid, bias_t);
     else epilogue_rows<T, float, NT, T64, T64>(ep, cs, batch, rowmap, tn * T64, N, tid, bias_f);
 }
-template __global__ void gemm64_kernel<bf16_t>(MatDesc, MatDesc, Epilogue, int, int, int, int);
-template __global__ void gemm64_kernel<float>(MatDesc, MatDesc, Epilogue, int, int, int, int);
+template __global__ void gemm64_kernel<bf16_t, 2>(MatDesc, MatDesc, Epilogue, int, int, int, int);
+template __global__ void gemm64_kernel<bf16_t, 3>(MatDesc, MatDesc, Epilogue, int, int, int, int);
+template __global__ void gemm64_kernel<float, 2>(MatDesc, MatDesc, Epilogue, int, int, int, int);
+template __global__ void gemm64_kernel<float, 3>(MatDesc, MatDesc, Epilogue, int, int, int, int);
 
 // =====================================================================================================================
 // 3x3 / stride 1 / pad 1 convolution with a STATIONARY INPUT HALO (bf16): the hot conv of the UNet (forward and dgrad).
@@ -1199,14 +1206,19 @@ static int launch_t(GemmArgs& g, hipStream_t st) {
         (long long)tiles_m * tiles_n * g.batch <= 128) {
         const int t64n = (g.N + T64 - 1) / T64;
         const dim3 grid64(((g.M + T64 - 1) / T64) * t64n, 1, g.batch);
-        constexpr int LDS64 = RING64 * 2 * T64 * ROW_BYTES;
-        static bool attr_set = false;
-        if (!attr_set) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm64_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS64) != hipSuccess)
-                return DDPM_ERR_LAUNCH;
-            attr_set = true;
-        }
-        hipLaunchKernelGGL((gemm64_kernel<T>), grid64, dim3(256), LDS64, st, g.A, g.B, g.ep, g.M, g.N, g.K, t64n);
+#define LAUNCH64(NG)                                                                                                     \
+    do {                                                                                                                 \
+        constexpr int LDS64 = NG * G64 * 2 * T64 * ROW_BYTES;                                                            \
+        static bool attr_set = false;                                                                                    \
+        if (!attr_set) {                                                                                                 \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm64_kernel<T, NG>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS64) != hipSuccess) \
+                return DDPM_ERR_LAUNCH;                                                                                  \
+            attr_set = true;                                                                                             \
+        }                                                                                                                \
+        hipLaunchKernelGGL((gemm64_kernel<T, NG>), grid64, dim3(256), LDS64, st, g.A, g.B, g.ep, g.M, g.N, g.K, t64n);   \
+    } while (0)
+        if ((long long)grid64.x * grid64.z <= 256) LAUNCH64(3); else LAUNCH64(2);
+#undef LAUNCH64
         g_last_variant = 4;
         return check_launch();
     }
