@@ -486,15 +486,27 @@ __device__ __forceinline__ void wait_tiles_in_flight(int tiles) {
 //           ~0.65 us/step with two tiles in flight), so more tiles in flight is what shortens the step.
 // NW = 4: 4 waves as 2(M) x 2(N), 64x64 per wave.  NW = 8: 8 waves as 4(M) x 2(N), 32x64 per wave — twice the waves per CU
 //         (two 512-thread blocks) to hide LDS-DMA latency and barrier skew; needs both operands on the DMA path.
+// XCD-aware block order.  Workgroups are handed to the 8 XCDs round-robin by linear id, and each XCD has its own L2: with the
+// natural order the blocks that share operand data (the N-tiles of one pixel tile, the output tiles of one split-K slice) sit
+// on 8 different XCDs and every L2 fetches the same lines again (measured on wgrad: the LDS-DMA stream alone took as long
+// as the whole kernel).  Logical id = (id % 8) * (total / 8) + id / 8 gives each XCD a CONTIGUOUS range of logical ids, so
+// neighbours in the logical order — which share data — run on the same XCD at about the same time.  The (< 8) ids past
+// the last multiple of 8 keep their own id.  DDPM_NO_XCD_SWIZZLE=1 (host side) passes xcd = 0 and turns it off.
+__device__ __forceinline__ int xcd_logical_id(int id, int total, int xcd) {
+    if (!xcd) return id;
+    const int per = total >> 3;
+    return id < (per << 3) ? (id & 7) * per + (id >> 3) : id;
+}
+
 #ifndef DEEP_ISSUE_KC
 #define DEEP_ISSUE_KC 1
 #endif
 
 template <typename T, bool TA, bool TB, int NBUF, int NW>
 __global__ __launch_bounds__(NW * 64, NW / 2)
-void gemm_kernel(MatDesc A, MatDesc B, Epilogue ep, int M, int N, int K, int k_per_split, int tiles_n) {
+void gemm_kernel(MatDesc A, MatDesc B, Epilogue ep, int M, int N, int K, int k_per_split, int tiles_n, int xcd) {
     HALO_WALL(0); HALO_STAMP(1);
-    static_assert(NBUF == 2 || (!TA && !TB), "the deep ring needs direct-to-LDS loads on both operands");
+    static_assert(NBUF == 2 || (Loader<T, TA, NW>::DMA && Loader<T, TB, NW>::DMA), "the deep ring needs direct-to-LDS loads on both operands");
     constexpr int NT = NW * 64;
     constexpr int MI = 8 / NW;                              // 32-row accumulator blocks per wave along M
     constexpr int NVEC = 1024 / NT;
@@ -506,7 +518,9 @@ void gemm_kernel(MatDesc A, MatDesc B, Epilogue ep, int M, int N, int K, int k_p
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;               // wave row block (of 32*MI rows) and column block (of 64)
-    const int bx = blockIdx.x, by = blockIdx.y, nsplit = gridDim.y, ntiles = gridDim.x;
+    const int nsplit = gridDim.y, ntiles = gridDim.x;
+    const int lid = xcd_logical_id(blockIdx.x + blockIdx.y * gridDim.x, ntiles * nsplit, xcd);     // tile fastest, then split
+    const int by = lid / ntiles, bx = lid - by * ntiles;
     const int tm = bx / tiles_n, tn = bx - tm * tiles_n;
     const int batch = blockIdx.z;
     const int k_begin = by * k_per_split;
@@ -534,14 +548,14 @@ void gemm_kernel(MatDesc A, MatDesc B, Epilogue ep, int M, int N, int K, int k_p
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     } else {
-        if constexpr (!TA && !TB) {
+        if constexpr (DMA_A && DMA_B) {
             // deep ring: NBUF-1 tiles go out before anything is consumed; wait for tile 0 only (counted vmcnt: DMA
             // instructions retire in order, 8 per tile pair)
 #pragma unroll
             for (int t = 0; t < NBUF - 1; ++t)
                 if (t < nsteps) {
-                    la.issue(k_begin + t * BK, k_end, smem + t * 2 * TILE_BYTES);
-                    lb.issue(k_begin + t * BK, k_end, smem + t * 2 * TILE_BYTES + TILE_BYTES);
+                    stage_a(k_begin + t * BK, smem + t * 2 * TILE_BYTES);
+                    stage_b(k_begin + t * BK, smem + t * 2 * TILE_BYTES + TILE_BYTES);
                 }
             wait_tiles_in_flight<32 / NW>(min(NBUF - 2, nsteps - 1));
             __builtin_amdgcn_s_barrier();
@@ -558,8 +572,12 @@ void gemm_kernel(MatDesc A, MatDesc B, Epilogue ep, int M, int N, int K, int k_p
         if (NBUF == 2) {
             if (more) {       // the other buffer was last read in step s-1: every wave is past that barrier
                 const int kn = k_begin + (s + 1) * BK;
+#ifndef GABL_NOISSUE_A              // GABL_*: timing-only ablations (scripts/ablate_gemm.sh), never defined in product builds
                 if constexpr (DMA_A) stage_a(kn, nxt); else la.load(kn, k_end, va);
+#endif
+#ifndef GABL_NOISSUE_B
                 if constexpr (DMA_B) stage_b(kn, nxt + TILE_BYTES); else lb.load(kn, k_end, vb);
+#endif
             }
         }
         const char* ta = cur;
@@ -567,23 +585,37 @@ void gemm_kernel(MatDesc A, MatDesc B, Epilogue ep, int M, int N, int K, int k_p
 #pragma unroll
         for (int kc = 0; kc < BK / KF; ++kc) {
             u32x4 fa[MI], fb[2];
+#ifndef GABL_NOREAD
 #pragma unroll
             for (int i = 0; i < MI; ++i) fa[i] = read_frag<T, TA>(ta, wm * (32 * MI) + i * 32, kc, lane);
 #pragma unroll
             for (int j = 0; j < 2; ++j) fb[j] = read_frag<T, TB>(tb, wn * 64 + j * 32, kc, lane);
+#else
+#pragma unroll
+            for (int i = 0; i < MI; ++i) fa[i] = u32x4{(unsigned)s, (unsigned)kc, (unsigned)i, (unsigned)lane};
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fb[j] = u32x4{(unsigned)s, (unsigned)kc, (unsigned)j, (unsigned)lane};
+#endif
+#ifndef GABL_NOMFMA
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) Mma<T>::run(fa[i], fb[j], acc[i][j]);
-            if constexpr (NBUF != 2 && !TA && !TB) {
+#else
+#pragma unroll
+            for (int i = 0; i < MI; ++i) asm volatile("" :: "v"(fa[i]));
+#pragma unroll
+            for (int j = 0; j < 2; ++j) asm volatile("" :: "v"(fb[j]));
+#endif
+            if constexpr (NBUF != 2 && DMA_A && DMA_B) {
                 // deep ring: the tile NBUF-1 steps ahead is requested in the MIDDLE of the step (its slot — the one of step
                 // s-1 — has been free since the last barrier), so the address arithmetic and the LDS-DMA issue overlap
                 // the MFMAs already queued instead of delaying the first one
                 if (kc == (DEEP_ISSUE_KC < BK / KF ? DEEP_ISSUE_KC : 0) && s + NBUF - 1 < nsteps) {
                     const int far_i = cur_i == 0 ? NBUF - 1 : cur_i - 1;
                     const int kn = k_begin + (s + NBUF - 1) * BK;
-                    la.issue(kn, k_end, smem + far_i * 2 * TILE_BYTES);
-                    lb.issue(kn, k_end, smem + far_i * 2 * TILE_BYTES + TILE_BYTES);
+                    stage_a(kn, smem + far_i * 2 * TILE_BYTES);
+                    stage_b(kn, smem + far_i * 2 * TILE_BYTES + TILE_BYTES);
                 }
             }
         }
@@ -681,7 +713,7 @@ constexpr int G64 = 2;            // K-steps per barrier group
 // blocks per CU, one group in flight) for larger ones where the second resident block hides what the shallower ring exposes.
 template <typename T, int NG>
 __global__ __launch_bounds__(256, NG == 2 ? 2 : 1)
-void gemm64_kernel(MatDesc A, MatDesc B, Epilogue ep, int M, int N, int K, int tiles_n) {
+void gemm64_kernel(MatDesc A, MatDesc B, Epilogue ep, int M, int N, int K, int tiles_n, int xcd) {
     constexpr int BK = 8 * Elem<T>::VEC, KF = Mma<T>::KF, NT = 256;
     constexpr int OP_BYTES = T64 * ROW_BYTES;             // one operand tile (8 KiB); stage = [A | B]
     constexpr int GROUP_BYTES = G64 * 2 * OP_BYTES;
@@ -689,7 +721,8 @@ void gemm64_kernel(MatDesc A, MatDesc B, Epilogue ep, int M, int N, int K, int t
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    const int tm = blockIdx.x / tiles_n, tn = blockIdx.x - tm * tiles_n;
+    const int lid = xcd_logical_id(blockIdx.x, gridDim.x, xcd);
+    const int tm = lid / tiles_n, tn = lid - tm * tiles_n;
     const int batch = blockIdx.z;
     Loader<T, false, 4, T64> la(A, batch, tm * T64, tid);
     Loader<T, false, 4, T64> lb(B, batch, tn * T64, tid);
@@ -758,10 +791,10 @@ void gemm64_kernel(MatDesc A, MatDesc B, Epilogue ep, int M, int N, int K, int t
     if (ep.mode == 0) epilogue_rows<T, T, NT, T64, T64>(ep, cs, batch, rowmap, tn * T64, N, tid, bias_t);
     else epilogue_rows<T, float, NT, T64, T64>(ep, cs, batch, rowmap, tn * T64, N, tid, bias_f);
 }
-template __global__ void gemm64_kernel<bf16_t, 2>(MatDesc, MatDesc, Epilogue, int, int, int, int);
-template __global__ void gemm64_kernel<bf16_t, 3>(MatDesc, MatDesc, Epilogue, int, int, int, int);
-template __global__ void gemm64_kernel<float, 2>(MatDesc, MatDesc, Epilogue, int, int, int, int);
-template __global__ void gemm64_kernel<float, 3>(MatDesc, MatDesc, Epilogue, int, int, int, int);
+template __global__ void gemm64_kernel<bf16_t, 2>(MatDesc, MatDesc, Epilogue, int, int, int, int, int);
+template __global__ void gemm64_kernel<bf16_t, 3>(MatDesc, MatDesc, Epilogue, int, int, int, int, int);
+template __global__ void gemm64_kernel<float, 2>(MatDesc, MatDesc, Epilogue, int, int, int, int, int);
+template __global__ void gemm64_kernel<float, 3>(MatDesc, MatDesc, Epilogue, int, int, int, int, int);
 
 // =====================================================================================================================
 // 3x3 / stride 1 / pad 1 convolution with a STATIONARY INPUT HALO (bf16): the hot conv of the UNet (forward and dgrad).
@@ -789,7 +822,7 @@ constexpr int C3_NI = 7;              // halo DMA parts of 512 vectors: up to 44
 // reserved per halo buffer.  LDS = 2*HROWS*128 + RING*16 KiB = 160 KiB in both instantiated configurations.
 template <int RING, int HROWS>
 __global__ __launch_bounds__(512, 2)
-void conv3x3_halo_kernel(Conv3Args a, int tiles_n) {
+void conv3x3_halo_kernel(Conv3Args a, int tiles_n, int xcd) {
     HALO_WALL(0); HALO_STAMP(1);
     typedef bf16_t T;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -800,7 +833,8 @@ void conv3x3_halo_kernel(Conv3Args a, int tiles_n) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    const int tmi = blockIdx.x / tiles_n, tn = blockIdx.x - tmi * tiles_n;
+    const int lid = xcd_logical_id(blockIdx.x, gridDim.x, xcd);
+    const int tmi = lid / tiles_n, tn = lid - tmi * tiles_n;
     const int tpi = a.tiles_y * a.tiles_x;
     const int grp = tmi / tpi, pt = tmi - grp * tpi;
     const int ty = pt / a.tiles_x, tx = pt - ty * a.tiles_x;
@@ -962,7 +996,7 @@ extern "C" int ddpm_debug_set_halo_timing(void* p) {
 #endif
 
 // Explicit instantiations: every (dtype, operand layout, ring depth, wave count) the launcher can pick.
-#define INST(T, TA, TB, NB, NWV) template __global__ void gemm_kernel<T, TA, TB, NB, NWV>(MatDesc, MatDesc, Epilogue, int, int, int, int, int);
+#define INST(T, TA, TB, NB, NWV) template __global__ void gemm_kernel<T, TA, TB, NB, NWV>(MatDesc, MatDesc, Epilogue, int, int, int, int, int, int);
 INST(bf16_t, false, false, 2, 4) INST(bf16_t, false, false, 2, 8) INST(bf16_t, false, false, 5, 4) INST(bf16_t, false, false, 5, 8)
 INST(bf16_t, false, true, 2, 4) INST(bf16_t, false, true, 2, 8)
 INST(bf16_t, true, false, 2, 4) INST(bf16_t, true, false, 2, 8)
@@ -1124,6 +1158,7 @@ template __global__ void attn_fwd_kernel<8>(MatDesc, MatDesc, MatDesc, bf16_t*, 
 // which kernel the most recent conv / GEMM call of this thread dispatched to (bench.py attributes its per-launch timings
 // with it): 1 gemm_kernel 4-wave, 2 gemm_kernel 8-wave, 3 gemm_kernel deep ring, 4 gemm64_kernel, 5 conv3x3_halo_kernel
 static thread_local int g_last_variant = 0;
+static const int g_xcd_swizzle = getenv("DDPM_NO_XCD_SWIZZLE") ? 0 : 1;
 
 struct GemmArgs {          // plain-C mirror filled by the extern "C" entry points
     MatDesc A, B;
@@ -1162,7 +1197,7 @@ static int conv3x3_halo_launch(GemmArgs& g, const void* x, long long x_ld, const
                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return DDPM_ERR_LAUNCH; \
             attr_set = true;                                                                                             \
         }                                                                                                                \
-        hipLaunchKernelGGL((conv3x3_halo_kernel<RING, HROWS>), grid, dim3(512), LDS, st, a, tiles_n);                    \
+        hipLaunchKernelGGL((conv3x3_halo_kernel<RING, HROWS>), grid, dim3(512), LDS, st, a, tiles_n, g_xcd_swizzle);                    \
     } while (0)
     g_last_variant = 5;
     if (HP <= 384) C3_LAUNCH(4, 384);      // one 16x16 patch: 2 x 48 KiB halo + 4 x 16 KiB weight ring
@@ -1215,7 +1250,7 @@ static int launch_t(GemmArgs& g, hipStream_t st) {
                 return DDPM_ERR_LAUNCH;                                                                                  \
             attr_set = true;                                                                                             \
         }                                                                                                                \
-        hipLaunchKernelGGL((gemm64_kernel<T, NG>), grid64, dim3(256), LDS64, st, g.A, g.B, g.ep, g.M, g.N, g.K, t64n);   \
+        hipLaunchKernelGGL((gemm64_kernel<T, NG>), grid64, dim3(256), LDS64, st, g.A, g.B, g.ep, g.M, g.N, g.K, t64n, g_xcd_swizzle);   \
     } while (0)
         if ((long long)grid64.x * grid64.z <= 256) LAUNCH64(3); else LAUNCH64(2);
 #undef LAUNCH64
@@ -1227,6 +1262,7 @@ static int launch_t(GemmArgs& g, hipStream_t st) {
     const int kps = steps_per * BK;
     // deep ring when the grid cannot keep two blocks on each of the 256 CUs anyway
     const bool deep = !g.A.trans && !g.B.trans && (long long)grid.x * grid.y * grid.z <= 256 && steps_per >= 3;
+
 #define LAUNCH(TA, TB, NB, NWV, LDS)                                                                                     \
     do {                                                                                                                 \
         static bool attr_set = false;   /* > 64 KiB of dynamic LDS needs the opt-in once per instantiation */            \
@@ -1236,7 +1272,7 @@ static int launch_t(GemmArgs& g, hipStream_t st) {
                 return DDPM_ERR_LAUNCH;                                                                                  \
             attr_set = true;                                                                                             \
         }                                                                                                                \
-        hipLaunchKernelGGL((gemm_kernel<T, TA, TB, NB, NWV>), grid, dim3(NWV * 64), (LDS), st, g.A, g.B, g.ep, g.M, g.N, g.K, kps, tiles_n); \
+        hipLaunchKernelGGL((gemm_kernel<T, TA, TB, NB, NWV>), grid, dim3(NWV * 64), (LDS), st, g.A, g.B, g.ep, g.M, g.N, g.K, kps, tiles_n, g_xcd_swizzle); \
         g_last_variant = NB != 2 ? 3 : (NWV == 8 ? 2 : 1);                                                               \
     } while (0)
     // 8-wave blocks whenever both operands take the DMA path (all bf16 products, fp32 with k-contiguous operands)
