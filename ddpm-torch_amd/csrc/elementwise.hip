@@ -146,6 +146,37 @@ extern "C" int ddpm_wgrad_unpack(const float* gpack, float* gflat, const long lo
     return check_launch();
 }
 
+// sum of the split-K slab copies of the packed weight gradients, many tensors in one launch (fixed order: deterministic).
+// table[i] = {src (device address of copy 0), dst (device address), length (floats), copies, stride between copies (floats)}
+__global__ void wgrad_reduce_kernel(const long long* __restrict__ table) {
+    const long long* d = table + 5 * (long long)blockIdx.y;
+    const float* src = reinterpret_cast<const float*>(d[0]);
+    float* dst = reinterpret_cast<float*>(d[1]);
+    const long long len = d[2], stride = d[4];
+    const int copies = (int)d[3];
+    const long long nv = len >> 2;
+    for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < nv; v += (long long)gridDim.x * blockDim.x) {
+        float4 a = reinterpret_cast<const float4*>(src)[v];
+        for (int c = 1; c < copies; ++c) {
+            const float4 b = reinterpret_cast<const float4*>(src + (long long)c * stride)[v];
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+        reinterpret_cast<float4*>(dst)[v] = a;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (len & 3)) {
+        const long long i = (nv << 2) + threadIdx.x;
+        float a = src[i];
+        for (int c = 1; c < copies; ++c) a += src[(long long)c * stride + i];
+        dst[i] = a;
+    }
+}
+extern "C" int ddpm_wgrad_reduce(const long long* table, int n_tensors, void* stream) {
+    if (!table) return DDPM_ERR_NULL;
+    if (n_tensors <= 0) return DDPM_OK;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(128, n_tensors), dim3(256), 0, (hipStream_t)stream, table);
+    return check_launch();
+}
+
 // ------------------------------------------------------------------ diffusion algebra (fp32, per-sample coefficients gathered by t)
 // q_sample: x_t = a[t]*x0 + b[t]*noise   (diffusion.py:92-97); separate roundings like the reference's op chain
 __global__ void q_sample_kernel(const float* __restrict__ x0, const float* __restrict__ noise, const long long* __restrict__ t,

@@ -51,7 +51,8 @@ struct Epilogue {
     const void* residual;     // T, [M][res_ld] or null
     long long res_ld, res_batch_stride;
     int accumulate;           // modes 0/1: out += result
-    int Cpad, Creal, RS;      // mode 4: col = tap*Cpad + c -> packed gradient dst[(row*RS + tap)*Creal + c]
+    int Cpad, Creal, RS;      // modes 4 / 5: col = tap*Cpad + c -> packed gradient dst[(row*RS + tap)*Creal + c]
+    long long slab_stride;    // mode 5: split s STORES its partial into copy s (out + s*slab_stride floats); the caller sums
     FastDiv dCpad;
     FastDiv dHW;              // mode 3: row -> (b, pixel)
     int HW;
@@ -409,9 +410,14 @@ __device__ __forceinline__ void epilogue_rows(const Epilogue& ep, const float* c
     }
 }
 
-// element-wise tail for the scatter / atomic output modes (2: fp32 atomic add, 3: NCHW fp32, 4: packed wgrad)
+// element-wise tail for the scatter / atomic output modes (2: fp32 atomic add, 3: NCHW fp32, 4: packed wgrad with atomics,
+// 5: packed wgrad, plain stores into the slab copy of this split; a fixed-order sum of the copies (ddpm_wgrad_reduce) then
+// gives bit-deterministic gradients.  fp32 atomics run at ~0.33 T elem/s on this chip and plain stores at > 2 T elem/s
+// (scripts/probes/atomic_rate.hip), but the atomics stay in L2 while the slabs cost ~33 MB of HBM traffic per layer:
+// end to end the two are equally fast)
 template <int NT>
-__device__ __forceinline__ void epilogue_scatter(const Epilogue& ep, const float* cs, int batch, int row0g, int col0g, int M, int N, int tid) {
+__device__ __forceinline__ void epilogue_scatter(const Epilogue& ep, const float* cs, int batch, int row0g, int col0g, int M, int N, int tid,
+                                                 int split) {
     // lanes run along n (coalesced atomics for modes 2 / 4); NCHW (mode 3) has N <= a few channels
     for (int idx = tid; idx < TILE * TILE; idx += NT) {
         const int rl = idx >> 7, cl = idx & (TILE - 1);
@@ -431,7 +437,9 @@ __device__ __forceinline__ void epilogue_scatter(const Epilogue& ep, const float
             const int c = col - (int)tap * ep.Cpad;
             if (c < ep.Creal) {
                 float* o = reinterpret_cast<float*>(ep.out) + ((long long)row * ep.RS + tap) * ep.Creal + c;
-                if (ep.accumulate) atomicAdd(o, v); else *o = v;
+                if (ep.mode == 5) o[(long long)split * ep.slab_stride] = v;
+                else if (ep.accumulate) atomicAdd(o, v);
+                else *o = v;
             }
         }
     }
@@ -695,7 +703,7 @@ void gemm_kernel(MatDesc A, MatDesc B, Epilogue ep, int M, int N, int K, int k_p
     auto rowmap = [&](int rl) { const int row = tm * TILE + rl; return row < M ? row : -1; };
     if (ep.mode == 0) epilogue_rows<T, T, NT, TILE, TILE>(ep, cs, batch, rowmap, tn * TILE, N, tid, bias_t);
     else if (ep.mode == 1) epilogue_rows<T, float, NT, TILE, TILE>(ep, cs, batch, rowmap, tn * TILE, N, tid, bias_f);
-    else epilogue_scatter<NT>(ep, cs, batch, tm * TILE, tn * TILE, M, N, tid);
+    else epilogue_scatter<NT>(ep, cs, batch, tm * TILE, tn * TILE, M, N, tid, by);
     HALO_STAMP(4); HALO_WALL(5);
 }
 
@@ -1232,8 +1240,9 @@ static int launch_t(GemmArgs& g, hipStream_t st) {
     int ksteps = (g.K + BK - 1) / BK;
     int steps_per = (ksteps + splits - 1) / splits;
     splits = (ksteps + steps_per - 1) / steps_per;
-    if (splits > 1 && g.ep.mode != 2 && g.ep.mode != 4 && !(g.ep.splitk_ws && g.ep.splitk_cnt)) return DDPM_ERR_SHAPE;
-    if (g.ep.mode == 2 || g.ep.mode == 4) { g.ep.splitk_ws = nullptr; g.ep.splitk_cnt = nullptr; }
+    if (splits > 1 && g.ep.mode != 2 && g.ep.mode != 4 && g.ep.mode != 5 && !(g.ep.splitk_ws && g.ep.splitk_cnt)) return DDPM_ERR_SHAPE;
+    if (g.ep.mode == 5 && splits != g.splits) return DDPM_ERR_SHAPE;      // every slab copy the caller will sum must be written
+    if (g.ep.mode == 2 || g.ep.mode == 4 || g.ep.mode == 5) { g.ep.splitk_ws = nullptr; g.ep.splitk_cnt = nullptr; }
     dim3 grid(tiles_m * tiles_n, splits, g.batch);
     // small grids of k-contiguous products: 64x64 tiles put 4x as many CUs to work (see gemm64_kernel)
     static const bool no_t64 = getenv("DDPM_GEMM_NO_T64") != nullptr;
@@ -1379,7 +1388,15 @@ extern "C" int ddpm_conv2d_nhwc(const void* x, long long x_ld, const void* w, vo
 // Weight gradient in PACKED layout: dw[n][r][s][c] += sum_{b,oy,ox} dy[b,oy,ox,n] * x[b, f(..), f(..), c]
 // (fp32 atomics, n < Nreal, c < Creal; rows of Creal contiguous floats -> coalesced).  ddpm_wgrad_unpack converts
 // every layer's packed gradient to the parameter layout [n][c][r][s] in one launch.
-extern "C" int ddpm_conv2d_wgrad_nhwc(const void* dy, long long dy_ld, const void* x, long long x_ld, float* dw,
+// number of split-K slices the kernels really use for a reduction of K with `splits` requested (whole K-steps per slice)
+extern "C" int ddpm_wgrad_effective_splits(int K, int splits, int dtype) {
+    const int BK = dtype == DDPM_BF16 ? 64 : 32;
+    if (K <= 0 || splits < 1) return 1;
+    const int ksteps = (K + BK - 1) / BK, steps_per = (ksteps + splits - 1) / splits;
+    return (ksteps + steps_per - 1) / steps_per;
+}
+
+extern "C" int ddpm_conv2d_wgrad_nhwc(const void* dy, long long dy_ld, const void* x, long long x_ld, float* dw, long long slab_stride,
                                       int B, int H, int W, int C, int Creal, int Ho, int Wo, int N, int Nreal, int R, int S,
                                       int stride, int pad_t, int pad_l, int upsample, int splits, int dtype, void* stream) {
     if (!dy || !x || !dw) return DDPM_ERR_NULL;
@@ -1393,7 +1410,11 @@ extern "C" int ddpm_conv2d_wgrad_nhwc(const void* dy, long long dy_ld, const voi
     conv_desc(g.B, x, x_ld, g.K, H, W, C, Ho, Wo, R, S, stride, pad_t, pad_l, upsample, 0);
     g.B.trans = 1;
     g.ep.out = dw; g.ep.mode = 4; g.ep.Cpad = C; g.ep.Creal = Creal; g.ep.RS = R * S; g.ep.dCpad = make_fastdiv((unsigned)C);
-    g.ep.accumulate = 1;      // always "+=" (atomics): the caller zero-fills once and may add several contributions
+    g.ep.accumulate = 1;      // slab_stride == 0: "+=" with atomics — the caller zero-fills once and may add several contributions
+    if (slab_stride > 0) {    // slab mode: split s stores its partial at dw + s*slab_stride; ddpm_wgrad_reduce sums the copies
+        if (slab_stride < (long long)Nreal * R * S * Creal || splits != ddpm_wgrad_effective_splits(g.K, splits, dtype)) return DDPM_ERR_SHAPE;
+        g.ep.mode = 5; g.ep.slab_stride = slab_stride;
+    } else if (slab_stride < 0) return DDPM_ERR_SHAPE;
     return ddpm_gemm_launch(g, (hipStream_t)stream);
 }
 

@@ -109,10 +109,15 @@ class SplitK:
         return splits, self.ws.data_ptr(), self.cnt.data_ptr()
 
 
-def conv2d_wgrad(dy, x, dw_ptr, Creal, Nreal, R, S, stride=1, pad_t=0, pad_l=0, upsample=0, splits=1):
+def conv2d_wgrad(dy, x, dw_ptr, Creal, Nreal, R, S, stride=1, pad_t=0, pad_l=0, upsample=0, splits=1, slab_stride=0):
+    """slab_stride = 0: atomics into dw_ptr; > 0: split s stores its partial at dw_ptr + 4*s*slab_stride (see ddpm_wgrad_reduce)."""
     _timed("gemm_tt", 2.0 * dy.rows * Nreal * R * S * x.C, lambda: _hip.call(
-        "ddpm_conv2d_wgrad_nhwc", dy.ptr, dy.ld, x.ptr, x.ld, dw_ptr, x.B, x.H, x.W, x.C, Creal, dy.H, dy.W, dy.C, Nreal, R, S,
+        "ddpm_conv2d_wgrad_nhwc", dy.ptr, dy.ld, x.ptr, x.ld, dw_ptr, slab_stride, x.B, x.H, x.W, x.C, Creal, dy.H, dy.W, dy.C, Nreal, R, S,
         stride, pad_t, pad_l, upsample, splits, x.dtype, _hip.stream()), f"wgrad M={Nreal} N={R * S * x.C} K={dy.rows} splits={splits}")
+
+
+def wgrad_effective_splits(K, splits, dtype):
+    return int(_hip.lib().ddpm_wgrad_effective_splits(K, splits, dtype))
 
 
 def gemm(a_ptr, a_ld, a_bs, a_trans, b_ptr, b_ld, b_bs, b_trans, c_ptr, c_ld, c_bs, M, N, K, dtype, batch=1, alpha=1.0,

@@ -236,6 +236,7 @@ class _ConvW:
 
 _WGRAD_TARGET_BLOCKS = int(os.environ.get("DDPM_WGRAD_BLOCKS", "512"))
 _FUSED_ATTENTION = os.environ.get("DDPM_FUSED_ATTENTION", "1") != "0"
+_WGRAD_SLABS = os.environ.get("DDPM_WGRAD_SLABS", "0") != "0"      # deterministic slab reduction instead of atomics
 
 
 class _Engine:
@@ -255,6 +256,7 @@ class _Engine:
             off += (p.numel() + 3) // 4 * 4        # keep every slice 16-byte aligned
         self.gtotal = off
         self.wdesc = None                          # device table for ddpm_wgrad_unpack (built on first backward)
+        self._gpack, self._slabs, self._slab_tables, self._eff_splits = None, {}, {}, {}
         m = model
         self.hid, self.E, self.L, self.n = m.hid_channels, m.time_embedding_dim, m.levels, m.num_res_blocks
         self.chs = [m.hid_channels * k for k in m.ch_multipliers]
@@ -430,15 +432,45 @@ class _Engine:
             self.tail = (conv_end, self.ptotal)
         return self.wdesc
 
-    def _wgrad(self, ctx, weight, dy, x, *args, **kw):
-        """Weight gradient into the staging buffer; then hand finished all-reduce chunks to the communicator."""
-        ops.conv2d_wgrad(dy, x, self._pptr(ctx, weight), *args, **kw)
+    def _wgrad(self, ctx, weight, dy, x, Creal, Nreal, R, S, splits=1, **kw):
+        """Weight gradient into the staging buffer; then hand finished all-reduce chunks to the communicator.
+
+        Default: the split-K slices add into the staging buffer with fp32 atomics (the 2-3 MB of hot lines stay in L2).
+        DDPM_WGRAD_SLABS=1: every slice STORES its partial into its own slab copy (persistent per-weight workspace) and one
+        multi-tensor launch sums the copies in a fixed order — bit-deterministic gradients at the same speed (measured
+        16.06 vs 16.10 ms per step: the ~33 MB of slab traffic per layer costs what the slow atomics cost)."""
+        key = (dy.rows, splits, x.dtype)
+        eff = self._eff_splits.get(key)
+        if eff is None:
+            eff = self._eff_splits[key] = ops.wgrad_effective_splits(dy.rows, splits, x.dtype)
+        if _WGRAD_SLABS and eff > 1:
+            n = Nreal * R * S * Creal
+            stride = (n + 3) // 4 * 4
+            slab = self._slabs.get(id(weight))
+            if slab is None or slab.numel() < eff * stride:
+                slab = self._slabs[id(weight)] = torch.empty(eff * stride, dtype=torch.float32, device=self.device)
+            ops.conv2d_wgrad(dy, x, slab.data_ptr(), Creal, Nreal, R, S, splits=eff, slab_stride=stride, **kw)
+            ctx["slab_rows"].append((slab.data_ptr(), self._pptr(ctx, weight), n, eff, stride))
+        else:
+            ops.conv2d_wgrad(dy, x, self._pptr(ctx, weight), Creal, Nreal, R, S, splits=eff, **kw)
         if ctx.get("pending") is not None:
             for ch in ctx["pending"]:
                 ch[2].discard(id(weight))
             while ctx["pending"] and not ctx["pending"][-1][2]:
                 a, b, _ = ctx["pending"].pop()
+                self._flush_slabs(ctx)                       # the chunk's conv gradients must be summed before they travel
                 ctx["works"].append(self._all_reduce(ctx["gpack"][a:b]))
+
+    def _flush_slabs(self, ctx):
+        """Sum the slab copies recorded since the last flush into the staging buffer (one launch)."""
+        rows = tuple(ctx["slab_rows"])
+        if not rows:
+            return
+        ctx["slab_rows"] = []
+        table = self._slab_tables.get(rows)
+        if table is None:                                    # addresses are stable (persistent buffers): built once per geometry
+            table = self._slab_tables[rows] = torch.tensor(rows, dtype=torch.int64, device=self.device)
+        _hip.call("ddpm_wgrad_reduce", table.data_ptr(), len(rows), _hip.stream())
 
     def _all_reduce(self, t):
         import torch.distributed as dist
@@ -671,8 +703,10 @@ class _Engine:
         H, W = gout.shape[2], gout.shape[3]
         dtb = torch.zeros((B, self.tb_total), dtype=torch.float32, device=self.device)
         wdesc = self._wgrad_table()
-        gpack = torch.zeros(self.ptotal, dtype=torch.float32, device=self.device)    # conv weight grads, packed [N][RS][C]
-        ctx = dict(gflat=gflat, gpack=gpack, ws=ws, B=B, dtb=dtb, pending=None, works=[])
+        if self._gpack is None or self._gpack.numel() != self.ptotal:
+            self._gpack = torch.empty(self.ptotal, dtype=torch.float32, device=self.device)
+        gpack = self._gpack.zero_()           # persistent (stable addresses for the slab-reduce tables): packed conv weight grads [N][RS][C] + tail
+        ctx = dict(gflat=gflat, gpack=gpack, ws=ws, B=B, dtb=dtb, pending=None, works=[], slab_rows=[])
         world = 1
         if self.pg is not None:
             import torch.distributed as dist
@@ -701,6 +735,7 @@ class _Engine:
             else:
                 self._conv_bwd(ctx, rec)
         self._temb_bwd(ctx, st)
+        self._flush_slabs(ctx)
         if self.pg is not None:
             assert not ctx["pending"], "a conv weight gradient was never produced"
             ctx["works"].append(self._all_reduce(gpack[self.tail[0]:self.tail[1]]))

@@ -39,14 +39,24 @@ int ddpm_conv2d_nhwc(const void* x, long long x_ld, const void* w, void* y, long
                      int dtype, void* stream);
 
 /* convolution_backward w.r.t. the weight (autograd of the sites above), into a PACKED gradient [Nreal][R][S][Creal]:
- *   dw[n][r][s][c] += sum_{b,oy,ox} dy[b,oy,ox,n] * x[b, f(..), f(..), c]      n < Nreal, c < Creal (fp32 atomics)
- * dy has N (>= Nreal) channels, x has C (>= Creal) channels (zero padding beyond the real counts).
+ *   dw[n][r][s][c] += sum_{b,oy,ox} dy[b,oy,ox,n] * x[b, f(..), f(..), c]      n < Nreal, c < Creal
+ * dy has N (>= Nreal) channels, x has C (>= Creal) channels (zero padding beyond the real counts).  The reduction over
+ * B*Ho*Wo is cut into `splits` slices that run as separate workgroups:
+ *   slab_stride == 0: every slice adds into dw with fp32 atomics (dw must be zero-filled / hold earlier contributions);
+ *   slab_stride  > 0: slice s STORES its partial at dw + s*slab_stride (floats) — `splits` must then equal
+ *                     ddpm_wgrad_effective_splits(B*Ho*Wo, splits, dtype) so that every copy is written — and
+ *                     ddpm_wgrad_reduce sums the copies in a fixed order (bit-deterministic gradients).
+ *                     table[i] = {src address of copy 0, dst address, floats, copies, stride}.
  * ddpm_wgrad_unpack rewrites all layers' packed gradients into the parameter layout [n][c][r][s] in one launch:
  * descs[i] = {src offset in gpack, dst offset in gflat (floats), N, C, R*S} as int64 (R*S = 1: plain segment copy);
  * every value is multiplied by `scale` (1/world_size after the data-parallel sum all-reduce of gpack). */
-int ddpm_conv2d_wgrad_nhwc(const void* dy, long long dy_ld, const void* x, long long x_ld, float* dw,
+int ddpm_conv2d_wgrad_nhwc(const void* dy, long long dy_ld, const void* x, long long x_ld, float* dw, long long slab_stride,
                            int B, int H, int W, int C, int Creal, int Ho, int Wo, int N, int Nreal, int R, int S,
                            int stride, int pad_t, int pad_l, int upsample, int splits, int dtype, void* stream);
+
+int ddpm_wgrad_effective_splits(int K, int splits, int dtype);
+
+int ddpm_wgrad_reduce(const long long* table, int n_tensors, void* stream);
 
 int ddpm_wgrad_unpack(const float* gpack, float* gflat, const long long* descs, int n_tensors, float scale, void* stream);
 

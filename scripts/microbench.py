@@ -42,7 +42,17 @@ def conv_case(B, H, C, N, R, dtype, kind="fwd"):
         tiles = -(-N // 128) * -(-(R * R * C) // 128)
         ksteps = B * H * H // (64 if dtype == torch.bfloat16 else 32)
         splits = max(1, min(512 // tiles, ksteps // (20 if ksteps >= 100 else 8)))      # the engine's rule (_Engine._splits)
-        fn = lambda: ops.conv2d_wgrad(y, x, dw.data_ptr(), C, N, R, R, pad_t=R // 2, pad_l=R // 2, splits=splits)
+        eff = ops.wgrad_effective_splits(B * H * H, splits, x.dtype)
+        if os.environ.get("WGRAD_ATOMICS") or eff == 1:
+            fn = lambda: ops.conv2d_wgrad(y, x, dw.data_ptr(), C, N, R, R, pad_t=R // 2, pad_l=R // 2, splits=eff)
+        else:                                                     # product path: slab copies + one fixed-order reduction
+            n = N * R * R * C
+            slabs = torch.empty(eff * n, device=DEV)
+            table = torch.tensor([[slabs.data_ptr(), dw.data_ptr(), n, eff, n]], dtype=torch.int64, device=DEV)
+
+            def fn():
+                ops.conv2d_wgrad(y, x, slabs.data_ptr(), C, N, R, R, pad_t=R // 2, pad_l=R // 2, splits=eff, slab_stride=n)
+                _hip.call("ddpm_wgrad_reduce", table.data_ptr(), 1, _hip.stream())
     t = timeit(fn)
     return t, flops / t / 1e12
 

@@ -138,14 +138,25 @@ class Emulator:
             return
         dst.set(dst.get() + out if acc else out)
 
-    def ddpm_conv2d_wgrad_nhwc(self, dy, dy_ld, x, x_ld, dw, B, H, W, C, Creal, Ho, Wo, N, Nreal, R, S, stride, pad_t, pad_l, ups,
+    def ddpm_conv2d_wgrad_nhwc(self, dy, dy_ld, x, x_ld, dw, slab_stride, B, H, W, C, Creal, Ho, Wo, N, Nreal, R, S, stride, pad_t, pad_l, ups,
                                splits, dt, st):
         xin = torch.from_numpy(Mat(x, B * H * W, C, x_ld, dt).get()).reshape(B, H, W, C).permute(0, 3, 1, 2)
         g = torch.from_numpy(Mat(dy, B * Ho * Wo, N, dy_ld, dt).get()).reshape(B, Ho, Wo, N).permute(0, 3, 1, 2)[:, :Nreal]
         can = _canvas(xin, Ho, Wo, R, S, stride, pad_t, pad_l, ups, 0)
         gw = torch.nn.grad.conv2d_weight(can.contiguous(), (Nreal, C, R, S), g.contiguous(), stride=stride)
-        arr = f32(dw, Nreal * Creal * R * S).reshape(Nreal, R, S, Creal)          # packed layout [n][r][s][c]
-        arr += gw[:, :Creal].permute(0, 2, 3, 1).numpy()
+        val = gw[:, :Creal].permute(0, 2, 3, 1).numpy()                            # packed layout [n][r][s][c]
+        if slab_stride == 0:
+            f32(dw, Nreal * Creal * R * S).reshape(Nreal, R, S, Creal)[...] += val
+        else:                                                                       # any partition over the copies is a valid result
+            for c in range(splits):
+                f32(dw + 4 * c * slab_stride, Nreal * Creal * R * S).reshape(Nreal, R, S, Creal)[...] = val if c == 0 else 0.0
+
+    def ddpm_wgrad_reduce(self, table, n, st):
+        for src, dst, length, copies, stride in i64(table, 5 * n).reshape(n, 5):
+            acc = np.zeros(int(length), dtype=np.float32)
+            for c in range(int(copies)):
+                acc += f32(int(src) + 4 * c * int(stride), int(length))
+            f32(int(dst), int(length))[...] = acc
 
     def ddpm_wgrad_unpack(self, gpack, gflat, descs, n, scale, st):
         d = i64(descs, 5 * n).reshape(n, 5)

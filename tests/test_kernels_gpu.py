@@ -162,8 +162,29 @@ def test_conv_wgrad(case, dt):
     xld, yld = C + 8, N + 8
     x, dy = r(B * H * W, xld, seed=1, dt=dt), r(B * Ho * Wo, yld, seed=2, dt=dt)
     dw = r(Nreal, Creal, R, R, seed=3)                          # accumulates on top of existing content
-    both("ddpm_conv2d_wgrad_nhwc", A(dy), yld, A(x), xld, A(dw, out=True, name="dw"), B, H, W, C, Creal, Ho, Wo, N, Nreal, R, R,
+    both("ddpm_conv2d_wgrad_nhwc", A(dy), yld, A(x), xld, A(dw, out=True, name="dw"), 0, B, H, W, C, Creal, Ho, Wo, N, Nreal, R, R,
          stride, pt, pl, ups, splits, dt, tol=1e-4 if dt == 0 else 3e-3)
+    # slab mode: every split stores its partial into its own copy; the fixed-order reduction must give the same gradient
+    K = B * Ho * Wo
+    for req in (1, 3):
+        eff = int(_hip.lib().ddpm_wgrad_effective_splits(K, req, dt))
+        n = Nreal * Creal * R * R
+        stride_f = (n + 3) // 4 * 4 + 8
+        slabs = torch.full((eff * stride_f,), 7.0).cuda()             # stale content must not leak into the result
+        xd, dyd = x.cuda(), dy.cuda()
+        _hip.call("ddpm_conv2d_wgrad_nhwc", dyd.data_ptr(), yld, xd.data_ptr(), xld, slabs.data_ptr(), stride_f, B, H, W, C, Creal, Ho, Wo,
+                  N, Nreal, R, R, stride, pt, pl, ups, eff, dt, _hip.stream())
+        out = torch.zeros(n).cuda()
+        table = torch.tensor([[slabs.data_ptr(), out.data_ptr(), n, eff, stride_f]], dtype=torch.int64).cuda()
+        _hip.call("ddpm_wgrad_reduce", table.data_ptr(), 1, _hip.stream())
+        ref = torch.zeros(n)
+        Emulator().call("ddpm_conv2d_wgrad_nhwc", dy.data_ptr(), yld, x.data_ptr(), xld, ref.data_ptr(), 0, B, H, W, C, Creal, Ho, Wo,
+                        N, Nreal, R, R, stride, pt, pl, ups, 1, dt, 0)
+        err = float((out.cpu() - ref).abs().max())
+        assert err <= (1e-4 if dt == 0 else 3e-3) * float(ref.abs().max()), (req, eff, err)
+    if dt == 1:
+        assert _hip.lib().ddpm_conv2d_wgrad_nhwc(dyd.data_ptr(), yld, xd.data_ptr(), xld, slabs.data_ptr(), 4, B, H, W, C, Creal, Ho, Wo,
+                                                 N, Nreal, R, R, stride, pt, pl, ups, eff, dt, _hip.stream()) == 1      # stride too small
 
 
 @pytest.mark.parametrize("dt", [0, 1])
