@@ -85,6 +85,25 @@ def test_backward_fp32_matches_oracle(emu, cfg):
         check(prm.grad, p[k].grad, 2e-4, atol=2e-5, name="grad." + k)
 
 
+def test_backward_slab_split_k_path_gives_the_same_gradients(emu, monkeypatch):
+    """DDPM_WGRAD_SLABS=1: split-K slices store into slab copies, ddpm_wgrad_reduce sums them — same gradients as the atomics."""
+    import ddpm_torch.models.unet as unet_mod
+    x, t, gy = rnd(2, 3, 16, 16, seed=3), torch.tensor([7, 912]), rnd(2, 3, 16, 16, seed=4)
+    grads = []
+    for slabs in (False, True):
+        monkeypatch.setattr(unet_mod, "_WGRAD_SLABS", slabs)
+        m, _ = make(TINY)
+        m.train()
+        eng = m.engine()
+        monkeypatch.setattr(eng, "_splits", lambda M, N, K: 3)            # force several slices on the tiny net
+        emu.log.clear()
+        (m(x, t) * gy).sum().backward()
+        assert ("ddpm_wgrad_reduce" in emu.log) == slabs
+        grads.append({k: p.grad.clone() for k, p in m.named_parameters()})
+    for k in grads[0]:
+        check(grads[1][k], grads[0][k], 1e-6, atol=1e-7, name="slab grad." + k)
+
+
 def test_state_dict_roundtrip_and_cache_refresh(emu):
     m, sd = make(TINY)
     m.eval()
