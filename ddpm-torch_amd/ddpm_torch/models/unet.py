@@ -18,6 +18,7 @@ through the C-ABI in ``csrc/`` (see ``include/ddpm_hip.h``):
 
 There is no CPU path: CPU tensors raise (the CPU restatement used for checking lives in ``oracle/``).
 """
+import contextlib
 import math
 import os
 
@@ -236,6 +237,7 @@ class _ConvW:
 
 _WGRAD_TARGET_BLOCKS = int(os.environ.get("DDPM_WGRAD_BLOCKS", "512"))
 _FUSED_ATTENTION = os.environ.get("DDPM_FUSED_ATTENTION", "1") != "0"
+_SIDE_STREAM = os.environ.get("DDPM_SIDE_STREAM", "1") != "0"      # weight / bias gradients on a second HIP stream
 _WGRAD_SLABS = os.environ.get("DDPM_WGRAD_SLABS", "0") != "0"      # deterministic slab reduction instead of atomics
 
 
@@ -256,7 +258,7 @@ class _Engine:
             off += (p.numel() + 3) // 4 * 4        # keep every slice 16-byte aligned
         self.gtotal = off
         self.wdesc = None                          # device table for ddpm_wgrad_unpack (built on first backward)
-        self._gpack, self._slabs, self._slab_tables, self._eff_splits = None, {}, {}, {}
+        self._gpack, self._slabs, self._slab_tables, self._eff_splits, self._side = None, {}, {}, {}, None
         m = model
         self.hid, self.E, self.L, self.n = m.hid_channels, m.time_embedding_dim, m.levels, m.num_res_blocks
         self.chs = [m.hid_channels * k for k in m.ch_multipliers]
@@ -432,6 +434,32 @@ class _Engine:
             self.tail = (conv_end, self.ptotal)
         return self.wdesc
 
+    @contextlib.contextmanager
+    def _leaf(self, ctx, *views):
+        """Weight / bias gradients are leaves of the backward graph: nothing downstream waits for them.  On the GPU they are
+        enqueued on a SIDE stream (ordered after the producer of their inputs by an event), so the MFMA-bound wgrad kernels
+        run next to the HBM-bound GroupNorm / softmax / element-wise kernels of the critical path instead of between them.
+        The inputs are kept alive until the backward ends (the caching allocator must not hand them out while the side
+        stream still reads them)."""
+        side = ctx.get("side")
+        if side is None:
+            yield
+            return
+        ctx["keep"].extend(views)
+        ev = torch.cuda.Event()
+        ev.record()                                  # inputs are final on the main stream here
+        with torch.cuda.stream(side):
+            side.wait_event(ev)
+            yield
+
+    def _join_side(self, ctx):
+        """Main stream waits for everything queued on the side stream so far."""
+        side = ctx.get("side")
+        if side is not None:
+            ev = torch.cuda.Event()
+            ev.record(side)
+            torch.cuda.current_stream().wait_event(ev)
+
     def _wgrad(self, ctx, weight, dy, x, Creal, Nreal, R, S, splits=1, **kw):
         """Weight gradient into the staging buffer; then hand finished all-reduce chunks to the communicator.
 
@@ -443,22 +471,24 @@ class _Engine:
         eff = self._eff_splits.get(key)
         if eff is None:
             eff = self._eff_splits[key] = ops.wgrad_effective_splits(dy.rows, splits, x.dtype)
-        if _WGRAD_SLABS and eff > 1:
-            n = Nreal * R * S * Creal
-            stride = (n + 3) // 4 * 4
-            slab = self._slabs.get(id(weight))
-            if slab is None or slab.numel() < eff * stride:
-                slab = self._slabs[id(weight)] = torch.empty(eff * stride, dtype=torch.float32, device=self.device)
-            ops.conv2d_wgrad(dy, x, slab.data_ptr(), Creal, Nreal, R, S, splits=eff, slab_stride=stride, **kw)
-            ctx["slab_rows"].append((slab.data_ptr(), self._pptr(ctx, weight), n, eff, stride))
-        else:
-            ops.conv2d_wgrad(dy, x, self._pptr(ctx, weight), Creal, Nreal, R, S, splits=eff, **kw)
+        with self._leaf(ctx, dy, x):
+            if _WGRAD_SLABS and eff > 1:
+                n = Nreal * R * S * Creal
+                stride = (n + 3) // 4 * 4
+                slab = self._slabs.get(id(weight))
+                if slab is None or slab.numel() < eff * stride:
+                    slab = self._slabs[id(weight)] = torch.empty(eff * stride, dtype=torch.float32, device=self.device)
+                ops.conv2d_wgrad(dy, x, slab.data_ptr(), Creal, Nreal, R, S, splits=eff, slab_stride=stride, **kw)
+                ctx["slab_rows"].append((slab.data_ptr(), self._pptr(ctx, weight), n, eff, stride))
+            else:
+                ops.conv2d_wgrad(dy, x, self._pptr(ctx, weight), Creal, Nreal, R, S, splits=eff, **kw)
         if ctx.get("pending") is not None:
             for ch in ctx["pending"]:
                 ch[2].discard(id(weight))
             while ctx["pending"] and not ctx["pending"][-1][2]:
                 a, b, _ = ctx["pending"].pop()
                 self._flush_slabs(ctx)                       # the chunk's conv gradients must be summed before they travel
+                self._join_side(ctx)                         # ... and produced: the communicator orders itself after the main stream
                 ctx["works"].append(self._all_reduce(ctx["gpack"][a:b]))
 
     def _flush_slabs(self, ctx):
@@ -467,6 +497,7 @@ class _Engine:
         if not rows:
             return
         ctx["slab_rows"] = []
+        self._join_side(ctx)
         table = self._slab_tables.get(rows)
         if table is None:                                    # addresses are stable (persistent buffers): built once per geometry
             table = self._slab_tables[rows] = torch.tensor(rows, dtype=torch.int64, device=self.device)
@@ -706,7 +737,14 @@ class _Engine:
         if self._gpack is None or self._gpack.numel() != self.ptotal:
             self._gpack = torch.empty(self.ptotal, dtype=torch.float32, device=self.device)
         gpack = self._gpack.zero_()           # persistent (stable addresses for the slab-reduce tables): packed conv weight grads [N][RS][C] + tail
-        ctx = dict(gflat=gflat, gpack=gpack, ws=ws, B=B, dtb=dtb, pending=None, works=[], slab_rows=[])
+        ctx = dict(gflat=gflat, gpack=gpack, ws=ws, B=B, dtb=dtb, pending=None, works=[], slab_rows=[], side=None, keep=[])
+        if _SIDE_STREAM and gout.is_cuda:
+            if self._side is None:
+                self._side = torch.cuda.Stream(device=self.device)
+            ctx["side"] = self._side
+            ev0 = torch.cuda.Event()
+            ev0.record()                              # the staging buffer is zeroed on the main stream
+            self._side.wait_event(ev0)
         world = 1
         if self.pg is not None:
             import torch.distributed as dist
@@ -736,6 +774,7 @@ class _Engine:
                 self._conv_bwd(ctx, rec)
         self._temb_bwd(ctx, st)
         self._flush_slabs(ctx)
+        self._join_side(ctx)
         if self.pg is not None:
             assert not ctx["pending"], "a conv weight gradient was never produced"
             ctx["works"].append(self._all_reduce(gpack[self.tail[0]:self.tail[1]]))
@@ -759,11 +798,12 @@ class _Engine:
     def _bias_grad(self, ctx, dy, biases, creal, slot=None):
         """db[c] = sum over pixels and batch of dy.  One owner: atomics straight into its gradient.  Several owners or a
         channel-padded dy: reduce into a gpack slot that the unpack table fans out."""
-        if slot is None:
-            assert dy.C == creal and len(biases) == 1
-            ops.colsum(dy, 0, 0, self._pptr(ctx, biases[0]))
-        else:
-            ops.colsum(dy, 0, 0, self._pptr(ctx, slot))
+        with self._leaf(ctx, dy):
+            if slot is None:
+                assert dy.C == creal and len(biases) == 1
+                ops.colsum(dy, 0, 0, self._pptr(ctx, biases[0]))
+            else:
+                ops.colsum(dy, 0, 0, self._pptr(ctx, slot))
 
     def _conv_bwd(self, ctx, rec):
         _, conv, x, out, k, stride, pt, pl, upsample = rec
