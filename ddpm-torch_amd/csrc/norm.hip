@@ -7,8 +7,9 @@
 //   gn_apply : grid (S, B) — combines the S partials (fp64), builds per-channel scale/shift in LDS and
 //              streams y = silu(x*a_c + b_c) [* keep/(1-p)]; the second read of x is an L2/MALL hit at
 //              the CIFAR sizes (<= 64 MB per tensor vs 256 MB Infinity Cache).
-// Backward mirrors it: gn_bwd_reduce (per-channel sums of dz and dz*xhat), gn_bwd_coef (per-sample group
-// coefficients + dgamma/dbeta atomics), gn_bwd_apply (dx).  SiLU and the dropout mask are recomputed.
+// Backward mirrors it: gn_bwd_reduce (per-slab per-channel sums of dz and dz*xhat), gn_bwd_apply (per-sample group
+// coefficients from those sums + dgamma/dbeta atomics by the slab-0 blocks, then dx).  SiLU and the dropout mask are
+// recomputed.
 #include "common.h"
 
 constexpr int GN_THREADS = 256;
@@ -323,45 +324,48 @@ __global__ void gn_bwd_reduce_kernel(const T* __restrict__ x, const T* __restric
     for (int c = t; c < s.C; c += nt) { o[2 * c] = sh1[c]; o[2 * c + 1] = sh2[c]; }
 }
 
-// one block per sample: combine slabs, group coefficients, dgamma/dbeta atomics
-__global__ void gn_bwd_coef_kernel(GnShape s, const float* __restrict__ partial, const float* __restrict__ gamma,
-                                   float* __restrict__ coef /*[B][G][2]*/, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+// dx = rstd * (dz*gamma - xhat*c1 - c2)   [+= when accumulate]
+template <typename T>
+__global__ void gn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx, GnShape s, long long dy_ld,
+                                    long long dx_ld, const float* __restrict__ stats, const float* __restrict__ partial,
+                                    float* __restrict__ dgamma, float* __restrict__ dbeta, GnApply a, int accumulate) {
+    constexpr int VEC = Elem<T>::VEC;
     __shared__ float sh1[GN_MAXC], sh2[GN_MAXC];
-    const int b = blockIdx.x, t = threadIdx.x;
-    for (int c = t; c < s.C; c += blockDim.x) {
+    __shared__ float sh_c1[64], sh_c2[64];
+    const int b = blockIdx.y, slab = blockIdx.x;
+    const int cx = threadIdx.x, py = threadIdx.y, PY = blockDim.y;
+    const int t = threadIdx.y * blockDim.x + threadIdx.x, nt = blockDim.x * blockDim.y;
+    const int p0 = slab * s.pix_per_slab, p1 = min(s.HW, p0 + s.pix_per_slab);
+    // group coefficients of this sample from the per-slab channel sums (every block of the sample recomputes them: a few
+    // KB from L2 instead of a third launch); the slab-0 block also owns the dgamma / dbeta contribution of the sample
+    for (int c = t; c < s.C; c += nt) {
         float a1 = 0.f, a2 = 0.f;
         for (int i = 0; i < s.S; ++i) {
             const float* o = partial + (((long long)b * s.S + i) * s.C + c) * 2;
             a1 += o[0]; a2 += o[1];
         }
-        sh1[c] = a1 * gamma[c]; sh2[c] = a2 * gamma[c];
-        if (dgamma) atomicAdd(dgamma + c, a1);
-        if (dbeta) atomicAdd(dbeta + c, a2);
+        const float gmc = a.gamma[c];
+        sh1[c] = a1 * gmc; sh2[c] = a2 * gmc;
+        if (slab == 0) {
+            if (dgamma) atomicAdd(dgamma + c, a1);
+            if (dbeta) atomicAdd(dbeta + c, a2);
+        }
     }
     __syncthreads();
     if (t < s.G) {
         float d1 = 0.f, d2 = 0.f;
         for (int c = t * s.cpg; c < (t + 1) * s.cpg; ++c) { d1 += sh1[c]; d2 += sh2[c]; }
         const float inv_n = 1.0f / ((float)s.HW * s.cpg);
-        coef[((long long)b * s.G + t) * 2] = d1 * inv_n;       // mean(dz*gamma*xhat) over the group
-        coef[((long long)b * s.G + t) * 2 + 1] = d2 * inv_n;   // mean(dz*gamma)
+        sh_c1[t] = d1 * inv_n;       // mean(dz*gamma*xhat) over the group
+        sh_c2[t] = d2 * inv_n;       // mean(dz*gamma)
     }
-}
-
-// dx = rstd * (dz*gamma - xhat*c1 - c2)   [+= when accumulate]
-template <typename T>
-__global__ void gn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx, GnShape s, long long dy_ld,
-                                    long long dx_ld, const float* __restrict__ stats, const float* __restrict__ coef, GnApply a, int accumulate) {
-    constexpr int VEC = Elem<T>::VEC;
-    const int b = blockIdx.y, slab = blockIdx.x;
-    const int cx = threadIdx.x, py = threadIdx.y, PY = blockDim.y;
-    const int p0 = slab * s.pix_per_slab, p1 = min(s.HW, p0 + s.pix_per_slab);
+    __syncthreads();
     float mean[VEC], rstd[VEC], gm[VEC], bt[VEC], c1[VEC], c2[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
         const int c = cx * VEC + j, g = c / s.cpg;
         mean[j] = stats[((long long)b * s.G + g) * 2]; rstd[j] = stats[((long long)b * s.G + g) * 2 + 1];
-        c1[j] = coef[((long long)b * s.G + g) * 2]; c2[j] = coef[((long long)b * s.G + g) * 2 + 1];
+        c1[j] = sh_c1[g]; c2[j] = sh_c2[g];
         gm[j] = a.gamma[c]; bt[j] = a.beta[c];
     }
     const float keep_scale = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
@@ -481,15 +485,13 @@ extern "C" int ddpm_groupnorm_silu_bwd(const void* x, long long x_ld, const void
     GnApply a = make_apply(gamma, beta, 0.f, silu, drop_p, seed, nullptr);
     hipStream_t st = (hipStream_t)stream;
     float* partial = workspace;                                   // [B][S][C][2]
-    float* coef = workspace + (long long)B * s.S * C * 2;         // [B][G][2]
     if (dtype == DDPM_BF16)
         hipLaunchKernelGGL(gn_bwd_reduce_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)x, (const bf16_t*)dy, s, dy_ld, stats, a, partial);
     else
         hipLaunchKernelGGL(gn_bwd_reduce_kernel<float>, grid, block, 0, st, (const float*)x, (const float*)dy, s, dy_ld, stats, a, partial);
-    hipLaunchKernelGGL(gn_bwd_coef_kernel, dim3(B), dim3(256), 0, st, s, partial, gamma, coef, dgamma, dbeta);
     if (dtype == DDPM_BF16)
-        hipLaunchKernelGGL(gn_bwd_apply_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx, s, dy_ld, dx_ld, stats, coef, a, accumulate);
+        hipLaunchKernelGGL(gn_bwd_apply_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx, s, dy_ld, dx_ld, stats, partial, dgamma, dbeta, a, accumulate);
     else
-        hipLaunchKernelGGL(gn_bwd_apply_kernel<float>, grid, block, 0, st, (const float*)x, (const float*)dy, (float*)dx, s, dy_ld, dx_ld, stats, coef, a, accumulate);
+        hipLaunchKernelGGL(gn_bwd_apply_kernel<float>, grid, block, 0, st, (const float*)x, (const float*)dy, (float*)dx, s, dy_ld, dx_ld, stats, partial, dgamma, dbeta, a, accumulate);
     return check_launch();
 }

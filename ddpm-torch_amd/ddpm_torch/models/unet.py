@@ -210,7 +210,7 @@ class _UNetFn(torch.autograd.Function):
         tape = []
         out = eng.forward(x, t, training, tape)
         ctx.eng, ctx.tape = eng, tape
-        eng.last_tape = tape                     # introspection hook for tests (dropout seeds, saved activations)
+        eng.last_tape = tape if eng.debug_keep_tape else None     # introspection hook for tests (dropout seeds, saved activations)
         return out
 
     @staticmethod
@@ -280,6 +280,7 @@ class _Engine:
         self._ws_key = None
         self.drop_calls = 0
         self.last_tape = None
+        self.debug_keep_tape = False               # tests set it to look at the tape after a step; costs the activations' lifetime
         self.splitk = ops.SplitK(self.device)
         self.pg = None                              # process group of the native data-parallel path (set_process_group)
         self.pack_table = self.pack_ptrs = self.pack_key = None
@@ -781,6 +782,12 @@ class _Engine:
             for w in ctx["works"]:
                 w.wait()                                   # the compute stream waits for the communicator; no host sync
         _hip.call("ddpm_wgrad_unpack", gpack.data_ptr(), gflat.data_ptr(), wdesc.data_ptr(), wdesc.shape[0], 1.0 / world, _hip.stream())
+        if not self.debug_keep_tape:
+            # the head record holds `st` and `st` holds the tape: break the cycle so that the saved activations go back to the
+            # allocator NOW (by reference count) instead of whenever the cyclic GC runs — with the cycle in place every few
+            # steps paid ~75 ms of fresh hipMalloc calls
+            st.pop("tape", None)
+            tape.clear()
         grads = []
         for p in self.params:
             o = self.goff[id(p)]

@@ -62,6 +62,7 @@ def test_forward_bf16_close(emu):
 def test_backward_fp32_matches_oracle(emu, cfg):
     m, sd = make(cfg)
     m.train()
+    m.engine().debug_keep_tape = True
     x, t, gy = rnd(2, 3, 16, 16, seed=3), torch.tensor([7, 912]), rnd(2, 3, 16, 16, seed=4)
     y = m(x, t)
     (y * gy).sum().backward()

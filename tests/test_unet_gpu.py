@@ -81,6 +81,7 @@ def test_backward_with_dropout_vs_oracle(dtype, bar):
     cfg = TINY3
     m, sd = make(cfg, dtype=dtype)
     m.train()
+    m.engine().debug_keep_tape = True
     x, t, gy = rnd(2, 3, 16, 16, seed=3), torch.tensor([7, 912]), rnd(2, 3, 16, 16, seed=4)
     y = m(x.to(DEV), t.to(DEV))
     (y * gy.to(DEV)).sum().backward()
