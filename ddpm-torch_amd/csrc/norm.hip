@@ -119,134 +119,237 @@ __global__ void gn_apply_kernel(const T* __restrict__ x, T* __restrict__ y, GnSh
     }
 }
 
-// ---- single-launch forward: one block owns (sample b, a chunk of GPB groups) = all HW pixels x seg_ch = GPB*cpg channels.
-// The slice (<= 64 KiB) is DMA'd into LDS once, statistics are taken from LDS (two-pass: mean, then centred variance),
-// and y is produced from the LDS copy: exactly one HBM read of x and one write of y, no partial-sum workspace, one launch.
+// ---- single-launch kernels: one block owns (sample b, a chunk of GPB groups) = all HW pixels x seg_ch = GPB*cpg channels,
+// and keeps that slice (<= 64 KiB) IN REGISTERS: thread (j, prow) holds the 16-byte vector column j of pixels prow,
+// prow + R, ... (NV of them, all requested before the first is used).  Statistics and group coefficients come from an
+// ordered LDS reduction of per-thread partials (deterministic), the output is produced from the registers: exactly one
+// HBM read of every input and one write of the output, one launch, no workspace.
 struct GnFused {
     int GPB, seg_ch, seg_vecs;     // groups per block, channels / 16-byte vectors per pixel segment
     int nta;                       // active threads: largest multiple of seg_vecs <= GN_THREADS (a thread keeps one vector column)
-    int rows_per_iter;             // nta / seg_vecs pixels per sweep of the block
-    int tpg;                       // threads cooperating on one group's statistics (GN_THREADS / GPB)
+    int rows_per_iter;             // R = nta / seg_vecs pixels per sweep of the block
+    int nv;                        // vectors per thread = ceil(HW / R)
 };
 
-template <typename T>
-__global__ __launch_bounds__(GN_THREADS)
-void gn_fused_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, GnShape s, GnFused f, GnApply a) {
-    constexpr int VEC = Elem<T>::VEC, ES = (int)sizeof(T);
-    extern __shared__ __attribute__((aligned(16))) char gsm[];
-    const int slice_bytes = s.HW * f.seg_ch * ES;
-    float* sh_a = reinterpret_cast<float*>(gsm + slice_bytes);       // [seg_ch] scale
-    float* sh_b = sh_a + f.seg_ch;                                    // [seg_ch] shift
-    float* sh_red = sh_b + f.seg_ch;                                  // [GN_THREADS / 64][GPB] cross-wave partials
-    float* sh_mean = sh_red + (GN_THREADS / 64) * 32;                 // [GPB]
-    float* sh_rstd = sh_mean + 32;                                    // [GPB]
-    const int b = blockIdx.y, c0 = blockIdx.x * f.seg_ch, tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nvec = s.HW * f.seg_vecs;
-    const bool active = tid < f.nta;
-    const int j = tid % f.seg_vecs, prow = tid / f.seg_vecs;          // this thread's vector column and first pixel
-
-    // phase 1: slice -> LDS (direct-to-LDS loads, vector v lands at byte 16 v)
-    {
-        const T* xb = x + ((long long)b * s.HW) * s.x_ld + c0;
-        const unsigned long long ad = (unsigned long long)xb;
-        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)ad), hi = __builtin_amdgcn_readfirstlane((unsigned)(ad >> 32));
-        const long long ext = ((long long)(s.HW - 1) * s.x_ld + f.seg_ch) * ES;
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0,
-                                                                           __builtin_amdgcn_readfirstlane((int)ext), 0x00020000);
-        int pp = prow;
-        for (int v0 = 0; v0 < nvec; v0 += f.nta, pp += f.rows_per_iter) {
-            // lanes past the slice (or past the last whole vector column set) stay masked: an LDS-DMA lane always writes
-            if (active && pp < s.HW) {
-                const unsigned off = (unsigned)(((long long)pp * s.x_ld + j * VEC) * ES);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(gsm + (v0 + wave * 64) * 16), 16, off, 0, 0, 0);
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __syncthreads();
-
-    // phase 2: statistics from LDS — tpg threads per group, each strides over the pixels of its group's cpg channels
-    {
-        const int g = tid / f.tpg, t = tid - g * f.tpg;                // tpg * GPB == GN_THREADS
-        const int chunks = s.cpg * ES / 8;                            // 8-byte pieces of one pixel's group segment
-        const char* base = gsm + g * s.cpg * ES;
-        const int pitch = f.seg_ch * ES;
-        auto reduce_group = [&](float v) -> float {
-            // deterministic: xor-butterfly inside the (<= 64 lane) thread set of the group, then fixed-order sum over waves
-            const int span = f.tpg < 64 ? f.tpg : 64;
-            for (int o = span >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-            if (f.tpg <= 64) return v;
-            __syncthreads();
-            if (lane == 0) sh_red[wave] = v;
-            __syncthreads();
-            const int w0 = g * (f.tpg >> 6);
-            float r = 0.f;
-            for (int w = 0; w < (f.tpg >> 6); ++w) r += sh_red[w0 + w];
-            return r;
-        };
-        float sum = 0.f;
-        for (int p = t; p < s.HW; p += f.tpg)
-            for (int q = 0; q < chunks; ++q) {
-                const uint2 u = *reinterpret_cast<const uint2*>(base + p * pitch + q * 8);
-                if (ES == 2) sum += (__uint_as_float(u.x << 16) + __uint_as_float(u.x & 0xffff0000u)) + (__uint_as_float(u.y << 16) + __uint_as_float(u.y & 0xffff0000u));
-                else sum += __uint_as_float(u.x) + __uint_as_float(u.y);
-            }
-        const float n = (float)s.HW * (float)s.cpg;
-        const float mean = reduce_group(sum) / n;
-        float sq = 0.f;
-        for (int p = t; p < s.HW; p += f.tpg)
-            for (int q = 0; q < chunks; ++q) {
-                const uint2 u = *reinterpret_cast<const uint2*>(base + p * pitch + q * 8);
-                if (ES == 2) {
-                    const float e0 = __uint_as_float(u.x << 16) - mean, e1 = __uint_as_float(u.x & 0xffff0000u) - mean;
-                    const float e2 = __uint_as_float(u.y << 16) - mean, e3 = __uint_as_float(u.y & 0xffff0000u) - mean;
-                    sq += (e0 * e0 + e1 * e1) + (e2 * e2 + e3 * e3);
-                } else {
-                    const float e0 = __uint_as_float(u.x) - mean, e1 = __uint_as_float(u.y) - mean;
-                    sq += e0 * e0 + e1 * e1;
-                }
-            }
-        const float var = reduce_group(sq) / n;
-        const float rstd = 1.0f / sqrtf(var + a.eps);
-        if (t == 0) {
-            sh_mean[g] = mean; sh_rstd[g] = rstd;
-            if (a.stats) {
-                const long long gi = (long long)b * s.G + blockIdx.x * f.GPB + g;
-                a.stats[gi * 2] = mean; a.stats[gi * 2 + 1] = rstd;
-            }
-        }
+// Ordered block reduction of per-thread channel partials: part[e] belongs to channel j*VEC + e of the segment.  On return
+// sh_ch[c] (c < seg_ch) holds the sum over all threads; sh_row is scratch of rows_per_iter * seg_ch floats.
+template <int VEC>
+__device__ __forceinline__ void gn_block_channel_sum(const float (&part)[VEC], const GnFused& f, bool active, int j, int prow, int tid,
+                                                     float* sh_row, float* sh_ch) {
+    __syncthreads();                                  // previous users of the scratch are done
+    if (active) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) sh_row[prow * f.seg_ch + j * VEC + e] = part[e];
     }
     __syncthreads();
     for (int c = tid; c < f.seg_ch; c += GN_THREADS) {
-        const int g = c / s.cpg;
-        const float sc = sh_rstd[g] * a.gamma[c0 + c];
-        sh_a[c] = sc; sh_b[c] = a.beta[c0 + c] - sh_mean[g] * sc;
+        float acc = 0.f;
+        for (int r = 0; r < f.rows_per_iter; ++r) acc += sh_row[r * f.seg_ch + c];
+        sh_ch[c] = acc;
     }
     __syncthreads();
+}
 
-    // phase 3: y = silu(x * a_c + b_c) [* keep / (1 - p)] from the LDS copy
-    if (active) {
-        float ca[VEC], cb[VEC];
+template <typename T, int NV>
+__global__ __launch_bounds__(GN_THREADS)
+void gn_reg_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, GnShape s, GnFused f, GnApply a) {
+    constexpr int VEC = Elem<T>::VEC;
+    extern __shared__ __attribute__((aligned(16))) float gsh[];
+    float* sh_row = gsh;                                              // [rows_per_iter][seg_ch]
+    float* sh_ch = sh_row + f.rows_per_iter * f.seg_ch;               // [seg_ch]
+    float* sh_mean = sh_ch + f.seg_ch;                                // [GPB]
+    float* sh_rstd = sh_mean + 32;                                    // [GPB]
+    const int b = blockIdx.y, c0 = blockIdx.x * f.seg_ch, tid = threadIdx.x;
+    const bool active = tid < f.nta;
+    const int j = tid % f.seg_vecs, prow = tid / f.seg_vecs;
+    const T* xb = x + ((long long)b * s.HW) * s.x_ld + c0 + j * VEC;
+    u32x4 v[NV];
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) { ca[e] = sh_a[j * VEC + e]; cb[e] = sh_b[j * VEC + e]; }
-        const float keep_scale = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
-        T* yb = y + ((long long)b * s.HW) * s.y_ld + c0 + j * VEC;
-        for (int p = prow; p < s.HW; p += f.rows_per_iter) {
-            float v[VEC];
-            Elem<T>::unpack(*reinterpret_cast<const u32x4*>(gsm + (p * f.seg_vecs + j) * 16), v);
+    for (int i = 0; i < NV; ++i) {
+        const int p = prow + i * f.rows_per_iter;
+        v[i] = (active && p < s.HW) ? ldg16(xb + (long long)p * s.x_ld) : zero16();
+    }
+    const float n = (float)s.HW * (float)s.cpg;
+    // mean
+    float part[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) part[e] = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        float fv[VEC];
+        Elem<T>::unpack(v[i], fv);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) part[e] += fv[e];              // padded pixels hold zeros
+    }
+    gn_block_channel_sum<VEC>(part, f, active, j, prow, tid, sh_row, sh_ch);
+    if (tid < f.GPB) {
+        float acc = 0.f;
+        for (int c = tid * s.cpg; c < (tid + 1) * s.cpg; ++c) acc += sh_ch[c];
+        sh_mean[tid] = acc / n;
+    }
+    __syncthreads();
+    float mean[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) mean[e] = sh_mean[(j * VEC + e) / s.cpg];
+    // centred variance
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) part[e] = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int p = prow + i * f.rows_per_iter;
+        if (p < s.HW) {
+            float fv[VEC];
+            Elem<T>::unpack(v[i], fv);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) { const float d = fv[e] - mean[e]; part[e] += d * d; }
+        }
+    }
+    gn_block_channel_sum<VEC>(part, f, active, j, prow, tid, sh_row, sh_ch);
+    if (tid < f.GPB) {
+        float acc = 0.f;
+        for (int c = tid * s.cpg; c < (tid + 1) * s.cpg; ++c) acc += sh_ch[c];
+        const float rstd = 1.0f / sqrtf(acc / n + a.eps);
+        sh_rstd[tid] = rstd;
+        if (a.stats) {
+            const long long gi = (long long)b * s.G + blockIdx.x * f.GPB + tid;
+            a.stats[gi * 2] = sh_mean[tid]; a.stats[gi * 2 + 1] = rstd;
+        }
+    }
+    __syncthreads();
+    if (!active) return;
+    float ca[VEC], cb[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+        const int c = j * VEC + e;
+        ca[e] = sh_rstd[c / s.cpg] * a.gamma[c0 + c];
+        cb[e] = a.beta[c0 + c] - mean[e] * ca[e];
+    }
+    const float keep_scale = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
+    T* yb = y + ((long long)b * s.HW) * s.y_ld + c0 + j * VEC;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int p = prow + i * f.rows_per_iter;
+        if (p >= s.HW) break;
+        float fv[VEC];
+        Elem<T>::unpack(v[i], fv);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            float z = fv[e] * ca[e] + cb[e];
+            if (a.silu) z = siluf_(z);
+            if (a.drop_p > 0.f) {
+                const unsigned long long idx = ((unsigned long long)b * s.HW + p) * s.C + c0 + j * VEC + e;
+                z = dropout_keep(a.seed, idx, a.thresh24) ? z * keep_scale : 0.f;
+            }
+            fv[e] = z;
+        }
+        stg16(yb + (long long)p * s.y_ld, Elem<T>::pack(fv));
+    }
+}
+
+// backward twin: x and dy slices in registers; pass 1 per-channel sums A1 = sum dz*xhat, A2 = sum dz -> dgamma / dbeta
+// (atomics across samples) and the group coefficients; pass 2 dx = rstd * (dz*gamma - xhat*c1 - c2) from the registers.
+template <typename T, int NV>
+__global__ __launch_bounds__(GN_THREADS)
+void gn_reg_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx, GnShape s, GnFused f, long long dy_ld,
+                       long long dx_ld, const float* __restrict__ stats, float* __restrict__ dgamma, float* __restrict__ dbeta, GnApply a,
+                       int accumulate) {
+    constexpr int VEC = Elem<T>::VEC;
+    extern __shared__ __attribute__((aligned(16))) float gsh[];
+    float* sh_row = gsh;
+    float* sh_ch = sh_row + f.rows_per_iter * f.seg_ch;
+    float* sh_c1 = sh_ch + f.seg_ch;
+    float* sh_c2 = sh_c1 + 32;
+    const int b = blockIdx.y, c0 = blockIdx.x * f.seg_ch, tid = threadIdx.x;
+    const bool active = tid < f.nta;
+    const int j = tid % f.seg_vecs, prow = tid / f.seg_vecs;
+    const T* xb = x + ((long long)b * s.HW) * s.x_ld + c0 + j * VEC;
+    const T* db = dy + ((long long)b * s.HW) * dy_ld + c0 + j * VEC;
+    u32x4 vx[NV], vd[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int p = prow + i * f.rows_per_iter;
+        const bool ok = active && p < s.HW;
+        vx[i] = ok ? ldg16(xb + (long long)p * s.x_ld) : zero16();
+        vd[i] = ok ? ldg16(db + (long long)p * dy_ld) : zero16();
+    }
+    float mean[VEC], rstd[VEC], gm[VEC], bt[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+        const int c = c0 + j * VEC + e, g = c / s.cpg;
+        mean[e] = stats[((long long)b * s.G + g) * 2]; rstd[e] = stats[((long long)b * s.G + g) * 2 + 1];
+        gm[e] = active ? a.gamma[c] : 0.f; bt[e] = active ? a.beta[c] : 0.f;
+    }
+    const float keep_scale = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
+    auto dz_of = [&](int p, int e, float xh, float d) -> float {
+        float dz = d;
+        if (a.drop_p > 0.f) {
+            const unsigned long long idx = ((unsigned long long)b * s.HW + p) * s.C + c0 + j * VEC + e;
+            dz = dropout_keep(a.seed, idx, a.thresh24) ? dz * keep_scale : 0.f;
+        }
+        if (a.silu) dz *= silu_gradf_(gm[e] * xh + bt[e]);
+        return dz;
+    };
+    float a1[VEC], a2[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) a1[e] = a2[e] = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int p = prow + i * f.rows_per_iter;
+        if (p < s.HW) {
+            float fx[VEC], fd[VEC];
+            Elem<T>::unpack(vx[i], fx); Elem<T>::unpack(vd[i], fd);
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
-                float z = v[e] * ca[e] + cb[e];
-                if (a.silu) z = siluf_(z);
-                if (a.drop_p > 0.f) {
-                    const unsigned long long idx = ((unsigned long long)b * s.HW + p) * s.C + c0 + j * VEC + e;
-                    z = dropout_keep(a.seed, idx, a.thresh24) ? z * keep_scale : 0.f;
-                }
-                v[e] = z;
+                const float xh = (fx[e] - mean[e]) * rstd[e];
+                const float dz = dz_of(p, e, xh, fd[e]);
+                a1[e] += dz * xh; a2[e] += dz;
             }
-            stg16(yb + (long long)p * s.y_ld, Elem<T>::pack(v));
         }
+    }
+    const float inv_n = 1.0f / ((float)s.HW * s.cpg);
+    gn_block_channel_sum<VEC>(a1, f, active, j, prow, tid, sh_row, sh_ch);
+    for (int c = tid; c < f.seg_ch; c += GN_THREADS) {
+        if (dgamma) atomicAdd(dgamma + c0 + c, sh_ch[c]);
+        sh_ch[c] *= a.gamma[c0 + c];
+    }
+    __syncthreads();
+    if (tid < f.GPB) {
+        float acc = 0.f;
+        for (int c = tid * s.cpg; c < (tid + 1) * s.cpg; ++c) acc += sh_ch[c];
+        sh_c1[tid] = acc * inv_n;
+    }
+    gn_block_channel_sum<VEC>(a2, f, active, j, prow, tid, sh_row, sh_ch);
+    for (int c = tid; c < f.seg_ch; c += GN_THREADS) {
+        if (dbeta) atomicAdd(dbeta + c0 + c, sh_ch[c]);
+        sh_ch[c] *= a.gamma[c0 + c];
+    }
+    __syncthreads();
+    if (tid < f.GPB) {
+        float acc = 0.f;
+        for (int c = tid * s.cpg; c < (tid + 1) * s.cpg; ++c) acc += sh_ch[c];
+        sh_c2[tid] = acc * inv_n;
+    }
+    __syncthreads();
+    if (!active) return;
+    float c1[VEC], c2[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { const int g = (j * VEC + e) / s.cpg; c1[e] = sh_c1[g]; c2[e] = sh_c2[g]; }
+    T* ob = dx + ((long long)b * s.HW) * dx_ld + c0 + j * VEC;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int p = prow + i * f.rows_per_iter;
+        if (p >= s.HW) break;
+        float fx[VEC], fd[VEC], o[VEC];
+        Elem<T>::unpack(vx[i], fx); Elem<T>::unpack(vd[i], fd);
+        if (accumulate) Elem<T>::unpack(ldg16(ob + (long long)p * dx_ld), o);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const float xh = (fx[e] - mean[e]) * rstd[e];
+            const float dz = dz_of(p, e, xh, fd[e]);
+            const float r = rstd[e] * (dz * gm[e] - xh * c1[e] - c2[e]);
+            o[e] = accumulate ? o[e] + r : r;
+        }
+        stg16(ob + (long long)p * dx_ld, Elem<T>::pack(o));
     }
 }
 
@@ -255,7 +358,6 @@ constexpr int GN_FUSED_SLICE = 64 * 1024;     // LDS bytes of activations per bl
 // picks the group chunk; false when no chunk of this geometry fits (falls back to the two-launch path)
 static bool gn_fused_plan(const GnShape& s, int esize, GnFused& f, size_t& lds_bytes) {
     const int vec = 16 / esize;
-    if ((s.cpg * esize) % 8) return false;
     int best = 0;
     for (int gpb = 1; gpb <= s.G && gpb <= 32; gpb <<= 1) {
         if (s.G % gpb || GN_THREADS % gpb) continue;
@@ -269,8 +371,14 @@ static bool gn_fused_plan(const GnShape& s, int esize, GnFused& f, size_t& lds_b
     // prefer >= 512 blocks (two per CU) as long as a pixel segment stays >= 128 bytes
     while (best > 1 && (long long)s.B * (s.G / best) < 512 && (best / 2) * s.cpg * esize >= 128 && ((best / 2) * s.cpg) % vec == 0) best >>= 1;
     f.GPB = best; f.seg_ch = best * s.cpg; f.seg_vecs = f.seg_ch / vec;
-    f.nta = (GN_THREADS / f.seg_vecs) * f.seg_vecs; f.rows_per_iter = f.nta / f.seg_vecs; f.tpg = GN_THREADS / best;
-    lds_bytes = (size_t)s.HW * f.seg_ch * esize + (2 * f.seg_ch + (GN_THREADS / 64) * 32 + 64) * sizeof(float);
+    f.nta = (GN_THREADS / f.seg_vecs) * f.seg_vecs; f.rows_per_iter = f.nta / f.seg_vecs;
+    f.nv = (s.HW + f.rows_per_iter - 1) / f.rows_per_iter;
+    if (f.nv > 16) return false;
+    // a block reads seg_ch * esize contiguous bytes per pixel: below a full 128-byte line two blocks (usually on different
+    // XCDs) fetch every line twice and the two streaming launches win (measured: 32^2 x 128 ch bf16 26 vs 25 us, 384 ch
+    // 106 vs 57 us; at >= 128 B the single launch wins: 16^2 x 256 ch 12.7 vs 16.8 us, 8^2 6.9 vs 11.4 us)
+    if (f.seg_ch * esize < 128) return false;
+    lds_bytes = ((size_t)f.rows_per_iter * f.seg_ch + f.seg_ch + 64) * sizeof(float);
     return true;
 }
 
@@ -444,20 +552,13 @@ extern "C" int ddpm_groupnorm_silu_fwd(const void* x, long long x_ld, void* y, l
     hipStream_t st = (hipStream_t)stream;
     GnFused f; size_t lds = 0;
     static const bool no_fused = getenv("DDPM_GN_NO_FUSED") != nullptr;
-    // measured (scripts/microbench.py): the single-launch kernel wins while the tensor is small (launch / latency bound
-    // 8x8 and 4x4 levels); on the big levels the two-launch path streams at the HBM rate and stays ahead
-    const bool small = (long long)B * HW * C * es <= (12ll << 20);
-    if (!no_fused && small && gn_fused_plan(s, es, f, lds)) {
+    if (!no_fused && gn_fused_plan(s, es, f, lds)) {      // register-resident single launch (1 read + 1 write of HBM)
         const dim3 fgrid(G / f.GPB, B);
-        if (dtype == DDPM_BF16) {
-            static bool attr = false;
-            if (!attr) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_fused_fwd_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, GN_FUSED_SLICE + 4096) != hipSuccess) return DDPM_ERR_LAUNCH; attr = true; }
-            hipLaunchKernelGGL(gn_fused_fwd_kernel<bf16_t>, fgrid, dim3(GN_THREADS), lds, st, (const bf16_t*)x, (bf16_t*)y, s, f, a);
-        } else {
-            static bool attr = false;
-            if (!attr) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_fused_fwd_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, GN_FUSED_SLICE + 4096) != hipSuccess) return DDPM_ERR_LAUNCH; attr = true; }
-            hipLaunchKernelGGL(gn_fused_fwd_kernel<float>, fgrid, dim3(GN_THREADS), lds, st, (const float*)x, (float*)y, s, f, a);
-        }
+#define GN_FWD(T, NV) hipLaunchKernelGGL((gn_reg_fwd_kernel<T, NV>), fgrid, dim3(GN_THREADS), lds, st, (const T*)x, (T*)y, s, f, a)
+#define GN_FWD_NV(T) do { if (f.nv <= 1) GN_FWD(T, 1); else if (f.nv <= 2) GN_FWD(T, 2); else if (f.nv <= 4) GN_FWD(T, 4); else if (f.nv <= 8) GN_FWD(T, 8); else GN_FWD(T, 16); } while (0)
+        if (dtype == DDPM_BF16) GN_FWD_NV(bf16_t); else GN_FWD_NV(float);
+#undef GN_FWD_NV
+#undef GN_FWD
         return check_launch();
     }
     if (dtype == DDPM_BF16) {
@@ -484,6 +585,17 @@ extern "C" int ddpm_groupnorm_silu_bwd(const void* x, long long x_ld, const void
     if (dy_ld % (16 / es) || dx_ld % (16 / es)) return DDPM_ERR_ALIGN;
     GnApply a = make_apply(gamma, beta, 0.f, silu, drop_p, seed, nullptr);
     hipStream_t st = (hipStream_t)stream;
+    GnFused f; size_t lds = 0;
+    static const bool no_fused = getenv("DDPM_GN_NO_FUSED") != nullptr || getenv("DDPM_GN_NO_FUSED_BWD") != nullptr;
+    if (!no_fused && gn_fused_plan(s, es, f, lds)) {      // register-resident single launch (x, dy read once, dx written once)
+        const dim3 fgrid(G / f.GPB, B);
+#define GN_BWD(T, NV) hipLaunchKernelGGL((gn_reg_bwd_kernel<T, NV>), fgrid, dim3(GN_THREADS), lds, st, (const T*)x, (const T*)dy, (T*)dx, s, f, dy_ld, dx_ld, stats, dgamma, dbeta, a, accumulate)
+#define GN_BWD_NV(T) do { if (f.nv <= 1) GN_BWD(T, 1); else if (f.nv <= 2) GN_BWD(T, 2); else if (f.nv <= 4) GN_BWD(T, 4); else if (f.nv <= 8) GN_BWD(T, 8); else GN_BWD(T, 16); } while (0)
+        if (dtype == DDPM_BF16) GN_BWD_NV(bf16_t); else GN_BWD_NV(float);
+#undef GN_BWD_NV
+#undef GN_BWD
+        return check_launch();
+    }
     float* partial = workspace;                                   // [B][S][C][2]
     if (dtype == DDPM_BF16)
         hipLaunchKernelGGL(gn_bwd_reduce_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)x, (const bf16_t*)dy, s, dy_ld, stats, a, partial);
