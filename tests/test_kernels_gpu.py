@@ -93,7 +93,7 @@ def test_conv_fwd(case, dt):
          B, H, W, C, Ho, Wo, N, R, R, stride, pt, pl, ups, dil, 0, 3, 1, None, None, dt, tol=TOL[0] if dt == 0 else 4e-3)
 
 
-@pytest.mark.parametrize("B,H,C,N", [(16, 32, 64, 128), (65, 16, 128, 192), (258, 8, 64, 128), (17, 32, 192, 256)])
+@pytest.mark.parametrize("B,H,C,N", [(16, 32, 64, 128), (65, 16, 128, 192), (258, 8, 64, 128), (17, 32, 192, 256), (4, 64, 64, 128)])
 def test_conv3x3_stationary_halo_path(B, H, C, N):
     """bf16 3x3/s1/p1 with >= 16384 output pixels takes the stationary-halo kernel: ragged image groups (B % NB != 0),
     N not a multiple of the tile, pitched operands and every epilogue fusion."""
