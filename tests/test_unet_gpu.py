@@ -65,6 +65,49 @@ def test_cifar_unet_forward_vs_oracle(dtype, bar):
     assert rel < bar
 
 
+# the other configurations of SURVEY.md §8(d): configs/celeba.json (64x64, attention at 16x16, no dropout) and
+# configs/celebahq.json (256x256, multipliers [1,1,2,2,4,4], attention at 16x16 with 512 channels)
+CELEBA = dict(in_channels=3, hid_channels=128, out_channels=3, ch_multipliers=[1, 2, 2, 2], num_res_blocks=2,
+              apply_attn=[False, False, True, False], drop_rate=0.0)
+CELEBAHQ = dict(in_channels=3, hid_channels=128, out_channels=3, ch_multipliers=[1, 1, 2, 2, 4, 4], num_res_blocks=2,
+                apply_attn=[False, False, False, False, True, False], drop_rate=0.0)
+
+
+@pytest.mark.parametrize("dtype,bar", [(torch.float32, FP32_BAR), (torch.bfloat16, 6e-2)])
+def test_celeba_unet_forward_backward_vs_oracle(dtype, bar):
+    """64x64 geometry: 4x4 halo patches per image, 16x16 attention reached at level 2, wgrad / dgrad at the larger levels."""
+    m, sd = make(CELEBA, dtype=dtype)
+    m.train()                                       # dropout 0: train mode only switches the tape on
+    x, t, gy = rnd(2, 3, 64, 64, seed=1), torch.tensor([11, 640]), rnd(2, 3, 64, 64, seed=2)
+    y = m(x.to(DEV), t.to(DEV))
+    p = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref = U.unet_forward(p, CELEBA, x, t, training=True)
+    rel = float((y.detach().cpu() - ref.detach()).abs().max() / ref.detach().abs().max())
+    print(f"celeba fwd {dtype}: rel err {rel:.3e}")
+    assert rel < bar
+    if dtype == torch.float32:
+        (y * gy.to(DEV)).sum().backward()
+        (ref * gy).sum().backward()
+        scales = {k: float(v.grad.abs().max()) for k, v in p.items()}
+        floor = 0.02 * sorted(scales.values())[len(scales) // 2]
+        worst = max(float((q.grad.cpu() - p[k].grad).abs().max()) / max(scales[k], floor) for k, q in m.named_parameters())
+        print(f"celeba grads: worst rel err {worst:.3e}")
+        assert worst < 3e-3
+
+
+def test_celebahq_unet_forward_vs_oracle():
+    """256x256, six levels, 512-channel attention (the three-launch attention path: the fused kernel covers C <= 256)."""
+    m, sd = make(CELEBAHQ, dtype=torch.bfloat16)
+    m.eval()
+    x, t = rnd(1, 3, 256, 256, seed=1), torch.tensor([500])
+    with torch.no_grad():
+        y = m(x.to(DEV), t.to(DEV))
+        ref = U.unet_forward(sd, CELEBAHQ, x, t)
+    rel = float((y.cpu() - ref).abs().max() / ref.abs().max())
+    print(f"celebahq fwd bf16: rel err {rel:.3e}")
+    assert rel < 6e-2
+
+
 def test_reference_smoke_config_checksum(golden):
     r = golden("g3_model.pt")["smoke"]
     cfg = dict(in_channels=3, hid_channels=128, out_channels=3, ch_multipliers=(1, 2, 3), num_res_blocks=2, apply_attn=(False, True, False))
