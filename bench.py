@@ -118,38 +118,57 @@ def main():
 
     out = None
     if rank == 0:
-        # ---- roofline of the dominant kernel: per-launch HIP events over one more training step
-        _ops.PROFILE = []
-        tr.step(x0, global_steps=args.warmup + args.steps + 1)
-        torch.cuda.synchronize()
-        prof, _ops.PROFILE = _ops.PROFILE, None
-        # every MFMA launch of that step, attributed to the kernel the library actually dispatched (ddpm_last_gemm_variant)
+        # ---- roofline of the dominant kernel: per-launch HIP events (recorded on the stream each kernel is launched on) over
+        # one more training step.  The product runs the weight-gradient kernels on a side stream NEXT to the critical path, so
+        # a launch's duration includes the slowdown from sharing the chip; `isolated` repeats the measurement with that
+        # overlap switched off (every kernel alone on the GPU), which is what says how good each kernel is by itself.
+        import ddpm_torch.models.unet as unet_mod
         VARIANT = {1: "gemm_kernel<4 waves,128x128>", 2: "gemm_kernel<8 waves,128x128>", 3: "gemm_kernel<deep ring,128x128>",
                    4: "gemm64_kernel<64x64>", 5: "conv3x3_halo_kernel<256px x 128>"}
-        agg, shapes = {}, {}
-        for kind, flops, a, b, shape, variant in prof:
-            dt_s = a.elapsed_time(b) * 1e-3
-            name = VARIANT.get(variant, "other") + (" wgrad (both operands k-strided)" if kind == "gemm_tt" else "")
-            e = agg.setdefault(name, [0, 0.0, 0.0])
-            e[0] += 1; e[1] += flops; e[2] += dt_s
-            e2 = shapes.setdefault(f"{name} | {kind} {shape}", [0, 0.0, 0.0])
-            e2[0] += 1; e2[1] += flops; e2[2] += dt_s
+        peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3
+
+        def profile_step(step_no):
+            _ops.PROFILE = []
+            tr.step(x0, global_steps=step_no)
+            torch.cuda.synchronize()
+            prof, _ops.PROFILE = _ops.PROFILE, None
+            agg, shapes = {}, {}
+            for kind, flops, a, b, shape, variant in prof:
+                dt_s = a.elapsed_time(b) * 1e-3
+                name = VARIANT.get(variant, "other") + (" wgrad (both operands k-strided)" if kind == "gemm_tt" else "")
+                e = agg.setdefault(name, [0, 0.0, 0.0])
+                e[0] += 1; e[1] += flops; e[2] += dt_s
+                e2 = shapes.setdefault(f"{name} | {kind} {shape}", [0, 0.0, 0.0])
+                e2[0] += 1; e2[1] += flops; e2[2] += dt_s
+            return agg, shapes
+
+        def table(agg):
+            return {k: {"launches": v[0], "gflop": round(v[1] / 1e9, 1), "ms": round(v[2] * 1e3, 3), "tflops": round(v[1] / v[2] / 1e12, 1),
+                        "avg_launch_us": round(v[2] / v[0] * 1e6, 2), "frac": round(v[1] / v[2] / 1e12 / peak, 4)}
+                    for k, v in sorted(agg.items(), key=lambda kv: -kv[1][2])}
+
+        agg, shapes = profile_step(args.warmup + args.steps + 1)
+        side_was = unet_mod._SIDE_STREAM
+        unet_mod._SIDE_STREAM = False
+        agg_iso, shapes_iso = profile_step(args.warmup + args.steps + 2)
+        unet_mod._SIDE_STREAM = side_was
         if os.environ.get("BENCH_SHAPES"):
             with open(os.environ["BENCH_SHAPES"], "w") as f:
-                for k, v in sorted(shapes.items(), key=lambda kv: -kv[1][2]):
+                for k, v in sorted(shapes_iso.items(), key=lambda kv: -kv[1][2]):
                     f.write(f"{v[2] * 1e3:8.3f} ms  n={v[0]:3d}  {v[1] / v[2] / 1e12:7.1f} TF  {k}\n")
         # dominant kernel = the one with the most GPU time in the step
         dom_name, dom = max(agg.items(), key=lambda kv: kv[1][2])
         achieved = dom[1] / dom[2] / 1e12
-        peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3
-        kernels = {k: {"launches": v[0], "gflop": round(v[1] / 1e9, 1), "ms": round(v[2] * 1e3, 3), "tflops": round(v[1] / v[2] / 1e12, 1),
-                       "avg_launch_us": round(v[2] / v[0] * 1e6, 2)} for k, v in sorted(agg.items(), key=lambda kv: -kv[1][2])}
         tot_f, tot_t = sum(v[1] for v in agg.values()), sum(v[2] for v in agg.values())
+        iso_f, iso_t = sum(v[1] for v in agg_iso.values()), sum(v[2] for v in agg_iso.values())
         roofline = {"bound": "mfma", "kernel": dom_name, "achieved": round(achieved, 1), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(achieved / peak, 4), "traffic": None,
                     "launches_per_step": dom[0], "avg_launch_us": round(dom[2] / dom[0] * 1e6, 2),
+                    "note": "durations as they occur in the product step (two HIP streams share the GPU); `isolated` = same step, one stream",
                     "all_mfma_kernels": {"tflops": round(tot_f / tot_t / 1e12, 1), "ms": round(tot_t * 1e3, 3), "frac": round(tot_f / tot_t / 1e12 / peak, 4)},
-                    "per_kernel": kernels}
+                    "per_kernel": table(agg),
+                    "isolated": {"all_mfma_kernels": {"tflops": round(iso_f / iso_t / 1e12, 1), "ms": round(iso_t * 1e3, 3), "frac": round(iso_f / iso_t / 1e12 / peak, 4)},
+                                 "per_kernel": table(agg_iso)}}
         # ---- sampling: the reference's p_sample (EMA weights are what generate.py samples with; same cost), B=128,
         # eval mode, fixed-large, seed 131071.  --sample-steps 1000 (default) runs the real 1000-step chain end to end;
         # a smaller S times an S-step chain (identical per-step work) and scales to 1000 steps.
