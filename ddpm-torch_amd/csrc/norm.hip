@@ -126,7 +126,8 @@ __global__ void gn_apply_kernel(const T* __restrict__ x, T* __restrict__ y, GnSh
 // HBM read of every input and one write of the output, one launch, no workspace.
 struct GnFused {
     int GPB, seg_ch, seg_vecs;     // groups per block, channels / 16-byte vectors per pixel segment
-    int nta;                       // active threads: largest multiple of seg_vecs <= GN_THREADS (a thread keeps one vector column)
+    int nt;                        // threads per block (256 or 512: a block holds up to nt * 16 vectors = 64 / 128 KiB)
+    int nta;                       // active threads: largest multiple of seg_vecs <= nt (a thread keeps one vector column)
     int rows_per_iter;             // R = nta / seg_vecs pixels per sweep of the block
     int nv;                        // vectors per thread = ceil(HW / R)
 };
@@ -142,7 +143,7 @@ __device__ __forceinline__ void gn_block_channel_sum(const float (&part)[VEC], c
         for (int e = 0; e < VEC; ++e) sh_row[prow * f.seg_ch + j * VEC + e] = part[e];
     }
     __syncthreads();
-    for (int c = tid; c < f.seg_ch; c += GN_THREADS) {
+    for (int c = tid; c < f.seg_ch; c += f.nt) {
         float acc = 0.f;
         for (int r = 0; r < f.rows_per_iter; ++r) acc += sh_row[r * f.seg_ch + c];
         sh_ch[c] = acc;
@@ -150,8 +151,8 @@ __device__ __forceinline__ void gn_block_channel_sum(const float (&part)[VEC], c
     __syncthreads();
 }
 
-template <typename T, int NV>
-__global__ __launch_bounds__(GN_THREADS)
+template <typename T, int NV, int NT>
+__global__ __launch_bounds__(NT)
 void gn_reg_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, GnShape s, GnFused f, GnApply a) {
     constexpr int VEC = Elem<T>::VEC;
     extern __shared__ __attribute__((aligned(16))) float gsh[];
@@ -248,8 +249,8 @@ void gn_reg_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, GnShape s, Gn
 
 // backward twin: x and dy slices in registers; pass 1 per-channel sums A1 = sum dz*xhat, A2 = sum dz -> dgamma / dbeta
 // (atomics across samples) and the group coefficients; pass 2 dx = rstd * (dz*gamma - xhat*c1 - c2) from the registers.
-template <typename T, int NV>
-__global__ __launch_bounds__(GN_THREADS)
+template <typename T, int NV, int NT>
+__global__ __launch_bounds__(NT)
 void gn_reg_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx, GnShape s, GnFused f, long long dy_ld,
                        long long dx_ld, const float* __restrict__ stats, float* __restrict__ dgamma, float* __restrict__ dbeta, GnApply a,
                        int accumulate) {
@@ -308,7 +309,7 @@ void gn_reg_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __r
     }
     const float inv_n = 1.0f / ((float)s.HW * s.cpg);
     gn_block_channel_sum<VEC>(a1, f, active, j, prow, tid, sh_row, sh_ch);
-    for (int c = tid; c < f.seg_ch; c += GN_THREADS) {
+    for (int c = tid; c < f.seg_ch; c += NT) {
         if (dgamma) atomicAdd(dgamma + c0 + c, sh_ch[c]);
         sh_ch[c] *= a.gamma[c0 + c];
     }
@@ -319,7 +320,7 @@ void gn_reg_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __r
         sh_c1[tid] = acc * inv_n;
     }
     gn_block_channel_sum<VEC>(a2, f, active, j, prow, tid, sh_row, sh_ch);
-    for (int c = tid; c < f.seg_ch; c += GN_THREADS) {
+    for (int c = tid; c < f.seg_ch; c += NT) {
         if (dbeta) atomicAdd(dbeta + c0 + c, sh_ch[c]);
         sh_ch[c] *= a.gamma[c0 + c];
     }
@@ -356,28 +357,33 @@ void gn_reg_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __r
 constexpr int GN_FUSED_SLICE = 64 * 1024;     // LDS bytes of activations per block: two blocks per CU
 
 // picks the group chunk; false when no chunk of this geometry fits (falls back to the two-launch path)
+static const long long gn_fused_max_bytes = getenv("DDPM_GN_FUSED_MAX_KB") ? atoll(getenv("DDPM_GN_FUSED_MAX_KB")) * 1024 : GN_FUSED_SLICE;
+// (128 KiB slices = 512-thread blocks work and make the 32^2 x 128-channel forward 10 % faster in isolation, but the training
+//  step measured 0.25 ms slower with them — A/B in one session, scripts/step_jitter.py — so the default stays at 64 KiB.)
+
 static bool gn_fused_plan(const GnShape& s, int esize, GnFused& f, size_t& lds_bytes) {
     const int vec = 16 / esize;
     int best = 0;
     for (int gpb = 1; gpb <= s.G && gpb <= 32; gpb <<= 1) {
-        if (s.G % gpb || GN_THREADS % gpb) continue;
+        if (s.G % gpb) continue;
         const int seg_ch = gpb * s.cpg;
         if (seg_ch % vec) continue;
-        if ((long long)s.HW * seg_ch * esize > GN_FUSED_SLICE) break;
-        if (seg_ch / vec > GN_THREADS) break;
+        if ((long long)s.HW * seg_ch * esize > gn_fused_max_bytes) break;       // 512 threads x 16 vectors at most
+        if (seg_ch / vec > 256) break;
         best = gpb;
     }
     if (!best) return false;
     // prefer >= 512 blocks (two per CU) as long as a pixel segment stays >= 128 bytes
     while (best > 1 && (long long)s.B * (s.G / best) < 512 && (best / 2) * s.cpg * esize >= 128 && ((best / 2) * s.cpg) % vec == 0) best >>= 1;
     f.GPB = best; f.seg_ch = best * s.cpg; f.seg_vecs = f.seg_ch / vec;
-    f.nta = (GN_THREADS / f.seg_vecs) * f.seg_vecs; f.rows_per_iter = f.nta / f.seg_vecs;
+    // a block reads seg_ch * esize contiguous bytes per pixel: below a full 128-byte line two blocks (usually on different
+    // XCDs) fetch every line twice and the two streaming launches win (measured: 32^2 x 128 ch bf16 in 64-byte segments 26
+    // vs 25 us, 384 ch 106 vs 57 us; at >= 128 B the single launch wins: 16^2 x 256 ch 12.7 vs 16.8 us, 8^2 6.9 vs 11.4 us)
+    if (f.seg_ch * esize < 128) return false;
+    f.nt = (long long)s.HW * f.seg_ch * esize > GN_FUSED_SLICE ? 512 : 256;
+    f.nta = (f.nt / f.seg_vecs) * f.seg_vecs; f.rows_per_iter = f.nta / f.seg_vecs;
     f.nv = (s.HW + f.rows_per_iter - 1) / f.rows_per_iter;
     if (f.nv > 16) return false;
-    // a block reads seg_ch * esize contiguous bytes per pixel: below a full 128-byte line two blocks (usually on different
-    // XCDs) fetch every line twice and the two streaming launches win (measured: 32^2 x 128 ch bf16 26 vs 25 us, 384 ch
-    // 106 vs 57 us; at >= 128 B the single launch wins: 16^2 x 256 ch 12.7 vs 16.8 us, 8^2 6.9 vs 11.4 us)
-    if (f.seg_ch * esize < 128) return false;
     lds_bytes = ((size_t)f.rows_per_iter * f.seg_ch + f.seg_ch + 64) * sizeof(float);
     return true;
 }
@@ -554,7 +560,8 @@ extern "C" int ddpm_groupnorm_silu_fwd(const void* x, long long x_ld, void* y, l
     static const bool no_fused = getenv("DDPM_GN_NO_FUSED") != nullptr;
     if (!no_fused && gn_fused_plan(s, es, f, lds)) {      // register-resident single launch (1 read + 1 write of HBM)
         const dim3 fgrid(G / f.GPB, B);
-#define GN_FWD(T, NV) hipLaunchKernelGGL((gn_reg_fwd_kernel<T, NV>), fgrid, dim3(GN_THREADS), lds, st, (const T*)x, (T*)y, s, f, a)
+#define GN_FWD(T, NV) do { if (f.nt == 512) hipLaunchKernelGGL((gn_reg_fwd_kernel<T, NV, 512>), fgrid, dim3(512), lds, st, (const T*)x, (T*)y, s, f, a); \
+                           else hipLaunchKernelGGL((gn_reg_fwd_kernel<T, NV, 256>), fgrid, dim3(256), lds, st, (const T*)x, (T*)y, s, f, a); } while (0)
 #define GN_FWD_NV(T) do { if (f.nv <= 1) GN_FWD(T, 1); else if (f.nv <= 2) GN_FWD(T, 2); else if (f.nv <= 4) GN_FWD(T, 4); else if (f.nv <= 8) GN_FWD(T, 8); else GN_FWD(T, 16); } while (0)
         if (dtype == DDPM_BF16) GN_FWD_NV(bf16_t); else GN_FWD_NV(float);
 #undef GN_FWD_NV
@@ -589,7 +596,8 @@ extern "C" int ddpm_groupnorm_silu_bwd(const void* x, long long x_ld, const void
     static const bool no_fused = getenv("DDPM_GN_NO_FUSED") != nullptr || getenv("DDPM_GN_NO_FUSED_BWD") != nullptr;
     if (!no_fused && gn_fused_plan(s, es, f, lds)) {      // register-resident single launch (x, dy read once, dx written once)
         const dim3 fgrid(G / f.GPB, B);
-#define GN_BWD(T, NV) hipLaunchKernelGGL((gn_reg_bwd_kernel<T, NV>), fgrid, dim3(GN_THREADS), lds, st, (const T*)x, (const T*)dy, (T*)dx, s, f, dy_ld, dx_ld, stats, dgamma, dbeta, a, accumulate)
+#define GN_BWD(T, NV) do { if (f.nt == 512) hipLaunchKernelGGL((gn_reg_bwd_kernel<T, NV, 512>), fgrid, dim3(512), lds, st, (const T*)x, (const T*)dy, (T*)dx, s, f, dy_ld, dx_ld, stats, dgamma, dbeta, a, accumulate); \
+                           else hipLaunchKernelGGL((gn_reg_bwd_kernel<T, NV, 256>), fgrid, dim3(256), lds, st, (const T*)x, (const T*)dy, (T*)dx, s, f, dy_ld, dx_ld, stats, dgamma, dbeta, a, accumulate); } while (0)
 #define GN_BWD_NV(T) do { if (f.nv <= 1) GN_BWD(T, 1); else if (f.nv <= 2) GN_BWD(T, 2); else if (f.nv <= 4) GN_BWD(T, 4); else if (f.nv <= 8) GN_BWD(T, 8); else GN_BWD(T, 16); } while (0)
         if (dtype == DDPM_BF16) GN_BWD_NV(bf16_t); else GN_BWD_NV(float);
 #undef GN_BWD_NV
