@@ -79,6 +79,8 @@ __device__ __forceinline__ float wave_max(float v) {
 
 __device__ __forceinline__ float sigmoidf_(float z) { return 1.0f / (1.0f + __expf(-z)); }
 __device__ __forceinline__ float siluf_(float z) { return z * sigmoidf_(z); }
+// hardware reciprocal (v_rcp_f32, 1 ulp) instead of the IEEE division: for values that are rounded to bf16 right after
+__device__ __forceinline__ float silu_fast_(float z) { return z * __builtin_amdgcn_rcpf(1.0f + __expf(-z)); }
 // d/dz [z*sigmoid(z)] = s*(1 + z*(1-s))
 __device__ __forceinline__ float silu_gradf_(float z) { float s = sigmoidf_(z); return s * (1.0f + z * (1.0f - s)); }
 

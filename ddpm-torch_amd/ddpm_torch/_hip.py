@@ -33,6 +33,8 @@ PROTOTYPES = {
     "ddpm_gn_workspace_floats": [I, I, I, I, I],
     "ddpm_last_gemm_variant": [I],
     "ddpm_attention_fwd": [P, L, P, L, I, I, I, F, I, P],
+    "ddpm_groupnorm_stats": [P, L, P, I, I, I, I, F, I, P],
+    "ddpm_conv3x3_gn_silu_nhwc": [P, L, P, P, P, I, I, P, P, L, P, P, L, P, L, I, I, I, I, I, I, P],
     "ddpm_timestep_embedding": [P, P, P, I, I, P],
     "ddpm_nchw_to_nhwc": [P, P, I, I, I, I, I, P],
     "ddpm_pack_weight": [P, P, P, I, I, I, I, I, I, I, P],

@@ -70,6 +70,19 @@ int ddpm_gemm(const void* a, long long a_ld, long long a_bs, int a_trans,
               int M, int N, int K, int batch, float alpha, int accumulate, int out_mode, int splits,
               int dtype, void* stream);
 
+/* Inference path: GroupNorm + SiLU folded into the input side of the following 3x3 / stride 1 / pad 1 convolution
+ * (DEFAULT_NORMALIZER + DEFAULT_NONLINEARITY + Conv2d of ResidualBlock.forward, ddpm_torch/models/unet.py:85-88, eval mode:
+ * dropout is the identity).  ddpm_groupnorm_stats writes stats[b][g] = (mean, 1/sqrt(var + eps)) of x in one launch;
+ * ddpm_conv3x3_gn_silu_nhwc then computes
+ *     y = conv3x3(silu?(gamma_c * (x - mean_bg) * rstd_bg + beta_c)) + bias (+ rowbias[b]) (+ residual)
+ * with the normalisation applied to the LDS-resident input tiles: the normalised activation is never written to HBM.
+ * bf16, C % 64 == 0, C % G == 0, H and W multiples of 16; other geometries return DDPM_ERR_SHAPE and the caller uses
+ * ddpm_groupnorm_silu_fwd + ddpm_conv2d_nhwc. */
+int ddpm_groupnorm_stats(const void* x, long long x_ld, float* stats, int B, int HW, int C, int G, float eps, int dtype, void* stream);
+int ddpm_conv3x3_gn_silu_nhwc(const void* x, long long x_ld, const float* gn_stats, const float* gamma, const float* beta, int G, int silu,
+                              const void* w, void* y, long long y_ld, const float* bias, const float* rowbias, long long rowbias_ld,
+                              const void* residual, long long res_ld, int B, int H, int W, int C, int N, int dtype, void* stream);
+
 /* Fused single-head attention forward (inference path) — replaces the three products of AttentionBlock.forward
  * (ddpm_torch/models/unet.py:41-52: einsum("bchw,bcHW->bhwHW") * C**-0.5, softmax over the key positions, einsum with v)
  * for a packed projection buffer qkv[B][L][ld] with q at channel 0, k at channel C and v at channel 2C:
