@@ -316,29 +316,38 @@ __device__ __forceinline__ void epilogue_bias(const Epilogue& ep, int col0g, int
     for (int j = 0; j < VO; ++j) bias[j] = (ep.bias && col + j < N) ? ep.bias[col + j] : 0.f;
 }
 
-template <typename T, typename OutT, int NT, int NROWS, int TN = 128, typename RowMap>
-__device__ __forceinline__ void epilogue_rows(const Epilogue& ep, const float* cs, int batch, RowMap rowmap, int col0g, int N, int tid,
-                                              const float (&bias)[16 / (int)sizeof(OutT)]) {
-    constexpr int VO = 16 / (int)sizeof(OutT);            // output elements per 16-byte vector
-    constexpr int VPR = TN / VO;                           // vectors per tile row
-    constexpr int CS_LD = TN + 4;                          // staging pitch (shadows the 128-column constant)
-    constexpr int PER_THREAD = (NROWS * VPR + NT - 1) / NT;
-    constexpr int ROWS_PER_PASS = NT / VPR;
-    const int cv = tid % VPR, r0 = tid / VPR;
-    const int col = col0g + cv * VO;
-    if (col >= N) return;
-    const bool full = col + VO <= N;
-    OutT* outb = reinterpret_cast<OutT*>(ep.out) + (long long)batch * ep.out_batch_stride;
-    const T* resb = ep.residual ? reinterpret_cast<const T*>(ep.residual) + (long long)batch * ep.res_batch_stride : nullptr;
-    // Rows are handled in batches of U: every global read of the batch (time bias, residual, accumulate target) is issued
-    // before the first one is consumed, so a thread pays one memory latency per batch instead of one per row.
-    constexpr int U = PER_THREAD < 4 ? PER_THREAD : 4;
-    const bool fast = full && ep.vec_ok;
-    const bool same = sizeof(T) == sizeof(OutT);
-    for (int i0 = 0; i0 < PER_THREAD; i0 += U) {
-        int rows[U];
-        float rbv[U][VO];
-        u32x4 resv[U], accv[U];
+// Row epilogue in two phases per batch of U rows: load() issues every global read of the batch (time bias, residual,
+// accumulate target), finish() consumes them together with the staged accumulators.  The kernels call load(0) BEFORE they
+// stage the accumulators through LDS, so that first (usually only) batch's memory latency hides under the staging.
+template <typename T, typename OutT, int NT, int NROWS, int TN, typename RowMap>
+struct RowEpilogue {
+    static constexpr int VO = 16 / (int)sizeof(OutT);     // output elements per 16-byte vector
+    static constexpr int VPR = TN / VO;                    // vectors per tile row
+    static constexpr int LD = TN + 4;                      // staging pitch
+    static constexpr int PER_THREAD = (NROWS * VPR + NT - 1) / NT;
+    static constexpr int ROWS_PER_PASS = NT / VPR;
+    static constexpr int U = PER_THREAD < 4 ? PER_THREAD : 4;
+    static constexpr bool SAME = sizeof(T) == sizeof(OutT);
+    const Epilogue& ep;
+    RowMap rowmap;
+    int N, cv, r0, col;
+    bool live, fast;
+    OutT* outb;
+    const T* resb;
+    int rows[U];
+    float rbv[U][VO];
+    u32x4 resv[U], accv[U];
+
+    __device__ __forceinline__ RowEpilogue(const Epilogue& ep_, int batch, RowMap rm, int col0g, int N_, int tid) : ep(ep_), rowmap(rm), N(N_) {
+        cv = tid % VPR; r0 = tid / VPR;
+        col = col0g + cv * VO;
+        live = col < N;
+        fast = col + VO <= N && ep.vec_ok;
+        outb = reinterpret_cast<OutT*>(ep.out) + (long long)batch * ep.out_batch_stride;
+        resb = ep.residual ? reinterpret_cast<const T*>(ep.residual) + (long long)batch * ep.res_batch_stride : nullptr;
+    }
+    __device__ __forceinline__ void load(int i0) {
+        if (!live) return;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int rl = r0 + (i0 + u) * ROWS_PER_PASS;
@@ -351,10 +360,13 @@ __device__ __forceinline__ void epilogue_rows(const Epilogue& ep, const float* c
                 for (int j = 0; j < VO; ++j) rbv[u][j] = (col + j < N) ? rb[j] : 0.f;
             }
             if (fast) {
-                if (resb && same) resv[u] = ldg16(resb + (long long)row * ep.res_ld + col);
+                if (resb && SAME) resv[u] = ldg16(resb + (long long)row * ep.res_ld + col);
                 if (ep.accumulate) accv[u] = ldg16(outb + (long long)row * ep.ldc + col);
             }
         }
+    }
+    __device__ __forceinline__ void finish(int i0, const float* cs, const float (&bias)[VO]) {
+        if (!live) return;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int row = rows[u];
@@ -363,7 +375,7 @@ __device__ __forceinline__ void epilogue_rows(const Epilogue& ep, const float* c
             float v[VO];
 #pragma unroll
             for (int j = 0; j < VO; j += 4) {
-                const f32x4 t = *reinterpret_cast<const f32x4*>(cs + rl * CS_LD + cv * VO + j);
+                const f32x4 t = *reinterpret_cast<const f32x4*>(cs + rl * LD + cv * VO + j);
                 v[j] = t.x; v[j + 1] = t.y; v[j + 2] = t.z; v[j + 3] = t.w;
             }
 #pragma unroll
@@ -375,7 +387,7 @@ __device__ __forceinline__ void epilogue_rows(const Epilogue& ep, const float* c
             OutT* o = outb + (long long)row * ep.ldc + col;
             if (fast) {
                 if (resb) {
-                    if (same) {
+                    if (SAME) {
                         float f[VO];
                         Elem<T>::unpack(resv[u], f);
 #pragma unroll
@@ -391,11 +403,7 @@ __device__ __forceinline__ void epilogue_rows(const Epilogue& ep, const float* c
 #pragma unroll
                     for (int j = 0; j < VO; ++j) v[j] += f[j];
                 }
-#ifndef EABL_NOSTORE
                 stg16(o, Elem<OutT>::pack(v));
-#else
-                if (v[0] == 1234.5f) stg16(o, Elem<OutT>::pack(v));
-#endif
             } else {
 #pragma unroll
                 for (int j = 0; j < VO; ++j) {
@@ -408,7 +416,12 @@ __device__ __forceinline__ void epilogue_rows(const Epilogue& ep, const float* c
             }
         }
     }
-}
+    // everything after the first batch (whose load() the caller issued before staging)
+    __device__ __forceinline__ void finish_all(const float* cs, const float (&bias)[VO]) {
+        finish(0, cs, bias);
+        for (int i0 = U; i0 < PER_THREAD; i0 += U) { load(i0); finish(i0, cs, bias); }
+    }
+};
 
 // element-wise tail for the scatter / atomic output modes (2: fp32 atomic add, 3: NCHW fp32, 4: packed wgrad with atomics,
 // 5: packed wgrad, plain stores into the slab copy of this split; a fixed-order sum of the copies (ddpm_wgrad_reduce) then
@@ -544,6 +557,11 @@ void gemm_kernel(MatDesc A, MatDesc B, Epilogue ep, int M, int N, int K, int k_p
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = (f32x16)(0.f);
 
+    // bias of this thread's output columns: requested now, consumed in the epilogue (its latency hides under the K loop)
+    float bias_v[Elem<T>::VEC];                            // mode 1 (fp32 output, 4 columns per thread) uses the first four
+    if (ep.mode == 0) epilogue_bias<T, NT>(ep, tn * TILE, N, tid, bias_v);
+    else if (ep.mode == 1) epilogue_bias<float, NT>(ep, tn * TILE, N, tid, *reinterpret_cast<float(*)[4]>(bias_v));
+
     u32x4 va[NVEC], vb[NVEC];
     constexpr bool DMA_A = Loader<T, TA, NW>::DMA, DMA_B = Loader<T, TB, NW>::DMA;
     auto stage_a = [&](int k0, char* tile) { if constexpr (TA) la.issue_tr(k0, k_end, tile); else la.issue(k0, k_end, tile); };
@@ -647,63 +665,75 @@ void gemm_kernel(MatDesc A, MatDesc B, Epilogue ep, int M, int N, int K, int k_p
 
     // accumulator (reg r, lane l) -> row (r&3) + 8*(r>>2) + 4*(l>>5), col l&31 of its 32x32 tile; stage as fp32 in LDS.
     float* cs = reinterpret_cast<float*>(smem);
-    float bias_t[Elem<T>::VEC], bias_f[4];
-    if (ep.mode == 0) epilogue_bias<T, NT>(ep, tn * TILE, N, tid, bias_t);
-    else if (ep.mode == 1) epilogue_bias<float, NT>(ep, tn * TILE, N, tid, bias_f);
-    {
-        const int rb = wm * (32 * MI) + 4 * (lane >> 5), cb = wn * 64 + (lane & 31);
-        static_for<MI * 32>([&](auto ic) {
-            constexpr int idx = decltype(ic)::v;
-            constexpr int i = idx >> 5, j = (idx >> 4) & 1, r = idx & 15;
-            cs[(rb + i * 32 + (r & 3) + 8 * (r >> 2)) * CS_LD + cb + j * 32] = acc[i][j][r];
-        });
-    }
-    __syncthreads();
-    HALO_STAMP(6);
-    if (nsplit > 1 && ep.splitk_ws) {
-        // In-launch split-K reduction (placement-independent: agent-scope release / acquire around one arrival ticket).
-        // Every split publishes its fp32 partial tile as a slab; the LAST arriver adds the other slabs to its own
-        // LDS-resident partial and runs the fused epilogue.  Counters return to zero, so no memset between launches.
-                const long long tile_id = (long long)batch * ntiles + bx;
-        float* slabs = ep.splitk_ws + tile_id * nsplit * (TILE * TILE);
-        float* mine = slabs + (long long)by * (TILE * TILE);
-        for (int v = tid; v < TILE * TILE / 4; v += NT) {
-            const int r = v >> 5, c4 = (v & 31) << 2;
-            *reinterpret_cast<f32x4*>(mine + r * TILE + c4) = *reinterpret_cast<const f32x4*>(cs + r * CS_LD + c4);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        float* flag = cs + TILE;                     // row 0, first padding column: the one shared array holds the flag too
-        if (tid == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const unsigned ticket = __hip_atomic_fetch_add(ep.splitk_cnt + tile_id, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            *flag = (ticket == (unsigned)(nsplit - 1)) ? 1.f : 0.f;
-        }
-        __syncthreads();
-        if (*flag == 0.f) return;
-        if (tid == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            __hip_atomic_store(ep.splitk_cnt + tile_id, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        __syncthreads();
-        // fixed summation order (slab 0, 1, 2, ...) whichever block happens to arrive last: bit-deterministic results
-        for (int v = tid; v < TILE * TILE / 4; v += NT) {
-            const int r = v >> 5, c4 = (v & 31) << 2;
-            const f32x4 own = *reinterpret_cast<const f32x4*>(cs + r * CS_LD + c4);
-            f32x4 a = (by == 0) ? own : *reinterpret_cast<const f32x4*>(slabs + r * TILE + c4);
-            for (int sp = 1; sp < nsplit; ++sp) {
-                const f32x4 b = (sp == (int)by) ? own : *reinterpret_cast<const f32x4*>(slabs + (long long)sp * (TILE * TILE) + r * TILE + c4);
-                a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
-            }
-            *reinterpret_cast<f32x4*>(cs + r * CS_LD + c4) = a;
-        }
-        __syncthreads();
-    }
     auto rowmap = [&](int rl) { const int row = tm * TILE + rl; return row < M ? row : -1; };
-    if (ep.mode == 0) epilogue_rows<T, T, NT, TILE, TILE>(ep, cs, batch, rowmap, tn * TILE, N, tid, bias_t);
-    else if (ep.mode == 1) epilogue_rows<T, float, NT, TILE, TILE>(ep, cs, batch, rowmap, tn * TILE, N, tid, bias_f);
-    else epilogue_scatter<NT>(ep, cs, batch, tm * TILE, tn * TILE, M, N, tid, by);
+    // accumulators -> fp32 LDS staging (+ the in-launch split-K reduction); false: this block only contributed a slab
+    auto stage = [&]() -> bool {
+        {
+            const int rb = wm * (32 * MI) + 4 * (lane >> 5), cb = wn * 64 + (lane & 31);
+            static_for<MI * 32>([&](auto ic) {
+                constexpr int idx = decltype(ic)::v;
+                constexpr int i = idx >> 5, j = (idx >> 4) & 1, r = idx & 15;
+                cs[(rb + i * 32 + (r & 3) + 8 * (r >> 2)) * CS_LD + cb + j * 32] = acc[i][j][r];
+            });
+        }
+        __syncthreads();
+        HALO_STAMP(6);
+        if (nsplit > 1 && ep.splitk_ws) {
+            // In-launch split-K reduction (placement-independent: agent-scope release / acquire around one arrival ticket).
+            // Every split publishes its fp32 partial tile as a slab; the LAST arriver adds the other slabs to its own
+            // LDS-resident partial and runs the fused epilogue.  Counters return to zero, so no memset between launches.
+                    const long long tile_id = (long long)batch * ntiles + bx;
+            float* slabs = ep.splitk_ws + tile_id * nsplit * (TILE * TILE);
+            float* mine = slabs + (long long)by * (TILE * TILE);
+            for (int v = tid; v < TILE * TILE / 4; v += NT) {
+                const int r = v >> 5, c4 = (v & 31) << 2;
+                *reinterpret_cast<f32x4*>(mine + r * TILE + c4) = *reinterpret_cast<const f32x4*>(cs + r * CS_LD + c4);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            float* flag = cs + TILE;                     // row 0, first padding column: the one shared array holds the flag too
+            if (tid == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const unsigned ticket = __hip_atomic_fetch_add(ep.splitk_cnt + tile_id, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                *flag = (ticket == (unsigned)(nsplit - 1)) ? 1.f : 0.f;
+            }
+            __syncthreads();
+            if (*flag == 0.f) return false;
+            if (tid == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                __hip_atomic_store(ep.splitk_cnt + tile_id, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __syncthreads();
+            // fixed summation order (slab 0, 1, 2, ...) whichever block happens to arrive last: bit-deterministic results
+            for (int v = tid; v < TILE * TILE / 4; v += NT) {
+                const int r = v >> 5, c4 = (v & 31) << 2;
+                const f32x4 own = *reinterpret_cast<const f32x4*>(cs + r * CS_LD + c4);
+                f32x4 a = (by == 0) ? own : *reinterpret_cast<const f32x4*>(slabs + r * TILE + c4);
+                for (int sp = 1; sp < nsplit; ++sp) {
+                    const f32x4 b = (sp == (int)by) ? own : *reinterpret_cast<const f32x4*>(slabs + (long long)sp * (TILE * TILE) + r * TILE + c4);
+                    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+                }
+                *reinterpret_cast<f32x4*>(cs + r * CS_LD + c4) = a;
+            }
+            __syncthreads();
+        }
+        return true;
+    };
+    if (ep.mode == 0) {
+        RowEpilogue<T, T, NT, TILE, TILE, decltype(rowmap)> re(ep, batch, rowmap, tn * TILE, N, tid);
+        re.load(0);
+        if (!stage()) return;
+        re.finish_all(cs, bias_v);
+    } else if (ep.mode == 1) {
+        RowEpilogue<T, float, NT, TILE, TILE, decltype(rowmap)> re(ep, batch, rowmap, tn * TILE, N, tid);
+        re.load(0);
+        if (!stage()) return;
+        re.finish_all(cs, *reinterpret_cast<float(*)[4]>(bias_v));
+    } else {
+        if (!stage()) return;
+        epilogue_scatter<NT>(ep, cs, batch, tm * TILE, tn * TILE, M, N, tid, by);
+    }
     HALO_STAMP(4); HALO_WALL(5);
 }
 
@@ -735,6 +765,9 @@ void gemm64_kernel(MatDesc A, MatDesc B, Epilogue ep, int M, int N, int K, int t
     Loader<T, false, 4, T64> la(A, batch, tm * T64, tid);
     Loader<T, false, 4, T64> lb(B, batch, tn * T64, tid);
     f32x16 acc0 = (f32x16)(0.f), acc1 = (f32x16)(0.f);   // two accumulators: consecutive MFMAs do not wait on each other
+    float bias_t[Elem<T>::VEC], bias_f[4];                // requested now, consumed in the epilogue
+    if (ep.mode == 0) epilogue_bias<T, NT, T64>(ep, tn * T64, N, tid, bias_t);
+    else epilogue_bias<float, NT, T64>(ep, tn * T64, N, tid, bias_f);
     const int ngroups = ((K + BK - 1) / BK + G64 - 1) / G64;
     // one group = G64 stages = 8 LDS-DMA instructions per wave (K-steps past the end fetch zeros: out-of-range offsets)
     auto issue_group = [&](int grp, int slot) {
@@ -783,9 +816,10 @@ void gemm64_kernel(MatDesc A, MatDesc B, Epilogue ep, int M, int N, int K, int t
     // epilogue: fp32 staging [64][68]
     constexpr int LD64 = T64 + 4;
     float* cs = reinterpret_cast<float*>(smem);
-    float bias_t[Elem<T>::VEC], bias_f[4];
-    if (ep.mode == 0) epilogue_bias<T, NT, T64>(ep, tn * T64, N, tid, bias_t);
-    else epilogue_bias<float, NT, T64>(ep, tn * T64, N, tid, bias_f);
+    auto rowmap = [&](int rl) { const int row = tm * T64 + rl; return row < M ? row : -1; };
+    RowEpilogue<T, T, NT, T64, T64, decltype(rowmap)> re_t(ep, batch, rowmap, tn * T64, N, tid);
+    RowEpilogue<T, float, NT, T64, T64, decltype(rowmap)> re_f(ep, batch, rowmap, tn * T64, N, tid);
+    if (ep.mode == 0) re_t.load(0); else re_f.load(0);
     {
         const int rb = wm * 32 + 4 * (lane >> 5), cb = wn * 32 + (lane & 31);
         static_for<16>([&](auto ic) {
@@ -795,9 +829,8 @@ void gemm64_kernel(MatDesc A, MatDesc B, Epilogue ep, int M, int N, int K, int t
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    auto rowmap = [&](int rl) { const int row = tm * T64 + rl; return row < M ? row : -1; };
-    if (ep.mode == 0) epilogue_rows<T, T, NT, T64, T64>(ep, cs, batch, rowmap, tn * T64, N, tid, bias_t);
-    else epilogue_rows<T, float, NT, T64, T64>(ep, cs, batch, rowmap, tn * T64, N, tid, bias_f);
+    if (ep.mode == 0) re_t.finish_all(cs, bias_t);
+    else re_f.finish_all(cs, bias_f);
 }
 template __global__ void gemm64_kernel<bf16_t, 2>(MatDesc, MatDesc, Epilogue, int, int, int, int, int);
 template __global__ void gemm64_kernel<bf16_t, 3>(MatDesc, MatDesc, Epilogue, int, int, int, int, int);
@@ -923,6 +956,8 @@ void conv3x3_halo_kernel(Conv3Args a, int tiles_n, int xcd) {
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = (f32x16)(0.f);
+    float bias[8];                                        // requested now, consumed in the epilogue
+    epilogue_bias<T, 512>(a.ep, tn * TILE, a.N, tid, bias);
 
     const int ni = (HP * 8 + 511) / 512;                 // halo DMA parts actually needed
     // GNF: halo chunk cc is normalised in place in its buffer `hb`.  gn_coef puts the per-channel scale / shift of the
@@ -1038,8 +1073,13 @@ void conv3x3_halo_kernel(Conv3Args a, int tiles_n, int xcd) {
     // epilogue: the whole 256 x 128 fp32 tile is staged at once (132 KiB of the now idle LDS) — one barrier, then every
     // thread streams 16-byte vectors out; nothing waits for the stores to be acknowledged.
     float* cs = reinterpret_cast<float*>(smem);
-    float bias[8];
-    epilogue_bias<T, 512>(a.ep, tn * TILE, a.N, tid, bias);
+    auto rowmap = [&](int p) {
+        const int il = p >> a.lPP, qq = p & ((1 << a.lPP) - 1);
+        const int gi = img0 + il;
+        return gi < a.B ? (gi * a.H + py0 + (qq >> a.lPW)) * a.W + px0 + (qq & (a.PW - 1)) : -1;
+    };
+    RowEpilogue<T, T, 512, 256, TILE, decltype(rowmap)> re(a.ep, 0, rowmap, tn * TILE, a.N, tid);
+    re.load(0);
     {
         const int rb = wm * 64 + 4 * (lane >> 5), cb = wn * 64 + (lane & 31);
         static_for<64>([&](auto ic) {
@@ -1051,12 +1091,7 @@ void conv3x3_halo_kernel(Conv3Args a, int tiles_n, int xcd) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     HALO_STAMP(6);
-    auto rowmap = [&](int p) {
-        const int il = p >> a.lPP, qq = p & ((1 << a.lPP) - 1);
-        const int gi = img0 + il;
-        return gi < a.B ? (gi * a.H + py0 + (qq >> a.lPW)) * a.W + px0 + (qq & (a.PW - 1)) : -1;
-    };
-    epilogue_rows<T, T, 512, 256, TILE>(a.ep, cs, 0, rowmap, tn * TILE, a.N, tid, bias);
+    re.finish_all(cs, bias);
     HALO_STAMP(4); HALO_WALL(5);
 }
 
