@@ -117,41 +117,42 @@ def main():
     loss = tr.current_stats["loss"]
 
     out = None
+    # ---- roofline of the dominant kernel: per-launch HIP events (recorded on the stream each kernel is launched on) over
+    # one more training step.  The product runs the weight-gradient kernels on a side stream NEXT to the critical path, so
+    # a launch's duration includes the slowdown from sharing the chip; `isolated` repeats the measurement with that
+    # overlap switched off (every kernel alone on the GPU), which is what says how good each kernel is by itself.
+    import ddpm_torch.models.unet as unet_mod
+    VARIANT = {1: "gemm_kernel<4 waves,128x128>", 2: "gemm_kernel<8 waves,128x128>", 3: "gemm_kernel<deep ring,128x128>",
+               4: "gemm64_kernel<64x64>", 5: "conv3x3_halo_kernel<256px x 128>"}
+    peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3
+
+    def profile_step(step_no):
+        _ops.PROFILE = []
+        tr.step(x0, global_steps=step_no)
+        torch.cuda.synchronize()
+        prof, _ops.PROFILE = _ops.PROFILE, None
+        agg, shapes = {}, {}
+        for kind, flops, a, b, shape, variant in prof:
+            dt_s = a.elapsed_time(b) * 1e-3
+            name = VARIANT.get(variant, "other") + (" wgrad (both operands k-strided)" if kind == "gemm_tt" else "")
+            e = agg.setdefault(name, [0, 0.0, 0.0])
+            e[0] += 1; e[1] += flops; e[2] += dt_s
+            e2 = shapes.setdefault(f"{name} | {kind} {shape}", [0, 0.0, 0.0])
+            e2[0] += 1; e2[1] += flops; e2[2] += dt_s
+        return agg, shapes
+
+    def table(agg):
+        return {k: {"launches": v[0], "gflop": round(v[1] / 1e9, 1), "ms": round(v[2] * 1e3, 3), "tflops": round(v[1] / v[2] / 1e12, 1),
+                    "avg_launch_us": round(v[2] / v[0] * 1e6, 2), "frac": round(v[1] / v[2] / 1e12 / peak, 4)}
+                for k, v in sorted(agg.items(), key=lambda kv: -kv[1][2])}
+
+    agg, shapes = profile_step(args.warmup + args.steps + 1)
+    side_was = unet_mod._SIDE_STREAM
+    unet_mod._SIDE_STREAM = False
+    agg_iso, shapes_iso = profile_step(args.warmup + args.steps + 2)
+    unet_mod._SIDE_STREAM = side_was
+    # (every rank ran the two extra steps above: with N > 1 they contain the gradient all-reduce and the loss reduce)
     if rank == 0:
-        # ---- roofline of the dominant kernel: per-launch HIP events (recorded on the stream each kernel is launched on) over
-        # one more training step.  The product runs the weight-gradient kernels on a side stream NEXT to the critical path, so
-        # a launch's duration includes the slowdown from sharing the chip; `isolated` repeats the measurement with that
-        # overlap switched off (every kernel alone on the GPU), which is what says how good each kernel is by itself.
-        import ddpm_torch.models.unet as unet_mod
-        VARIANT = {1: "gemm_kernel<4 waves,128x128>", 2: "gemm_kernel<8 waves,128x128>", 3: "gemm_kernel<deep ring,128x128>",
-                   4: "gemm64_kernel<64x64>", 5: "conv3x3_halo_kernel<256px x 128>"}
-        peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3
-
-        def profile_step(step_no):
-            _ops.PROFILE = []
-            tr.step(x0, global_steps=step_no)
-            torch.cuda.synchronize()
-            prof, _ops.PROFILE = _ops.PROFILE, None
-            agg, shapes = {}, {}
-            for kind, flops, a, b, shape, variant in prof:
-                dt_s = a.elapsed_time(b) * 1e-3
-                name = VARIANT.get(variant, "other") + (" wgrad (both operands k-strided)" if kind == "gemm_tt" else "")
-                e = agg.setdefault(name, [0, 0.0, 0.0])
-                e[0] += 1; e[1] += flops; e[2] += dt_s
-                e2 = shapes.setdefault(f"{name} | {kind} {shape}", [0, 0.0, 0.0])
-                e2[0] += 1; e2[1] += flops; e2[2] += dt_s
-            return agg, shapes
-
-        def table(agg):
-            return {k: {"launches": v[0], "gflop": round(v[1] / 1e9, 1), "ms": round(v[2] * 1e3, 3), "tflops": round(v[1] / v[2] / 1e12, 1),
-                        "avg_launch_us": round(v[2] / v[0] * 1e6, 2), "frac": round(v[1] / v[2] / 1e12 / peak, 4)}
-                    for k, v in sorted(agg.items(), key=lambda kv: -kv[1][2])}
-
-        agg, shapes = profile_step(args.warmup + args.steps + 1)
-        side_was = unet_mod._SIDE_STREAM
-        unet_mod._SIDE_STREAM = False
-        agg_iso, shapes_iso = profile_step(args.warmup + args.steps + 2)
-        unet_mod._SIDE_STREAM = side_was
         if os.environ.get("BENCH_SHAPES"):
             with open(os.environ["BENCH_SHAPES"], "w") as f:
                 for k, v in sorted(shapes_iso.items(), key=lambda kv: -kv[1][2]):
