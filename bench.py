@@ -189,6 +189,19 @@ def main():
                 "samples_per_s_1000_steps": round(B_PER_GPU / (s_el / S * 1000), 4),
                 "model_tflops": round(B_PER_GPU * FWD_GFLOP_PER_SAMPLE / (s_el / S) / 1e3, 1),
                 "mode": "hipGraph replay of the captured step" if os.environ.get("DDPM_TORCH_AMD_GRAPH", "1") != "0" else "eager"}
+        # batch sweep (SURVEY.md §8d "M2: B=128 and a sweep"): 50-step chains (identical per-step work), scaled to 1000 steps
+        sweep = {}
+        if S == 1000 and not os.environ.get("BENCH_NO_SWEEP"):
+            swdif = ddpm_torch.GaussianDiffusion(ddpm_torch.get_beta_schedule("linear", 1e-4, 0.02, 50), "eps", "fixed-large", "mse")
+            for sb in (32, 256, 512):
+                swdif.p_sample(model, shape=(sb, 3, 32, 32), device=dev, seed=3)      # capture / warm-up for this batch size
+                torch.cuda.synchronize()
+                w0 = time.perf_counter()
+                swdif.p_sample(model, shape=(sb, 3, 32, 32), device=dev, seed=4)
+                torch.cuda.synchronize()
+                w_el = (time.perf_counter() - w0) / 50
+                sweep[str(sb)] = {"ms_per_step": round(w_el * 1e3, 3), "samples_per_s_1000_steps": round(sb / (w_el * 1000), 3)}
+            samp["batch_sweep"] = sweep
         out = {"metric": "training imgs/s/GPU + 1000-step DDPM samples/s, CIFAR-10 UNet @1/2/4/8 MI355X",
                "value": round(imgs_per_s, 2), "unit": "imgs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
