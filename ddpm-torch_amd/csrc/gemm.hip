@@ -859,6 +859,7 @@ struct Conv3Args {
     const float* gn_stats;            // [B][G][2] = (mean, rstd) of x
     const float* gn_gamma; const float* gn_beta;
     int gn_G, gn_cpg, gn_silu;
+    FastDiv d_tiles_n, d_tpi, d_tiles_x, d_halo_img, d_halo_w;     // host-prepared divisors: no runtime integer division in the prologue
     Epilogue ep;
 };
 constexpr int C3_NI = 7;              // halo DMA parts of 512 vectors: up to 448 halo pixels x 8 chunks
@@ -882,10 +883,10 @@ void conv3x3_halo_kernel(Conv3Args a, int tiles_n, int xcd) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int lid = xcd_logical_id(blockIdx.x, gridDim.x, xcd);
-    const int tmi = lid / tiles_n, tn = lid - tmi * tiles_n;
+    const int tmi = (int)fdiv((unsigned)lid, a.d_tiles_n), tn = lid - tmi * tiles_n;
     const int tpi = a.tiles_y * a.tiles_x;
-    const int grp = tmi / tpi, pt = tmi - grp * tpi;
-    const int ty = pt / a.tiles_x, tx = pt - ty * a.tiles_x;
+    const int grp = (int)fdiv((unsigned)tmi, a.d_tpi), pt = tmi - grp * tpi;
+    const int ty = (int)fdiv((unsigned)pt, a.d_tiles_x), tx = pt - ty * a.tiles_x;
     const int py0 = ty * a.PH, px0 = tx * a.PW, img0 = grp * a.NB;
     const int HH = a.PH + 2, HWd = a.PW + 2, HP = a.NB * HH * HWd;
     const int ES = 2;
@@ -907,8 +908,8 @@ void conv3x3_halo_kernel(Conv3Args a, int tiles_n, int xcd) {
 #pragma unroll
     for (int i = 0; i < C3_NI; ++i) {
         const int v = tid + 512 * i, hp = v >> 3;
-        const int img = hp / (HH * HWd), rem = hp - img * (HH * HWd);
-        const int hy = rem / HWd, hx = rem - hy * HWd;
+        const int img = (int)fdiv((unsigned)hp, a.d_halo_img), rem = hp - img * (HH * HWd);
+        const int hy = (int)fdiv((unsigned)rem, a.d_halo_w), hx = rem - hy * HWd;
         const int iy = py0 + hy - 1, ix = px0 + hx - 1, gi = img0 + img;
         const bool ok = hp < HP && gi < a.B && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
         const int lc = (v & 7) ^ (((hx >> 1) ^ ((hy & a.ky) << 2)) & 7);
@@ -979,7 +980,7 @@ void conv3x3_halo_kernel(Conv3Args a, int tiles_n, int xcd) {
         if (ho == OOB) return;
         const float* coef = reinterpret_cast<const float*>(hb + HP * ROW_BYTES);
         const int v = tid + 512 * i, hp = v >> 3;                    // NB == 1: one image per block
-        const int hy = hp / HWd, hx = hp - hy * HWd;
+        const int hy = (int)fdiv((unsigned)hp, a.d_halo_w), hx = hp - hy * HWd;
         const int lc = (v & 7) ^ (((hx >> 1) ^ ((hy & a.ky) << 2)) & 7);
         u32x4* pv = reinterpret_cast<u32x4*>(hb + v * 16);
         float f[8];
@@ -1294,6 +1295,9 @@ static int conv3x3_halo_launch(GemmArgs& g, const void* x, long long x_ld, const
     a.PH = PH; a.PW = PW; a.NB = NB; a.lPW = ilog2(PW); a.lPP = ilog2(PH * PW);
     a.ky = PW == 8 ? 1 : 0;
     a.tiles_y = H / PH; a.tiles_x = W / PW;
+    a.d_tiles_n = make_fastdiv((unsigned)((N + TILE - 1) / TILE)); a.d_tpi = make_fastdiv((unsigned)(a.tiles_y * a.tiles_x));
+    a.d_tiles_x = make_fastdiv((unsigned)a.tiles_x);
+    a.d_halo_img = make_fastdiv((unsigned)((PH + 2) * (PW + 2))); a.d_halo_w = make_fastdiv((unsigned)(PW + 2));
     a.ep = g.ep;
     const int groups = (B + NB - 1) / NB, tiles_n = (N + TILE - 1) / TILE;
     const dim3 grid(groups * a.tiles_y * a.tiles_x * tiles_n);
