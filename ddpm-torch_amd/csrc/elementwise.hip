@@ -315,12 +315,14 @@ extern "C" int ddpm_silu_bwd(const float* x, const float* dy, float* dx, long lo
 
 // ------------------------------------------------------------------ column sums of an NHWC gradient (bias / time-bias grads)
 // per_sample[b][c] += sum_p dy[b][p][c]   and/or   total[c] += sum_{b,p} dy   (both fp32 atomics into zero-initialised
-// buffers; grid = (pixel slabs, B) so that large activations use every CU)
+// buffers; grid = (pixel slabs, B)).  Every block ends with one atomic per channel on the SAME C addresses of `total`, and
+// same-address atomics serialise at ~27 ns each: with ~1024 small blocks the kernel took 28 us whatever the tensor size.
+// Hence few (~256) large blocks of 1024 threads: 4x fewer atomics per address, still 16 waves per CU for the streaming.
 template <typename T>
 __global__ void colsum_kernel(const T* __restrict__ dy, long long ld, float* __restrict__ per_sample, long long ps_ld,
                               float* __restrict__ total, int HW, int C, int pix_per_slab) {
     constexpr int VEC = Elem<T>::VEC;
-    __shared__ float sh[2048];
+    __shared__ float sh[8192];
     const int b = blockIdx.y;
     const int cx = threadIdx.x, py = threadIdx.y;
     const int t = threadIdx.y * blockDim.x + threadIdx.x, nt = blockDim.x * blockDim.y;
@@ -329,6 +331,7 @@ __global__ void colsum_kernel(const T* __restrict__ dy, long long ld, float* __r
 #pragma unroll
     for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
     const T* base = dy + (long long)b * HW * ld + cx * VEC;
+#pragma unroll 4
     for (int p = p0 + py; p < p1; p += blockDim.y) {
         float f[VEC];
         Elem<T>::unpack(ldg16(base + (long long)p * ld), f);
@@ -336,7 +339,7 @@ __global__ void colsum_kernel(const T* __restrict__ dy, long long ld, float* __r
         for (int j = 0; j < VEC; ++j) acc[j] += f[j];
     }
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) sh[py * C + cx * VEC + j] = acc[j];          // [PY][C] scratch, PY*C <= 2048
+    for (int j = 0; j < VEC; ++j) sh[py * C + cx * VEC + j] = acc[j];          // [PY][C] scratch, PY*C <= 8192
     __syncthreads();
     for (int c = t; c < C; c += nt) {
         float a = 0.f;
@@ -351,8 +354,8 @@ extern "C" int ddpm_colsum(const void* dy, long long ld, float* per_sample, long
     if (C % vec || ld % vec || C > 2048 || C / vec > 256) return DDPM_ERR_SHAPE;
     if (!aligned16(dy)) return DDPM_ERR_ALIGN;
     const int cv = C / vec;
-    int py = 256 / cv; if (py > HW) py = HW; if (py < 1) py = 1;
-    int S = (1024 + B - 1) / B;                       // ~1024 blocks in total, >= 4 pixel iterations each
+    int py = 1024 / cv; if (py > HW) py = HW; if (py < 1) py = 1;
+    int S = (256 + B - 1) / B;                        // ~256 blocks in total, >= 4 pixel iterations each
     const int maxS = (HW + 4 * py - 1) / (4 * py);
     if (S > maxS) S = maxS;
     if (S < 1) S = 1;

@@ -34,6 +34,7 @@ __global__ void gn_stats_kernel(const T* __restrict__ x, GnShape s, float* __res
 #pragma unroll
     for (int j = 0; j < VEC; ++j) sum[j] = sq[j] = 0.f;
     const T* xb = x + ((long long)b * s.HW) * s.x_ld + cx * VEC;
+#pragma unroll 4
     for (int p = p0 + py; p < p1; p += PY) {
         float f[VEC];
         Elem<T>::unpack(ldg16(xb + (long long)p * s.x_ld), f);
@@ -409,6 +410,7 @@ __global__ void gn_bwd_reduce_kernel(const T* __restrict__ x, const T* __restric
     const float keep_scale = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
     const T* xb = x + ((long long)b * s.HW) * s.x_ld + cx * VEC;
     const T* db = dy + ((long long)b * s.HW) * dy_ld + cx * VEC;
+#pragma unroll 4
     for (int p = p0 + py; p < p1; p += PY) {
         float f[VEC], d[VEC];
         Elem<T>::unpack(ldg16(xb + (long long)p * s.x_ld), f);
