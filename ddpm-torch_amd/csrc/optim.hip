@@ -73,17 +73,28 @@ extern "C" int ddpm_adam_ema_step(float* p, const float* g, float* m, float* v, 
 // ---------------------------------------------------------------------------------------------- multi-tensor forms
 // One launch over ALL parameter tensors (304 for the CIFAR UNet).  table[i] = {p, g, m, v, shadow (or 0), numel} as int64;
 // grid = (blocks per tensor, n_tensors), grid-stride inside a tensor.
+// total_sq is a bank of MT_SUMSQ_LANES accumulators: ~5000 blocks ending in an atomic on ONE address serialise at ~27 ns each
+// (the kernel took 127 us for 143 MB); striped over 64 addresses the atomics vanish under the streaming read.
+constexpr int MT_SUMSQ_LANES = 64;
 __global__ void mt_sumsq_kernel(const long long* __restrict__ table, float* __restrict__ total_sq) {
     __shared__ float sh[4];
     const long long* row = table + 6 * (long long)blockIdx.y;
     const float* g = reinterpret_cast<const float*>(row[1]);
     const long long n = row[5];
     float acc = 0.f;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) acc += g[i] * g[i];
+    const long long nv = (reinterpret_cast<unsigned long long>(g) & 15) == 0 ? n >> 2 : 0;      // float4 body when aligned
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long long)gridDim.x * blockDim.x) {
+        const float4 v = reinterpret_cast<const float4*>(g)[i];
+        acc += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    }
+    for (long long i = (nv << 2) + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) acc += g[i] * g[i];
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) { const float s = sh[0] + sh[1] + sh[2] + sh[3]; if (s != 0.f) atomicAdd(total_sq, s); }
+    if (threadIdx.x == 0) {
+        const float s = sh[0] + sh[1] + sh[2] + sh[3];
+        if (s != 0.f) atomicAdd(total_sq + ((blockIdx.y * gridDim.x + blockIdx.x) & (MT_SUMSQ_LANES - 1)), s);
+    }
 }
 __global__ void mt_adam_ema_kernel(const long long* __restrict__ table, const float* __restrict__ total_sq, float max_norm, float lr,
                                    float beta1, float beta2, float eps, float bc1, float bc2, float ema_w) {
@@ -96,23 +107,42 @@ __global__ void mt_adam_ema_kernel(const long long* __restrict__ table, const fl
     const long long n = row[5];
     float clip = 1.f;
     if (total_sq && max_norm > 0.f) {
-        const float c = max_norm / (sqrtf(total_sq[0]) + 1e-6f);
+        float tot = 0.f;
+        for (int i = 0; i < MT_SUMSQ_LANES; ++i) tot += total_sq[i];           // fixed order: every block gets the same value
+        const float c = max_norm / (sqrtf(tot) + 1e-6f);
         clip = c < 1.f ? c : 1.f;
     }
     const float step = lr / bc1;
     const float sqrt_bc2 = sqrtf(bc2);
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        const float gi = g[i] * clip;
-        const float mi = beta1 * m[i] + (1.f - beta1) * gi;
-        const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
-        m[i] = mi; v[i] = vi;
+    auto upd = [&](float& pi, float gi, float& mi, float& vi, float& si) {
+        gi *= clip;
+        mi = beta1 * mi + (1.f - beta1) * gi;
+        vi = beta2 * vi + (1.f - beta2) * gi * gi;
         const float denom = sqrtf(vi) / sqrt_bc2 + eps;             // torch.optim.Adam: (sqrt(v) / sqrt(bias_correction2)) + eps
-        const float pi = p[i] - step * (mi / denom);
-        p[i] = pi;
-        if (shadow) shadow[i] += ema_w * (pi - shadow[i]);
+        pi = pi - step * (mi / denom);
+        si += ema_w * (pi - si);
+    };
+    // 16-byte body when every array is aligned (parameters, flat gradient slices and optimizer state all are), scalar tail
+    const unsigned long long al = reinterpret_cast<unsigned long long>(p) | reinterpret_cast<unsigned long long>(g) | reinterpret_cast<unsigned long long>(m) |
+                                  reinterpret_cast<unsigned long long>(v) | reinterpret_cast<unsigned long long>(shadow);
+    const long long nv = (al & 15) == 0 ? n >> 2 : 0;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long long)gridDim.x * blockDim.x) {
+        float4 p4 = reinterpret_cast<float4*>(p)[i], m4 = reinterpret_cast<float4*>(m)[i], v4 = reinterpret_cast<float4*>(v)[i];
+        const float4 g4 = reinterpret_cast<const float4*>(g)[i];
+        float4 s4 = shadow ? reinterpret_cast<float4*>(shadow)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        upd(p4.x, g4.x, m4.x, v4.x, s4.x); upd(p4.y, g4.y, m4.y, v4.y, s4.y);
+        upd(p4.z, g4.z, m4.z, v4.z, s4.z); upd(p4.w, g4.w, m4.w, v4.w, s4.w);
+        reinterpret_cast<float4*>(p)[i] = p4; reinterpret_cast<float4*>(m)[i] = m4; reinterpret_cast<float4*>(v)[i] = v4;
+        if (shadow) reinterpret_cast<float4*>(shadow)[i] = s4;
+    }
+    for (long long i = (nv << 2) + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        float pi = p[i], mi = m[i], vi = v[i], si = shadow ? shadow[i] : 0.f;
+        upd(pi, g[i], mi, vi, si);
+        p[i] = pi; m[i] = mi; v[i] = vi;
+        if (shadow) shadow[i] = si;
     }
 }
-// total_sq[0] must be zero on entry to the norm pass.
+// the total_sq bank must be zero on entry to the norm pass.
 extern "C" int ddpm_mt_grad_sumsq(const long long* table, int n_tensors, float* total_sq, void* stream) {
     if (!table || !total_sq) return DDPM_ERR_NULL;
     if (n_tensors <= 0) return DDPM_OK;

@@ -64,7 +64,7 @@ class _FusedUpdate:
             rows.append([p.data_ptr(), 0, st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), 0 if sh is None else sh.data_ptr(), p.numel()])
         self.host = torch.tensor(rows, dtype=torch.int64).pin_memory()
         self.table = torch.empty_like(self.host, device=dev)
-        self.total = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.total = torch.zeros(64, dtype=torch.float32, device=dev)      # striped ||g||^2 accumulators (ddpm_mt_grad_sumsq)
         self.key = [p.data_ptr() for p in self.params]
         self.steps = int(self.opt.state[self.params[0]]["step"].item())
 

@@ -166,7 +166,9 @@ int ddpm_adam_ema_step(float* p, const float* g, float* m, float* v, float* shad
                        float ema_w, void* stream);
 
 /* multi-tensor forms: ONE launch over every parameter tensor.  table[i] = {p, g, m, v, shadow (0 = none), numel} (int64).
- * ddpm_mt_grad_sumsq: total_sq[0] (zero on entry) += sum ||g_i||^2.  ddpm_mt_adam_ema: the fused update above for all i. */
+ * ddpm_mt_grad_sumsq: total_sq is a bank of 64 floats (zero on entry) whose SUM receives sum ||g_i||^2 (striped so that the
+ * final atomics of ~5000 blocks do not serialise on one address).  ddpm_mt_adam_ema: the fused update above for all i, with the
+ * clipping norm taken from the sum of that bank. */
 int ddpm_mt_grad_sumsq(const long long* table, int n_tensors, float* total_sq, void* stream);
 int ddpm_mt_adam_ema(const long long* table, int n_tensors, const float* total_sq, float max_norm, float lr, float beta1,
                      float beta2, float eps, float bias_corr1, float bias_corr2, float ema_w, void* stream);
