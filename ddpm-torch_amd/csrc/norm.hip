@@ -641,7 +641,11 @@ extern "C" int ddpm_groupnorm_silu_bwd(const void* x, long long x_ld, const void
     hipStream_t st = (hipStream_t)stream;
     GnFused f; size_t lds = 0;
     static const bool no_fused = getenv("DDPM_GN_NO_FUSED") != nullptr || getenv("DDPM_GN_NO_FUSED_BWD") != nullptr;
-    if (!no_fused && gn_fused_plan(s, es, f, lds)) {      // register-resident single launch (x, dy read once, dx written once)
+    // register-resident single launch (x, dy read once, dx written once) — for the small slices only: with x AND dy held in
+    // registers the kernel needs > 128 VGPRs from 8 vectors per thread on and then cannot share a CU with the weight-gradient
+    // blocks of the side stream; measured end to end (6 alternating pairs) the two streaming launches are 0.13 ms per step
+    // faster on the 16^2 / 32^2 tensors, while the 4^2 / 8^2 tensors (<= 2 vectors per thread) keep the single launch.
+    if (!no_fused && gn_fused_plan(s, es, f, lds) && f.nv <= 2) {
         const dim3 fgrid(G / f.GPB, B);
 #define GN_BWD(T, NV) do { if (f.nt == 512) hipLaunchKernelGGL((gn_reg_bwd_kernel<T, NV, 512>), fgrid, dim3(512), lds, st, (const T*)x, (const T*)dy, (T*)dx, s, f, dy_ld, dx_ld, stats, dgamma, dbeta, a, accumulate); \
                            else hipLaunchKernelGGL((gn_reg_bwd_kernel<T, NV, 256>), fgrid, dim3(256), lds, st, (const T*)x, (const T*)dy, (T*)dx, s, f, dy_ld, dx_ld, stats, dgamma, dbeta, a, accumulate); } while (0)
