@@ -523,7 +523,10 @@ __device__ __forceinline__ int xcd_logical_id(int id, int total, int xcd) {
 #define DEEP_ISSUE_KC 1
 #endif
 
-template <typename T, bool TA, bool TB, int NBUF, int NW>
+// SCAT: instantiation for the scatter / atomic output modes only (the weight-gradient products): without the row epilogue's
+// prefetch registers the kernel needs fewer VGPRs, which leaves room on the SIMDs for the critical-path kernels that run
+// next to it on the other stream.
+template <typename T, bool TA, bool TB, int NBUF, int NW, bool SCAT = false>
 __global__ __launch_bounds__(NW * 64, NW / 2)
 void gemm_kernel(MatDesc A, MatDesc B, Epilogue ep, int M, int N, int K, int k_per_split, int tiles_n, int xcd) {
     HALO_WALL(0); HALO_STAMP(1);
@@ -559,8 +562,10 @@ void gemm_kernel(MatDesc A, MatDesc B, Epilogue ep, int M, int N, int K, int k_p
 
     // bias of this thread's output columns: requested now, consumed in the epilogue (its latency hides under the K loop)
     float bias_v[Elem<T>::VEC];                            // mode 1 (fp32 output, 4 columns per thread) uses the first four
-    if (ep.mode == 0) epilogue_bias<T, NT>(ep, tn * TILE, N, tid, bias_v);
-    else if (ep.mode == 1) epilogue_bias<float, NT>(ep, tn * TILE, N, tid, *reinterpret_cast<float(*)[4]>(bias_v));
+    if constexpr (!SCAT) {
+        if (ep.mode == 0) epilogue_bias<T, NT>(ep, tn * TILE, N, tid, bias_v);
+        else if (ep.mode == 1) epilogue_bias<float, NT>(ep, tn * TILE, N, tid, *reinterpret_cast<float(*)[4]>(bias_v));
+    }
 
     u32x4 va[NVEC], vb[NVEC];
     constexpr bool DMA_A = Loader<T, TA, NW>::DMA, DMA_B = Loader<T, TB, NW>::DMA;
@@ -720,7 +725,10 @@ void gemm_kernel(MatDesc A, MatDesc B, Epilogue ep, int M, int N, int K, int k_p
         }
         return true;
     };
-    if (ep.mode == 0) {
+    if constexpr (SCAT) {
+        if (!stage()) return;
+        epilogue_scatter<NT>(ep, cs, batch, tm * TILE, tn * TILE, M, N, tid, by);
+    } else if (ep.mode == 0) {
         RowEpilogue<T, T, NT, TILE, TILE, decltype(rowmap)> re(ep, batch, rowmap, tn * TILE, N, tid);
         re.load(0);
         if (!stage()) return;
@@ -1111,6 +1119,7 @@ INST(bf16_t, true, true, 2, 4) INST(bf16_t, true, true, 2, 8)
 INST(float, false, false, 2, 4) INST(float, false, false, 2, 8) INST(float, false, false, 5, 4) INST(float, false, false, 5, 8)
 INST(float, false, true, 2, 4) INST(float, true, false, 2, 4) INST(float, true, true, 2, 4)
 #undef INST
+template __global__ void gemm_kernel<bf16_t, true, true, 2, 8, true>(MatDesc, MatDesc, Epilogue, int, int, int, int, int, int);
 
 // =====================================================================================================================
 // Fused single-head attention forward (inference): O = softmax(Q K^T * scale) V for one image per blockIdx.y, 128 queries
@@ -1414,7 +1423,20 @@ static int launch_t(GemmArgs& g, hipStream_t st) {
     } else if (g.A.trans && !g.B.trans) {
         if constexpr (BF) { if (w8) LAUNCH(true, false, 2, 8, lds2); else LAUNCH(true, false, 2, 4, lds2); } else LAUNCH(true, false, 2, 4, lds2);
     } else {
-        if constexpr (BF) { if (w8) LAUNCH(true, true, 2, 8, lds2); else LAUNCH(true, true, 2, 4, lds2); } else LAUNCH(true, true, 2, 4, lds2);
+        if constexpr (BF) {
+            static const bool no_scat = getenv("DDPM_GEMM_NO_SCAT") != nullptr;
+            if (w8 && g.ep.mode >= 2 && !no_scat) {          // weight gradients: the scatter-only instantiation
+                static bool attr_set = false;
+                if (!attr_set) {
+                    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, true, true, 2, 8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2) != hipSuccess)
+                        return DDPM_ERR_LAUNCH;
+                    attr_set = true;
+                }
+                hipLaunchKernelGGL((gemm_kernel<T, true, true, 2, 8, true>), grid, dim3(512), lds2, st, g.A, g.B, g.ep, g.M, g.N, g.K, kps, tiles_n, g_xcd_swizzle);
+                g_last_variant = 2;
+            } else if (w8) LAUNCH(true, true, 2, 8, lds2);
+            else LAUNCH(true, true, 2, 4, lds2);
+        } else LAUNCH(true, true, 2, 4, lds2);
     }
 #undef LAUNCH
     return check_launch();
