@@ -89,14 +89,16 @@ extern "C" int ddpm_pack_weight(const float* w, void* wf, void* wd, int N, int C
     return check_launch();
 }
 
-// all layers in ONE launch: descs[i] = {w, wf, wd, N, C, R, Cp, Np} (8 x int64; R == S); grid = (blocks, n_tensors)
+// all layers in ONE launch: descs[i] = {w, wf, wd, N, C, R | flags, Cp, Np} (8 x int64; R == S; flag 0x100: wd receives the
+// 4x4 stride-2 effective dgrad kernel of an upsample conv, see below); grid = (blocks, n_tensors)
 template <typename T>
 __global__ void pack_weight_multi_kernel(const long long* __restrict__ descs) {
     const long long* d = descs + 8 * (long long)blockIdx.y;
     const float* w = reinterpret_cast<const float*>(d[0]);
     T* wf = reinterpret_cast<T*>(d[1]);
     T* wd = reinterpret_cast<T*>(d[2]);
-    const int N = (int)d[3], C = (int)d[4], R = (int)d[5], Cp = (int)d[6], Np = (int)d[7];
+    const int N = (int)d[3], C = (int)d[4], R = (int)d[5] & 0xff, Cp = (int)d[6], Np = (int)d[7];
+    const bool up_dgrad = ((int)d[5] & 0x100) != 0;
     const int RS = R * R;
     if (wf) {
         const long long n = (long long)N * RS * Cp;
@@ -106,7 +108,27 @@ __global__ void pack_weight_multi_kernel(const long long* __restrict__ descs) {
             Elem<T>::st(wf + i, c < C ? w[((long long)nn * C + c) * RS + tap] : 0.f);
         }
     }
-    if (wd) {
+    if (wd && up_dgrad) {
+        // Gradient of (nearest-2x upsample -> 3x3 / pad 1 conv) w.r.t. its LOW-resolution input, as ONE strided conv over dy:
+        //   dx[i][j] = sum_{a,b in {0,1}} sum_{r,s} dy[2i+a+r-1][2j+b+s-1] * D[r][s]        (D = flipped 3x3 dgrad kernel)
+        //            = sum_{P,Q in 0..3} dy[2i+P-1][2j+Q-1] * E[P][Q],   E[P][Q] = sum_{a+r=P} sum_{b+s=Q} D[r][s]
+        // i.e. a 4x4 / stride 2 / pad 1 convolution: 16 taps on a quarter of the pixels instead of 9 taps at full resolution
+        // plus a 2x2 reduction pass.  E is formed in fp32 from the master weights and rounded once.  Layout [C][4][4][Np].
+        const long long n = (long long)C * 16 * Np;
+        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+            const int nn = (int)(i % Np); const long long r1 = i / Np;
+            const int tap = (int)(r1 % 16); const int c = (int)(r1 / 16);
+            const int P = tap >> 2, Q = tap & 3;
+            float acc = 0.f;
+            if (nn < N)
+                for (int a = 0; a < 2; ++a)
+                    for (int b = 0; b < 2; ++b) {
+                        const int r = P - a, s2 = Q - b;
+                        if (r >= 0 && r < 3 && s2 >= 0 && s2 < 3) acc += w[((long long)nn * C + c) * 9 + (8 - (r * 3 + s2))];
+                    }
+            Elem<T>::st(wd + i, acc);
+        }
+    } else if (wd) {
         const long long n = (long long)C * RS * Np;
         for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
             const int nn = (int)(i % Np); const long long r1 = i / Np;

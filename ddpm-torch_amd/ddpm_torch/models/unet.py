@@ -224,7 +224,7 @@ class _UNetFn(torch.autograd.Function):
 
 class _ConvW:
     """Packed device copies of one conv weight, refreshed when the master parameter changes."""
-    __slots__ = ("mod", "N", "C", "R", "Cp", "Np", "wf", "wd", "ver", "src")
+    __slots__ = ("mod", "N", "C", "R", "Cp", "Np", "wf", "wd", "ver", "src", "up")
 
     def __init__(self, mod, vec):
         self.mod = mod
@@ -233,10 +233,12 @@ class _ConvW:
         self.Np = -(-self.N // vec) * vec
         self.wf = self.wd = None
         self.ver = self.src = None
+        self.up = False                # conv behind a nearest-2x upsample: its dgrad pack is the 4x4 / stride-2 effective kernel
 
 
 _WGRAD_TARGET_BLOCKS = int(os.environ.get("DDPM_WGRAD_BLOCKS", "512"))
 _FUSED_ATTENTION = os.environ.get("DDPM_FUSED_ATTENTION", "1") != "0"
+_UP_DGRAD_FUSED = os.environ.get("DDPM_UP_DGRAD_FUSED", "1") != "0"    # upsample convs: dgrad as one 4x4 stride-2 conv
 _FOLD_MAX_CHANNELS = 128
 _FOLD_MIN_PIXELS = 16384            # below this the small-grid kernels serve the layer better than the 256-pixel-tile conv
 _FOLD_GN = os.environ.get("DDPM_FOLD_GN", "1") != "0"               # inference: GroupNorm+SiLU folded into the 3x3 convs
@@ -325,6 +327,7 @@ class _Engine:
                 regblock(mods[j])
             if i != 0:
                 reg(mods[self.n + 1][1])
+                self.convs[id(mods[self.n + 1][1])].up = _UP_DGRAD_FUSED
         reg(m.out_conv[2])
 
     # ---------------------------------------------------------------- derived weight caches
@@ -339,8 +342,8 @@ class _Engine:
                 if cw.wf is None:
                     cw.wf = torch.empty(cw.N * cw.R * cw.R * cw.Cp, dtype=self.T, device=self.device)
                 if need_dgrad and cw.wd is None:
-                    cw.wd = torch.empty(cw.C * cw.R * cw.R * cw.Np, dtype=self.T, device=self.device)
-                rows.append([cw.mod.weight.data_ptr(), cw.wf.data_ptr(), _hip.ptr(cw.wd), cw.N, cw.C, cw.R, cw.Cp, cw.Np])
+                    cw.wd = torch.empty(cw.C * (16 if cw.up else cw.R * cw.R) * cw.Np, dtype=self.T, device=self.device)
+                rows.append([cw.mod.weight.data_ptr(), cw.wf.data_ptr(), _hip.ptr(cw.wd), cw.N, cw.C, cw.R | (0x100 if cw.up else 0), cw.Cp, cw.Np])
             self.pack_table = torch.tensor(rows, dtype=torch.int64, device=self.device)
             self.pack_ptrs, self.pack_has_dgrad, self.pack_key = ptrs, self.pack_has_dgrad or need_dgrad, None
         if key != self.pack_key:
@@ -847,7 +850,12 @@ class _Engine:
         self._bias_grad(ctx, dy, [conv.bias], cw.N)
         if first:
             return                                          # no gradient w.r.t. the input image
-        if upsample:
+        if upsample and cw.up:
+            # d/dx of (nearest-2x upsample -> 3x3 conv) = one 4x4 / stride-2 / pad-1 conv over dy with the summed taps the pack
+            # kernel prepared: 16 taps on a quarter of the pixels, no full-resolution intermediate, no 2x2 reduction pass
+            g, acc = self._grad_target(x)
+            ops.conv2d(dy, cw.wd.data_ptr(), g.ptr, g.ld, cw.C, 4, 4, x.H, x.W, stride=2, pad_t=1, pad_l=1, accumulate=acc, splitk=self.splitk)
+        elif upsample:
             tmp = self._new(B, dy.H, dy.W, cw.C)            # dgrad at the upsampled resolution, then 2x2 sum
             ops.conv2d(dy, cw.wd.data_ptr(), tmp.ptr, tmp.ld, cw.C, k, k, dy.H, dy.W, pad_t=k - 1 - pt, pad_l=k - 1 - pl, splitk=self.splitk)
             g, acc = self._grad_target(x)

@@ -256,7 +256,20 @@ class Emulator:
 
     def ddpm_pack_weight_multi(self, descs, n, dt, st):
         for w, wf, wd, N, C, R, Cp, Np in i64(descs, 8 * n).reshape(n, 8):
-            self.ddpm_pack_weight(int(w), int(wf), int(wd), int(N), int(C), int(R), int(R), int(Cp), int(Np), dt, st)
+            w, wf, wd, N, C, R, Cp, Np = int(w), int(wf), int(wd), int(N), int(C), int(R), int(Cp), int(Np)
+            if R & 0x100 and wd:                  # upsample conv: wd = 4x4 / stride-2 effective dgrad kernel [C][4][4][Np]
+                self.ddpm_pack_weight(w, wf, 0, N, C, 3, 3, Cp, Np, dt, st)
+                W = f32(w, N * C * 9).reshape(N, C, 3, 3)
+                D = W[:, :, ::-1, ::-1]                                     # flipped taps: D[r][s] = W[2-r][2-s]
+                E = np.zeros((N, C, 4, 4), dtype=np.float32)
+                for a in range(2):
+                    for b in range(2):
+                        E[:, :, a:a + 3, b:b + 3] += D
+                out = np.zeros((C, 4, 4, Np), dtype=np.float32)
+                out[..., :N] = E.transpose(1, 2, 3, 0)
+                Mat(wd, C * 16, Np, Np, dt).set(out.reshape(C * 16, Np))
+            else:
+                self.ddpm_pack_weight(w, wf, wd, N, C, R & 0xff, R & 0xff, Cp, Np, dt, st)
 
     def ddpm_q_sample(self, x0, noise, t, ca, cb, xt, B, n, st):
         tt = i64(t, B)

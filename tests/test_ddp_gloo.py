@@ -54,7 +54,7 @@ def test_two_rank_gradients_are_averaged(tmp_path, mode):
     for k, g0 in recs[0]["grads"].items():
         assert torch.allclose(g0, recs[1]["grads"][k], rtol=0, atol=0) or float((g0 - recs[1]["grads"][k]).abs().max()) < 1e-7, k
         scale = max(float(want[k].abs().max()), 1e-4)
-        assert float((g0 - want[k]).abs().max()) <= 3e-4 * scale + 2e-6, k
+        assert float((g0 - want[k]).abs().max()) <= 3e-4 * scale + 5e-6, k      # analytically-zero grads (bias under GroupNorm) are fp32 noise
     if mode == "native":
         a, b = (torch.load(os.path.join(tmp_path, f"after_step_{r}.pt"), weights_only=True) for r in range(2))
         for k in a:
