@@ -199,22 +199,42 @@ extern "C" int ddpm_wgrad_reduce(const long long* table, int n_tensors, void* st
     return check_launch();
 }
 
+// dst_i = a_i (+ b_i) for many small fp32 tensors in one launch (the concatenated time-bias projection: every
+// ResidualBlock.fc weight into its rows of one matrix, fc.bias + conv1.bias into one vector — both are added at the same
+// place, unet.py:85-86).  table[i] = {a, b (or 0), dst, numel} as int64; grid = (blocks, n_tensors).
+__global__ void mt_gather_kernel(const long long* __restrict__ table) {
+    const long long* d = table + 4 * (long long)blockIdx.y;
+    const float* a = reinterpret_cast<const float*>(d[0]);
+    const float* b = reinterpret_cast<const float*>(d[1]);
+    float* dst = reinterpret_cast<float*>(d[2]);
+    const long long n = d[3];
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        dst[i] = b ? a[i] + b[i] : a[i];
+}
+extern "C" int ddpm_mt_gather_f32(const long long* table, int n_tensors, void* stream) {
+    if (!table) return DDPM_ERR_NULL;
+    if (n_tensors <= 0) return DDPM_OK;
+    hipLaunchKernelGGL(mt_gather_kernel, dim3(8, n_tensors), dim3(256), 0, (hipStream_t)stream, table);
+    return check_launch();
+}
+
 // ------------------------------------------------------------------ diffusion algebra (fp32, per-sample coefficients gathered by t)
 // q_sample: x_t = a[t]*x0 + b[t]*noise   (diffusion.py:92-97); separate roundings like the reference's op chain
 __global__ void q_sample_kernel(const float* __restrict__ x0, const float* __restrict__ noise, const long long* __restrict__ t,
-                                const float* __restrict__ ca, const float* __restrict__ cb, float* __restrict__ xt, int B, int n) {
+                                const float* __restrict__ ca, const float* __restrict__ cb, float* __restrict__ xt, int B, int n, int T) {
     const long long tot = (long long)B * n;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += (long long)gridDim.x * blockDim.x) {
         const int b = (int)(i / n);
         const long long tt = t[b];
-        xt[i] = __fadd_rn(__fmul_rn(ca[tt], x0[i]), __fmul_rn(cb[tt], noise[i]));
+        // a timestep outside the table (torch.gather raises in the reference, diffusion.py:83) cannot raise here: poison the sample
+        xt[i] = (unsigned long long)tt < (unsigned long long)T ? __fadd_rn(__fmul_rn(ca[tt], x0[i]), __fmul_rn(cb[tt], noise[i])) : __builtin_nanf("");
     }
 }
 extern "C" int ddpm_q_sample(const float* x0, const float* noise, const long long* t, const float* sqrt_ab, const float* sqrt_1mab,
-                             float* xt, int B, int n, void* stream) {
+                             float* xt, int B, int n, int T, void* stream) {
     if (!x0 || !noise || !t || !sqrt_ab || !sqrt_1mab || !xt) return DDPM_ERR_NULL;
-    if (B <= 0 || n <= 0) return DDPM_ERR_SHAPE;
-    hipLaunchKernelGGL(q_sample_kernel, dim3(grid_for((long long)B * n)), dim3(256), 0, (hipStream_t)stream, x0, noise, t, sqrt_ab, sqrt_1mab, xt, B, n);
+    if (B <= 0 || n <= 0 || T <= 0) return DDPM_ERR_SHAPE;
+    hipLaunchKernelGGL(q_sample_kernel, dim3(grid_for((long long)B * n)), dim3(256), 0, (hipStream_t)stream, x0, noise, t, sqrt_ab, sqrt_1mab, xt, B, n, T);
     return check_launch();
 }
 
@@ -260,11 +280,16 @@ extern "C" int ddpm_mse_bwd(const float* pred, const float* target, const float*
 struct StepTables { const float *recip, *recip_m1, *coef1, *coef2, *logvar; };
 __global__ void p_step_kernel(const float* __restrict__ x_t, const float* __restrict__ out, const float* __restrict__ z,
                               const long long* __restrict__ t, StepTables tb, float* __restrict__ x_prev, float* __restrict__ pred_x0,
-                              int B, int n, int mean_type, int clip) {
+                              int B, int n, int mean_type, int clip, int T) {
     const long long tot = (long long)B * n;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += (long long)gridDim.x * blockDim.x) {
         const int b = (int)(i / n);
         const long long tt = t[b];
+        if ((unsigned long long)tt >= (unsigned long long)T) {          // index outside the tables: poison instead of reading out of bounds
+            x_prev[i] = __builtin_nanf("");
+            if (pred_x0) pred_x0[i] = __builtin_nanf("");
+            continue;
+        }
         const float xt = x_t[i], o = out[i];
         float x0, mean;
         if (mean_type == 0) {            // eps (diffusion.py:145-148)
@@ -275,7 +300,7 @@ __global__ void p_step_kernel(const float* __restrict__ x_t, const float* __rest
             const float c1 = tb.coef1[tt], c2 = tb.coef2[tt];
             x0 = __fsub_rn(__fdiv_rn(o, c1), __fmul_rn(__fdiv_rn(c2, c1), xt));
         }
-        if (clip) x0 = fminf(fmaxf(x0, -1.f), 1.f);
+        if (clip) x0 = x0 != x0 ? x0 : fminf(fmaxf(x0, -1.f), 1.f);      // torch.clamp propagates NaN (a diverged model must stay visible)
         if (mean_type == 2) mean = o;
         else mean = __fadd_rn(__fmul_rn(tb.coef1[tt], x0), __fmul_rn(tb.coef2[tt], xt));
         const float mask = tt > 0 ? 1.f : 0.f;
@@ -286,11 +311,11 @@ __global__ void p_step_kernel(const float* __restrict__ x_t, const float* __rest
 }
 extern "C" int ddpm_p_sample_step(const float* x_t, const float* model_out, const float* z, const long long* t,
                                   const float* sqrt_recip_ab, const float* sqrt_recip_m1_ab, const float* post_coef1, const float* post_coef2,
-                                  const float* logvar, float* x_prev, float* pred_x0, int B, int n, int mean_type, int clip, void* stream) {
+                                  const float* logvar, float* x_prev, float* pred_x0, int B, int n, int mean_type, int clip, int T, void* stream) {
     if (!x_t || !model_out || !z || !t || !x_prev || !sqrt_recip_ab || !sqrt_recip_m1_ab || !post_coef1 || !post_coef2 || !logvar) return DDPM_ERR_NULL;
-    if (B <= 0 || n <= 0 || mean_type < 0 || mean_type > 2) return DDPM_ERR_SHAPE;
+    if (B <= 0 || n <= 0 || T <= 0 || mean_type < 0 || mean_type > 2) return DDPM_ERR_SHAPE;
     StepTables tb{sqrt_recip_ab, sqrt_recip_m1_ab, post_coef1, post_coef2, logvar};
-    hipLaunchKernelGGL(p_step_kernel, dim3(grid_for((long long)B * n)), dim3(256), 0, (hipStream_t)stream, x_t, model_out, z, t, tb, x_prev, pred_x0, B, n, mean_type, clip);
+    hipLaunchKernelGGL(p_step_kernel, dim3(grid_for((long long)B * n)), dim3(256), 0, (hipStream_t)stream, x_t, model_out, z, t, tb, x_prev, pred_x0, B, n, mean_type, clip, T);
     return check_launch();
 }
 

@@ -22,6 +22,14 @@ struct GnShape {
     int pix_per_slab;
 };
 
+// Pivot of group g of sample b: the group's first stored element.  The streaming kernels accumulate sum(x - k) and
+// sum((x - k)^2) instead of raw moments: with k within a few standard deviations of the mean the single-pass variance keeps
+// its accuracy when |mean| >> std (raw fp32 moments lose (mean/std)^2 * 1e-7 of relative precision).
+template <typename T>
+__device__ __forceinline__ float gn_pivot(const T* __restrict__ x, long long x_ld, int HW, int b, int g, int cpg) {
+    return Elem<T>::ld(x + (long long)b * HW * x_ld + g * cpg);
+}
+
 // thread (cx, py): channel-vector cx fixed, pixels py, py+PY, ...  (blockDim = (CV, PY))
 template <typename T>
 __global__ void gn_stats_kernel(const T* __restrict__ x, GnShape s, float* __restrict__ partial /*[B][S][G][2]*/) {
@@ -30,16 +38,16 @@ __global__ void gn_stats_kernel(const T* __restrict__ x, GnShape s, float* __res
     const int b = blockIdx.y, slab = blockIdx.x;
     const int cx = threadIdx.x, py = threadIdx.y, PY = blockDim.y;
     const int p0 = slab * s.pix_per_slab, p1 = min(s.HW, p0 + s.pix_per_slab);
-    float sum[VEC], sq[VEC];
+    float sum[VEC], sq[VEC], piv[VEC];
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) sum[j] = sq[j] = 0.f;
+    for (int j = 0; j < VEC; ++j) { sum[j] = sq[j] = 0.f; piv[j] = gn_pivot(x, s.x_ld, s.HW, b, (cx * VEC + j) / s.cpg, s.cpg); }
     const T* xb = x + ((long long)b * s.HW) * s.x_ld + cx * VEC;
 #pragma unroll 4
     for (int p = p0 + py; p < p1; p += PY) {
         float f[VEC];
         Elem<T>::unpack(ldg16(xb + (long long)p * s.x_ld), f);
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) { sum[j] += f[j]; sq[j] += f[j] * f[j]; }
+        for (int j = 0; j < VEC; ++j) { const float d = f[j] - piv[j]; sum[j] += d; sq[j] += d * d; }
     }
     // ordered (deterministic) cross-thread reduction: row py of the [PY][C] scratch, then a fixed-order column sum
 #pragma unroll
@@ -64,8 +72,13 @@ struct GnApply {
     const float* gamma; const float* beta;
     float eps; int silu;
     float drop_p; unsigned thresh24; unsigned long long seed;   // dropout after SiLU (unet.py:87); p = 0 disables
+    const unsigned long long* seed_dev;                         // optional device word added to `seed` (hipGraph replays: the per-step part of the seed lives in memory)
     float* stats;              // [B][G][2] (mean, rstd) saved for backward, or null
 };
+
+__device__ __forceinline__ unsigned long long gn_seed(const GnApply& a) {
+    return (a.drop_p > 0.f && a.seed_dev) ? a.seed + a.seed_dev[0] : a.seed;
+}
 
 template <typename T>
 __global__ void gn_apply_kernel(const T* __restrict__ x, T* __restrict__ y, GnShape s, const float* __restrict__ partial, GnApply a) {
@@ -81,9 +94,10 @@ __global__ void gn_apply_kernel(const T* __restrict__ x, T* __restrict__ y, GnSh
             sum += o[0]; sq += o[1];
         }
         const double n = (double)s.HW * s.cpg;
-        const double mean = sum / n;
-        double var = sq / n - mean * mean;
+        const double dmean = sum / n;                       // moments of (x - pivot): see gn_pivot
+        double var = sq / n - dmean * dmean;
         if (var < 0.0) var = 0.0;
+        const double mean = (double)gn_pivot(x, s.x_ld, s.HW, b, t, s.cpg) + dmean;
         const float rstd = (float)(1.0 / sqrt(var + (double)a.eps));
         sh_mean[t] = (float)mean; sh_rstd[t] = rstd;
         if (a.stats && slab == 0) { a.stats[((long long)b * s.G + t) * 2] = (float)mean; a.stats[((long long)b * s.G + t) * 2 + 1] = rstd; }
@@ -103,6 +117,7 @@ __global__ void gn_apply_kernel(const T* __restrict__ x, T* __restrict__ y, GnSh
     const T* xb = x + ((long long)b * s.HW) * s.x_ld + cx * VEC;
     T* yb = y + ((long long)b * s.HW) * s.y_ld + cx * VEC;
     const float keep_scale = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
+    const unsigned long long seed = gn_seed(a);
     for (int p = p0 + py; p < p1; p += PY) {
         float f[VEC];
         Elem<T>::unpack(ldg16(xb + (long long)p * s.x_ld), f);
@@ -112,7 +127,7 @@ __global__ void gn_apply_kernel(const T* __restrict__ x, T* __restrict__ y, GnSh
             if (a.silu) z = siluf_(z);
             if (a.drop_p > 0.f) {
                 unsigned long long idx = ((unsigned long long)b * s.HW + p) * s.C + cx * VEC + j;
-                z = dropout_keep(a.seed, idx, a.thresh24) ? z * keep_scale : 0.f;
+                z = dropout_keep(seed, idx, a.thresh24) ? z * keep_scale : 0.f;
             }
             f[j] = z;
         }
@@ -227,6 +242,7 @@ void gn_reg_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, GnShape s, Gn
         cb[e] = a.beta[c0 + c] - mean[e] * ca[e];
     }
     const float keep_scale = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
+    const unsigned long long seed = gn_seed(a);
     T* yb = y + ((long long)b * s.HW) * s.y_ld + c0 + j * VEC;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -240,7 +256,7 @@ void gn_reg_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, GnShape s, Gn
             if (a.silu) z = siluf_(z);
             if (a.drop_p > 0.f) {
                 const unsigned long long idx = ((unsigned long long)b * s.HW + p) * s.C + c0 + j * VEC + e;
-                z = dropout_keep(a.seed, idx, a.thresh24) ? z * keep_scale : 0.f;
+                z = dropout_keep(seed, idx, a.thresh24) ? z * keep_scale : 0.f;
             }
             fv[e] = z;
         }
@@ -282,11 +298,12 @@ void gn_reg_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __r
         gm[e] = active ? a.gamma[c] : 0.f; bt[e] = active ? a.beta[c] : 0.f;
     }
     const float keep_scale = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
+    const unsigned long long seed = gn_seed(a);
     auto dz_of = [&](int p, int e, float xh, float d) -> float {
         float dz = d;
         if (a.drop_p > 0.f) {
             const unsigned long long idx = ((unsigned long long)b * s.HW + p) * s.C + c0 + j * VEC + e;
-            dz = dropout_keep(a.seed, idx, a.thresh24) ? dz * keep_scale : 0.f;
+            dz = dropout_keep(seed, idx, a.thresh24) ? dz * keep_scale : 0.f;
         }
         if (a.silu) dz *= silu_gradf_(gm[e] * xh + bt[e]);
         return dz;
@@ -408,6 +425,7 @@ __global__ void gn_bwd_reduce_kernel(const T* __restrict__ x, const T* __restric
         gm[j] = a.gamma[c]; bt[j] = a.beta[c]; a1[j] = a2[j] = 0.f;
     }
     const float keep_scale = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
+    const unsigned long long seed = gn_seed(a);
     const T* xb = x + ((long long)b * s.HW) * s.x_ld + cx * VEC;
     const T* db = dy + ((long long)b * s.HW) * dy_ld + cx * VEC;
 #pragma unroll 4
@@ -421,7 +439,7 @@ __global__ void gn_bwd_reduce_kernel(const T* __restrict__ x, const T* __restric
             float dz = d[j];
             if (a.drop_p > 0.f) {
                 unsigned long long idx = ((unsigned long long)b * s.HW + p) * s.C + cx * VEC + j;
-                dz = dropout_keep(a.seed, idx, a.thresh24) ? dz * keep_scale : 0.f;
+                dz = dropout_keep(seed, idx, a.thresh24) ? dz * keep_scale : 0.f;
             }
             if (a.silu) dz *= silu_gradf_(gm[j] * xh + bt[j]);
             a1[j] += dz * xh; a2[j] += dz;
@@ -485,6 +503,7 @@ __global__ void gn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict
         gm[j] = a.gamma[c]; bt[j] = a.beta[c];
     }
     const float keep_scale = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
+    const unsigned long long seed = gn_seed(a);
     const T* xb = x + ((long long)b * s.HW) * s.x_ld + cx * VEC;
     const T* db = dy + ((long long)b * s.HW) * dy_ld + cx * VEC;
     T* ob = dx + ((long long)b * s.HW) * dx_ld + cx * VEC;
@@ -499,7 +518,7 @@ __global__ void gn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict
             float dz = d[j];
             if (a.drop_p > 0.f) {
                 unsigned long long idx = ((unsigned long long)b * s.HW + p) * s.C + cx * VEC + j;
-                dz = dropout_keep(a.seed, idx, a.thresh24) ? dz * keep_scale : 0.f;
+                dz = dropout_keep(seed, idx, a.thresh24) ? dz * keep_scale : 0.f;
             }
             if (a.silu) dz *= silu_gradf_(gm[j] * xh + bt[j]);
             const float r = rstd[j] * (dz * gm[j] - xh * c1[j] - c2[j]);
@@ -522,16 +541,16 @@ void gn_sample_stats_kernel(const T* __restrict__ x, GnShape s, float eps, float
     const int cx = tid % cv, py = tid / cv;
     float* sh_sum = gsh;
     float* sh_sq = gsh + PY * s.C;
-    float sum[VEC], sq[VEC];
+    float sum[VEC], sq[VEC], piv[VEC];
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) sum[j] = sq[j] = 0.f;
+    for (int j = 0; j < VEC; ++j) { sum[j] = sq[j] = 0.f; piv[j] = gn_pivot(x, s.x_ld, s.HW, b, (cx * VEC + j) / s.cpg, s.cpg); }
     if (py < PY) {
         const T* xb = x + ((long long)b * s.HW) * s.x_ld + cx * VEC;
         for (int p = py; p < s.HW; p += PY) {
             float f[VEC];
             Elem<T>::unpack(ldg16(xb + (long long)p * s.x_ld), f);
 #pragma unroll
-            for (int j = 0; j < VEC; ++j) { sum[j] += f[j]; sq[j] += f[j] * f[j]; }
+            for (int j = 0; j < VEC; ++j) { const float d = f[j] - piv[j]; sum[j] += d; sq[j] += d * d; }
         }
 #pragma unroll
         for (int j = 0; j < VEC; ++j) { sh_sum[py * s.C + cx * VEC + j] = sum[j]; sh_sq[py * s.C + cx * VEC + j] = sq[j]; }
@@ -546,9 +565,10 @@ void gn_sample_stats_kernel(const T* __restrict__ x, GnShape s, float eps, float
     if (tid < s.G) {
         double a = 0.0, q = 0.0;
         for (int c = tid * s.cpg; c < (tid + 1) * s.cpg; ++c) { a += sh_sum[c]; q += sh_sq[c]; }
-        const double n = (double)s.HW * s.cpg, mean = a / n;
-        double var = q / n - mean * mean;
+        const double n = (double)s.HW * s.cpg, dmean = a / n;
+        double var = q / n - dmean * dmean;
         if (var < 0.0) var = 0.0;
+        const double mean = (double)gn_pivot(x, s.x_ld, s.HW, b, tid, s.cpg) + dmean;
         stats[((long long)b * s.G + tid) * 2] = (float)mean;
         stats[((long long)b * s.G + tid) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
     }
@@ -577,8 +597,9 @@ static int gn_geometry(int B, int HW, int C, int G, long long x_ld, long long y_
     return DDPM_OK;
 }
 
-static GnApply make_apply(const float* gamma, const float* beta, float eps, int silu, float drop_p, unsigned long long seed, float* stats) {
-    GnApply a; a.gamma = gamma; a.beta = beta; a.eps = eps; a.silu = silu; a.drop_p = drop_p; a.seed = seed; a.stats = stats;
+static GnApply make_apply(const float* gamma, const float* beta, float eps, int silu, float drop_p, unsigned long long seed, float* stats,
+                          const unsigned long long* seed_dev = nullptr) {
+    GnApply a; a.seed_dev = seed_dev; a.gamma = gamma; a.beta = beta; a.eps = eps; a.silu = silu; a.drop_p = drop_p; a.seed = seed; a.stats = stats;
     double th = (double)drop_p * 16777216.0;
     a.thresh24 = th <= 0 ? 0u : (th >= 16777216.0 ? 16777216u : (unsigned)(th + 0.5));
     return a;
@@ -593,7 +614,7 @@ extern "C" long long ddpm_gn_workspace_floats(int B, int HW, int C, int G, int d
 
 extern "C" int ddpm_groupnorm_silu_fwd(const void* x, long long x_ld, void* y, long long y_ld, const float* gamma, const float* beta,
                                        float* stats, float* workspace, int B, int HW, int C, int G, float eps, int silu,
-                                       float drop_p, unsigned long long seed, int dtype, void* stream) {
+                                       float drop_p, unsigned long long seed, const unsigned long long* seed_dev, int dtype, void* stream) {
     if (!x || !y || !gamma || !beta || !workspace) return DDPM_ERR_NULL;
     if (!aligned16(x) || !aligned16(y)) return DDPM_ERR_ALIGN;
     GnShape s; dim3 block, grid;
@@ -601,7 +622,7 @@ extern "C" int ddpm_groupnorm_silu_fwd(const void* x, long long x_ld, void* y, l
     if (dtype != DDPM_BF16 && dtype != DDPM_F32) return DDPM_ERR_DTYPE;
     int rc = gn_geometry(B, HW, C, G, x_ld, y_ld, es, s, block, grid);
     if (rc) return rc;
-    GnApply a = make_apply(gamma, beta, eps, silu, drop_p, seed, stats);
+    GnApply a = make_apply(gamma, beta, eps, silu, drop_p, seed, stats, seed_dev);
     hipStream_t st = (hipStream_t)stream;
     GnFused f; size_t lds = 0;
     static const bool no_fused = getenv("DDPM_GN_NO_FUSED") != nullptr;
@@ -628,7 +649,7 @@ extern "C" int ddpm_groupnorm_silu_fwd(const void* x, long long x_ld, void* y, l
 extern "C" int ddpm_groupnorm_silu_bwd(const void* x, long long x_ld, const void* dy, long long dy_ld, void* dx, long long dx_ld,
                                        const float* gamma, const float* beta, const float* stats, float* dgamma, float* dbeta,
                                        float* workspace, int B, int HW, int C, int G, int silu, float drop_p, unsigned long long seed,
-                                       int accumulate, int dtype, void* stream) {
+                                       const unsigned long long* seed_dev, int accumulate, int dtype, void* stream) {
     if (!x || !dy || !dx || !gamma || !beta || !stats || !workspace) return DDPM_ERR_NULL;
     if (!aligned16(x) || !aligned16(dy) || !aligned16(dx)) return DDPM_ERR_ALIGN;
     if (dtype != DDPM_BF16 && dtype != DDPM_F32) return DDPM_ERR_DTYPE;
@@ -637,7 +658,7 @@ extern "C" int ddpm_groupnorm_silu_bwd(const void* x, long long x_ld, const void
     int rc = gn_geometry(B, HW, C, G, x_ld, x_ld, es, s, block, grid);
     if (rc) return rc;
     if (dy_ld % (16 / es) || dx_ld % (16 / es)) return DDPM_ERR_ALIGN;
-    GnApply a = make_apply(gamma, beta, 0.f, silu, drop_p, seed, nullptr);
+    GnApply a = make_apply(gamma, beta, 0.f, silu, drop_p, seed, nullptr, seed_dev);
     hipStream_t st = (hipStream_t)stream;
     GnFused f; size_t lds = 0;
     static const bool no_fused = getenv("DDPM_GN_NO_FUSED") != nullptr || getenv("DDPM_GN_NO_FUSED_BWD") != nullptr;

@@ -96,8 +96,12 @@ __global__ void mt_sumsq_kernel(const long long* __restrict__ table, float* __re
         if (s != 0.f) atomicAdd(total_sq + ((blockIdx.y * gridDim.x + blockIdx.x) & (MT_SUMSQ_LANES - 1)), s);
     }
 }
+// hyper (optional, device memory): {lr, bias_corr1, bias_corr2, ema_w} — overrides the by-value arguments, so that a hipGraph
+// captured once can be replayed with the step-dependent scalars of every training step (LR schedule, bias corrections, EMA
+// warm-up) written to memory by the host before the replay.
 __global__ void mt_adam_ema_kernel(const long long* __restrict__ table, const float* __restrict__ total_sq, float max_norm, float lr,
-                                   float beta1, float beta2, float eps, float bc1, float bc2, float ema_w) {
+                                   float beta1, float beta2, float eps, float bc1, float bc2, float ema_w, const float* __restrict__ hyper) {
+    if (hyper) { lr = hyper[0]; bc1 = hyper[1]; bc2 = hyper[2]; ema_w = hyper[3]; }
     const long long* row = table + 6 * (long long)blockIdx.y;
     float* p = reinterpret_cast<float*>(row[0]);
     const float* g = reinterpret_cast<const float*>(row[1]);
@@ -150,10 +154,10 @@ extern "C" int ddpm_mt_grad_sumsq(const long long* table, int n_tensors, float* 
     return check_launch();
 }
 extern "C" int ddpm_mt_adam_ema(const long long* table, int n_tensors, const float* total_sq, float max_norm, float lr, float beta1,
-                                float beta2, float eps, float bias_corr1, float bias_corr2, float ema_w, void* stream) {
+                                float beta2, float eps, float bias_corr1, float bias_corr2, float ema_w, const float* hyper_dev, void* stream) {
     if (!table) return DDPM_ERR_NULL;
     if (n_tensors <= 0) return DDPM_OK;
     hipLaunchKernelGGL(mt_adam_ema_kernel, dim3(32, n_tensors), dim3(256), 0, (hipStream_t)stream, table, total_sq, max_norm, lr, beta1, beta2, eps,
-                       bias_corr1, bias_corr2, ema_w);
+                       bias_corr1, bias_corr2, ema_w, hyper_dev);
     return check_launch();
 }

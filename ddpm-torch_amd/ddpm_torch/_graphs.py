@@ -1,0 +1,83 @@
+"""hipGraph plumbing shared by the captured training step and the captured sampling step.
+
+A *segmented* graph is a list of hipGraphs captured back to back from ONE pass over a Python body, with an optional
+host callback between consecutive segments.  The body receives ``cut(fn)``: it ends the segment being captured,
+remembers ``fn`` and opens the next segment.  ``replay()`` then launches segment 0, calls its ``fn``, launches
+segment 1, ... — which is how the data-parallel training step keeps its RCCL all-reduces OUT of the captured work
+(they are issued eagerly between two segments, exactly where the eager backward issues them) while everything
+else — ~1000 kernel launches per step — is replayed from a handful of graph launches.
+
+All segments share one private memory pool and are always replayed in capture order on one stream, so activations
+allocated in one segment and released in a later one keep their addresses from replay to replay.
+"""
+import torch
+
+__all__ = ["SegmentedGraph"]
+
+
+class SegmentedGraph:
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.stream = torch.cuda.Stream(device=self.device)
+        self.pool = torch.cuda.graph_pool_handle()
+        self.segments = []              # [(CUDAGraph, callback or None)]
+        self._open = None
+        self._generators = []
+
+    def register_generator(self, gen):
+        """A non-default torch.Generator consumed inside the body (its state is advanced on every replay)."""
+        if gen is not None:
+            self._generators.append(gen)
+
+    # ------------------------------------------------------------------ capture
+    def _begin(self):
+        g = torch.cuda.CUDAGraph()
+        for gen in self._generators:
+            g.register_generator_state(gen)
+        # thread_local: other host threads (the communicator's watchdog polls events) must not invalidate the capture
+        g.capture_begin(pool=self.pool, capture_error_mode="thread_local")
+        self._open = g
+
+    def _end(self, callback):
+        g, self._open = self._open, None
+        g.capture_end()
+        self.segments.append((g, callback))
+
+    def _cut(self, callback):
+        self._end(callback)
+        self._begin()
+
+    def capture(self, body):
+        """Run ``body(cut)`` once under stream capture (nothing executes).  On failure the partial capture is discarded and
+        the exception propagates; the caller falls back to eager execution."""
+        assert not self.segments and self._open is None
+        torch.cuda.synchronize(self.device)
+        cur = torch.cuda.current_stream(self.device)
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            self._begin()
+            try:
+                body(self._cut)
+                self._end(None)
+            except BaseException:
+                if self._open is not None:
+                    try:
+                        self._open.capture_end()
+                    except Exception:
+                        pass
+                    self._open = None
+                self.segments.clear()
+                raise
+        cur.wait_stream(self.stream)
+        return self
+
+    # ------------------------------------------------------------------ replay
+    def replay(self):
+        for g, callback in self.segments:
+            g.replay()
+            if callback is not None:
+                callback()
+
+    @property
+    def launches(self):
+        return len(self.segments)

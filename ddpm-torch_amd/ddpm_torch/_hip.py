@@ -28,8 +28,8 @@ PROTOTYPES = {
     "ddpm_wgrad_reduce": [P, I, P],
     "ddpm_wgrad_unpack": [P, P, P, I, F, P],
     "ddpm_gemm": [P, L, L, I, P, L, L, I, P, L, L, P, P, L, L, I, I, I, I, F, I, I, I, I, P],
-    "ddpm_groupnorm_silu_fwd": [P, L, P, L, P, P, P, P, I, I, I, I, F, I, F, U, I, P],
-    "ddpm_groupnorm_silu_bwd": [P, L, P, L, P, L, P, P, P, P, P, P, I, I, I, I, I, F, U, I, I, P],
+    "ddpm_groupnorm_silu_fwd": [P, L, P, L, P, P, P, P, I, I, I, I, F, I, F, U, P, I, P],
+    "ddpm_groupnorm_silu_bwd": [P, L, P, L, P, L, P, P, P, P, P, P, I, I, I, I, I, F, U, P, I, I, P],
     "ddpm_gn_workspace_floats": [I, I, I, I, I],
     "ddpm_last_gemm_variant": [I],
     "ddpm_attention_fwd": [P, L, P, L, I, I, I, F, I, P],
@@ -39,10 +39,10 @@ PROTOTYPES = {
     "ddpm_nchw_to_nhwc": [P, P, I, I, I, I, I, P],
     "ddpm_pack_weight": [P, P, P, I, I, I, I, I, I, I, P],
     "ddpm_pack_weight_multi": [P, I, I, P],
-    "ddpm_q_sample": [P, P, P, P, P, P, I, I, P],
+    "ddpm_q_sample": [P, P, P, P, P, P, I, I, I, P],
     "ddpm_mse_fwd": [P, P, P, I, I, P],
     "ddpm_mse_bwd": [P, P, P, P, I, I, P],
-    "ddpm_p_sample_step": [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, P],
+    "ddpm_p_sample_step": [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, P],
     "ddpm_gather_i64": [P, P, P, I, P],
     "ddpm_add_i64": [P, I, L, P],
     "ddpm_silu_fwd": [P, P, L, P],
@@ -54,7 +54,8 @@ PROTOTYPES = {
     "ddpm_softmax_bwd": [P, P, P, L, I, I, P],
     "ddpm_dropout_mask": [P, L, F, U, P],
     "ddpm_mt_grad_sumsq": [P, I, P, P],
-    "ddpm_mt_adam_ema": [P, I, P, F, F, F, F, F, F, F, F, P],
+    "ddpm_mt_adam_ema": [P, I, P, F, F, F, F, F, F, F, F, P, P],
+    "ddpm_mt_gather_f32": [P, I, P],
     "ddpm_sumsq_accumulate": [P, L, P, P, P],
     "ddpm_adam_ema_step": [P, P, P, P, P, L, P, F, F, F, F, F, F, F, F, P],
 }
@@ -111,6 +112,11 @@ def require_cuda(*tensors):
         if t is not None and not t.is_cuda:
             raise RuntimeError("ddpm_torch (MI355X build) runs on CUDA/HIP tensors only; "
                                "got a CPU tensor and there is no CPU fallback")
+
+
+def on_device(t):
+    """True when the C-ABI kernels can address ``t`` (a CUDA/HIP tensor)."""
+    return t.is_cuda
 
 
 def ptr(t):

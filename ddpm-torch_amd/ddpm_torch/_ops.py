@@ -134,9 +134,11 @@ def gn_workspace_floats(B, HW, C, dtype):
     return n
 
 
-def gn_fwd(x, y, gamma, beta, stats, ws, silu, drop_p=0.0, seed=0):
+def gn_fwd(x, y, gamma, beta, stats, ws, silu, drop_p=0.0, seed=0, seed_dev=0):
+    """seed_dev: address of a device uint64 added to `seed` inside the kernel (0 = none) — the per-step part of the dropout
+    seed when the step is a replayed hipGraph."""
     _hip.call("ddpm_groupnorm_silu_fwd", x.ptr, x.ld, y.ptr, y.ld, _hip.ptr(gamma), _hip.ptr(beta), _hip.ptr(stats), _hip.ptr(ws),
-         x.B, x.H * x.W, x.C, GN_GROUPS, GN_EPS, int(silu), float(drop_p), seed, x.dtype, _hip.stream())
+         x.B, x.H * x.W, x.C, GN_GROUPS, GN_EPS, int(silu), float(drop_p), seed, seed_dev, x.dtype, _hip.stream())
 
 
 def gn_stats(x, stats):
@@ -152,9 +154,9 @@ def conv3x3_gn(x, stats, gamma, beta, w_ptr, y_ptr, y_ld, N, silu=True, bias=0, 
         f"conv+gn M={x.B * x.H * x.W} N={N} K={9 * x.C} 3x3")
 
 
-def gn_bwd(x, dy, dx, gamma, beta, stats, dgamma_ptr, dbeta_ptr, ws, silu, drop_p=0.0, seed=0, accumulate=0):
+def gn_bwd(x, dy, dx, gamma, beta, stats, dgamma_ptr, dbeta_ptr, ws, silu, drop_p=0.0, seed=0, accumulate=0, seed_dev=0):
     _hip.call("ddpm_groupnorm_silu_bwd", x.ptr, x.ld, dy.ptr, dy.ld, dx.ptr, dx.ld, _hip.ptr(gamma), _hip.ptr(beta), _hip.ptr(stats), dgamma_ptr, dbeta_ptr,
-         _hip.ptr(ws), x.B, x.H * x.W, x.C, GN_GROUPS, int(silu), float(drop_p), seed, accumulate, x.dtype, _hip.stream())
+         _hip.ptr(ws), x.B, x.H * x.W, x.C, GN_GROUPS, int(silu), float(drop_p), seed, seed_dev, accumulate, x.dtype, _hip.stream())
 
 
 def colsum(dy, per_sample_ptr, ps_ld, total_ptr):

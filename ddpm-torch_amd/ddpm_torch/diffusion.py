@@ -19,6 +19,7 @@ import os
 import torch
 
 from . import _hip
+from ._graphs import SegmentedGraph
 
 __all__ = ["get_beta_schedule", "GaussianDiffusion"]
 
@@ -152,7 +153,7 @@ class GaussianDiffusion:
         out = torch.empty_like(x_0)
         B = x_0.shape[0]
         _hip.call("ddpm_q_sample", x_0.data_ptr(), noise.data_ptr(), t.data_ptr(), self._tab("sqrt_alphas_bar", x_0.device).data_ptr(),
-             self._tab("sqrt_one_minus_alphas_bar", x_0.device).data_ptr(), out.data_ptr(), B, x_0[0].numel(), _hip.stream())
+             self._tab("sqrt_one_minus_alphas_bar", x_0.device).data_ptr(), out.data_ptr(), B, x_0[0].numel(), len(self.sqrt_alphas_bar), _hip.stream())
         return out
 
     def q_posterior_mean_var(self, x_0, x_t, t):
@@ -167,17 +168,25 @@ class GaussianDiffusion:
         if noise is None:
             noise = torch.randn_like(x_0)
         x_t = self.q_sample(x_0, t, noise=noise)
-        if self.model_mean_type == "eps":
-            target = noise
-        elif self.model_mean_type == "x_0":
-            target = x_0
-        elif self.model_mean_type == "mean":
-            target = self.q_posterior_mean_var(x_0=x_0, x_t=x_t, t=t)[0]
-        else:
-            raise NotImplementedError(self.model_mean_type)
+        target = self.loss_target(x_0, x_t, t, noise)
         model_out = denoise_fn(x_t, t)
         pred, target = self._prep(model_out, target)
         return _AutogradMSE.apply(pred, target)
+
+    def loss_target(self, x_0, x_t, t, noise):
+        """What the model output is regressed on (diffusion.py:225-236)."""
+        if self.model_mean_type == "eps":
+            return noise
+        if self.model_mean_type == "x_0":
+            return x_0
+        if self.model_mean_type == "mean":
+            return self.q_posterior_mean_var(x_0=x_0, x_t=x_t, t=t)[0]
+        raise NotImplementedError(self.model_mean_type)
+
+    def supports_direct_step(self):
+        """True when Trainer may run its autograd-free step: the loss is the plain MSE on a target that does not depend on
+        the model (the reference's 'kl' loss would need the variance terms)."""
+        return self.loss_type == "mse" and self.model_mean_type in _MEAN_CODE
 
     # ------------------------------------------------------------------ reverse process
     def _step(self, x_t, model_out, z, t, clip_denoised, want_pred):
@@ -187,7 +196,8 @@ class GaussianDiffusion:
         pred = torch.empty_like(x_t) if want_pred else None
         tabs = [self._tab(n, dev).data_ptr() for n in _STEP_TABLES]
         _hip.call("ddpm_p_sample_step", x_t.data_ptr(), model_out.data_ptr(), z.data_ptr(), t.data_ptr(), *tabs, out.data_ptr(),
-             _hip.ptr(pred), x_t.shape[0], x_t[0].numel(), _MEAN_CODE[self.model_mean_type], int(bool(clip_denoised)), _hip.stream())
+             _hip.ptr(pred), x_t.shape[0], x_t[0].numel(), _MEAN_CODE[self.model_mean_type], int(bool(clip_denoised)),
+             len(self.posterior_mean_coef1), _hip.stream())
         return out, pred
 
     def p_mean_var(self, denoise_fn, x_t, t, clip_denoised, return_pred):
@@ -214,24 +224,25 @@ class GaussianDiffusion:
 
         The step body (model call, noise draw, fused update, t -= 1) has static shapes, so it is captured ONCE into a
         hipGraph and replayed: at 32x32 the eager loop is bound by ~250 kernel launches per step, not by the GPU.
+        The captured step is cached per (denoiser, shape) — later calls only re-seed and replay.
         RNG consumption (x_T first, then one z per step incl. t = 0) and results are identical to the eager loop;
         set DDPM_TORCH_AMD_GRAPH=0 to force eager."""
         device = torch.device(device)
         _hip.require_cuda(torch.empty(0, device=device))        # no CPU fallback: sampling runs on the GPU only
         B = (shape or noise.shape)[0]
+        steps = self._num_steps()
+        if (on_step is None and z_stream is None and steps >= 4 and device.type == "cuda"
+                and os.environ.get("DDPM_TORCH_AMD_GRAPH", "1") != "0" and not torch.cuda.is_current_stream_capturing()):
+            done = self._graph_loop(denoise_fn, tuple(shape or noise.shape), device, noise, seed, steps)
+            if done is not None:
+                return done
         rng = torch.Generator(device).manual_seed(seed) if seed is not None else None       # diffusion.py:164-166
         if noise is None:
             x_t = torch.empty(shape, device=device).normal_(generator=rng)                  # x_T first, then one z per step
         else:
             x_t = noise.to(device)
-        steps = self._num_steps()
         t = torch.full((B,), steps - 1, dtype=torch.int64, device=device)
         x_t = x_t.contiguous().float().clone()
-        if (on_step is None and z_stream is None and steps >= 4 and device.type == "cuda"
-                and os.environ.get("DDPM_TORCH_AMD_GRAPH", "1") != "0" and not torch.cuda.is_current_stream_capturing()):
-            done = self._graph_loop(denoise_fn, x_t, t, rng, steps)
-            if done is not None:
-                return done
         for ti in range(steps - 1, -1, -1):
             t.fill_(ti)
             out = denoise_fn(x_t, self._model_t(t))
@@ -241,50 +252,88 @@ class GaussianDiffusion:
                 on_step(ti, pred)
         return x_t
 
-    def _graph_loop(self, denoise_fn, x_t, t, rng, steps):
-        """Capture one sampling step as a hipGraph and replay it ``steps`` times; returns None if capture is not possible
-        (the caller then runs the eager loop from the untouched state)."""
-        dev = x_t.device
-        z = torch.empty_like(x_t)
-        tabs = [self._tab(n, dev) for n in _STEP_TABLES]
-        mean_code = _MEAN_CODE[self.model_mean_type]
-        B, n = x_t.shape[0], x_t[0].numel()
+    # ---- captured sampling step
+    @staticmethod
+    def _engines_of(denoise_fn):
+        """Engines of every UNet of this package reachable from ``denoise_fn`` (their derived weight copies must be
+        brought up to date eagerly before a captured step is replayed)."""
+        from .models.unet import UNet
+        if not isinstance(denoise_fn, torch.nn.Module):
+            return None
+        return [m.engine() for m in denoise_fn.modules() if isinstance(m, UNet)]
 
-        def body():
+    def _graph_loop(self, denoise_fn, shape, device, noise, seed, steps):
+        """Replay the captured sampling step ``steps`` times; returns None if capture is not possible (the caller then
+        runs the eager loop; no RNG state has been consumed)."""
+        cache = self.__dict__.setdefault("_sample_graphs", {})
+        engines = self._engines_of(denoise_fn)
+        key = (id(denoise_fn), shape, str(device), seed is None, getattr(denoise_fn, "training", None),
+               tuple(e.T for e in engines) if engines else None)
+        ent = cache.get(key)
+        if ent is not None and ent["ref"]() is not denoise_fn:
+            ent = None                                            # the id was recycled by another object
+        if ent is None:
+            ent = self._capture_sample_step(denoise_fn, shape, device, seed is None)
+            if ent is None:
+                return None
+            if engines is not None:                               # arbitrary callables are captured per call: nothing tells us when their weights change
+                import weakref
+                ent["ref"] = weakref.ref(denoise_fn)
+                if len(cache) >= 8:
+                    cache.pop(next(iter(cache)))
+                cache[key] = ent
+        x_t, t, rng, graph = ent["x_t"], ent["t"], ent["rng"], ent["graph"]
+        for e in engines or ():
+            e.ensure_fresh()
+        if rng is not None:
+            rng.manual_seed(seed)
+        if noise is None:
+            x_t.normal_(generator=rng)                            # x_T first, then one z per step (diffusion.py:166-171)
+        else:
+            x_t.copy_(noise)
+        t.fill_(steps - 1)
+        for _ in range(steps):
+            graph.replay()
+        return x_t.clone()
+
+    def _capture_sample_step(self, denoise_fn, shape, device, default_rng):
+        dev = device
+        x_t = torch.zeros(shape, dtype=torch.float32, device=dev)
+        z = torch.empty_like(x_t)
+        B, n = shape[0], x_t[0].numel()
+        t = torch.full((B,), self._num_steps() - 1, dtype=torch.int64, device=dev)
+        rng = None if default_rng else torch.Generator(dev)
+        tabs = [self._tab(n_, dev) for n_ in _STEP_TABLES]
+        mean_code = _MEAN_CODE[self.model_mean_type]
+        T = len(self.posterior_mean_coef1)
+
+        def body(cut=None):
             out = denoise_fn(x_t, self._model_t(t)).contiguous().float()
             z.normal_(generator=rng)
             _hip.call("ddpm_p_sample_step", x_t.data_ptr(), out.data_ptr(), z.data_ptr(), t.data_ptr(), *[tb.data_ptr() for tb in tabs],
-                      x_t.data_ptr(), 0, B, n, mean_code, 1, _hip.stream())            # in place: each element is read once, then written
+                      x_t.data_ptr(), 0, B, n, mean_code, 1, T, _hip.stream())         # in place: each element is read once, then written
             _hip.call("ddpm_add_i64", t.data_ptr(), B, -1, _hip.stream())
 
-        # warm-up on a side stream (lazy kernel / cache initialisation), from a snapshot so that no state is consumed
-        snap_x, snap_t = x_t.clone(), t.clone()
         gen = rng if rng is not None else torch.cuda.default_generators[dev.index if dev.index is not None else torch.cuda.current_device()]
         snap_rng = gen.get_state()
-        graph = None
         try:
+            # warm-up on a side stream (lazy kernel / cache initialisation) on scratch state: nothing the caller sees is consumed
             side = torch.cuda.Stream(device=dev)
             side.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(side):
                 body()
             torch.cuda.current_stream(dev).wait_stream(side)
-            x_t.copy_(snap_x); t.copy_(snap_t); gen.set_state(snap_rng)
-            graph = torch.cuda.CUDAGraph()
-            if rng is not None:
-                graph.register_generator_state(rng)
-            with torch.cuda.graph(graph):
-                body()
+            gen.set_state(snap_rng)
+            graph = SegmentedGraph(dev)
+            graph.register_generator(rng)
+            graph.capture(body)
         except Exception as e:                                   # capture not possible for this denoise_fn: eager loop instead
             import warnings
             warnings.warn(f"hipGraph capture of the sampling step failed ({type(e).__name__}: {e}); running the eager loop")
             torch.cuda.synchronize(dev)
-            x_t.copy_(snap_x); t.copy_(snap_t); gen.set_state(snap_rng)
+            gen.set_state(snap_rng)
             return None
-        # capture does not execute: state is still the snapshot.  Replay the step `steps` times.
-        x_t.copy_(snap_x); t.copy_(snap_t)
-        for _ in range(steps):
-            graph.replay()
-        return x_t.clone()
+        return {"x_t": x_t, "t": t, "z": z, "rng": rng, "graph": graph, "ref": lambda: denoise_fn}
 
     def _num_steps(self):
         return self.timesteps

@@ -178,7 +178,7 @@ class UNet(nn.Module):
         if self._pg is not None and broadcast:
             with torch.no_grad():
                 for p in self.parameters():
-                    dist.broadcast(p.data, src=dist.get_global_rank(self._pg, 0), group=self._pg)
+                    dist.broadcast(p.detach(), src=dist.get_global_rank(self._pg, 0), group=self._pg)   # detach() shares the version counter, .data does not
         if self._eng is not None:
             self._eng.pg = self._pg
         return self
@@ -195,6 +195,10 @@ class UNet(nn.Module):
 
     def forward(self, x, t):
         _hip.require_cuda(x, t)
+        if x.requires_grad and torch.is_grad_enabled():
+            # the reference returns d/dx through autograd (unet.py:205-233); the hand-written backward stops at in_conv
+            raise NotImplementedError("gradients with respect to the input image are not implemented on the MI355X path; "
+                                      "pass x.detach() (training never needs d/dx: x_t is data)")
         eng = self.engine()
         params = eng.params
         if torch.is_grad_enabled() and any(p.requires_grad for p in params):
@@ -264,6 +268,7 @@ class _Engine:
         self.gtotal = off
         self.wdesc = None                          # device table for ddpm_wgrad_unpack (built on first backward)
         self._gpack, self._slabs, self._slab_tables, self._eff_splits, self._side = None, {}, {}, {}, None
+        self._works = []                           # outstanding all-reduce handles of the native data-parallel backward
         m = model
         self.hid, self.E, self.L, self.n = m.hid_channels, m.time_embedding_dim, m.levels, m.num_res_blocks
         self.chs = [m.hid_channels * k for k in m.ch_multipliers]
@@ -279,7 +284,7 @@ class _Engine:
         half = self.hid // 2
         rate = math.log(10000) / (half - 1)
         self.freqs = torch.exp(-torch.arange(half, dtype=torch.float32) * rate).to(self.device)   # functions.py:19-20
-        self.fc_w = self.fc_b = None
+        self.fc_w = self.fc_b = self.fc_table = None       # concatenated time-bias projection (persistent: graph replays read it)
         self.fc_ver = None
         self._ws = None
         self._ws_key = None
@@ -334,7 +339,7 @@ class _Engine:
     def _refresh_packs(self, need_dgrad):
         """Re-derive every conv's packed copies in ONE launch when any master weight changed (optimizer step,
         load_state_dict, EMA swap: all bump ``_version``) or the dgrad copies are needed for the first time."""
-        key = tuple(cw.mod.weight._version for cw in self.convs.values())
+        key = self._pack_versions()
         ptrs = tuple(cw.mod.weight.data_ptr() for cw in self.convs.values())
         if self.pack_table is None or ptrs != self.pack_ptrs or (need_dgrad and not self.pack_has_dgrad):
             rows = []
@@ -347,22 +352,66 @@ class _Engine:
             self.pack_table = torch.tensor(rows, dtype=torch.int64, device=self.device)
             self.pack_ptrs, self.pack_has_dgrad, self.pack_key = ptrs, self.pack_has_dgrad or need_dgrad, None
         if key != self.pack_key:
-            _hip.call("ddpm_pack_weight_multi", self.pack_table.data_ptr(), self.pack_table.shape[0], self.dcode, _hip.stream())
+            self._launch_pack()
             self.pack_key = key
+
+    def _pack_versions(self):
+        return tuple(cw.mod.weight._version for cw in self.convs.values())
+
+    def _launch_pack(self):
+        _hip.call("ddpm_pack_weight_multi", self.pack_table.data_ptr(), self.pack_table.shape[0], self.dcode, _hip.stream())
 
     def _packed(self, conv, need_dgrad):
         return self.convs[id(conv)]
 
+    def _fc_versions(self):
+        return tuple((rb.fc.weight._version, rb.fc.bias._version, rb.conv1.bias._version, rb.fc.weight.data_ptr()) for rb in self.res_blocks)
+
     def _fc_all(self):
         """Concatenated time-bias projection: rows = all ResidualBlock.fc weights; bias = fc.bias + conv1.bias
-        (both are added at the same place, unet.py:85-86), so conv1's epilogue adds one per-sample vector."""
-        key = tuple((rb.fc.weight._version, rb.fc.bias._version, rb.conv1.bias._version, rb.fc.weight.data_ptr()) for rb in self.res_blocks)
+        (both are added at the same place, unet.py:85-86), so conv1's epilogue adds one per-sample vector.  The two
+        buffers are persistent and re-filled by ONE multi-tensor launch when a member parameter changed."""
+        key = self._fc_versions()
+        if self.fc_table is None or key[0][3] != self.fc_ptr0 or any(k[3] != q for k, q in zip(key, self.fc_ptrs)):
+            E = self.E
+            if self.fc_w is None:
+                self.fc_w = self._f32(self.tb_total, E)
+                self.fc_b = self._f32(self.tb_total)
+            rows = []
+            for rb in self.res_blocks:
+                o, c = self.tb_off[id(rb)], rb.out_channels
+                rows.append([rb.fc.weight.data_ptr(), 0, self.fc_w.data_ptr() + 4 * o * E, c * E])
+                rows.append([rb.fc.bias.data_ptr(), rb.conv1.bias.data_ptr(), self.fc_b.data_ptr() + 4 * o, c])
+            self.fc_table = torch.tensor(rows, dtype=torch.int64, device=self.device)
+            self.fc_ptrs = tuple(k[3] for k in key)
+            self.fc_ptr0 = key[0][3]
+            self.fc_ver = None
         if key != self.fc_ver:
-            with torch.no_grad():
-                self.fc_w = torch.cat([rb.fc.weight for rb in self.res_blocks], dim=0).contiguous()
-                self.fc_b = torch.cat([rb.fc.bias + rb.conv1.bias for rb in self.res_blocks], dim=0).contiguous()
+            self._launch_fc()
             self.fc_ver = key
         return self.fc_w, self.fc_b
+
+    def _launch_fc(self):
+        _hip.call("ddpm_mt_gather_f32", self.fc_table.data_ptr(), self.fc_table.shape[0], _hip.stream())
+
+    # ---- derived-copy management for replayed hipGraphs (the kernels of a captured step read the packed copies through
+    # fixed addresses; nothing inside a graph can look at version counters)
+    def ensure_fresh(self, need_dgrad=False):
+        """Eagerly bring every derived copy (packed conv weights, concatenated time-bias projection) up to date with the
+        master parameters — what forward() does on entry; callers replaying a captured graph do it before the replay."""
+        self._refresh_packs(need_dgrad)
+        self._fc_all()
+
+    def refresh_unconditionally(self):
+        """Launch the derivation kernels regardless of version counters (the tail of a captured training step: the
+        parameters it has just updated are re-packed inside the same graph)."""
+        self._launch_pack()
+        self._launch_fc()
+
+    def mark_fresh(self):
+        """The derived copies match the current parameter versions (after a replay whose tail re-derived them)."""
+        self.pack_key = self._pack_versions()
+        self.fc_ver = self._fc_versions()
 
     def _workspace(self, B, H, W):
         key = (B, H, W)
@@ -496,7 +545,8 @@ class _Engine:
                 a, b, _ = ctx["pending"].pop()
                 self._flush_slabs(ctx)                       # the chunk's conv gradients must be summed before they travel
                 self._join_side(ctx)                         # ... and produced: the communicator orders itself after the main stream
-                ctx["works"].append(self._all_reduce(ctx["gpack"][a:b]))
+                works, chunk = ctx["works"], ctx["gpack"][a:b]
+                self._comm(ctx, lambda works=works, chunk=chunk: works.append(self._all_reduce(chunk)))
 
     def _flush_slabs(self, ctx):
         """Sum the slab copies recorded since the last flush into the staging buffer (one launch)."""
@@ -509,6 +559,13 @@ class _Engine:
         if table is None:                                    # addresses are stable (persistent buffers): built once per geometry
             table = self._slab_tables[rows] = torch.tensor(rows, dtype=torch.int64, device=self.device)
         _hip.call("ddpm_wgrad_reduce", table.data_ptr(), len(rows), _hip.stream())
+
+    def _comm(self, ctx, fn):
+        """Run a communicator call now, or — while the step is being captured — between two graph segments at replay time."""
+        if ctx.get("cut") is None:
+            fn()
+        else:
+            ctx["cut"](fn)
 
     def _all_reduce(self, t):
         import torch.distributed as dist
@@ -531,7 +588,9 @@ class _Engine:
         return out
 
     # ================================================================ forward
-    def forward(self, x, t, training, tape):
+    def forward(self, x, t, training, tape, seed_dev=0):
+        """``seed_dev``: address of a device uint64 holding the per-step part of the dropout seed (captured training step:
+        the host rewrites that word before every replay); 0 = the whole seed travels by value."""
         m = self.m
         if x.dim() != 4 or x.shape[1] != m.in_channels:
             raise ValueError(f"expected x of shape [B, {m.in_channels}, H, W], got {tuple(x.shape)}")
@@ -548,9 +607,9 @@ class _Engine:
         st = dict(B=B, ws=ws, save=save, training=training, tape=tape)
         drop_p = float(m.drop_rate) if training else 0.0
         st["drop_p"] = drop_p
-        if drop_p > 0:
-            self.drop_calls += 1
-            st["seed"] = (torch.initial_seed() * 0x9E3779B97F4A7C15 + self.drop_calls * 0x632BE59BD9B4E019) & ((1 << 63) - 1)
+        st["seed_dev"] = seed_dev if drop_p > 0 else 0
+        if drop_p > 0 and not seed_dev:
+            st["seed"] = self.next_dropout_seed()
         else:
             st["seed"] = 0
 
@@ -649,6 +708,11 @@ class _Engine:
             tape.append(("head", cur, act, stats, st))
         return out
 
+    def next_dropout_seed(self):
+        """Per-forward dropout seed (every block offsets it by its own constant): advances with each training forward."""
+        self.drop_calls += 1
+        return (torch.initial_seed() * 0x9E3779B97F4A7C15 + self.drop_calls * 0x632BE59BD9B4E019) & ((1 << 63) - 1)
+
     # ---- forward pieces (each appends what its backward needs)
     def _conv(self, st, conv, x, out, k, stride=1, upsample=0):
         cw = self._packed(conv, st["save"])
@@ -715,7 +779,7 @@ class _Engine:
             a2 = self._new(B, x.H, x.W, Cout)
             stats2 = self._f32(B, ops.GN_GROUPS, 2) if save else None
             seed = (st["seed"] + 0x51ED27 * (self.tb_off[id(rb)] + 1)) & ((1 << 63) - 1) if st["drop_p"] > 0 else 0
-            ops.gn_fwd(h1, a2, rb.norm2.weight, rb.norm2.bias, stats2, ws, silu=True, drop_p=st["drop_p"], seed=seed)
+            ops.gn_fwd(h1, a2, rb.norm2.weight, rb.norm2.bias, stats2, ws, silu=True, drop_p=st["drop_p"], seed=seed, seed_dev=st["seed_dev"])
             ops.conv2d(a2, c2.wf.data_ptr(), out.ptr, out.ld, Cout, 3, 3, x.H, x.W, pad_t=1, pad_l=1,
                        bias=rb.conv2.bias.data_ptr(), res_ptr=res_ptr, res_ld=res_ld, splitk=self.splitk)
         if save:
@@ -751,9 +815,14 @@ class _Engine:
             st["tape"].append(("attn", ab, x, out, hn, stats, qkv, prob, o))
 
     # ================================================================ backward
-    def backward(self, tape, gout):
+    def backward(self, tape, gout, gflat=None, cut=None):
+        """Replays the tape in reverse.  ``gflat``: caller-owned flat gradient buffer (stable address for captured steps).
+        ``cut(fn)``: when the step is being captured as a sequence of hipGraphs, the communicator calls are not captured —
+        ``cut`` ends the current graph segment, registers ``fn`` to run eagerly between the segments at replay time, and
+        opens the next segment."""
         m = self.m
-        gflat = torch.empty(self.gtotal, dtype=torch.float32, device=self.device)   # written only by the final unpack
+        if gflat is None:
+            gflat = torch.empty(self.gtotal, dtype=torch.float32, device=self.device)   # written only by the final unpack
         head = tape[-1]
         st = head[4]
         B, ws = st["B"], st["ws"]
@@ -764,7 +833,8 @@ class _Engine:
         if self._gpack is None or self._gpack.numel() != self.ptotal:
             self._gpack = torch.empty(self.ptotal, dtype=torch.float32, device=self.device)
         gpack = self._gpack.zero_()           # persistent (stable addresses for the slab-reduce tables): packed conv weight grads [N][RS][C] + tail
-        ctx = dict(gflat=gflat, gpack=gpack, ws=ws, B=B, dtb=dtb, pending=None, works=[], slab_rows=[], side=None, keep=[])
+        ctx = dict(gflat=gflat, gpack=gpack, ws=ws, B=B, dtb=dtb, pending=None, works=self._works, slab_rows=[], side=None, keep=[], cut=cut,
+                   seed_dev=st.get("seed_dev", 0))
         if _SIDE_STREAM and gout.is_cuda:
             if self._side is None:
                 self._side = torch.cuda.Stream(device=self.device)
@@ -804,9 +874,14 @@ class _Engine:
         self._join_side(ctx)
         if self.pg is not None:
             assert not ctx["pending"], "a conv weight gradient was never produced"
-            ctx["works"].append(self._all_reduce(gpack[self.tail[0]:self.tail[1]]))
-            for w in ctx["works"]:
-                w.wait()                                   # the compute stream waits for the communicator; no host sync
+            works, tail = ctx["works"], gpack[self.tail[0]:self.tail[1]]
+
+            def finish():
+                works.append(self._all_reduce(tail))
+                for w in works:
+                    w.wait()                               # the compute stream waits for the communicator; no host sync
+                works.clear()
+            self._comm(ctx, finish)
         _hip.call("ddpm_wgrad_unpack", gpack.data_ptr(), gflat.data_ptr(), wdesc.data_ptr(), wdesc.shape[0], 1.0 / world, _hip.stream())
         if not self.debug_keep_tape:
             # the head record holds `st` and `st` holds the tape: break the cycle so that the saved activations go back to the
@@ -881,7 +956,7 @@ class _Engine:
         # GN2 + SiLU + dropout
         dh1 = self._new(B, x.H, x.W, Cout)
         ops.gn_bwd(h1, da2, dh1, rb.norm2.weight, rb.norm2.bias, stats2, self._pptr(ctx, rb.norm2.weight), self._pptr(ctx, rb.norm2.bias),
-                   ws, silu=True, drop_p=drop_p, seed=seed)
+                   ws, silu=True, drop_p=drop_p, seed=seed, seed_dev=ctx["seed_dev"])
         # time bias (+conv1 bias): per-sample column sums into the concatenated dtb
         ops.colsum(dh1, ctx["dtb"].data_ptr() + 4 * self.tb_off[id(rb)], self.tb_total, 0)
         # conv1

@@ -1,16 +1,28 @@
-"""Training-step semantics of the reference's ``Trainer`` / ``EMA`` (``ddpm_torch/utils/train.py:64-346`` of
-tqch/ddpm-torch) on top of the MI355X engine.
+"""``Trainer`` / ``EMA`` with the reference's constructor and call contracts (``ddpm_torch/utils/train.py:64-367`` of
+tqch/ddpm-torch), rebuilt around the MI355X engine.
 
-What one ``Trainer.step`` does is the contract (utils/train.py:148-170): per-rank (t, noise) from a seeded device
-generator -> ``diffusion.train_losses`` -> mean loss / num_accum -> backward -> every ``num_accum`` steps: global-norm
-clip, optimizer step, zero_grad(set_to_none), LR schedule step, EMA update -> loss reduce to rank 0.
-The forward/backward under ``loss.backward()`` is the hand-written HIP engine (one autograd node for the UNet, one for
-the eps-MSE); EMA runs as multi-tensor ops over all 304 parameters instead of a Python loop.
-Epoch loop / checkpoint I/O are thin host plumbing kept compatible with the reference's checkpoint layout.
+What one ``Trainer.step`` computes is the contract (utils/train.py:148-170): per-rank ``t`` then ``noise`` from a seeded
+device generator -> ``diffusion.train_losses`` -> mean loss / num_accum -> backward -> every ``num_accum`` steps
+global-norm clip, Adam step, ``zero_grad(set_to_none)``, LR-schedule step, EMA update -> loss reduce to rank 0 ->
+``loss.item()`` into the running statistics.  How it is executed here:
+
+* **direct step** (the normal case: the model is this package's ``UNet``, ``torch.optim.Adam`` with one plain parameter
+  group, ``num_accum == 1``, eps/x_0/mean-MSE loss): no autograd graph at all — the engine's hand-written forward and
+  backward are called back to back, the eps-MSE and its gradient are two kernels, clip + Adam + EMA are two multi-tensor
+  launches over a pointer table, and the packed weight copies are re-derived at the end of the step.  All step-dependent
+  scalars (learning rate, Adam bias corrections, EMA weight, the per-step part of the dropout seed) are read by the
+  kernels from a small device buffer, so the whole step is shape-static and is **captured once into hipGraphs and
+  replayed** (``_graphs.SegmentedGraph``): ~1000 launches per step become one graph launch (plus one per gradient
+  all-reduce chunk in data-parallel runs: the RCCL calls stay outside the graphs, between segments).
+* **autograd step** (anything else: DDP-wrapped or user-wrapped models, gradient accumulation, other optimisers):
+  ``loss.backward()`` through the engine's single autograd node, then the fused multi-tensor update when the optimiser
+  qualifies, else the plain torch calls.
+
+Checkpoints keep the reference's on-disk layout ({model, optimizer, ema, scheduler, epoch, ...}, utils/train.py:249-276).
 """
-import math
 import os
 import re
+import warnings
 import weakref
 from contextlib import nullcontext
 
@@ -20,148 +32,103 @@ import torch.nn as nn
 from torch.nn.parallel import DistributedDataParallel as DDP
 
 from .. import _hip
+from .._graphs import SegmentedGraph
 
 __all__ = ["Trainer", "EMA", "ModelWrapper", "DummyScheduler", "RunningStatistics"]
 
-
-class _FusedUpdate:
-    """clip_grad_norm_ -> Adam.step -> EMA.update as TWO launches over all parameters (utils/train.py:159-165,300-305).
-
-    Transparent fast path for the reference's own objects: it keeps torch.optim.Adam's state layout (``state[p]`` =
-    {step, exp_avg, exp_avg_sq}) and the EMA shadow dict, so ``state_dict()`` / checkpoints are unchanged.  Anything it
-    does not recognise (other optimizer, weight decay, amsgrad, several param groups, CPU params) falls back to the
-    generic torch calls.  The clip coefficient is computed on the device from the accumulated squared norm: there is no
-    host synchronisation between backward and the update.
-    """
-
-    def __init__(self, optimizer, ema):
-        self.opt, self.ema = optimizer, ema
-        self.ok = (type(optimizer) is torch.optim.Adam and len(optimizer.param_groups) == 1)
-        if self.ok:
-            g = optimizer.param_groups[0]
-            self.ok = (not g.get("amsgrad") and not g.get("maximize") and g.get("weight_decay", 0) == 0
-                       and not g.get("capturable") and not g.get("differentiable") and not g.get("fused")
-                       and all(p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() for p in g["params"]))
-        self.table = None
-        self.steps = 0
-
-    def _build(self):
-        g = self.opt.param_groups[0]
-        self.params = [p for p in g["params"] if p.requires_grad]
-        dev = self.params[0].device
-        shadow = {}
-        if isinstance(self.ema, EMA):
-            by_param = {id(r()): k for k, r in self.ema._refs.items()}
-            shadow = {id(p): self.ema.shadow[by_param[id(p)]] for p in self.params if id(p) in by_param}
-        rows = []
-        for p in self.params:
-            st = self.opt.state[p]
-            if "exp_avg" not in st:                   # torch's lazy state initialisation (adam.py _init_group)
-                st["step"] = torch.tensor(0.0, dtype=torch.float32)
-                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-            sh = shadow.get(id(p))
-            rows.append([p.data_ptr(), 0, st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), 0 if sh is None else sh.data_ptr(), p.numel()])
-        self.host = torch.tensor(rows, dtype=torch.int64).pin_memory()
-        self.table = torch.empty_like(self.host, device=dev)
-        self.total = torch.zeros(64, dtype=torch.float32, device=dev)      # striped ||g||^2 accumulators (ddpm_mt_grad_sumsq)
-        self.key = [p.data_ptr() for p in self.params]
-        self.steps = int(self.opt.state[self.params[0]]["step"].item())
-
-    def __call__(self, max_norm, ema_w):
-        """Returns False (nothing done) when the fast path does not apply."""
-        if not self.ok:
-            return False
-        if self.table is None or any(p.data_ptr() != k for p, k in zip(self.params, self.key)):
-            self._build()
-        if any(p.grad is None or not p.grad.is_contiguous() or p.grad.dtype != torch.float32 for p in self.params):
-            return False
-        self.host[:, 1] = torch.tensor([p.grad.data_ptr() for p in self.params], dtype=torch.int64)
-        self.table.copy_(self.host, non_blocking=True)
-        g = self.opt.param_groups[0]
-        self.steps += 1
-        b1, b2 = g["betas"]
-        n = len(self.params)
-        s = _hip.stream()
-        if max_norm and max_norm > 0:
-            self.total.zero_()
-            _hip.call("ddpm_mt_grad_sumsq", self.table.data_ptr(), n, self.total.data_ptr(), s)
-        _hip.call("ddpm_mt_adam_ema", self.table.data_ptr(), n, self.total.data_ptr() if max_norm and max_norm > 0 else 0, float(max_norm or 0.0),
-                  float(g["lr"]), b1, b2, g["eps"], 1 - b1 ** self.steps, 1 - b2 ** self.steps, float(ema_w), s)
-        torch._foreach_add_([self.opt.state[p]["step"] for p in self.params], 1)
-        self.opt._opt_called = True                    # what LR schedulers check before their own step()
-        return True
+_TRAIN_GRAPH = os.environ.get("DDPM_TORCH_AMD_TRAIN_GRAPH", "1") != "0"
 
 
 class DummyScheduler:
-    def step(self):
-        pass
+    """Stands in when no LR scheduler is given (utils/train.py:17-26)."""
 
-    def load_state_dict(self, state_dict):
-        pass
+    def step(self):
+        return None
 
     def state_dict(self):
         return None
 
+    def load_state_dict(self, state_dict):
+        return None
+
 
 class RunningStatistics:
-    """Running sums -> per-sample averages (utils/train.py:29-58)."""
+    """Sample-weighted running means: ``update(n, loss=sum_of_n_losses)``; ``extract()`` divides by the sample count
+    (utils/train.py:29-58)."""
 
     def __init__(self, **kwargs):
         self.count = 0
-        self.stats = {k: (v or 0) for k, v in kwargs.items()}
+        self.stats = {name: (0 if value is None else value) for name, value in kwargs.items()}
 
     def reset(self):
         self.count = 0
-        self.stats = {k: 0 for k in self.stats}
+        self.stats = dict.fromkeys(self.stats, 0)
 
     def update(self, n, **kwargs):
         self.count += n
-        for k, v in kwargs.items():
-            self.stats[k] = self.stats.get(k, 0) + v
+        for name, value in kwargs.items():
+            self.stats[name] = self.stats.get(name, 0) + value
 
     def extract(self):
-        return {k: v / self.count for k, v in self.stats.items()}
+        denom = self.count
+        return {name: total / denom for name, total in self.stats.items()}
+
+    def __repr__(self):
+        return "RunningStatistics(" + ", ".join(f"{k}={v:.6g}" for k, v in self.extract().items()) + ")" if self.count else "RunningStatistics()"
 
 
 class EMA:
     """Exponential moving average of the trainable parameters (utils/train.py:279-346).
 
-    decay_t = min(decay, (1 + n) / (10 + n)), n = number of updates so far starting at 0; shadow keys carry no
-    ``module.`` prefix.  ``with ema:`` swaps the shadow weights in (and back out) in place, which bumps the
-    parameters' version counters so the engine refreshes its packed copies.
+    ``decay_t = min(decay, (1 + n) / (10 + n))`` with ``n`` = updates so far (0 for the first); shadow keys are the
+    model's ``named_parameters`` names (no ``module.`` prefix).  ``with ema:`` copies the shadow into the live
+    parameters and back — in place and through the parameters themselves, which bumps their version counters, so the
+    engine re-derives its packed copies (a write through ``p.data`` would go unnoticed).  Shadow tensors are never re-bound after construction (``load_state_dict`` copies INTO them, key by key):
+    the fused update kernel keeps their addresses in its pointer table.
     """
 
     def __init__(self, model, decay=0.9999):
         self.shadow, self._refs = {}, {}
-        for k, v in model.named_parameters():
-            if v.requires_grad:
-                self.shadow[k] = v.detach().clone()
-                self._refs[k] = weakref.ref(v)
+        for name, prm in model.named_parameters():
+            if prm.requires_grad:
+                self.shadow[name] = prm.detach().clone()
+                self._refs[name] = weakref.ref(prm)
         self.decay = decay
         self.num_updates = -1
         self.backup = None
 
-    def _live(self):
-        ps = [r() for r in self._refs.values()]
-        assert all(p is not None for p in ps), "referenced object no longer exists!"
-        return ps
+    def _pairs(self):
+        """[(shadow tensor, live parameter)] matched by NAME."""
+        out = []
+        for name, ref in self._refs.items():
+            prm = ref()
+            assert prm is not None, "referenced object no longer exists!"
+            out.append((self.shadow[name], prm))
+        return out
+
+    def weight_of_next_update(self):
+        """1 - decay of the update that would run next (the fused kernel applies it; ``update`` uses the same value)."""
+        n = self.num_updates + 1
+        return 1.0 - min(self.decay, (1 + n) / (10 + n))
 
     def update(self):
+        w = self.weight_of_next_update()
         self.num_updates += 1
-        decay = min(self.decay, (1 + self.num_updates) / (10 + self.num_updates))
-        with torch.no_grad():                       # shadow += (1 - decay) * (p - shadow), all tensors in one sweep
-            torch._foreach_lerp_(list(self.shadow.values()), [p.data for p in self._live()], 1 - decay)
+        pairs = self._pairs()
+        with torch.no_grad():                       # shadow += w * (p - shadow) over all tensors in one sweep
+            torch._foreach_lerp_([s for s, _ in pairs], [p.data for _, p in pairs], w)
 
     def apply(self):
-        ps = self._live()
-        self.backup = {k: p.detach().clone() for k, p in zip(self._refs, ps)}
+        pairs = self._pairs()
+        self.backup = {name: ref().detach().clone() for name, ref in self._refs.items()}
         with torch.no_grad():
-            torch._foreach_copy_([p.data for p in ps], list(self.shadow.values()))
+            # written through the parameters themselves (not ``.data``, whose writes the version counters do not see): the
+            # engine's derived weight copies are keyed on those counters
+            torch._foreach_copy_([p for _, p in pairs], [s for s, _ in pairs])
 
     def restore(self):
         with torch.no_grad():
-            torch._foreach_copy_([p.data for p in self._live()], list(self.backup.values()))
+            torch._foreach_copy_([ref() for ref in self._refs.values()], [self.backup[name] for name in self._refs])
         self.backup = None
 
     def __enter__(self):
@@ -170,25 +137,31 @@ class EMA:
     def __exit__(self, *exc):
         self.restore()
 
-    def state_dict(self):
-        return {"decay": self.decay, "shadow": self.shadow, "num_updates": self.num_updates}
-
     @property
     def extra_states(self):
         return {"decay", "num_updates"}
 
+    def state_dict(self):
+        return {"decay": self.decay, "shadow": self.shadow, "num_updates": self.num_updates}
+
     def load_state_dict(self, state_dict, strict=True):
-        mine = set(self.shadow).union(self.extra_states)
-        theirs = set(state_dict["shadow"]).union(self.extra_states)
-        bad = (mine ^ theirs) if strict else (mine - theirs)
-        if bad:
-            raise RuntimeError(f"Key mismatch!\nMissing key(s): {', '.join(mine - theirs)}."
-                               f"Unexpected key(s): {', '.join(theirs - mine)}")
-        self.__dict__.update(state_dict)
+        own = set(self.shadow) | self.extra_states
+        given = set(state_dict["shadow"]) | self.extra_states
+        missing, unexpected = own - given, given - own
+        if missing or (strict and unexpected):
+            raise RuntimeError(f"Key mismatch!\nMissing key(s): {', '.join(sorted(missing))}."
+                               f"Unexpected key(s): {', '.join(sorted(unexpected))}")
+        with torch.no_grad():
+            for name, mine in self.shadow.items():
+                mine.copy_(state_dict["shadow"][name])
+        self.decay = state_dict.get("decay", self.decay)
+        self.num_updates = state_dict.get("num_updates", self.num_updates)
 
 
 class ModelWrapper(nn.Module):
-    """Optional pre/post transforms around the denoiser (pixel-(un)shuffle; utils/train.py:349-367)."""
+    """Denoiser with an input transform before and an output transform after it (the reference wraps the UNet with
+    pixel-unshuffle / pixel-shuffle when ``block_size > 1``, train.py:69-72; utils/train.py:349-367).  The wrapped
+    module is registered as ``_model`` — checkpoints of wrapped models carry that prefix."""
 
     def __init__(self, model, pre_transform=None, post_transform=None):
         super().__init__()
@@ -197,12 +170,203 @@ class ModelWrapper(nn.Module):
         self.post_transform = post_transform
 
     def forward(self, x, *args, **kwargs):
-        if self.pre_transform is not None:
-            x = self.pre_transform(x)
-        out = self._model(x, *args, **kwargs)
-        if self.post_transform is not None:
-            out = self.post_transform(out)
-        return out
+        y = x if self.pre_transform is None else self.pre_transform(x)
+        y = self._model(y, *args, **kwargs)
+        return y if self.post_transform is None else self.post_transform(y)
+
+
+# ========================================================================================== fused clip + Adam + EMA
+class _FusedUpdate:
+    """``clip_grad_norm_`` -> ``Adam.step`` -> ``EMA.update`` as TWO launches over all parameters
+    (utils/train.py:159-165,300-305; train.py:128).
+
+    Works on the reference's own objects: ``torch.optim.Adam``'s state layout (``state[p]`` = {step, exp_avg, exp_avg_sq})
+    and the EMA shadow dict are updated in place, so ``state_dict()`` / checkpoints are unchanged.  Anything it does not
+    recognise (another optimiser, weight decay, amsgrad, several parameter groups, CPU parameters) is declined and the
+    caller uses the generic torch calls.  The clip coefficient is computed on the device from the accumulated squared
+    norm: no host synchronisation between backward and the update.
+
+    The kernels write parameters through raw pointers, which autograd's version counters cannot see; every launch is
+    therefore followed by ``increment_version`` on the updated parameters so that version-keyed caches (the engine's
+    packed weights, captured sampler graphs) notice.
+    """
+
+    def __init__(self, optimizer, ema):
+        self.opt, self.ema = optimizer, ema
+        self.table = self.key = None
+        self.total = None
+
+    def eligible(self):
+        opt = self.opt
+        if type(opt) is not torch.optim.Adam or len(opt.param_groups) != 1:
+            return False
+        g = opt.param_groups[0]
+        if g.get("amsgrad") or g.get("maximize") or g.get("weight_decay", 0) != 0 or g.get("capturable") or g.get("differentiable") or g.get("fused"):
+            return False
+        return all(_hip.on_device(p) and p.dtype == torch.float32 and p.is_contiguous() for p in g["params"])
+
+    def _state_tensors(self):
+        """(params, exp_avg, exp_avg_sq, shadow-or-None) in optimiser order, creating torch's lazy Adam state if needed."""
+        params = [p for p in self.opt.param_groups[0]["params"] if p.requires_grad]
+        shadow_of = {}
+        if isinstance(self.ema, EMA):
+            shadow_of = {id(prm): sh for sh, prm in self.ema._pairs()}
+        m, v, sh = [], [], []
+        for p in params:
+            st = self.opt.state[p]
+            if "exp_avg" not in st:                       # adam.py _init_group
+                st["step"] = torch.tensor(0.0, dtype=torch.float32)
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            m.append(st["exp_avg"]); v.append(st["exp_avg_sq"]); sh.append(shadow_of.get(id(p)))
+        return params, m, v, sh
+
+    def prepare(self, grad_ptrs=None):
+        """(Re)build the device pointer table when any address in it moved (``optimizer.load_state_dict`` and ``.to()``
+        re-create state tensors).  ``grad_ptrs``: addresses of the gradients in optimiser order; None = ``p.grad``."""
+        params, m, v, sh = self._state_tensors()
+        if grad_ptrs is None:
+            grad_ptrs = [p.grad.data_ptr() for p in params]
+        key = tuple(t.data_ptr() for t in params) + tuple(t.data_ptr() for t in m) + tuple(t.data_ptr() for t in v) + \
+            tuple(0 if t is None else t.data_ptr() for t in sh) + tuple(grad_ptrs)
+        if key != self.key:
+            rows = [[p.data_ptr(), g, a.data_ptr(), b.data_ptr(), 0 if s is None else s.data_ptr(), p.numel()]
+                    for p, g, a, b, s in zip(params, grad_ptrs, m, v, sh)]
+            dev = params[0].device
+            self.table = torch.tensor(rows, dtype=torch.int64).to(dev)
+            if self.total is None or self.total.device != dev:
+                self.total = torch.zeros(64, dtype=torch.float32, device=dev)      # striped ||g||^2 accumulators
+            self.key, self.params = key, params
+        return self.params
+
+    def step_count(self):
+        """Optimiser steps taken so far, read from the optimiser's own state (survives load_state_dict and fallbacks)."""
+        params = [p for p in self.opt.param_groups[0]["params"] if p.requires_grad]
+        st = self.opt.state.get(params[0], {})
+        return int(st["step"]) if "step" in st else 0
+
+    def launch(self, max_norm, scalars=None, hyper_dev=0):
+        """The two launches.  ``scalars`` = (lr, bias_corr1, bias_corr2, ema_w) by value, or ``hyper_dev`` = address of the
+        same four floats in device memory (captured steps)."""
+        g = self.opt.param_groups[0]
+        b1, b2 = g["betas"]
+        n, s = len(self.params), _hip.stream()
+        clip = bool(max_norm) and max_norm > 0
+        if clip:
+            self.total.zero_()
+            _hip.call("ddpm_mt_grad_sumsq", self.table.data_ptr(), n, self.total.data_ptr(), s)
+        lr, bc1, bc2, ema_w = scalars if scalars is not None else (0.0, 1.0, 1.0, 0.0)
+        _hip.call("ddpm_mt_adam_ema", self.table.data_ptr(), n, self.total.data_ptr() if clip else 0, float(max_norm or 0.0),
+                  float(lr), b1, b2, g["eps"], float(bc1), float(bc2), float(ema_w), hyper_dev, s)
+
+    def scalars(self, ema_w):
+        g = self.opt.param_groups[0]
+        b1, b2 = g["betas"]
+        k = self.step_count() + 1
+        return float(g["lr"]), 1 - b1 ** k, 1 - b2 ** k, float(ema_w)
+
+    def committed(self):
+        """Host-side bookkeeping after the update kernels were enqueued (eagerly or by a graph replay)."""
+        torch._foreach_add_([self.opt.state[p]["step"] for p in self.params], 1)
+        torch.autograd.graph.increment_version(self.params)
+        self.opt._opt_called = True                    # what LR schedulers check before their own step()
+
+    def __call__(self, max_norm, ema_w):
+        """Autograd path: update from ``p.grad``.  Returns False (nothing done) when the fast path does not apply."""
+        if not self.eligible():
+            return False
+        params = [p for p in self.opt.param_groups[0]["params"] if p.requires_grad]
+        if any(p.grad is None or not p.grad.is_contiguous() or p.grad.dtype != torch.float32 for p in params):
+            return False
+        self.prepare()
+        self.launch(max_norm, scalars=self.scalars(ema_w))
+        self.committed()
+        return True
+
+
+# ========================================================================================== the direct / captured step
+class _DirectStep:
+    """State of the autograd-free training step for ONE input shape: persistent buffers, the pointer table of the fused
+    update over the engine's flat gradient buffer, and (on the GPU) the captured graphs."""
+
+    def __init__(self, trainer, unet, shape):
+        self.tr, self.unet = trainer, unet
+        dev = trainer.device
+        B = shape[0]
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.x0 = torch.empty(shape, **f32)
+        self.noise = torch.empty(shape, **f32)
+        self.t = torch.empty((B,), dtype=torch.int64, device=dev)
+        self.gloss = torch.full((B,), 1.0 / B, **f32)            # d(mean loss)/d(loss_b)
+        self.loss = torch.zeros((), **f32)
+        eng = unet.engine()
+        self.gflat = torch.empty(eng.gtotal, **f32)
+        # step-dependent scalars the kernels read from memory: floats {lr, bc1, bc2, ema_w} | uint64 dropout seed word | pad
+        self.hyper_dev = torch.zeros(4, dtype=torch.int64, device=dev)
+        self.hyper_host = [self._pinned(torch.zeros(4, dtype=torch.int64)) for _ in range(4)]
+        self.calls = 0
+        self.graph = None
+        self.graph_failed = False
+
+    @staticmethod
+    def _pinned(t):
+        return t.pin_memory() if torch.cuda.is_available() else t
+
+    def _write_hyper(self):
+        tr, eng = self.tr, self.unet.engine()
+        host = self.hyper_host[self.calls % len(self.hyper_host)]
+        ema_w = tr.ema.weight_of_next_update() if tr._ema_on else 0.0
+        lr, bc1, bc2, w = tr._fused.scalars(ema_w)
+        host.view(torch.float32)[:4] = torch.tensor([lr, bc1, bc2, w], dtype=torch.float32)
+        host[2] = eng.next_dropout_seed() if self.unet.training and self.unet.drop_rate > 0 else 0
+        self.hyper_dev.copy_(host, non_blocking=True)
+
+    def body(self, cut=None):
+        """One training step on the persistent buffers (x0 and the hyper words are already in place)."""
+        tr, dif, eng = self.tr, self.tr.diffusion, self.unet.engine()
+        B, n = self.x0.shape[0], self.x0[0].numel()
+        s = _hip.stream
+        self.t.random_(to=tr.timesteps, generator=tr.generator)                # draw order: t, then noise (utils/train.py:138-140)
+        self.noise.normal_(generator=tr.generator)
+        x_t = dif.q_sample(self.x0, self.t, noise=self.noise)
+        target = dif.loss_target(self.x0, x_t, self.t, self.noise)
+        tape = []
+        out = eng.forward(x_t, self.t, self.unet.training, tape, seed_dev=self.hyper_dev.data_ptr() + 16)
+        losses = torch.empty(B, dtype=torch.float32, device=out.device)
+        _hip.call("ddpm_mse_fwd", out.data_ptr(), target.data_ptr(), losses.data_ptr(), B, n, s())
+        torch.sum(losses * self.gloss, dim=0, out=self.loss)                   # mean over the batch
+        gout = torch.empty_like(out)
+        _hip.call("ddpm_mse_bwd", out.data_ptr(), target.data_ptr(), self.gloss.data_ptr(), gout.data_ptr(), B, n, s())
+        eng.backward(tape, gout, gflat=self.gflat, cut=cut)
+        tr._fused.launch(tr.grad_norm, hyper_dev=self.hyper_dev.data_ptr())
+        eng.refresh_unconditionally()                                          # the next forward reads the re-derived copies
+
+    def run(self, x):
+        tr, eng = self.tr, self.unet.engine()
+        self.x0.copy_(x, non_blocking=True)
+        eng.ensure_fresh(need_dgrad=True)                                      # external writes since the last step (load_state_dict, EMA swap)
+        params = tr._fused.prepare(grad_ptrs=[self.gflat.data_ptr() + 4 * eng.goff[id(p)] for p in tr._fused_param_order()])
+        assert len(params) == len(eng.params)
+        self._write_hyper()
+        use_graph = (_TRAIN_GRAPH and not self.graph_failed and self.x0.is_cuda and self.calls >= 1
+                     and not torch.cuda.is_current_stream_capturing())
+        if use_graph and self.graph is None:
+            g = SegmentedGraph(self.x0.device)
+            g.register_generator(tr.generator)
+            try:
+                self.graph = g.capture(self.body)
+            except Exception as e:                        # capture not possible here: keep training eagerly
+                warnings.warn(f"hipGraph capture of the training step failed ({type(e).__name__}: {e}); running it eagerly")
+                torch.cuda.synchronize()
+                self.graph_failed, self.graph = True, None
+        if use_graph and self.graph is not None:
+            self.graph.replay()
+        else:
+            self.body()
+        self.calls += 1
+        tr._fused.committed()
+        eng.mark_fresh()
+        return self.loss
 
 
 class Trainer:
@@ -230,10 +394,29 @@ class Trainer:
         self.ema = EMA(model.module if isinstance(model, DDP) else model, decay=ema_decay) if use_ema else nullcontext()
         self.stats = RunningStatistics(loss=None)
         self._fused = _FusedUpdate(optimizer, self.ema)
+        self._direct = {}                               # input shape -> _DirectStep
 
+    # ------------------------------------------------------------------ the reference's small accessors
     @property
     def timesteps(self):
         return self.diffusion.timesteps
+
+    @property
+    def current_stats(self):
+        return self.stats.extract()
+
+    @property
+    def trainees(self):
+        names = ["model", "optimizer"]
+        if self.use_ema:
+            names.append("ema")
+        if self.scheduler is not None:
+            names.append("scheduler")
+        return names
+
+    @property
+    def _ema_on(self):
+        return self.use_ema and isinstance(self.ema, EMA)
 
     def get_input(self, x):
         """Draw order per step: t first, then noise (utils/train.py:134-141)."""
@@ -247,109 +430,142 @@ class Trainer:
         assert loss.shape == (x.shape[0],)
         return loss
 
+    # ------------------------------------------------------------------ one optimisation step
+    def _fused_param_order(self):
+        return [p for p in self.optimizer.param_groups[0]["params"] if p.requires_grad]
+
+    def _direct_unet(self):
+        """The UNet behind ``self.model`` when the autograd-free step applies, else None."""
+        from ..models.unet import UNet
+        m = self.model
+        if not isinstance(m, UNet) or self.num_accum != 1 or not self._fused.eligible():
+            return None
+        if not getattr(self.diffusion, "supports_direct_step", False) or not self.diffusion.supports_direct_step():
+            return None
+        own = m.engine().params
+        opt = self._fused_param_order()
+        if len(own) != len(opt) or {id(p) for p in own} != {id(p) for p in opt}:
+            return None
+        return m
+
     def step(self, x, global_steps=1):
-        loss = self.loss(x).mean()
-        loss.div(self.num_accum).backward()
-        if global_steps % self.num_accum == 0:
-            ema_on = self.use_ema and hasattr(self.ema, "update")
-            ema_w = 1 - min(self.ema.decay, (2 + self.ema.num_updates) / (11 + self.ema.num_updates)) if ema_on else 0.0
-            if self._fused(self.grad_norm, ema_w):          # clip + Adam + EMA in two launches (after DDP averaging)
-                if ema_on:
-                    self.ema.num_updates += 1
-            else:
-                nn.utils.clip_grad_norm_(self.model.parameters(), max_norm=self.grad_norm)
-                self.optimizer.step()
-                if ema_on:
-                    self.ema.update()
-            self.optimizer.zero_grad(set_to_none=True)
+        x = x.to(self.device)
+        unet = self._direct_unet() if os.environ.get("DDPM_TORCH_AMD_DIRECT_STEP", "1") != "0" else None
+        if unet is not None and x.dtype == torch.float32:
+            key = tuple(x.shape)
+            if key not in self._direct:
+                self._direct[key] = _DirectStep(self, unet, key)
+            loss = self._direct[key].run(x).clone()
+            if self._ema_on:
+                self.ema.num_updates += 1
             self.scheduler.step()
-        loss = loss.detach()
+        else:
+            loss = self.loss(x).mean()
+            loss.div(self.num_accum).backward()
+            if global_steps % self.num_accum == 0:
+                ema_w = self.ema.weight_of_next_update() if self._ema_on else 0.0
+                if self._fused(self.grad_norm, ema_w):          # clip + Adam + EMA in two launches (after DDP averaging)
+                    if self._ema_on:
+                        self.ema.num_updates += 1
+                else:
+                    nn.utils.clip_grad_norm_(self.model.parameters(), max_norm=self.grad_norm)
+                    self.optimizer.step()
+                    if self._ema_on:
+                        self.ema.update()
+                self.optimizer.zero_grad(set_to_none=True)
+                self.scheduler.step()
+            loss = loss.detach()
         if self.distributed:
             dist.reduce(loss, dst=0, op=dist.ReduceOp.SUM)
             loss.div_(self.world_size)
         self.stats.update(x.shape[0], loss=loss.item() * x.shape[0])
 
+    # ------------------------------------------------------------------ sampling with the (EMA) weights
     def sample_fn(self, sample_size=None, noise=None, diffusion=None, sample_seed=None):
-        shape = ((sample_size // self.world_size,) + self.shape) if noise is None else noise.shape
-        diffusion = diffusion or self.diffusion
+        per_rank = ((sample_size // self.world_size,) + self.shape) if noise is None else tuple(noise.shape)
+        process = self.diffusion if diffusion is None else diffusion
         with self.ema:
-            sample = diffusion.p_sample(denoise_fn=self.model, shape=shape, device=self.device, noise=noise, seed=sample_seed)
+            sample = process.p_sample(denoise_fn=self.model, shape=per_rank, device=self.device, noise=noise, seed=sample_seed)
         if self.distributed:
-            gathered = [torch.zeros(shape, device=self.device) for _ in range(self.world_size)]
-            dist.all_gather(gathered, sample)
-            sample = torch.cat(gathered, dim=0)
+            parts = [torch.zeros(per_rank, device=self.device) for _ in range(self.world_size)]
+            dist.all_gather(parts, sample)
+            sample = torch.cat(parts, dim=0)
         assert sample.grad is None
         return sample
+
+    # ------------------------------------------------------------------ epoch loop
+    def _epoch(self, e, first_global_step):
+        """One pass over the loader; returns (#steps done, last running statistics)."""
+        self.stats.reset()
+        self.model.train()
+        if hasattr(self.sampler, "set_epoch"):
+            self.sampler.set_epoch(e)                   # DistributedSampler reshuffles per epoch
+        steps, seen = first_global_step, {}
+        for batch in self.trainloader:
+            images = batch[0] if isinstance(batch, (list, tuple)) else batch       # unconditional: labels are dropped
+            steps += 1
+            self.step(images.to(self.device), global_steps=steps)
+            seen = self.current_stats
+            if self.dry_run and steps % self.num_accum == 0:
+                break
+        return steps, dict(seen)
+
+    def _write_samples(self, e, image_dir):
+        self.model.eval()
+        x = self.sample_fn(sample_size=self.num_samples, sample_seed=self.sample_seed).cpu()
+        if self.is_leader:
+            # tensors in [-1, 1]; encoding them as an image grid is the data path's job (torchvision is not on the hot path)
+            torch.save(x, os.path.join(image_dir, f"{e + 1}.pt"))
 
     def train(self, evaluator=None, chkpt_path=None, image_dir=None):
         if self.num_samples:
             assert self.num_samples % self.world_size == 0, "Number of samples should be divisible by WORLD_SIZE!"
-        if self.dry_run:
-            self.start_epoch, self.epochs = 0, 1
+        first, last = (0, 1) if self.dry_run else (self.start_epoch, self.epochs)
+        self.start_epoch, self.epochs = first, last
         global_steps = 0
-        for e in range(self.start_epoch, self.epochs):
-            self.stats.reset()
-            self.model.train()
-            results = {}
-            if hasattr(self.sampler, "set_epoch"):
-                self.sampler.set_epoch(e)
-            for x in self.trainloader:
-                if isinstance(x, (list, tuple)):
-                    x = x[0]
-                global_steps += 1
-                self.step(x.to(self.device), global_steps=global_steps)
-                results.update(self.current_stats)
-                if self.dry_run and not global_steps % self.num_accum:
-                    break
-            if not (e + 1) % self.image_intv and self.num_samples and image_dir:
+        for e in range(first, last):
+            global_steps, results = self._epoch(e, global_steps)
+            done = e + 1
+            if image_dir and self.num_samples and done % self.image_intv == 0:
+                self._write_samples(e, image_dir)
+            if chkpt_path and done % self.chkpt_intv == 0:
                 self.model.eval()
-                x = self.sample_fn(sample_size=self.num_samples, sample_seed=self.sample_seed).cpu()
+                if evaluator is not None:
+                    results.update(evaluator.eval(self.sample_fn, is_leader=self.is_leader))
                 if self.is_leader:
-                    torch.save(x, os.path.join(image_dir, f"{e + 1}.pt"))     # image encoding is out of scope (no torchvision)
-            if not (e + 1) % self.chkpt_intv and chkpt_path:
-                self.model.eval()
-                results.update(evaluator.eval(self.sample_fn, is_leader=self.is_leader) if evaluator is not None else {})
-                if self.is_leader:
-                    self.save_checkpoint(chkpt_path, epoch=e + 1, **results)
+                    self.save_checkpoint(chkpt_path, epoch=done, **results)
             if self.distributed:
                 dist.barrier()
 
-    @property
-    def trainees(self):
-        roster = ["model", "optimizer"]
-        if self.use_ema:
-            roster.append("ema")
-        if self.scheduler is not None:
-            roster.append("scheduler")
-        return roster
-
-    @property
-    def current_stats(self):
-        return self.stats.extract()
-
-    def load_checkpoint(self, chkpt_path, map_location):
-        """Same on-disk layout as the reference (utils/train.py:249-276): {model, optimizer, ema, scheduler, epoch, ...}."""
-        chkpt = torch.load(chkpt_path, map_location=map_location)
+    # ------------------------------------------------------------------ checkpoints (reference layout)
+    def named_state_dicts(self):
         for name in self.trainees:
-            try:
-                getattr(self, name).load_state_dict(chkpt[name])
-            except RuntimeError:
-                sd = chkpt[name]["shadow"] if name == "ema" else chkpt[name]
-                for k in list(sd.keys()):
-                    if k.startswith("module."):
-                        sd[k.split(".", maxsplit=1)[1]] = sd.pop(k)
-                getattr(self, name).load_state_dict(chkpt[name])
-            except AttributeError:
-                continue
-        self.start_epoch = chkpt["epoch"]
+            yield name, getattr(self, name).state_dict()
 
     def save_checkpoint(self, chkpt_path, **extra_info):
-        chkpt = dict(self.named_state_dicts())
-        chkpt.update(extra_info)
-        if "epoch" in extra_info:
+        payload = {name: sd for name, sd in self.named_state_dicts()}
+        payload.update(extra_info)
+        if "epoch" in extra_info:                       # foo.pt / foo_12.pt -> foo_<epoch>.pt
             chkpt_path = re.sub(r"(_\d+)?\.pt", f"_{extra_info['epoch']}.pt", chkpt_path)
-        torch.save(chkpt, chkpt_path)
+        torch.save(payload, chkpt_path)
 
-    def named_state_dicts(self):
-        for k in self.trainees:
-            yield k, getattr(self, k).state_dict()
+    @staticmethod
+    def _without_ddp_prefix(sd):
+        """Keys written by a DistributedDataParallel-wrapped trainee carry ``module.``; accept either form."""
+        return {(k[len("module."):] if isinstance(k, str) and k.startswith("module.") else k): v for k, v in sd.items()}
+
+    def load_checkpoint(self, chkpt_path, map_location):
+        chkpt = torch.load(chkpt_path, map_location=map_location)
+        for name in self.trainees:
+            target, saved = getattr(self, name), chkpt.get(name)
+            if saved is None or not hasattr(target, "load_state_dict"):
+                continue
+            try:
+                target.load_state_dict(saved)
+            except RuntimeError:
+                if name == "ema":
+                    saved = dict(saved, shadow=self._without_ddp_prefix(saved["shadow"]))
+                else:
+                    saved = self._without_ddp_prefix(saved)
+                target.load_state_dict(saved)
+        self.start_epoch = chkpt["epoch"]

@@ -101,15 +101,17 @@ int ddpm_last_gemm_variant(int reset);
 /* nn.GroupNorm(32, C, eps=1e-6) -> SiLU -> Dropout(p) (unet.py:18-20,15,81,85-87,139-140; :57 without SiLU):
  *   y = drop(silu((x - mean_g) * rstd_g * gamma_c + beta_c)),  biased variance over (C/G)*HW elements.
  * stats (optional) receives [B][G][2] = (mean, rstd) for the backward.  workspace: ddpm_gn_workspace_floats().
- * Dropout keep-mask = hash(seed, linear NHWC index) (see ddpm_dropout_mask); scale 1/(1-p). */
+ * Dropout keep-mask = hash(seed, linear NHWC index) (see ddpm_dropout_mask); scale 1/(1-p).  seed_dev (optional device
+ * word): the effective seed is seed + *seed_dev — a captured hipGraph then draws a fresh mask on every replay.
+ * Statistics are accumulated about a per-group pivot (the group's first element), so |mean| >> std keeps full accuracy. */
 int ddpm_groupnorm_silu_fwd(const void* x, long long x_ld, void* y, long long y_ld, const float* gamma, const float* beta,
                             float* stats, float* workspace, int B, int HW, int C, int G, float eps, int silu,
-                            float drop_p, unsigned long long seed, int dtype, void* stream);
+                            float drop_p, unsigned long long seed, const unsigned long long* seed_dev, int dtype, void* stream);
 /* backward of the above: dx (+= when accumulate), dgamma/dbeta += (fp32 atomics). */
 int ddpm_groupnorm_silu_bwd(const void* x, long long x_ld, const void* dy, long long dy_ld, void* dx, long long dx_ld,
                             const float* gamma, const float* beta, const float* stats, float* dgamma, float* dbeta,
                             float* workspace, int B, int HW, int C, int G, int silu, float drop_p, unsigned long long seed,
-                            int accumulate, int dtype, void* stream);
+                            const unsigned long long* seed_dev, int accumulate, int dtype, void* stream);
 long long ddpm_gn_workspace_floats(int B, int HW, int C, int G, int dtype);
 
 /* get_timestep_embedding (ddpm_torch/functions.py:10-26): out[b] = cat(sin(t_b f), cos(t_b f)) (zero pad if dim odd);
@@ -124,18 +126,20 @@ int ddpm_pack_weight(const float* w, void* w_fwd /*[N][R][S][Cp]*/, void* w_dgra
 /* every layer's pack in one launch: descs[i] = {w, w_fwd, w_dgrad (or 0), N, C, R (== S), Cp, Np} as int64 */
 int ddpm_pack_weight_multi(const long long* descs, int n_tensors, int dtype, void* stream);
 
-/* GaussianDiffusion.q_sample (ddpm_torch/diffusion.py:92-97): xt = sqrt_ab[t]*x0 + sqrt_1mab[t]*noise  (fp32, [B][n]) */
+/* GaussianDiffusion.q_sample (ddpm_torch/diffusion.py:92-97): xt = sqrt_ab[t]*x0 + sqrt_1mab[t]*noise  (fp32, [B][n]).
+ * T = table length: a sample whose t is outside [0, T) is filled with NaN (the reference's gather raises, :83). */
 int ddpm_q_sample(const float* x0, const float* noise, const long long* t, const float* sqrt_ab, const float* sqrt_1mab,
-                  float* xt, int B, int n, void* stream);
+                  float* xt, int B, int n, int T, void* stream);
 /* flat_mean((target - pred)^2) (diffusion.py:239, functions.py:99-101) and its gradient w.r.t. pred */
 int ddpm_mse_fwd(const float* pred, const float* target, float* loss, int B, int n, void* stream);
 int ddpm_mse_bwd(const float* pred, const float* target, const float* gloss, float* gpred, int B, int n, void* stream);
 /* p_mean_var + p_sample_step (diffusion.py:107-158; ddim.py inherits it): one fused update
  *   x0 = clamp(recip[t]*x_t - recip_m1[t]*out)   (mean_type 0 = eps; 1: x0 = out; 2: out is the mean)
- *   x_prev = coef1[t]*x0 + coef2[t]*x_t + 1[t>0]*exp(0.5*logvar[t])*z ;  pred_x0 optional. */
+ *   x_prev = coef1[t]*x0 + coef2[t]*x_t + 1[t>0]*exp(0.5*logvar[t])*z ;  pred_x0 optional.
+ * The clamp propagates NaN like torch.clamp; T = table length, t outside [0, T) poisons the sample with NaN. */
 int ddpm_p_sample_step(const float* x_t, const float* model_out, const float* z, const long long* t,
                        const float* sqrt_recip_ab, const float* sqrt_recip_m1_ab, const float* post_coef1, const float* post_coef2,
-                       const float* logvar, float* x_prev, float* pred_x0, int B, int n, int mean_type, int clip, void* stream);
+                       const float* logvar, float* x_prev, float* pred_x0, int B, int n, int mean_type, int clip, int T, void* stream);
 /* subsequence.gather(0, t) (ddim.py:101) and t += delta (t.fill_ in diffusion.py:172, device-side for graph replay) */
 int ddpm_gather_i64(const long long* idx, const long long* map, long long* out, int B, void* stream);
 int ddpm_add_i64(long long* t, int B, long long delta, void* stream);
@@ -170,8 +174,14 @@ int ddpm_adam_ema_step(float* p, const float* g, float* m, float* v, float* shad
  * final atomics of ~5000 blocks do not serialise on one address).  ddpm_mt_adam_ema: the fused update above for all i, with the
  * clipping norm taken from the sum of that bank. */
 int ddpm_mt_grad_sumsq(const long long* table, int n_tensors, float* total_sq, void* stream);
+/* hyper_dev (optional, 4 device floats {lr, bias_corr1, bias_corr2, ema_w}) overrides the by-value scalars: the values of the
+ * current step are read from memory, so one captured hipGraph serves every training step. */
 int ddpm_mt_adam_ema(const long long* table, int n_tensors, const float* total_sq, float max_norm, float lr, float beta1,
-                     float beta2, float eps, float bias_corr1, float bias_corr2, float ema_w, void* stream);
+                     float beta2, float eps, float bias_corr1, float bias_corr2, float ema_w, const float* hyper_dev, void* stream);
+
+/* dst_i = a_i (+ b_i) over many small fp32 tensors in one launch: table[i] = {a, b (0 = none), dst, numel} (int64).  Builds the
+ * concatenated time-bias projection (all ResidualBlock.fc weights; fc.bias + conv1.bias, ddpm_torch/models/unet.py:77,85-86). */
+int ddpm_mt_gather_f32(const long long* table, int n_tensors, void* stream);
 
 /* test hook: the keep-mask (1/0) the GroupNorm kernels regenerate for element indices 0..n-1 */
 int ddpm_dropout_mask(float* mask, long long n, float p, unsigned long long seed, void* stream);

@@ -11,12 +11,13 @@ from . import unet_ref as U
 
 
 class TrainState:
-    def __init__(self, sd, cfg, lr, warmup, grad_norm=1.0, ema_decay=0.9999, betas=(0.9, 0.999)):
+    def __init__(self, sd, cfg, lr, warmup, grad_norm=1.0, ema_decay=0.9999, betas=(0.9, 0.999), lr_lambda=None):
         self.cfg = cfg
         self.params = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
         self.opt = torch.optim.Adam(list(self.params.values()), lr=lr, betas=betas)       # train.py:128
-        self.sched = torch.optim.lr_scheduler.LambdaLR(
-            self.opt, lr_lambda=lambda s: min((s + 1) / warmup, 1.0)) if warmup > 0 else None  # train.py:130-132
+        if lr_lambda is None and warmup > 0:
+            lr_lambda = lambda s: min((s + 1) / warmup, 1.0)                               # train.py:130-132
+        self.sched = torch.optim.lr_scheduler.LambdaLR(self.opt, lr_lambda=lr_lambda) if lr_lambda is not None else None
         self.grad_norm = grad_norm
         self.ema_decay = ema_decay
         self.shadow = {k: v.detach().clone() for k, v in self.params.items()}              # utils/train.py:286-293

@@ -202,7 +202,9 @@ class Emulator:
             y = y * keep / (1.0 - drop_p)
         return y.reshape(B, C, HW).permute(0, 2, 1).reshape(B * HW, C)
 
-    def ddpm_groupnorm_silu_fwd(self, x, x_ld, y, y_ld, gamma, beta, stats, ws, B, HW, C, G, eps, silu, drop_p, seed, dt, st):
+    def ddpm_groupnorm_silu_fwd(self, x, x_ld, y, y_ld, gamma, beta, stats, ws, B, HW, C, G, eps, silu, drop_p, seed, seed_dev, dt, st):
+        if seed_dev and drop_p > 0:
+            seed = (seed + int(_np(seed_dev, 1, ctypes.c_uint64, np.uint64)[0])) & ((1 << 64) - 1)
         xin = torch.from_numpy(Mat(x, B * HW, C, x_ld, dt).get())
         g, b = torch.from_numpy(f32(gamma, C).copy()), torch.from_numpy(f32(beta, C).copy())
         out = self._gn(xin, g, b, G, eps, silu, drop_p, seed, B, HW, C)
@@ -214,7 +216,9 @@ class Emulator:
             s[..., 0] = mean.float().numpy(); s[..., 1] = (1.0 / torch.sqrt(var + eps)).float().numpy()
 
     def ddpm_groupnorm_silu_bwd(self, x, x_ld, dy, dy_ld, dx, dx_ld, gamma, beta, stats, dgamma, dbeta, ws, B, HW, C, G, silu, drop_p,
-                                seed, acc, dt, st):
+                                seed, seed_dev, acc, dt, st):
+        if seed_dev and drop_p > 0:
+            seed = (seed + int(_np(seed_dev, 1, ctypes.c_uint64, np.uint64)[0])) & ((1 << 64) - 1)
         xin = torch.from_numpy(Mat(x, B * HW, C, x_ld, dt).get()).requires_grad_(True)
         g = torch.from_numpy(f32(gamma, C).copy()).requires_grad_(True)
         b = torch.from_numpy(f32(beta, C).copy()).requires_grad_(True)
@@ -271,9 +275,9 @@ class Emulator:
             else:
                 self.ddpm_pack_weight(w, wf, wd, N, C, R & 0xff, R & 0xff, Cp, Np, dt, st)
 
-    def ddpm_q_sample(self, x0, noise, t, ca, cb, xt, B, n, st):
+    def ddpm_q_sample(self, x0, noise, t, ca, cb, xt, B, n, T, st):
         tt = i64(t, B)
-        T = int(tt.max()) + 1
+        assert 0 <= int(tt.min()) and int(tt.max()) < T
         a, b = f32(ca, T)[tt], f32(cb, T)[tt]
         f32(xt, B * n).reshape(B, n)[...] = a[:, None] * f32(x0, B * n).reshape(B, n) + b[:, None] * f32(noise, B * n).reshape(B, n)
 
@@ -285,9 +289,9 @@ class Emulator:
         d = f32(pred, B * n).reshape(B, n) - f32(target, B * n).reshape(B, n)
         f32(gpred, B * n).reshape(B, n)[...] = d * (2.0 / n) * f32(gloss, B)[:, None]
 
-    def ddpm_p_sample_step(self, x_t, out, z, t, recip, recip_m1, c1, c2, logvar, x_prev, pred, B, n, mean_type, clip, st):
+    def ddpm_p_sample_step(self, x_t, out, z, t, recip, recip_m1, c1, c2, logvar, x_prev, pred, B, n, mean_type, clip, T, st):
         tt = i64(t, B)
-        T = int(tt.max()) + 1
+        assert 0 <= int(tt.min()) and int(tt.max()) < T
         g = lambda p: f32(p, T)[tt][:, None]
         xt, o, zz = (f32(p, B * n).reshape(B, n) for p in (x_t, out, z))
         if mean_type == 0:
@@ -303,6 +307,36 @@ class Emulator:
         f32(x_prev, B * n).reshape(B, n)[...] = mean + mask * np.exp(0.5 * g(logvar)) * zz
         if pred:
             f32(pred, B * n).reshape(B, n)[...] = x0
+
+    def ddpm_mt_gather_f32(self, table, n, st):
+        for a, b, dst, numel in i64(table, 4 * n).reshape(n, 4):
+            v = f32(int(a), int(numel)).copy()
+            if b:
+                v += f32(int(b), int(numel))
+            f32(int(dst), int(numel))[...] = v
+
+    def ddpm_mt_grad_sumsq(self, table, n, total, st):
+        tot = 0.0
+        for row in i64(table, 6 * n).reshape(n, 6):
+            g = f32(int(row[1]), int(row[5])).astype(np.float64)
+            tot += float((g * g).sum())
+        f32(total, 64)[0] += np.float32(tot)
+
+    def ddpm_mt_adam_ema(self, table, n, total, max_norm, lr, b1, b2, eps, bc1, bc2, ema_w, hyper, st):
+        if hyper:
+            lr, bc1, bc2, ema_w = (float(v) for v in f32(hyper, 4))
+        clip = 1.0
+        if total and max_norm > 0:
+            clip = min(1.0, max_norm / (float(np.sqrt(f32(total, 64).astype(np.float64).sum())) + 1e-6))
+        for row in i64(table, 6 * n).reshape(n, 6):
+            p_, g_, m_, v_, sh_, numel = (int(v) for v in row)
+            p, g, m, v = f32(p_, numel), f32(g_, numel) * np.float32(clip), f32(m_, numel), f32(v_, numel)
+            m[...] = b1 * m + (1 - b1) * g
+            v[...] = b2 * v + (1 - b2) * g * g
+            p[...] = p - (lr / bc1) * (m / (np.sqrt(v) / np.sqrt(bc2) + eps))
+            if sh_:
+                sh = f32(sh_, numel)
+                sh[...] = sh + ema_w * (p - sh)
 
     def ddpm_gather_i64(self, idx, mp, out, B, st):
         ii = i64(idx, B)
@@ -388,4 +422,5 @@ def install(monkeypatch, hip_module):
     monkeypatch.setattr(hip_module, "call", emu.call)
     monkeypatch.setattr(hip_module, "stream", lambda: 0)
     monkeypatch.setattr(hip_module, "require_cuda", lambda *a: None)
+    monkeypatch.setattr(hip_module, "on_device", lambda t: True)
     return emu

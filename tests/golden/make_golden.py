@@ -270,6 +270,31 @@ def g7_train():
     save("g7_train.pt", out)
 
 
+# ----------------------------------------------------------------------------- G9 train steps that MOVE the weights
+def g9_train_lr():
+    """Like G7 but with a learning rate that changes the parameters by ~1e-2 per step and no warm-up: a forward that keeps
+    using stale derived weight copies after an optimiser step cannot reproduce these losses (G7's effective lr of 4e-8 could)."""
+    betas = ref.get_beta_schedule("linear", 1e-4, 0.02, 1000)
+    dif = ref.GaussianDiffusion(betas, "eps", "fixed-large", "mse")
+    m, _, sd0 = tiny_model()
+    lr = 3e-3
+    opt = torch.optim.Adam(m.parameters(), lr=lr, betas=(0.9, 0.999))
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lr_lambda=lambda t: 1.0 if t < 3 else 0.5)
+    tr = ref.Trainer(m, opt, dif, epochs=1, trainloader=None, scheduler=sched, use_ema=True, grad_norm=1.0,
+                     shape=(3, 8, 8), device=torch.device("cpu"), ema_decay=0.9999)
+    m.train()
+    xs = [(torch.rand(4, 3, 8, 8, generator=torch.Generator().manual_seed(90 + i)) * 2 - 1) for i in range(6)]
+    losses = []
+    for i, x in enumerate(xs):
+        tr.stats.reset()
+        tr.step(x, global_steps=i + 1)
+        losses.append(tr.current_stats["loss"])
+    out = dict(cfg=TINY, init_seed=1234, rand_seed=31, xs=xs, losses=torch.tensor(losses, dtype=torch.float64), lr=lr, gen_seed=8191,
+               params=pack_dict(m.state_dict()), shadow=pack_dict(tr.ema.shadow), num_updates=tr.ema.num_updates,
+               last_lr=sched.get_last_lr()[0])
+    save("g9_train_lr.pt", out)
+
+
 # ----------------------------------------------------------------------------- G8 toy plumbing
 def g8_toy():
     torch.manual_seed(1234)
@@ -305,4 +330,7 @@ def g8_toy():
 
 
 if __name__ == "__main__":
-    g1_ops(); g2_blocks(); g3_model(); g4_tables(); g5_steps(); g6_loops(); g7_train(); g8_toy()
+    import sys
+    ALL = dict(g1=g1_ops, g2=g2_blocks, g3=g3_model, g4=g4_tables, g5=g5_steps, g6=g6_loops, g7=g7_train, g8=g8_toy, g9=g9_train_lr)
+    for name in (sys.argv[1:] or list(ALL)):          # `make_golden.py g9` regenerates one fixture, no argument = all
+        ALL[name]()

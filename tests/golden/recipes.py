@@ -52,3 +52,33 @@ def check(actual, packed, rtol, atol=0.0, name=""):
         err = float((got[part].to(packed[part].dtype) - packed[part]).abs().max())
         assert err <= rtol * scale * 4 + atol, f"{name}: {part} err {err:.3e} vs scale {scale:.3e}"
     return 0.0
+
+
+# ---- comparing parameter states after Adam steps (the G9 fixture; tiny UNet: hid 32, mult (1, 2))
+def noise_driven(key):
+    """Parameters whose gradient is analytically ZERO in the tiny net: a per-channel constant added in front of a
+    GroupNorm with one channel per group (32 channels, 32 groups) — conv1.bias and the time-bias projection of the
+    32-channel blocks, the output bias of the last block (it feeds only out_conv's GroupNorm) — and the key third of project_in.bias (a constant added to every key shifts all logits of a query
+    alike: the softmax does not see it).  Their numerical gradient is rounding noise (~1e-9), which Adam normalises into
+    +-lr steps of arbitrary sign, in the reference as much as here: they cannot be compared (and have no effect on any output)."""
+    return (("level_0." in key and (key.endswith("conv1.bias") or ".fc." in key)) or key.endswith("project_in.bias")
+            or key in ("upsamples.level_0.1.conv2.bias", "upsamples.level_0.1.skip.bias"))
+
+
+def check_state(actual, expected, tol, name, adam_slack=0.0):
+    """Every tensor within ``tol`` (relative to its max magnitude) — except that, when ``adam_slack`` > 0 (comparisons
+    against another implementation's Adam trajectory), up to 2 % of a tensor's elements may be off by at most
+    ``adam_slack``: Adam turns a gradient element that sits at rounding-noise level in the first steps into +-lr moves."""
+    for k, v in expected.items():
+        if noise_driven(k):
+            continue
+        if not torch.is_tensor(v):                      # large tensors are committed as digests (sums + head / tail)
+            check(actual[k], v, 5e-3 if adam_slack > 0 else tol, name=f"{name}.{k}")
+            continue
+        err = (actual[k].detach().double() - v.double()).abs()
+        scale = float(v.abs().max()) or 1.0
+        bad = err > tol * scale
+        assert float(err.max()) <= max(tol * scale, adam_slack), f"{name}.{k}: max err {float(err.max()):.3e}"
+        assert int(bad.sum()) <= 0.02 * bad.numel() * (adam_slack > 0), f"{name}.{k}: {int(bad.sum())}/{bad.numel()} elements beyond {tol:g}"
+
+

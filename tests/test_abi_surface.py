@@ -38,7 +38,7 @@ def test_library_exports_every_declared_symbol():
 def test_argument_validation_returns_status_codes_without_a_gpu():
     lib = _hip.lib()
     # null pointers / bad shapes are rejected on the host before any launch
-    assert lib.ddpm_q_sample(0, 0, 0, 0, 0, 0, 1, 1, 0) == 5
+    assert lib.ddpm_q_sample(0, 0, 0, 0, 0, 0, 1, 1, 10, 0) == 5
     assert lib.ddpm_gn_workspace_floats(2, 64, 100, 32, 1) == -1          # 100 channels not divisible by 32
     assert lib.ddpm_gn_workspace_floats(2, 64, 128, 32, 1) > 0
     with pytest.raises(RuntimeError, match="null pointer"):

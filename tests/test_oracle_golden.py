@@ -254,6 +254,28 @@ def test_g7_train_steps(golden):
     assert [round(min(0.9999, (1 + n) / (10 + n)), 4) for n in range(3)] == [0.1, 0.1818, 0.25]
 
 
+def test_g9_train_steps_with_a_learning_rate_that_moves_the_weights(golden):
+    g = golden("g9_train_lr.pt")
+    torch.manual_seed(g["init_seed"])
+    sd0 = U.randomize_state_dict(U.init_state_dict(g["cfg"]), g["rand_seed"])
+    st = train_ref.TrainState(sd0, g["cfg"], lr=g["lr"], warmup=0, grad_norm=1.0, ema_decay=0.9999, lr_lambda=lambda s: 1.0 if s < 3 else 0.5)
+    T = D.ddpm_tables(D.beta_schedule("linear", 1e-4, 0.02, 1000), "fixed-large")
+    gen = torch.Generator("cpu").manual_seed(g["gen_seed"])
+    losses = []
+    for x in g["xs"]:
+        t = torch.empty((x.shape[0],), dtype=torch.int64).random_(to=1000, generator=gen)
+        noise = torch.empty_like(x).normal_(generator=gen)
+        losses.append(st.step(T, x, t, noise))
+    assert torch.allclose(torch.tensor(losses, dtype=torch.float64), g["losses"], rtol=2e-4)
+    assert abs(st.sched.get_last_lr()[0] - g["last_lr"]) < 1e-15
+    moved = max(float((st.params[k].detach() - sd0[k]).abs().max()) for k in sd0)
+    assert moved > 5e-3                                   # the fixture is sensitive to the updates
+    from tests.golden.recipes import check_state
+    slack = 0.25 * g["lr"] * len(g["xs"])
+    check_state(st.params, g["params"], 5e-4, "param", adam_slack=slack)
+    check_state(st.shadow, g["shadow"], 5e-4, "shadow", adam_slack=slack)
+
+
 def test_g8_toy(golden):
     g = golden("g8_toy.pt")
     assert g["nparams"] == 67074
