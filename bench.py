@@ -126,11 +126,15 @@ def main():
                4: "gemm64_kernel<64x64>", 5: "conv3x3_halo_kernel<256px x 128>"}
     peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3
 
+    import ddpm_torch.utils.train as train_mod
+
     def profile_step(step_no):
+        graph_was, train_mod._TRAIN_GRAPH = train_mod._TRAIN_GRAPH, False       # per-launch events need the eager form of the step
         _ops.PROFILE = []
         tr.step(x0, global_steps=step_no)
         torch.cuda.synchronize()
         prof, _ops.PROFILE = _ops.PROFILE, None
+        train_mod._TRAIN_GRAPH = graph_was
         agg, shapes = {}, {}
         for kind, flops, a, b, shape, variant in prof:
             dt_s = a.elapsed_time(b) * 1e-3

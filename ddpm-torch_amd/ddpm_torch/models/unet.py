@@ -815,39 +815,65 @@ class _Engine:
             st["tape"].append(("attn", ab, x, out, hn, stats, qkv, prob, o))
 
     # ================================================================ backward
-    def backward(self, tape, gout, gflat=None, cut=None):
-        """Replays the tape in reverse.  ``gflat``: caller-owned flat gradient buffer (stable address for captured steps).
-        ``cut(fn)``: when the step is being captured as a sequence of hipGraphs, the communicator calls are not captured —
-        ``cut`` ends the current graph segment, registers ``fn`` to run eagerly between the segments at replay time, and
-        opens the next segment."""
-        m = self.m
+    def _open_backward(self, st, gflat=None, cut=None):
+        """Gradient staging buffers + stream / communicator bookkeeping of one backward pass."""
+        B, ws = st["B"], st["ws"]
         if gflat is None:
             gflat = torch.empty(self.gtotal, dtype=torch.float32, device=self.device)   # written only by the final unpack
-        head = tape[-1]
-        st = head[4]
-        B, ws = st["B"], st["ws"]
-        gout = gout.contiguous().float()
-        H, W = gout.shape[2], gout.shape[3]
         dtb = torch.zeros((B, self.tb_total), dtype=torch.float32, device=self.device)
-        wdesc = self._wgrad_table()
+        self._wgrad_table()
         if self._gpack is None or self._gpack.numel() != self.ptotal:
             self._gpack = torch.empty(self.ptotal, dtype=torch.float32, device=self.device)
         gpack = self._gpack.zero_()           # persistent (stable addresses for the slab-reduce tables): packed conv weight grads [N][RS][C] + tail
         ctx = dict(gflat=gflat, gpack=gpack, ws=ws, B=B, dtb=dtb, pending=None, works=self._works, slab_rows=[], side=None, keep=[], cut=cut,
-                   seed_dev=st.get("seed_dev", 0))
-        if _SIDE_STREAM and gout.is_cuda:
+                   seed_dev=st.get("seed_dev", 0), world=1)
+        if _SIDE_STREAM and gflat.is_cuda:
             if self._side is None:
                 self._side = torch.cuda.Stream(device=self.device)
             ctx["side"] = self._side
             ev0 = torch.cuda.Event()
             ev0.record()                              # the staging buffer is zeroed on the main stream
             self._side.wait_event(ev0)
-        world = 1
         if self.pg is not None:
             import torch.distributed as dist
-            world = dist.get_world_size(self.pg)
+            ctx["world"] = dist.get_world_size(self.pg)
             # chunks in execution order; the backward finishes them from the last one backwards
             ctx["pending"] = [(a, b, set(mem)) for a, b, mem in self.chunks]
+        return ctx
+
+    def _close_backward(self, ctx, st):
+        """Time-embedding path, outstanding reductions / collectives, then ONE launch that rewrites the staging buffer into
+        the flat parameter-order gradient (x 1/world)."""
+        gpack, gflat = ctx["gpack"], ctx["gflat"]
+        self._temb_bwd(ctx, st)
+        self._flush_slabs(ctx)
+        self._join_side(ctx)
+        if self.pg is not None:
+            assert not ctx["pending"], "a conv weight gradient was never produced"
+            works, tail = ctx["works"], gpack[self.tail[0]:self.tail[1]]
+
+            def finish():
+                works.append(self._all_reduce(tail))
+                for w in works:
+                    w.wait()                               # the compute stream waits for the communicator; no host sync
+                works.clear()
+            self._comm(ctx, finish)
+        wdesc = self._wgrad_table()
+        _hip.call("ddpm_wgrad_unpack", gpack.data_ptr(), gflat.data_ptr(), wdesc.data_ptr(), wdesc.shape[0], 1.0 / ctx["world"], _hip.stream())
+        return gflat
+
+    def backward(self, tape, gout, gflat=None, cut=None):
+        """Replays the tape in reverse.  ``gflat``: caller-owned flat gradient buffer (stable address for captured steps).
+        ``cut(fn)``: when the step is being captured as a sequence of hipGraphs, the communicator calls are not captured —
+        ``cut`` ends the current graph segment, registers ``fn`` to run eagerly between the segments at replay time, and
+        opens the next segment."""
+        m = self.m
+        head = tape[-1]
+        st = head[4]
+        B, ws = st["B"], st["ws"]
+        gout = gout.contiguous().float()
+        H, W = gout.shape[2], gout.shape[3]
+        ctx = self._open_backward(st, gflat, cut)
         # ---- head
         _, cur, act, stats, _ = head
         norm, conv = m.out_conv[0], m.out_conv[2]
@@ -869,20 +895,7 @@ class _Engine:
                 self._attn_bwd(ctx, rec)
             else:
                 self._conv_bwd(ctx, rec)
-        self._temb_bwd(ctx, st)
-        self._flush_slabs(ctx)
-        self._join_side(ctx)
-        if self.pg is not None:
-            assert not ctx["pending"], "a conv weight gradient was never produced"
-            works, tail = ctx["works"], gpack[self.tail[0]:self.tail[1]]
-
-            def finish():
-                works.append(self._all_reduce(tail))
-                for w in works:
-                    w.wait()                               # the compute stream waits for the communicator; no host sync
-                works.clear()
-            self._comm(ctx, finish)
-        _hip.call("ddpm_wgrad_unpack", gpack.data_ptr(), gflat.data_ptr(), wdesc.data_ptr(), wdesc.shape[0], 1.0 / world, _hip.stream())
+        gflat = self._close_backward(ctx, st)
         if not self.debug_keep_tape:
             # the head record holds `st` and `st` holds the tape: break the cycle so that the saved activations go back to the
             # allocator NOW (by reference count) instead of whenever the cyclic GC runs — with the cycle in place every few
@@ -1028,6 +1041,7 @@ class _Engine:
         ops.gemm(dtb.data_ptr(), Ct, 0, 0, fc_w.data_ptr(), E, 0, 1, ds_t.data_ptr(), E, 0, B, E, Ct, F, out_mode=2, splits=max(1, Ct // 256))
         dt_emb = self._f32(B, E)
         _hip.call("ddpm_silu_bwd", t_emb.data_ptr(), ds_t.data_ptr(), dt_emb.data_ptr(), B * E, 0, _hip.stream())
+        ctx["dt_emb"] = dt_emb                                  # d/d(t_emb): what the reference's ResidualBlock hands back to the embedding MLP
         lin2, lin1 = m.embed[2], m.embed[0]
         ops.gemm(dt_emb.data_ptr(), E, 0, 1, s1.data_ptr(), E, 0, 1, self._pptr(ctx, lin2.weight), E, 0, E, E, B, F, out_mode=1)
         ops.colsum(View(dt_emb, 1, B, 1, E), 0, 0, self._pptr(ctx, lin2.bias))

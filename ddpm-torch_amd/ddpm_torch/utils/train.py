@@ -193,7 +193,7 @@ class _FusedUpdate:
 
     def __init__(self, optimizer, ema):
         self.opt, self.ema = optimizer, ema
-        self.table = self.key = None
+        self.table = self.key = self.sig = None
         self.total = None
 
     def eligible(self):
@@ -221,9 +221,27 @@ class _FusedUpdate:
             m.append(st["exp_avg"]); v.append(st["exp_avg_sq"]); sh.append(shadow_of.get(id(p)))
         return params, m, v, sh
 
-    def prepare(self, grad_ptrs=None):
-        """(Re)build the device pointer table when any address in it moved (``optimizer.load_state_dict`` and ``.to()``
-        re-create state tensors).  ``grad_ptrs``: addresses of the gradients in optimiser order; None = ``p.grad``."""
+    def _signature(self, grad_ptrs):
+        """Cheap per-step check that nothing the table points at has moved: first / last entries of every column.  (Whole
+        columns move together: ``.to()`` re-creates all parameters, ``optimizer.load_state_dict`` all moments; the EMA never
+        re-binds its shadow tensors.)"""
+        group = self.opt.param_groups[0]["params"]
+        sig = []
+        for p in (group[0], group[-1]):
+            st = self.opt.state.get(p, {})
+            sig += [p.data_ptr(), st["exp_avg"].data_ptr() if "exp_avg" in st else 0, st["exp_avg_sq"].data_ptr() if "exp_avg_sq" in st else 0]
+        if isinstance(self.ema, EMA) and self.ema.shadow:
+            sig.append(next(iter(self.ema.shadow.values())).data_ptr())
+        if grad_ptrs is not None:
+            sig += [grad_ptrs[0], grad_ptrs[-1], len(grad_ptrs)]
+        return tuple(sig)
+
+    def prepare(self, grad_ptrs=None, stable_grads=False):
+        """(Re)build the device pointer table when an address in it moved (``optimizer.load_state_dict`` and ``.to()``
+        re-create state tensors).  ``grad_ptrs``: addresses of the gradients in optimiser order; None = ``p.grad``.
+        ``stable_grads``: the gradients live in a persistent buffer — a cheap signature decides whether to look closer."""
+        if stable_grads and self.table is not None and self._signature(grad_ptrs) == self.sig:
+            return self.params
         params, m, v, sh = self._state_tensors()
         if grad_ptrs is None:
             grad_ptrs = [p.grad.data_ptr() for p in params]
@@ -237,6 +255,7 @@ class _FusedUpdate:
             if self.total is None or self.total.device != dev:
                 self.total = torch.zeros(64, dtype=torch.float32, device=dev)      # striped ||g||^2 accumulators
             self.key, self.params = key, params
+        self.sig = self._signature(grad_ptrs) if stable_grads else None
         return self.params
 
     def step_count(self):
@@ -304,6 +323,7 @@ class _DirectStep:
         # step-dependent scalars the kernels read from memory: floats {lr, bc1, bc2, ema_w} | uint64 dropout seed word | pad
         self.hyper_dev = torch.zeros(4, dtype=torch.int64, device=dev)
         self.hyper_host = [self._pinned(torch.zeros(4, dtype=torch.int64)) for _ in range(4)]
+        self.grad_ptrs = None
         self.calls = 0
         self.graph = None
         self.graph_failed = False
@@ -326,8 +346,11 @@ class _DirectStep:
         tr, dif, eng = self.tr, self.tr.diffusion, self.unet.engine()
         B, n = self.x0.shape[0], self.x0[0].numel()
         s = _hip.stream
-        self.t.random_(to=tr.timesteps, generator=tr.generator)                # draw order: t, then noise (utils/train.py:138-140)
-        self.noise.normal_(generator=tr.generator)
+        if tr.input_source is not None:
+            tr.input_source(self.t, self.noise)                                # parity tests: an injected (t, noise) stream
+        else:
+            self.t.random_(to=tr.timesteps, generator=tr.generator)            # draw order: t, then noise (utils/train.py:138-140)
+            self.noise.normal_(generator=tr.generator)
         x_t = dif.q_sample(self.x0, self.t, noise=self.noise)
         target = dif.loss_target(self.x0, x_t, self.t, self.noise)
         tape = []
@@ -345,10 +368,12 @@ class _DirectStep:
         tr, eng = self.tr, self.unet.engine()
         self.x0.copy_(x, non_blocking=True)
         eng.ensure_fresh(need_dgrad=True)                                      # external writes since the last step (load_state_dict, EMA swap)
-        params = tr._fused.prepare(grad_ptrs=[self.gflat.data_ptr() + 4 * eng.goff[id(p)] for p in tr._fused_param_order()])
+        if self.grad_ptrs is None:
+            self.grad_ptrs = [self.gflat.data_ptr() + 4 * eng.goff[id(p)] for p in tr._fused_param_order()]
+        params = tr._fused.prepare(grad_ptrs=self.grad_ptrs, stable_grads=True)
         assert len(params) == len(eng.params)
         self._write_hyper()
-        use_graph = (_TRAIN_GRAPH and not self.graph_failed and self.x0.is_cuda and self.calls >= 1
+        use_graph = (_TRAIN_GRAPH and not self.graph_failed and self.x0.is_cuda and self.calls >= 1 and tr.input_source is None
                      and not torch.cuda.is_current_stream_capturing())
         if use_graph and self.graph is None:
             g = SegmentedGraph(self.x0.device)
@@ -394,7 +419,8 @@ class Trainer:
         self.ema = EMA(model.module if isinstance(model, DDP) else model, decay=ema_decay) if use_ema else nullcontext()
         self.stats = RunningStatistics(loss=None)
         self._fused = _FusedUpdate(optimizer, self.ema)
-        self._direct = {}                               # input shape -> _DirectStep
+        self._direct = {}                               # (input shape, train/eval) -> _DirectStep
+        self.input_source = None                        # optional fn(t_buf, noise_buf) filling the step's (t, noise) in place (parity tests)
 
     # ------------------------------------------------------------------ the reference's small accessors
     @property
@@ -440,6 +466,8 @@ class Trainer:
         m = self.model
         if not isinstance(m, UNet) or self.num_accum != 1 or not self._fused.eligible():
             return None
+        if "get_input" in self.__dict__ or "loss" in self.__dict__ or type(self).get_input is not Trainer.get_input or type(self).loss is not Trainer.loss:
+            return None                                 # a customised input / loss: keep the generic autograd step
         if not getattr(self.diffusion, "supports_direct_step", False) or not self.diffusion.supports_direct_step():
             return None
         own = m.engine().params
@@ -452,9 +480,9 @@ class Trainer:
         x = x.to(self.device)
         unet = self._direct_unet() if os.environ.get("DDPM_TORCH_AMD_DIRECT_STEP", "1") != "0" else None
         if unet is not None and x.dtype == torch.float32:
-            key = tuple(x.shape)
+            key = (tuple(x.shape), bool(unet.training))
             if key not in self._direct:
-                self._direct[key] = _DirectStep(self, unet, key)
+                self._direct[key] = _DirectStep(self, unet, key[0])
             loss = self._direct[key].run(x).clone()
             if self._ema_on:
                 self.ema.num_updates += 1

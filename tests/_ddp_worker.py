@@ -1,5 +1,6 @@
-"""Worker for tests/test_ddp_gloo.py: one rank of a world_size-2 gloo job on CPU.  The engine runs unmodified; its C-ABI
-calls go to tests/abi_emulator.py (the HIP kernels need a GPU, the data-parallel LOGIC does not)."""
+"""Worker for tests/test_ddp_gloo.py (one rank of a world_size-2 gloo job on CPU: the engine runs unmodified, its C-ABI
+calls go to tests/abi_emulator.py — the HIP kernels need a GPU, the data-parallel LOGIC does not) and for
+tests/test_multi_gpu.py (device kind "cuda": one rank per visible GPU over the "nccl" = RCCL backend, real kernels)."""
 import os
 import sys
 
@@ -20,13 +21,20 @@ def install_emulator():
     _hip.call = emu.call
     _hip.stream = lambda: 0
     _hip.require_cuda = lambda *a: None
+    _hip.on_device = lambda t: True
 
 
-def run(rank, world, port, mode, out_dir):
+def run(rank, world, port, mode, out_dir, kind="cpu"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     torch.set_num_threads(1)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    install_emulator()
+    if kind == "cuda":
+        torch.cuda.set_device(rank)
+        dev = torch.device("cuda", rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world)            # "nccl" is RCCL on ROCm
+    else:
+        dev = torch.device("cpu")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        install_emulator()
     import ddpm_torch
     from oracle import unet_ref as U
     torch.manual_seed(100 + rank)                        # different initial weights per rank: the broadcast must fix that
@@ -36,27 +44,42 @@ def run(rank, world, port, mode, out_dir):
         model.load_state_dict(U.randomize_state_dict(ddpm_torch.UNet(**TINY).state_dict(), 17))
     g = torch.Generator().manual_seed(1000 + rank)       # each rank sees its own shard
     x, gy, t = torch.randn(2, 3, 8, 8, generator=g), torch.randn(2, 3, 8, 8, generator=g), torch.randint(0, 1000, (2,), generator=g)
-    if mode == "native":
+    model.to(dev)
+    native = mode.startswith("native")
+    if native:
         model.set_process_group()                         # broadcast + chunked all-reduce inside the hand-written backward
         net = model
     else:
-        net = torch.nn.parallel.DistributedDataParallel(model)     # the reference's wrapper (train.py:110) must keep working
+        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[rank] if kind == "cuda" else None)     # the reference's wrapper (train.py:110) must keep working
     net.train()
-    y = net(x, t)
-    (y * gy).sum().backward()
-    grads = {k: p.grad.clone() for k, p in model.named_parameters()}
-    torch.save(dict(grads=grads, sd={k: v.clone() for k, v in model.state_dict().items()}, x=x, gy=gy, t=t), os.path.join(out_dir, f"{mode}_{rank}.pt"))
-    if mode == "native":                                  # a full distributed Trainer.step on top (loss reduce to rank 0 included)
+    y = net(x.to(dev), t.to(dev))
+    (y * gy.to(dev)).sum().backward()
+    cpu = lambda d: {k: v.detach().cpu().clone() for k, v in d.items()}
+    grads = cpu({k: p.grad for k, p in model.named_parameters()})
+    torch.save(dict(grads=grads, sd=cpu(model.state_dict()), x=x, gy=gy, t=t), os.path.join(out_dir, f"{mode}_{rank}.pt"))
+    if native:
+        # full distributed Trainer.steps on top (loss reduce to rank 0 included).  "native": the direct step, captured into
+        # graph segments on a GPU (the all-reduces run between the segments); "native_eager": same step without capture
+        if mode == "native_eager":
+            from ddpm_torch.utils import train as train_mod
+            train_mod._TRAIN_GRAPH = False
         dif = ddpm_torch.GaussianDiffusion(ddpm_torch.get_beta_schedule("linear", 1e-4, 0.02, 1000), "eps", "fixed-large", "mse")
         opt = torch.optim.Adam(model.parameters(), lr=1e-3)
         tr = ddpm_torch.Trainer(model, opt, dif, epochs=1, trainloader=None, sampler=object(), use_ema=True, shape=(3, 8, 8),
-                                device=torch.device("cpu"), distributed=True, rank=rank)
+                                device=dev, distributed=True, rank=rank)
         model.zero_grad(set_to_none=True)
-        tr.step(x.clamp(-1, 1))
-        torch.save({k: v.clone() for k, v in model.state_dict().items()}, os.path.join(out_dir, f"after_step_{rank}.pt"))
+        losses = []
+        for i in range(4 if kind == "cuda" else 1):
+            tr.stats.reset()
+            tr.step(x.clamp(-1, 1).to(dev), global_steps=i + 1)
+            losses.append(tr.current_stats["loss"])
+        ds = tr._direct.get(((2, 3, 8, 8), True))
+        torch.save(dict(sd=cpu(model.state_dict()), shadow=cpu(tr.ema.shadow), losses=losses,
+                        segments=None if ds is None or ds.graph is None else ds.graph.launches,
+                        direct=ds is not None), os.path.join(out_dir, f"after_step_{mode}_{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
 
 if __name__ == "__main__":
-    run(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5])
+    run(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5], *(sys.argv[6:7]))

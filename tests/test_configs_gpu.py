@@ -1,0 +1,249 @@
+"""-m gpu: the BASELINE.json configurations round 1 left unexercised, the bf16 gradient bar on the real CIFAR geometry, and
+the captured (hipGraph) training / sampling steps against their eager twins and the reference fixtures."""
+import os
+
+import pytest
+import torch
+
+import ddim as ddim_mod
+import ddpm_torch
+from ddpm_torch import _hip
+from ddpm_torch.utils import train as train_mod
+from oracle import unet_ref as U
+from tests.golden.recipes import check, check_state, rnd
+from tests.test_unet_gpu import CELEBAHQ, CIFAR, DEV, make, tiny_from_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _grad_report(model, ref_params, floor_frac):
+    scales = {k: float(v.grad.abs().max()) for k, v in ref_params.items()}
+    floor = floor_frac * sorted(scales.values())[len(scales) // 2]
+    rows = sorted(((float((q.grad.cpu() - ref_params[k].grad).abs().max()) / max(scales[k], floor), k) for k, q in model.named_parameters()), reverse=True)
+    return rows, scales
+
+
+def _masks_from_tape(m, drop_rate):
+    eng, names, masks = m.engine(), {id(mod): name for name, mod in m.named_modules()}, {}
+    for rec in eng.last_tape:
+        if rec[0] != "res":
+            continue
+        h1, seed = rec[6], rec[9]
+        n = h1.B * h1.H * h1.W * h1.C
+        mk = torch.empty(n, device=DEV)
+        _hip.call("ddpm_dropout_mask", mk.data_ptr(), n, drop_rate, seed, _hip.stream())
+        masks[names[id(rec[1])] + "."] = mk.cpu().reshape(h1.B, h1.H, h1.W, h1.C).permute(0, 3, 1, 2)
+    return masks
+
+
+def test_celebahq_256_fp32_forward_backward_vs_oracle():
+    """configs/celebahq.json at its real resolution: K = 9216 reductions, 1024-channel GroupNorms, 65536-pixel images per
+    sample and the 512-channel attention — forward <= 1e-3, every parameter gradient <= 3e-3 (fp32 mode)."""
+    m, sd = make(CELEBAHQ, dtype=torch.float32)
+    m.train()
+    x, t, gy = rnd(1, 3, 256, 256, seed=1), torch.tensor([417]), rnd(1, 3, 256, 256, seed=2)
+    y = m(x.to(DEV), t.to(DEV))
+    (y * gy.to(DEV)).sum().backward()
+    torch.cuda.synchronize()
+    p = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref = U.unet_forward(p, CELEBAHQ, x, t, training=True)
+    (ref * gy).sum().backward()
+    rel = float((y.detach().cpu() - ref.detach()).abs().max() / ref.detach().abs().max())
+    rows, scales = _grad_report(m, p, 0.02)
+    print(f"celebahq 256 fp32: fwd rel {rel:.3e}; worst grads " + ", ".join(f"{k}={e:.2e}" for e, k in rows[:4]))
+    assert rel < 1e-3
+    assert rows[0][0] < 3e-3, rows[:4]
+
+
+def test_celebahq_256_bf16_train_step_properties():
+    """BASELINE config 5 per-GPU work (B = 2, bf16, dropout 0): a full Trainer.step twice — finite loss of the right size,
+    every parameter finite and moved, EMA shadow follows, and the step is reproducible from the same seeds."""
+    finals = []
+    for rep in range(2):
+        m, _ = make(CELEBAHQ, dtype=torch.bfloat16)
+        m.train()
+        dif = ddpm_torch.GaussianDiffusion(ddpm_torch.get_beta_schedule("linear", 1e-4, 0.02, 1000), "eps", "fixed-small", "mse")
+        opt = torch.optim.Adam(m.parameters(), lr=2e-5)
+        tr = ddpm_torch.Trainer(m, opt, dif, epochs=1, trainloader=None, use_ema=True, shape=(3, 256, 256), device=torch.device(DEV))
+        x = (torch.rand(2, 3, 256, 256, generator=torch.Generator().manual_seed(5)) * 2 - 1).to(DEV)
+        before = {k: v.detach().clone() for k, v in m.named_parameters()}
+        for i in range(2):
+            tr.stats.reset()
+            tr.step(x, global_steps=i + 1)
+            assert 0.2 < tr.current_stats["loss"] < 5.0, tr.current_stats
+        moved = 0
+        for k, v in m.named_parameters():
+            assert torch.isfinite(v).all(), k
+            moved += int(float((v.detach() - before[k]).abs().max()) > 0)
+        assert moved >= 0.95 * len(before)
+        assert tr.ema.num_updates == 1
+        finals.append(tr.current_stats["loss"])
+    assert finals[0] == pytest.approx(finals[1], rel=2e-3)          # atomics in the weight gradients: not bit-identical
+
+
+def test_cifar_geometry_bf16_gradients_vs_oracle():
+    """bf16 mode on the real CIFAR network (B = 4, dropout masks injected into the oracle): per-tensor gradient error
+    relative to the tensor's largest gradient <= 5e-2 (floor: 10 % of the median tensor scale for the analytically-zero ones)."""
+    m, sd = make(CIFAR, dtype=torch.bfloat16)
+    m.train()
+    m.engine().debug_keep_tape = True
+    x, t, gy = rnd(4, 3, 32, 32, seed=3), torch.tensor([7, 912, 300, 650]), rnd(4, 3, 32, 32, seed=4)
+    y = m(x.to(DEV), t.to(DEV))
+    (y * gy.to(DEV)).sum().backward()
+    masks = _masks_from_tape(m, CIFAR["drop_rate"])
+    p = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ref = U.unet_forward(p, CIFAR, x, t, training=True, masks=masks)
+    (ref * gy).sum().backward()
+    rel = float((y.detach().cpu() - ref.detach()).abs().max() / ref.detach().abs().max())
+    rows, scales = _grad_report(m, p, 0.1)
+    import statistics
+    med = statistics.median(e for e, _ in rows)
+    print(f"cifar bf16 grads: fwd rel {rel:.3e}; median tensor err {med:.2e}; worst " + ", ".join(f"{k}={e:.2e}" for e, k in rows[:5]))
+    assert rel < 4e-2
+    assert rows[0][0] < 5e-2, rows[:5]
+
+
+# ----------------------------------------------------------------------------------------------- training step variants
+def _g9_trainer(g, dtype=torch.float32):
+    torch.manual_seed(g["init_seed"])
+    m = ddpm_torch.UNet(**g["cfg"])
+    m.load_state_dict(U.randomize_state_dict(m.state_dict(), g["rand_seed"]))
+    m.to(DEV).set_compute_dtype(dtype)
+    dif = ddpm_torch.GaussianDiffusion(ddpm_torch.get_beta_schedule("linear", 1e-4, 0.02, 1000), "eps", "fixed-large", "mse")
+    opt = torch.optim.Adam(m.parameters(), lr=g["lr"], betas=(0.9, 0.999))
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lr_lambda=lambda s: 1.0 if s < 3 else 0.5)
+    tr = ddpm_torch.Trainer(m, opt, dif, epochs=1, trainloader=None, scheduler=sched, use_ema=True, grad_norm=1.0, shape=(3, 8, 8),
+                            device=torch.device(DEV), ema_decay=0.9999)
+    m.train()
+    return m, opt, sched, tr
+
+
+def _reference_stream(g):
+    gen = torch.Generator("cpu").manual_seed(g["gen_seed"])       # the reference's CPU (t, noise) stream (utils/train.py:115,138-140)
+
+    def fill(t_buf, noise_buf):
+        t_buf.copy_(torch.empty(t_buf.shape, dtype=torch.int64).random_(to=1000, generator=gen))
+        noise_buf.copy_(torch.empty(noise_buf.shape).normal_(generator=gen))
+    return fill
+
+
+@pytest.mark.parametrize("path", ["direct", "autograd"])
+def test_steps_that_move_the_weights_vs_reference_fixture(golden, monkeypatch, path):
+    """G9 on the GPU (fp32 mode): lr 3e-3 without warm-up — losses after the first step depend on every derived weight copy
+    being re-derived from the updated parameters."""
+    g = golden("g9_train_lr.pt")
+    monkeypatch.setenv("DDPM_TORCH_AMD_DIRECT_STEP", "1" if path == "direct" else "0")
+    m, opt, sched, tr = _g9_trainer(g)
+    fill = _reference_stream(g)
+    if path == "direct":
+        tr.input_source = fill
+    else:
+        def get_input(x):
+            t, noise = torch.empty(x.shape[0], dtype=torch.int64), torch.empty(x.shape)
+            fill(t, noise)
+            return {"x_0": x.to(DEV), "t": t.to(DEV), "noise": noise.to(DEV)}
+        tr.get_input = get_input
+    losses = []
+    for i, x in enumerate(g["xs"]):
+        tr.stats.reset()
+        tr.step(x, global_steps=i + 1)
+        losses.append(tr.current_stats["loss"])
+    print(path, losses)
+    assert torch.allclose(torch.tensor(losses, dtype=torch.float64), g["losses"], rtol=1e-3), (losses, g["losses"])
+    slack = 0.25 * g["lr"] * len(g["xs"])
+    check_state({k: v.cpu() for k, v in m.state_dict().items()}, g["params"], 2e-3, "param", adam_slack=slack)
+    check_state({k: v.cpu() for k, v in tr.ema.shadow.items()}, g["shadow"], 2e-3, "shadow", adam_slack=slack)
+    assert tr.ema.num_updates == g["num_updates"]
+    m.eval()
+    x, t = rnd(2, 3, 8, 8, seed=5), torch.tensor([3, 700])
+    with torch.no_grad():
+        check(m(x.to(DEV), t.to(DEV)).cpu(), U.unet_forward({k: v.cpu() for k, v in m.state_dict().items()}, g["cfg"], x, t), 1e-3, name="fwd after steps")
+
+
+@pytest.mark.parametrize("cfg_name,dtype", [("tiny3", torch.float32), ("cifar", torch.bfloat16)])
+def test_captured_training_step_equals_the_eager_step(monkeypatch, cfg_name, dtype):
+    """The hipGraph-replayed step consumes the generator, the dropout seeds, the LR schedule and the bias corrections exactly
+    like the eager direct step: after 6 steps (1 eager + capture + 5 replays) losses / parameters / EMA / Adam state agree
+    (tolerance = atomic-order noise of the weight gradients), and the replayed forward sees the updated weights."""
+    from tests.test_unet_gpu import TINY3
+    cfg = TINY3 if cfg_name == "tiny3" else CIFAR
+    hw, B = (16, 4) if cfg_name == "tiny3" else (32, 8)
+    runs = []
+    for graph in (True, False):
+        monkeypatch.setattr(train_mod, "_TRAIN_GRAPH", graph)
+        torch.manual_seed(11)
+        m, _ = make(cfg, dtype=dtype)
+        m.train()
+        dif = ddpm_torch.GaussianDiffusion(ddpm_torch.get_beta_schedule("linear", 1e-4, 0.02, 1000), "eps", "fixed-large", "mse")
+        opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+        sched = torch.optim.lr_scheduler.LambdaLR(opt, lr_lambda=lambda s: min((s + 1) / 4, 1.0))
+        tr = ddpm_torch.Trainer(m, opt, dif, epochs=1, trainloader=None, scheduler=sched, use_ema=True, shape=(3, hw, hw), device=torch.device(DEV))
+        xs = [(torch.rand(B, 3, hw, hw, generator=torch.Generator().manual_seed(40 + i)) * 2 - 1).to(DEV) for i in range(6)]
+        losses = []
+        for i, x in enumerate(xs):
+            tr.stats.reset()
+            tr.step(x, global_steps=i + 1)
+            losses.append(tr.current_stats["loss"])
+        ds = next(iter(tr._direct.values()))
+        assert (ds.graph is not None) == graph and not ds.graph_failed
+        if graph:
+            assert ds.graph.launches == 1                        # single GPU: the whole step is ONE graph launch
+        first = next(iter(m.parameters()))
+        runs.append(dict(losses=losses, params={k: v.detach().cpu().clone() for k, v in m.named_parameters()},
+                         shadow={k: v.cpu().clone() for k, v in tr.ema.shadow.items()}, step=int(opt.state[first]["step"]),
+                         m1=opt.state[first]["exp_avg"].cpu().clone(), lr=sched.get_last_lr()[0], upd=tr.ema.num_updates))
+    a, b = runs
+    print(cfg_name, a["losses"], b["losses"])
+    tol = 2e-4 if dtype == torch.float32 else 3e-2
+    assert a["step"] == b["step"] == 6 and a["lr"] == b["lr"] and a["upd"] == b["upd"] == 5
+    assert torch.allclose(torch.tensor(a["losses"]), torch.tensor(b["losses"]), rtol=tol)
+    assert a["losses"][-1] < a["losses"][0]                      # it trains
+    for k in a["params"]:
+        scale = float(b["params"][k].abs().max()) or 1.0
+        assert float((a["params"][k] - b["params"][k]).abs().max()) <= (tol * scale + 6 * 1e-3 * 0.3), k
+    check(a["m1"], b["m1"], tol * 10, atol=1e-6, name="exp_avg")
+
+
+def test_sampler_graph_is_cached_and_follows_weight_changes(golden, monkeypatch):
+    """Second p_sample with the same (model, shape) replays the cached graph (no new capture); swapping the EMA weights in
+    (in-place parameter writes) is picked up by the eager refresh before the replay: results equal the eager loop's."""
+    m, _ = tiny_from_golden(golden("g3_model.pt"))
+    m.eval()
+    dif = ddpm_torch.GaussianDiffusion(ddpm_torch.get_beta_schedule("linear", 1e-4, 0.02, 60), "eps", "fixed-large", "mse")
+    captures = []
+    orig = dif._capture_sample_step
+    monkeypatch.setattr(dif, "_capture_sample_step", lambda *a, **k: (captures.append(1), orig(*a, **k))[1])
+    a1 = dif.p_sample(m, shape=(2, 3, 8, 8), device=DEV, seed=5)
+    a2 = dif.p_sample(m, shape=(2, 3, 8, 8), device=DEV, seed=5)
+    a3 = dif.p_sample(m, shape=(2, 3, 8, 8), device=DEV, seed=6)
+    assert len(captures) == 1 and torch.equal(a1, a2) and not torch.equal(a1, a3)
+    with torch.no_grad():
+        for p in m.parameters():
+            p.mul_(1.01)                                         # what `with ema:` does: in-place writes through the parameters
+    b_graph = dif.p_sample(m, shape=(2, 3, 8, 8), device=DEV, seed=5)
+    monkeypatch.setenv("DDPM_TORCH_AMD_GRAPH", "0")
+    b_eager = dif.p_sample(m, shape=(2, 3, 8, 8), device=DEV, seed=5)
+    assert len(captures) == 1
+    assert torch.equal(b_graph, b_eager) and not torch.equal(b_graph, a1)
+    # injected x_T (the `noise=` argument) through the cached graph
+    monkeypatch.setenv("DDPM_TORCH_AMD_GRAPH", "1")
+    xT = torch.randn(2, 3, 8, 8, generator=torch.Generator().manual_seed(3)).to(DEV)
+    c_graph = dif.p_sample(m, noise=xT, device=DEV, seed=9)
+    monkeypatch.setenv("DDPM_TORCH_AMD_GRAPH", "0")
+    c_eager = dif.p_sample(m, noise=xT, device=DEV, seed=9)
+    assert torch.equal(c_graph, c_eager)
+
+
+def test_ddim50_celeba_quadratic_eta1_vs_eager(monkeypatch):
+    """BASELINE config 4 network at 64x64 (B = 2): DDIM (quadratic, eta = 1: noise is consumed) graph == eager, finite."""
+    from tests.test_unet_gpu import CELEBA
+    m, _ = make(CELEBA, dtype=torch.bfloat16)
+    m.eval()
+    betas = ddpm_torch.get_beta_schedule("linear", 1e-4, 0.02, 1000)
+    for sched, eta in (("linear", 0.0), ("quadratic", 1.0)):
+        dd = ddim_mod.DDIM(betas, "eps", "fixed-small", "mse", eta=eta, subsequence=ddim_mod.get_selection_schedule(sched, 50, 1000))
+        monkeypatch.setenv("DDPM_TORCH_AMD_GRAPH", "1")
+        a = dd.p_sample(m, shape=(2, 3, 64, 64), device=DEV, seed=131071)
+        monkeypatch.setenv("DDPM_TORCH_AMD_GRAPH", "0")
+        b = dd.p_sample(m, shape=(2, 3, 64, 64), device=DEV, seed=131071)
+        assert torch.isfinite(a).all() and torch.equal(a, b), (sched, float((a - b).abs().max()))

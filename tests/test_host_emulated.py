@@ -207,3 +207,42 @@ def test_cpu_tensors_fail_loudly_without_emulation():
     dif = ddpm_torch.GaussianDiffusion(ddpm_torch.get_beta_schedule("linear", 1e-4, 0.02, 10), "eps", "fixed-small", "mse")
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         dif.q_sample(torch.zeros(1, 3, 4, 4), torch.zeros(1, dtype=torch.int64), torch.zeros(1, 3, 4, 4))
+
+
+def test_reference_fixtures_through_the_abi_harness(emu, golden):
+    """The G1 / G2 / G5 cases of tests/fixture_cases.py with the ABI emulated: checks the harness the GPU run uses."""
+    from tests import fixture_cases as FC
+    FC.run_g1(golden("g1_ops.pt"), "cpu", dt=0)
+    FC.run_g2(golden("g2_blocks.pt"), "cpu")
+    FC.run_g5(golden("g5_steps.pt"), golden("g3_model.pt"), "cpu")
+
+
+def test_product_tables_equal_the_reference_tables(golden):
+    """Every attribute the reference's GaussianDiffusion / DDIM keep (fp64), compared to the G4 fixture directly."""
+    g = golden("g4_tables.pt")
+    names = ("betas", "alphas_bar", "sqrt_alphas_bar", "sqrt_one_minus_alphas_bar", "sqrt_recip_alphas_bar", "sqrt_recip_m1_alphas_bar",
+             "posterior_var", "posterior_logvar_clipped", "posterior_mean_coef1", "posterior_mean_coef2")
+    extra = ("fixed_model_var", "fixed_model_logvar", "alphas", "alphas_bar_prev", "sqrt_alphas_bar_prev")
+
+    def compare(obj, rec, tag):
+        for n in names + extra:
+            if n in rec and torch.is_tensor(rec[n]):
+                got = getattr(obj, n)
+                assert got.dtype == torch.float64 and got.shape == rec[n].shape, (tag, n)
+                assert float((got - rec[n]).abs().max()) <= 1e-12 * max(1.0, float(rec[n].abs().max())), (tag, n)
+        for n in ("model_mean_type", "model_var_type", "loss_type", "timesteps"):
+            assert getattr(obj, n) == rec[n], (tag, n)
+
+    lin = ddpm_torch.get_beta_schedule("linear", 1e-4, 0.02, 1000)
+    for vt in ("fixed-small", "fixed-large"):
+        compare(ddpm_torch.GaussianDiffusion(lin, "eps", vt, "mse"), g["ddpm_" + vt], "ddpm_" + vt)
+    compare(ddpm_torch.GaussianDiffusion(ddpm_torch.get_beta_schedule("linear", 1e-3, 0.2, 100), "eps", "fixed-large", "mse"), g["toy_fixed-large"], "toy")
+    for sched in ("quad", "warmup10", "warmup50", "const", "jsd"):
+        assert torch.equal(ddpm_torch.get_beta_schedule(sched, 1e-4, 0.02, 1000), g["betas_" + sched]), sched
+    for sched, size in (("linear", 50), ("quadratic", 100)):
+        sub = ddim_mod.get_selection_schedule(sched, size, 1000)
+        assert torch.equal(sub, g[f"sel_{sched}_{size}"])
+        for eta in (0.0, 1.0):
+            for vt in ("fixed-small", "fixed-large"):
+                compare(ddim_mod.DDIM(lin, "eps", vt, "mse", eta=eta, subsequence=sub), g[f"ddim_{sched}_{size}_eta{eta}_{vt}"], f"ddim {sched} {eta} {vt}")
+    assert torch.equal(ddim_mod.get_selection_schedule("quadratic", 50, 1000), g["sel_quadratic_50"])

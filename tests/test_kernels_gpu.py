@@ -257,7 +257,7 @@ def test_groupnorm_fwd_bwd(dt, B, HW, C, silu, drop):
     y = torch.zeros(B * HW, ld, dtype=DT[dt])
     seed = 0x1234567 if drop else 0
     both("ddpm_groupnorm_silu_fwd", A(x), ld, A(y, out=True, name="y"), ld, A(gamma), A(beta), A(stats, out=True, name="stats"), A(ws),
-         B, HW, C, 32, 1e-6, silu, drop, seed, dt, tol=TOL[dt] * (5 if dt == 0 else 1.5))
+         B, HW, C, 32, 1e-6, silu, drop, seed, None, dt, tol=TOL[dt] * (5 if dt == 0 else 1.5))
     dy = r(B * HW, ld, seed=4, dt=dt)
     # exact statistics from fp64 for the backward inputs
     xg = x.float().reshape(B, HW, ld)[:, :, :C].reshape(B, HW, 32, C // 32).permute(0, 2, 1, 3).reshape(B, 32, -1).double()
@@ -266,8 +266,49 @@ def test_groupnorm_fwd_bwd(dt, B, HW, C, silu, drop):
     for acc in (0, 1):
         dx = r(B * HW, ld, seed=7, dt=dt)
         both("ddpm_groupnorm_silu_bwd", A(x), ld, A(dy), ld, A(dx, out=True, name="dx"), ld, A(gamma), A(beta), A(stats),
-             A(dgamma.clone(), out=True, name="dgamma"), A(dbeta.clone(), out=True, name="dbeta"), A(ws), B, HW, C, 32, silu, drop, seed, acc, dt,
+             A(dgamma.clone(), out=True, name="dgamma"), A(dbeta.clone(), out=True, name="dbeta"), A(ws), B, HW, C, 32, silu, drop, seed, None, acc, dt,
              tol=2e-4 if dt == 0 else 2e-2)
+    if drop:
+        # the per-step part of the seed read from a device word (captured training step): seed + *word
+        word = torch.tensor([0x5DEECE66D], dtype=torch.int64)
+        y2 = torch.zeros(B * HW, ld, dtype=DT[dt])
+        both("ddpm_groupnorm_silu_fwd", A(x), ld, A(y2, out=True, name="y_devseed"), ld, A(gamma), A(beta), None, A(ws),
+             B, HW, C, 32, 1e-6, silu, drop, seed, A(word), dt, tol=TOL[dt] * (5 if dt == 0 else 1.5))
+        dx = r(B * HW, ld, seed=7, dt=dt)
+        both("ddpm_groupnorm_silu_bwd", A(x), ld, A(dy), ld, A(dx, out=True, name="dx_devseed"), ld, A(gamma), A(beta), A(stats),
+             None, None, A(ws), B, HW, C, 32, silu, drop, seed, A(word), 0, dt, tol=2e-4 if dt == 0 else 2e-2)
+
+
+@pytest.mark.parametrize("dt", [0, 1])
+@pytest.mark.parametrize("B,HW,C", [(2, 1024, 128), (2, 256, 256), (3, 64, 256), (2, 4096, 128)])
+def test_groupnorm_statistics_with_mean_far_from_zero(dt, B, HW, C):
+    """|mean| / std = 500 (50 +- 0.1, the case a single-pass sum / sum-of-squares loses in fp32): every path — streaming
+    two-launch, register-resident, statistics-only — must reproduce the two-pass fp64 statistics."""
+    x = (r(B * HW, C, seed=1, scale=0.1) + 50.0)
+    x = x + torch.arange(C).float()[None, :] * 0.01                       # channels of a group differ a little
+    xq = x.to(DT[dt])
+    gamma, beta = 1 + 0.2 * r(C, seed=2), 0.1 * r(C, seed=3)
+    xg = xq.float().reshape(B, HW, 32, C // 32).permute(0, 2, 1, 3).reshape(B, 32, -1).double()
+    mean, var = xg.mean(-1), xg.var(-1, unbiased=False)
+    want = torch.stack([mean, 1.0 / torch.sqrt(var + 1e-6)], -1).float()
+    nws = int(_hip.lib().ddpm_gn_workspace_floats(B, HW, C, 32, dt))
+    gd, bd = gamma.cuda(), beta.cuda()                        # named: a temporary's storage is recycled as soon as its pointer is taken
+    for entry in ("fwd", "stats"):
+        stats = torch.zeros(B, 32, 2, device="cuda")
+        xd = xq.cuda()
+        if entry == "fwd":
+            y, ws = torch.empty_like(xd), torch.zeros(nws, device="cuda")
+            _hip.call("ddpm_groupnorm_silu_fwd", xd.data_ptr(), C, y.data_ptr(), C, gd.data_ptr(), bd.data_ptr(), stats.data_ptr(),
+                      ws.data_ptr(), B, HW, C, 32, 1e-6, 0, 0.0, 0, 0, dt, _hip.stream())
+            ref = ((xg - mean[..., None]) / torch.sqrt(var + 1e-6)[..., None]).reshape(B, 32, HW, C // 32).permute(0, 2, 1, 3).reshape(B * HW, C)
+            ref = ref * gamma.double() + beta.double()
+            err = float((y.cpu().double() - ref).abs().max()) / float(ref.abs().max())
+            assert err < (2e-3 if dt == 0 else 1.5e-2), (entry, err)
+        else:
+            _hip.call("ddpm_groupnorm_stats", xd.data_ptr(), C, stats.data_ptr(), B, HW, C, 32, 1e-6, dt, _hip.stream())
+        got = stats.cpu()
+        assert float((got[..., 0] - want[..., 0]).abs().max()) < 1e-4 * 50, entry
+        assert float(((got[..., 1] - want[..., 1]) / want[..., 1]).abs().max()) < 1e-3, (entry, got[0, :3], want[0, :3])
 
 
 @pytest.mark.parametrize("B,L,C", [(3, 256, 256), (2, 128, 128), (2, 384, 256)])
@@ -321,7 +362,7 @@ def test_diffusion_algebra_kernels():
     tabs = [torch.rand(T, generator=torch.Generator().manual_seed(10 + i)) + 0.1 for i in range(4)]
     logvar = -torch.rand(T, generator=torch.Generator().manual_seed(20)) * 9
     xt = torch.zeros(B, n)
-    both("ddpm_q_sample", A(x0), A(noise), A(t), A(tabs[0]), A(tabs[1]), A(xt, out=True, name="xt"), B, n, tol=1e-6)
+    both("ddpm_q_sample", A(x0), A(noise), A(t), A(tabs[0]), A(tabs[1]), A(xt, out=True, name="xt"), B, n, T, tol=1e-6)
     loss = torch.zeros(B)
     both("ddpm_mse_fwd", A(out), A(noise), A(loss, out=True, name="loss"), B, n, tol=1e-5)
     g = torch.zeros(B, n)
@@ -330,7 +371,21 @@ def test_diffusion_algebra_kernels():
         for clip in (0, 1):
             xp, px0 = torch.zeros(B, n), torch.zeros(B, n)
             both("ddpm_p_sample_step", A(x0), A(out), A(z), A(t), A(tabs[0]), A(tabs[1]), A(tabs[2]), A(tabs[3]), A(logvar),
-                 A(xp, out=True, name="x_prev"), A(px0, out=True, name="pred_x0"), B, n, mean_type, clip, tol=2e-6)
+                 A(xp, out=True, name="x_prev"), A(px0, out=True, name="pred_x0"), B, n, mean_type, clip, T, tol=2e-6)
+    # NaN model output stays NaN through the clamp (torch.clamp semantics); an index outside the tables poisons its sample
+    bad_out = out.clone(); bad_out[1, 5] = float("nan")
+    xp = torch.zeros(B, n, device="cuda")
+    dev = [v.cuda() for v in (x0, bad_out, z, t, tabs[0], tabs[1], tabs[2], tabs[3], logvar)]
+    _hip.call("ddpm_p_sample_step", *[v.data_ptr() for v in dev], xp.data_ptr(), 0, B, n, 0, 1, T, _hip.stream())
+    assert torch.isnan(xp[1, 5]) and int(torch.isnan(xp).sum()) == 1
+    t_bad = torch.tensor([0, 1, 500, 1000, 250]).cuda()                       # 1000 is outside a table of length 1000
+    dev[1], dev[3] = out.cuda(), t_bad
+    _hip.call("ddpm_p_sample_step", *[v.data_ptr() for v in dev], xp.data_ptr(), 0, B, n, 0, 1, T, _hip.stream())
+    assert torch.isnan(xp[3]).all() and not torch.isnan(xp[[0, 1, 2, 4]]).any()
+    xq = torch.zeros(B, n, device="cuda")
+    noise_d = noise.cuda()
+    _hip.call("ddpm_q_sample", dev[0].data_ptr(), noise_d.data_ptr(), t_bad.data_ptr(), dev[4].data_ptr(), dev[5].data_ptr(), xq.data_ptr(), B, n, T, _hip.stream())
+    assert torch.isnan(xq[3]).all() and not torch.isnan(xq[[0, 1, 2, 4]]).any()
     idx, mp, o = torch.tensor([3, 0, 49]), torch.arange(0, 1000, 20), torch.zeros(3, dtype=torch.int64)
     both("ddpm_gather_i64", A(idx), A(mp), A(o, out=True, name="gather"), 3, tol=0.0)
     tt = torch.tensor([5, 5, 5])
@@ -387,3 +442,67 @@ def test_fused_adam_ema_matches_torch_adam():
         assert abs(float(tot.sqrt()) - float(gs.norm())) < 1e-3 * float(gs.norm())
     assert float((p.cpu() - ref.detach()).abs().max()) < 2e-6
     assert float((sh.cpu() - shadow_ref).abs().max()) < 2e-6
+
+
+def test_multi_tensor_update_with_scalars_from_device_memory():
+    """ddpm_mt_grad_sumsq + ddpm_mt_adam_ema over a pointer table, scalars by value and from the device `hyper` words (the
+    captured training step), against torch.optim.Adam + clip_grad_norm_ + the EMA recurrence."""
+    sizes = [4096, 37, 1000, 128 * 128 * 9, 3]
+    ps = [r(n, seed=10 + i) for i, n in enumerate(sizes)]
+    refs = [p.clone().requires_grad_(True) for p in ps]
+    opt = torch.optim.Adam(refs, lr=3e-3, betas=(0.9, 0.999), eps=1e-8)
+    shadow_ref = [p.clone() for p in ps]
+    for hyper_mode in (False, True):
+        P = [p.clone().cuda() for p in ps]
+        M, V, S = [torch.zeros_like(p) for p in P], [torch.zeros_like(p) for p in P], [p.clone() for p in P]
+        G = [torch.empty_like(p) for p in P]
+        table = torch.tensor([[p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), s_.data_ptr(), p.numel()] for p, g, m, v, s_ in zip(P, G, M, V, S)],
+                             dtype=torch.int64).cuda()
+        total = torch.zeros(64, device="cuda")
+        hyper = torch.zeros(4, device="cuda")
+        if not hyper_mode:
+            refs = [p.clone().requires_grad_(True) for p in ps]
+            opt = torch.optim.Adam(refs, lr=3e-3, betas=(0.9, 0.999), eps=1e-8)
+            shadow_ref = [p.clone() for p in ps]
+        else:
+            refs = [p.clone().requires_grad_(True) for p in ps]
+            opt = torch.optim.Adam(refs, lr=3e-3, betas=(0.9, 0.999), eps=1e-8)
+            shadow_ref = [p.clone() for p in ps]
+        for step in range(1, 4):
+            gs = [r(n, seed=100 * step + i, scale=0.5) for i, n in enumerate(sizes)]
+            for q, g_ in zip(refs, gs):
+                q.grad = g_.clone()
+            norm = torch.nn.utils.clip_grad_norm_(refs, 1.0)
+            opt.step()
+            d = min(0.9999, step / (9 + step))
+            for sr, q in zip(shadow_ref, refs):
+                sr += (1 - d) * (q.detach() - sr)
+            for g_dev, g_ in zip(G, gs):
+                g_dev.copy_(g_)
+            total.zero_()
+            _hip.call("ddpm_mt_grad_sumsq", table.data_ptr(), len(P), total.data_ptr(), _hip.stream())
+            assert abs(float(total.sum().sqrt()) - float(norm)) < 1e-4 * float(norm)
+            sc = (3e-3, 1 - 0.9 ** step, 1 - 0.999 ** step, 1 - d)
+            if hyper_mode:
+                hyper.copy_(torch.tensor(sc))
+                _hip.call("ddpm_mt_adam_ema", table.data_ptr(), len(P), total.data_ptr(), 1.0, 0.0, 0.9, 0.999, 1e-8, 1.0, 1.0, 0.0, hyper.data_ptr(), _hip.stream())
+            else:
+                _hip.call("ddpm_mt_adam_ema", table.data_ptr(), len(P), total.data_ptr(), 1.0, *sc[:1], 0.9, 0.999, 1e-8, *sc[1:], 0, _hip.stream())
+        for p, q, s_, sr in zip(P, refs, S, shadow_ref):
+            assert float((p.cpu() - q.detach()).abs().max()) < 3e-6, hyper_mode
+            assert float((s_.cpu() - sr).abs().max()) < 3e-6, hyper_mode
+
+
+def test_multi_tensor_gather():
+    a = [r(n, seed=i) for i, n in enumerate((512 * 128, 128, 7, 4096))]
+    b = [r(n, seed=10 + i) for i, n in enumerate((512 * 128, 128, 7, 4096))]
+    A_, B_ = [t.cuda() for t in a], [t.cuda() for t in b]
+    dst = torch.zeros(sum(t.numel() for t in a) + 8, device="cuda")
+    rows, off = [], 0
+    for i, (x, y) in enumerate(zip(A_, B_)):
+        rows.append([x.data_ptr(), y.data_ptr() if i % 2 else 0, dst.data_ptr() + 4 * off, x.numel()])
+        off += x.numel()
+    table = torch.tensor(rows, dtype=torch.int64).cuda()
+    _hip.call("ddpm_mt_gather_f32", table.data_ptr(), len(rows), _hip.stream())
+    want = torch.cat([x + y if i % 2 else x for i, (x, y) in enumerate(zip(a, b))])
+    assert torch.equal(dst[:off].cpu(), want) and float(dst[off:].abs().max()) == 0
