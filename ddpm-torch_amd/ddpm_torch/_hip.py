@@ -20,11 +20,13 @@ _ERR = {1: "bad shape / divisibility", 2: "unsupported dtype", 3: "misaligned po
 P, I, L, F, U = c_void_p, c_int, c_longlong, c_float, c_ulonglong
 
 # name -> argtypes; every function returns int status (0 = OK) except ddpm_gn_workspace_floats and
-# ddpm_last_gemm_variant / ddpm_wgrad_effective_splits (plain values).
+# ddpm_last_gemm_variant / ddpm_wgrad_effective_splits / ddpm_conv3x3_wgrad_splits (plain values).
 PROTOTYPES = {
     "ddpm_conv2d_nhwc": [P, L, P, P, L, P, P, L, P, L] + [I] * 14 + [I, I, I, P, P, I, P],
     "ddpm_conv2d_wgrad_nhwc": [P, L, P, L, P, L] + [I] * 17 + [P],
     "ddpm_wgrad_effective_splits": [I, I, I],
+    "ddpm_conv3x3_wgrad_splits": [I, I, I, I, I, I],
+    "ddpm_conv3x3_wgrad_nhwc": [P, L, P, L, P, L, P, L, I, I, I, I, I, I, I, I, P],
     "ddpm_wgrad_reduce": [P, I, P],
     "ddpm_wgrad_unpack": [P, P, P, I, F, P],
     "ddpm_gemm": [P, L, L, I, P, L, L, I, P, L, L, P, P, L, L, I, I, I, I, F, I, I, I, I, P],

@@ -116,6 +116,18 @@ def conv2d_wgrad(dy, x, dw_ptr, Creal, Nreal, R, S, stride=1, pad_t=0, pad_l=0, 
         stride, pad_t, pad_l, upsample, splits, x.dtype, _hip.stream()), f"wgrad M={Nreal} N={R * S * x.C} K={dy.rows} splits={splits}")
 
 
+def conv3x3_wgrad_splits(B, H, W, C, N, splits=0):
+    """Slab copies the patch-stationary 3x3 wgrad kernel writes for this geometry; 0 = geometry not covered."""
+    return int(_hip.lib().ddpm_conv3x3_wgrad_splits(B, H, W, C, N, splits))
+
+
+def conv3x3_wgrad(dy, x, dw_ptr, slab_stride, dbias_ptr, bias_stride, Nreal, splits):
+    """dw[n][3][3][c] (+ dbias) of a 3x3 / stride 1 / pad 1 conv by the patch-stationary kernel (bf16)."""
+    _timed("wgrad3x3", 2.0 * dy.rows * Nreal * 9 * x.C, lambda: _hip.call(
+        "ddpm_conv3x3_wgrad_nhwc", dy.ptr, dy.ld, x.ptr, x.ld, dw_ptr, slab_stride, dbias_ptr, bias_stride, x.B, x.H, x.W, x.C, dy.C, Nreal,
+        splits, x.dtype, _hip.stream()), f"wgrad3x3 M={Nreal} N={9 * x.C} K={dy.rows} splits={splits}")
+
+
 def wgrad_effective_splits(K, splits, dtype):
     return int(_hip.lib().ddpm_wgrad_effective_splits(K, splits, dtype))
 

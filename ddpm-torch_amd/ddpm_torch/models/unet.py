@@ -248,6 +248,8 @@ _FOLD_MIN_PIXELS = 16384            # below this the small-grid kernels serve th
 _FOLD_GN = os.environ.get("DDPM_FOLD_GN", "1") != "0"               # inference: GroupNorm+SiLU folded into the 3x3 convs
 _SIDE_STREAM = os.environ.get("DDPM_SIDE_STREAM", "1") != "0"      # weight / bias gradients on a second HIP stream
 _WGRAD_SLABS = os.environ.get("DDPM_WGRAD_SLABS", "0") != "0"      # deterministic slab reduction instead of atomics
+_WGRAD3 = os.environ.get("DDPM_WGRAD3", "1") != "0"                # patch-stationary kernel for the 3x3 / stride-1 weight gradients
+_WGRAD3_ATOMIC = os.environ.get("DDPM_WGRAD3_ATOMIC", "0") != "0"  # ... with fp32 atomics instead of slab copies
 
 
 class _Engine:
@@ -516,28 +518,59 @@ class _Engine:
             ev.record(side)
             torch.cuda.current_stream().wait_event(ev)
 
-    def _wgrad(self, ctx, weight, dy, x, Creal, Nreal, R, S, splits=1, **kw):
-        """Weight gradient into the staging buffer; then hand finished all-reduce chunks to the communicator.
+    def _wgrad(self, ctx, weight, dy, x, Creal, Nreal, R, S, splits=1, bias=None, **kw):
+        """Weight gradient into the staging buffer; then hand finished all-reduce chunks to the communicator.  ``bias`` = staging
+        key of the bias gradient when it is the plain column sum of the same ``dy``: returns True when this call produced it too.
 
-        Default: the split-K slices add into the staging buffer with fp32 atomics (the 2-3 MB of hot lines stay in L2).
-        DDPM_WGRAD_SLABS=1: every slice STORES its partial into its own slab copy (persistent per-weight workspace) and one
-        multi-tensor launch sums the copies in a fixed order — bit-deterministic gradients at the same speed (measured
-        16.06 vs 16.10 ms per step: the ~33 MB of slab traffic per layer costs what the slow atomics cost)."""
-        key = (dy.rows, splits, x.dtype)
-        eff = self._eff_splits.get(key)
-        if eff is None:
-            eff = self._eff_splits[key] = ops.wgrad_effective_splits(dy.rows, splits, x.dtype)
-        with self._leaf(ctx, dy, x):
-            if _WGRAD_SLABS and eff > 1:
-                n = Nreal * R * S * Creal
-                stride = (n + 3) // 4 * 4
-                slab = self._slabs.get(id(weight))
-                if slab is None or slab.numel() < eff * stride:
-                    slab = self._slabs[id(weight)] = torch.empty(eff * stride, dtype=torch.float32, device=self.device)
-                ops.conv2d_wgrad(dy, x, slab.data_ptr(), Creal, Nreal, R, S, splits=eff, slab_stride=stride, **kw)
-                ctx["slab_rows"].append((slab.data_ptr(), self._pptr(ctx, weight), n, eff, stride))
-            else:
-                ops.conv2d_wgrad(dy, x, self._pptr(ctx, weight), Creal, Nreal, R, S, splits=eff, **kw)
+        3x3 / stride 1 / pad 1, bf16 (the bulk of the FLOPs): the patch-stationary kernel (csrc/wgrad.hip).  Its small output
+        tiles need few reduction slices; every slice STORES its partial into its own slab copy (persistent per-weight workspace)
+        and one multi-tensor launch sums the copies in a fixed order — bit-deterministic gradients (DDPM_WGRAD3_ATOMIC=1: fp32
+        atomics instead).  It also accumulates the bias gradient from the dy fragments it reads.
+
+        Everything else: the transposed-operand GEMM; its split-K slices add into the staging buffer with fp32 atomics, or
+        (DDPM_WGRAD_SLABS=1) store slab copies as above."""
+        did_bias = False
+        patch = 0
+        if (_WGRAD3 and self.T == torch.bfloat16 and R == 3 and S == 3 and not kw.get("upsample") and kw.get("stride", 1) == 1
+                and kw.get("pad_t") == 1 and kw.get("pad_l") == 1 and Creal == x.C):
+            pkey = ("w3", x.B, x.H, x.W, x.C, dy.C)
+            patch = self._eff_splits.get(pkey)
+            if patch is None:
+                patch = self._eff_splits[pkey] = ops.conv3x3_wgrad_splits(x.B, x.H, x.W, x.C, dy.C)
+        if patch:
+            bias_ptr = self._pptr(ctx, bias) if bias is not None else 0
+            with self._leaf(ctx, dy, x):
+                if _WGRAD3_ATOMIC:
+                    ops.conv3x3_wgrad(dy, x, self._pptr(ctx, weight), 0, bias_ptr, 0, Nreal, patch)
+                else:
+                    n = Nreal * 9 * Creal
+                    stride = (n + 3) // 4 * 4
+                    bstride = (Nreal + 3) // 4 * 4
+                    slab = self._slabs.get(id(weight))
+                    if slab is None or slab.numel() < patch * (stride + bstride):
+                        slab = self._slabs[id(weight)] = torch.empty(patch * (stride + bstride), dtype=torch.float32, device=self.device)
+                    bslab = slab.data_ptr() + 4 * patch * stride
+                    ops.conv3x3_wgrad(dy, x, slab.data_ptr(), stride, bslab if bias is not None else 0, bstride, Nreal, patch)
+                    ctx["slab_rows"].append((slab.data_ptr(), self._pptr(ctx, weight), n, patch, stride))
+                    if bias is not None:
+                        ctx["slab_rows"].append((bslab, bias_ptr, Nreal, patch, bstride))
+            did_bias = bias is not None
+        else:
+            key = (dy.rows, splits, x.dtype)
+            eff = self._eff_splits.get(key)
+            if eff is None:
+                eff = self._eff_splits[key] = ops.wgrad_effective_splits(dy.rows, splits, x.dtype)
+            with self._leaf(ctx, dy, x):
+                if _WGRAD_SLABS and eff > 1:
+                    n = Nreal * R * S * Creal
+                    stride = (n + 3) // 4 * 4
+                    slab = self._slabs.get(id(weight))
+                    if slab is None or slab.numel() < eff * stride:
+                        slab = self._slabs[id(weight)] = torch.empty(eff * stride, dtype=torch.float32, device=self.device)
+                    ops.conv2d_wgrad(dy, x, slab.data_ptr(), Creal, Nreal, R, S, splits=eff, slab_stride=stride, **kw)
+                    ctx["slab_rows"].append((slab.data_ptr(), self._pptr(ctx, weight), n, eff, stride))
+                else:
+                    ops.conv2d_wgrad(dy, x, self._pptr(ctx, weight), Creal, Nreal, R, S, splits=eff, **kw)
         if ctx.get("pending") is not None:
             for ch in ctx["pending"]:
                 ch[2].discard(id(weight))
@@ -547,6 +580,7 @@ class _Engine:
                 self._join_side(ctx)                         # ... and produced: the communicator orders itself after the main stream
                 works, chunk = ctx["works"], ctx["gpack"][a:b]
                 self._comm(ctx, lambda works=works, chunk=chunk: works.append(self._all_reduce(chunk)))
+        return did_bias
 
     def _flush_slabs(self, ctx):
         """Sum the slab copies recorded since the last flush into the staging buffer (one launch)."""
@@ -964,8 +998,9 @@ class _Engine:
         # conv2
         da2 = self._new(B, x.H, x.W, Cout)
         ops.conv2d(dout, c2.wd.data_ptr(), da2.ptr, da2.ld, Cout, 3, 3, x.H, x.W, pad_t=1, pad_l=1, splitk=self.splitk)
-        self._wgrad(ctx, rb.conv2.weight, dout, a2, Cout, Cout, 3, 3, pad_t=1, pad_l=1, splits=self._splits(Cout, 9 * Cout, dout.rows))
-        self._bias_grad(ctx, dout, [rb.conv2.bias], Cout, slot=("b2", id(rb)) if rb.has_skip else None)
+        b2 = ("b2", id(rb)) if rb.has_skip else rb.conv2.bias
+        if not self._wgrad(ctx, rb.conv2.weight, dout, a2, Cout, Cout, 3, 3, pad_t=1, pad_l=1, splits=self._splits(Cout, 9 * Cout, dout.rows), bias=b2):
+            self._bias_grad(ctx, dout, [rb.conv2.bias], Cout, slot=("b2", id(rb)) if rb.has_skip else None)
         # GN2 + SiLU + dropout
         dh1 = self._new(B, x.H, x.W, Cout)
         ops.gn_bwd(h1, da2, dh1, rb.norm2.weight, rb.norm2.bias, stats2, self._pptr(ctx, rb.norm2.weight), self._pptr(ctx, rb.norm2.bias),

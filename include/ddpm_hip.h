@@ -56,6 +56,20 @@ int ddpm_conv2d_wgrad_nhwc(const void* dy, long long dy_ld, const void* x, long 
 
 int ddpm_wgrad_effective_splits(int K, int splits, int dtype);
 
+/* The same gradient for the 3x3 / stride 1 / pad 1 sites (ResidualBlock.conv1 / conv2, ddpm_torch/models/unet.py:76,79), bf16, by a
+ * patch-stationary kernel: a block keeps a 64 x 32 x 9-tap output tile and walks 16x16 pixel patches whose dy tile and x halo are
+ * staged in LDS once for all nine taps; the reduction over pixels is cut into few slices.  Also produces the bias gradient
+ * dbias[n] = sum_{b,y,x} dy[b,y,x,n] (optional) from the dy fragments it reads anyway.
+ *   slab_stride == 0: fp32 atomics into dw [Nreal][3][3][C] / dbias [Nreal];
+ *   slab_stride  > 0: slice s stores at dw + s*slab_stride (and dbias + s*bias_stride); all ddpm_conv3x3_wgrad_splits(...)
+ *                     copies are written in full and ddpm_wgrad_reduce sums them in a fixed order (deterministic).
+ * C % 32 == 0, N % 8 == 0 and H = W in {4, 8} or H, W multiples of 16; otherwise DDPM_ERR_SHAPE (use ddpm_conv2d_wgrad_nhwc).
+ * splits <= 0: chosen by the library. */
+int ddpm_conv3x3_wgrad_splits(int B, int H, int W, int C, int N, int splits);
+int ddpm_conv3x3_wgrad_nhwc(const void* dy, long long dy_ld, const void* x, long long x_ld, float* dw, long long slab_stride,
+                            float* dbias, long long bias_stride, int B, int H, int W, int C, int N, int Nreal, int splits,
+                            int dtype, void* stream);
+
 int ddpm_wgrad_reduce(const long long* table, int n_tensors, void* stream);
 
 int ddpm_wgrad_unpack(const float* gpack, float* gflat, const long long* descs, int n_tensors, float scale, void* stream);

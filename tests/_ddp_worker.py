@@ -16,8 +16,7 @@ TINY = dict(in_channels=3, hid_channels=32, out_channels=3, ch_multipliers=[1, 2
 def install_emulator():
     from ddpm_torch import _hip
     from tests.abi_emulator import Emulator
-    emu = Emulator()
-    _hip.lib()
+    emu = Emulator(_hip.lib())
     _hip.call = emu.call
     _hip.stream = lambda: 0
     _hip.require_cuda = lambda *a: None

@@ -151,6 +151,18 @@ class Emulator:
             for c in range(splits):
                 f32(dw + 4 * c * slab_stride, Nreal * Creal * R * S).reshape(Nreal, R, S, Creal)[...] = val if c == 0 else 0.0
 
+    def ddpm_conv3x3_wgrad_nhwc(self, dy, dy_ld, x, x_ld, dw, slab_stride, dbias, bias_stride, B, H, W, C, N, Nreal, splits, dt, st):
+        copies = self.real_lib.ddpm_conv3x3_wgrad_splits(B, H, W, C, N, splits) if self.real_lib is not None else max(splits, 1)
+        assert copies > 0
+        self.ddpm_conv2d_wgrad_nhwc(dy, dy_ld, x, x_ld, dw, slab_stride, B, H, W, C, C, H, W, N, Nreal, 3, 3, 1, 1, 1, 0, copies, dt, st)
+        if dbias:
+            v = Mat(dy, B * H * W, N, dy_ld, dt).get()[:, :Nreal].sum(0)
+            if slab_stride == 0:
+                f32(dbias, Nreal)[...] += v
+            else:
+                for c in range(copies):
+                    f32(dbias + 4 * c * bias_stride, Nreal)[...] = v if c == copies - 1 else 0.0
+
     def ddpm_wgrad_reduce(self, table, n, st):
         for src, dst, length, copies, stride in i64(table, 5 * n).reshape(n, 5):
             acc = np.zeros(int(length), dtype=np.float32)
@@ -417,8 +429,8 @@ class Emulator:
 
 def install(monkeypatch, hip_module):
     """Route the product's ABI calls to the emulator for the duration of a test."""
-    emu = Emulator()
     real_lib = hip_module.lib()                      # the real .so still answers host-side geometry queries
+    emu = Emulator(real_lib)
     monkeypatch.setattr(hip_module, "call", emu.call)
     monkeypatch.setattr(hip_module, "stream", lambda: 0)
     monkeypatch.setattr(hip_module, "require_cuda", lambda *a: None)

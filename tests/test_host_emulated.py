@@ -246,3 +246,23 @@ def test_product_tables_equal_the_reference_tables(golden):
             for vt in ("fixed-small", "fixed-large"):
                 compare(ddim_mod.DDIM(lin, "eps", vt, "mse", eta=eta, subsequence=sub), g[f"ddim_{sched}_{size}_eta{eta}_{vt}"], f"ddim {sched} {eta} {vt}")
     assert torch.equal(ddim_mod.get_selection_schedule("quadratic", 50, 1000), g["sel_quadratic_50"])
+
+
+def test_backward_routes_3x3_weight_gradients_through_the_patch_kernel(emu, monkeypatch):
+    """bf16 training: 3x3 / stride-1 weight gradients (and conv2's bias gradient) go through ddpm_conv3x3_wgrad_nhwc with slab
+    copies + ddpm_wgrad_reduce; same gradients as the generic path with its separate column sums."""
+    import ddpm_torch.models.unet as unet_mod
+    x, t, gy = rnd(2, 3, 16, 16, seed=3), torch.tensor([7, 912]), rnd(2, 3, 16, 16, seed=4)
+    grads = []
+    for patch in (True, False):
+        monkeypatch.setattr(unet_mod, "_WGRAD3", patch)
+        m, _ = make(TINY, dtype=torch.bfloat16)
+        m.train()
+        emu.log.clear()
+        (m(x, t) * gy).sum().backward()
+        assert ("ddpm_conv3x3_wgrad_nhwc" in emu.log) == patch
+        assert ("ddpm_wgrad_reduce" in emu.log) == patch
+        grads.append(({k: p.grad.clone() for k, p in m.named_parameters()}, emu.log.count("ddpm_colsum")))
+    assert grads[0][1] < grads[1][1]                             # folded bias gradients: fewer column-sum launches
+    for k in grads[0][0]:
+        check(grads[0][0][k], grads[1][0][k], 1e-5, atol=1e-6, name="patch grad." + k)

@@ -506,3 +506,69 @@ def test_multi_tensor_gather():
     _hip.call("ddpm_mt_gather_f32", table.data_ptr(), len(rows), _hip.stream())
     want = torch.cat([x + y if i % 2 else x for i, (x, y) in enumerate(zip(a, b))])
     assert torch.equal(dst[:off].cpu(), want) and float(dst[off:].abs().max()) == 0
+
+
+WG3_CASES = [
+    # B, H, W, C, N, Nreal, splits
+    ("32x32", 3, 32, 32, 64, 128, 128, 0),
+    ("16x16_wide", 2, 16, 16, 128, 256, 256, 0),
+    ("16x48_ragged_n", 2, 16, 48, 32, 72, 72, 3),
+    ("8x8_odd_batch", 5, 8, 8, 64, 64, 64, 0),
+    ("4x4_ragged", 9, 4, 4, 32, 96, 96, 2),
+    ("64x64_one_slice", 1, 64, 64, 32, 64, 60, 1),
+    ("full_batch_cifar_level0", 128, 32, 32, 128, 128, 128, 0),
+]
+
+
+@pytest.mark.parametrize("case", WG3_CASES, ids=[c[0] for c in WG3_CASES])
+def test_conv3x3_wgrad_patch_kernel(case):
+    """Patch-stationary 3x3 weight gradient (+ folded bias gradient) against the emulator: atomics mode on top of existing
+    content, slab mode over stale copies followed by the fixed-order reduction; pitched operands, ragged image groups,
+    out-channel tiles that run past N."""
+    _, B, H, W, C, N, Nreal, splits = case
+    dt = 1
+    xld, yld = C + 8, N + 16
+    x, dy = r(B * H * W, xld, seed=1, dt=dt), r(B * H * W, yld, seed=2, dt=dt)
+    copies = int(_hip.lib().ddpm_conv3x3_wgrad_splits(B, H, W, C, N, splits))
+    assert copies >= 1
+    n = Nreal * 9 * C
+    ref_w, ref_b = torch.zeros(n), torch.zeros(Nreal)
+    Emulator(_hip.lib()).call("ddpm_conv3x3_wgrad_nhwc", dy.data_ptr(), yld, x.data_ptr(), xld, ref_w.data_ptr(), 0, ref_b.data_ptr(), 0,
+                              B, H, W, C, N, Nreal, splits, dt, 0)
+    xd, dyd = x.cuda(), dy.cuda()
+    tol = 4e-3
+    # atomics on top of existing content
+    w0, b0 = r(n, seed=3), r(Nreal, seed=4)
+    wd, bd = w0.cuda(), b0.cuda()
+    _hip.call("ddpm_conv3x3_wgrad_nhwc", dyd.data_ptr(), yld, xd.data_ptr(), xld, wd.data_ptr(), 0, bd.data_ptr(), 0, B, H, W, C, N, Nreal, splits, dt, _hip.stream())
+    assert float((wd.cpu() - w0 - ref_w).abs().max()) <= tol * float(ref_w.abs().max()), "atomic dw"
+    assert float((bd.cpu() - b0 - ref_b).abs().max()) <= tol * float(ref_b.abs().max()), "atomic dbias"
+    # slab copies + fixed-order reduction, twice: bit-identical
+    stride, bstride = (n + 3) // 4 * 4 + 8, (Nreal + 3) // 4 * 4 + 4
+    outs = []
+    for rep in range(2):
+        slabs = torch.full((copies * (stride + bstride),), 7.0 + rep).cuda()          # stale content must not leak
+        bptr = slabs.data_ptr() + 4 * copies * stride
+        _hip.call("ddpm_conv3x3_wgrad_nhwc", dyd.data_ptr(), yld, xd.data_ptr(), xld, slabs.data_ptr(), stride, bptr, bstride,
+                  B, H, W, C, N, Nreal, splits, dt, _hip.stream())
+        out_w, out_b = torch.zeros(n).cuda(), torch.zeros(Nreal).cuda()
+        table = torch.tensor([[slabs.data_ptr(), out_w.data_ptr(), n, copies, stride], [bptr, out_b.data_ptr(), Nreal, copies, bstride]], dtype=torch.int64).cuda()
+        _hip.call("ddpm_wgrad_reduce", table.data_ptr(), 2, _hip.stream())
+        outs.append((out_w.cpu(), out_b.cpu()))
+    assert float((outs[0][0] - ref_w).abs().max()) <= tol * float(ref_w.abs().max()), "slab dw"
+    assert float((outs[0][1] - ref_b).abs().max()) <= tol * float(ref_b.abs().max()), "slab dbias"
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])       # deterministic
+    # without a bias pointer nothing else changes
+    w2 = torch.zeros(n).cuda()
+    _hip.call("ddpm_conv3x3_wgrad_nhwc", dyd.data_ptr(), yld, xd.data_ptr(), xld, w2.data_ptr(), 0, 0, 0, B, H, W, C, N, Nreal, splits, dt, _hip.stream())
+    assert float((w2.cpu() - ref_w).abs().max()) <= tol * float(ref_w.abs().max())
+
+
+def test_conv3x3_wgrad_patch_kernel_rejects_unsupported_geometry():
+    lib = _hip.lib()
+    assert lib.ddpm_conv3x3_wgrad_splits(2, 32, 32, 8, 128, 0) == 0          # C not a multiple of 32 (in_conv)
+    assert lib.ddpm_conv3x3_wgrad_splits(2, 12, 12, 64, 64, 0) == 0          # neither 4x4 / 8x8 nor multiples of 16
+    assert lib.ddpm_conv3x3_wgrad_splits(2, 32, 32, 64, 3, 0) == 0           # N not a multiple of 8 (out_conv, unpadded)
+    t = torch.zeros(64, device="cuda")
+    assert lib.ddpm_conv3x3_wgrad_nhwc(t.data_ptr(), 64, t.data_ptr(), 64, t.data_ptr(), 0, 0, 0, 2, 12, 12, 64, 64, 64, 0, 1, _hip.stream()) == 1
+    assert lib.ddpm_conv3x3_wgrad_nhwc(t.data_ptr(), 64, t.data_ptr(), 64, t.data_ptr(), 0, 0, 0, 2, 16, 16, 64, 64, 64, 0, 0, _hip.stream()) == 2     # fp32
