@@ -42,6 +42,8 @@ struct Wg3Args {
     int stages, stages_per_split;
     int tiles_n, tiles_c;
     int atomic;                      // 1: atomicAdd into dw / dbias; 0: plain stores into slab copy `split`
+    unsigned long long* dbg;         // ABL & 32 builds: per-wave cycle totals [block][wave][4] = {loop, barrier wait, lgkm waits, dma wait}
+    int ablate;                      // timing experiments only (DDPM_WG_ABLATE): 1 no DMA, 2 no MFMA, 4 no fragment reads, 8 no output
     FastDiv d_tiles, d_tiles_c, d_tpi, d_tiles_x, d_halo_img, d_halo_w;
 };
 
@@ -64,7 +66,9 @@ __device__ __forceinline__ uint2 tr_read(const char* p) {
 
 // STAGE_PX: pixels per stage (256: one 16x16 patch; 128: 2 images of 8x8 / 8 images of 4x4).  PW: patch width (16 / 8 / 4).
 // RING: LDS stages in flight + 1.  NI_DY / NI_X: DMA instructions per thread per stage for the dy tile / the halo.
-template <int STAGE_PX, int PW, int RING>
+// Wave w = (k group w >> 1, out-channel half w & 1).  16-wide patches: k group g owns patch rows 4g .. 4g+3 of the stage;
+// smaller images: k-steps g, g + 4, ...
+template <int STAGE_PX, int PW, int RING, int ABL = 0>      // ABL: compile-time ablations for timing experiments (4 no fragment reads, 16 no barrier)
 __global__ __launch_bounds__(512, 2)
 void wgrad3x3_kernel(Wg3Args a) {
     constexpr int KSTEPS = STAGE_PX / 16;                  // 16-pixel k-steps per stage
@@ -106,25 +110,27 @@ void wgrad3x3_kernel(Wg3Args a) {
     // logical chunk is XOR-swizzled by ((p >> 1) & 1) << 2 on the source side so that the four k-rows one transpose read touches
     // (p, p+1, p+2, p+3) fall on four different 32-byte bank groups.  Halo: v -> halo pixel v >> 2, chunk v & 3 (64-byte rows:
     // four consecutive rows already cover the 64 banks exactly once).
-    int dy_il[NI_DY]; unsigned dy_rel[NI_DY];
-#pragma unroll
-    for (int i = 0; i < NI_DY; ++i) {
-        const int v = tid + 512 * i, p = v >> 3;
-        const int lc = (v & 7) ^ (((p >> 1) & 1) << 2);
+    // (vector i of a thread is 64 stage pixels / 128 halo pixels after vector i-1: the plans keep one base per thread)
+    unsigned dy_rel0, dy_delta; int dy_il0, dy_il_delta;
+    {
+        const int p = tid >> 3;
+        const int lc = (tid & 7) ^ (((p >> 1) & 1) << 2);
         const int il = p >> a.lPP, q = p & (PP - 1), py = q / PW, px = q - py * PW;
         const int n = tn * TN + lc * 8;
-        dy_il[i] = n < a.N ? il : (1 << 20);                                   // channel block outside dy: always out of range
-        dy_rel[i] = (unsigned)((((long long)(il * a.H + py) * a.W + px) * a.dy_ld + n) * 2);
+        dy_il0 = n < a.N ? il : (1 << 20);                                     // channel block outside dy: always out of range
+        dy_rel0 = (unsigned)((((long long)(il * a.H + py) * a.W + px) * a.dy_ld + n) * 2);
+        // 64 stage pixels further: whole images (small images) or 64 / PW patch rows of the same image
+        dy_il_delta = 64 >> a.lPP;
+        dy_delta = (unsigned)((dy_il_delta ? (long long)dy_il_delta * a.H * a.W : (long long)(64 / PW) * a.W) * a.dy_ld * 2);
     }
-    int x_il[NI_X], x_hy[NI_X], x_hx[NI_X]; unsigned x_c2[NI_X];
+    unsigned x_pos[NI_X];                                                      // (hy + 1) << 16 | (hx + 1) << 8 | il ; 0xffffffff: no pixel
+    const unsigned x_c2 = (unsigned)((tc * TC + (tid & 3) * 8) * 2);
 #pragma unroll
     for (int i = 0; i < NI_X; ++i) {
-        const int v = tid + 512 * i, hp = v >> 2;
+        const int hp = (tid >> 2) + 128 * i;
         const int il = (int)fdiv((unsigned)hp, a.d_halo_img), rem = hp - il * (HH * HW);
         const int hy = (int)fdiv((unsigned)rem, a.d_halo_w), hx = rem - hy * HW;
-        x_il[i] = hp < HP ? il : (1 << 20);
-        x_hy[i] = hy - 1; x_hx[i] = hx - 1;
-        x_c2[i] = (unsigned)((tc * TC + (v & 3) * 8) * 2);
+        x_pos[i] = hp < HP ? ((unsigned)hy << 16 | (unsigned)hx << 8 | (unsigned)il) : 0xffffffffu;
     }
     auto issue_stage = [&](int st, int slot) {
         const int grp = (int)fdiv((unsigned)st, a.d_tpi), pt = st - grp * tpi;
@@ -134,14 +140,15 @@ void wgrad3x3_kernel(Wg3Args a) {
         const unsigned base = (unsigned)((((long long)(img0 * a.H + py0) * a.W + px0) * a.dy_ld) * 2);
 #pragma unroll
         for (int i = 0; i < NI_DY; ++i) {
-            const unsigned o = (img0 + dy_il[i] < a.B) ? base + dy_rel[i] : OOB;
+            const unsigned o = (img0 + dy_il0 + i * dy_il_delta < a.B) ? base + dy_rel0 + i * dy_delta : OOB;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rdy, (__attribute__((address_space(3))) void*)(dst + (wave * 64 + 512 * i) * 16), 16, o, 0, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < NI_X; ++i) {
-            const int gi = img0 + x_il[i], iy = py0 + x_hy[i], ix = px0 + x_hx[i];
-            const bool ok = gi < a.B && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-            const unsigned o = ok ? (unsigned)((((long long)(gi * a.H + iy) * a.W + ix) * a.x_ld) * 2) + x_c2[i] : OOB;
+            const unsigned xp = x_pos[i];
+            const int gi = img0 + (int)(xp & 0xff), iy = py0 + (int)(xp >> 16) - 1, ix = px0 + (int)((xp >> 8) & 0xff) - 1;
+            const bool ok = xp != 0xffffffffu && gi < a.B && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+            const unsigned o = ok ? (unsigned)((((long long)(gi * a.H + iy) * a.W + ix) * a.x_ld) * 2) + x_c2 : OOB;
             const int rel = (wave * 64 + 512 * i) * 16;
             char* to = (rel + 1024 <= X_BYTES) ? dst + DY_BYTES + rel : smem + DUMP_OFF;       // wave-uniform
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)to, 16, o, 0, 0, 0);
@@ -163,6 +170,7 @@ void wgrad3x3_kernel(Wg3Args a) {
     const int k_lo = 8 * h + q4, k_hi = k_lo + 4;
     const int b_lo = ((k_lo / PW) * HW + (k_lo % PW)) * X_ROW + (mcol >> 3) * 16 + (mcol & 7) * 2;
     const int b_hi = ((k_hi / PW) * HW + (k_hi % PW)) * X_ROW + (mcol >> 3) * 16 + (mcol & 7) * 2;
+    const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)smem;
 
     f32x16 acc[9];
 #pragma unroll
@@ -170,94 +178,228 @@ void wgrad3x3_kernel(Wg3Args a) {
     float bsum = 0.f;                                    // column sum of dy for n = wn*32 + (lane & 31), this lane's k half
     const bool want_bias = a.dbias != nullptr && tc == 0;
 
-    // ---- prologue: RING-1 stages in flight, wait for the first
+    // The transpose reads are INLINE ASM on purpose: hipcc treats the ds_read_tr builtin as a possible alias of every pending
+    // LDS-DMA and puts `s_waitcnt vmcnt(0)` in front of it, which drains the whole stage ring on every iteration (measured: the
+    // first version of this kernel spent 4.5 us per stage against 1.1 us of MFMA work).  With asm reads the LGKM counter is
+    // ours to manage: a group of reads is issued one MFMA group ahead of its use and retired by `s_waitcnt lgkmcnt(0)` tied to
+    // the destination registers (in/out operands), so no MFMA can be scheduled above the wait that covers its operands.
+#define TR_READ(dst, addr, off) do { if constexpr (!(ABL & 4)) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off)); else dst = uint2{addr, (unsigned)(off)}; } while (0)
+    struct Frag { uint2 lo, hi; };
+    auto frag4 = [](const Frag& f) { return __builtin_bit_cast(bf16x8, u32x4{f.lo.x, f.lo.y, f.hi.x, f.hi.y}); };
+    auto bias_add = [&](const Frag& f) {
+        bsum += __uint_as_float(f.lo.x << 16) + __uint_as_float(f.lo.x & 0xffff0000u) + __uint_as_float(f.lo.y << 16) + __uint_as_float(f.lo.y & 0xffff0000u)
+              + __uint_as_float(f.hi.x << 16) + __uint_as_float(f.hi.x & 0xffff0000u) + __uint_as_float(f.hi.y << 16) + __uint_as_float(f.hi.y & 0xffff0000u);
+    };
+#define WAIT3(F) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(F[0].lo), "+v"(F[0].hi), "+v"(F[1].lo), "+v"(F[1].hi), "+v"(F[2].lo), "+v"(F[2].hi) :: "memory")
+
+    if constexpr (PW == 16) {
+        // ---- 16-wide patches: a k-step is one patch row.  The wave owns patch rows 4 wk .. 4 wk + 3 and walks the SIX halo rows they
+        // touch: halo row hr feeds tap row r of patch row hr - r, so its three shifted fragments (s = 0, 1, 2) are read once and used
+        // by up to nine MFMAs — 18 + 4 fragment reads per stage instead of 36 + 4.  Order of the halo rows inside a stage:
+        //     4 | 5 + 0 | 1 | 2 | -- barrier -- | 3
+        // every group of fragment reads is issued under the MFMAs of the group before it, and the LAST group (nine MFMAs) runs after
+        // the barrier that releases the next stage, covering that stage's first reads and the DMA issue for the slot just freed.
+        auto bases = [&](int slot, unsigned& ab, unsigned& bl, unsigned& bh) {
+            const unsigned stage0 = lds0 + slot * STAGE_BYTES;
+            ab = stage0 + (4 * wk) * 16 * DY_ROW + a_off;
+            bl = stage0 + DY_BYTES + (4 * wk) * HW * X_ROW + b_lo;
+            bh = stage0 + DY_BYTES + (4 * wk) * HW * X_ROW + b_hi;
+        };
+#define READ_ROW(F, hr) do { _Pragma("unroll") for (int sft = 0; sft < 3; ++sft) { TR_READ(F[sft].lo, blo0, ((hr) * HW + sft) * X_ROW); TR_READ(F[sft].hi, bhi0, ((hr) * HW + sft) * X_ROW); } } while (0)
+#define READ_A(FA) do { _Pragma("unroll") for (int j = 0; j < 4; ++j) { TR_READ(FA[j].lo, abase, j * 16 * DY_ROW); TR_READ(FA[j].hi, abase, j * 16 * DY_ROW + 4 * DY_ROW); } } while (0)
+#define WAIT_A(FA) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(FA[0].lo), "+v"(FA[0].hi), "+v"(FA[1].lo), "+v"(FA[1].hi), "+v"(FA[2].lo), "+v"(FA[2].hi), "+v"(FA[3].lo), "+v"(FA[3].hi) :: "memory")
+#define MMA_ROW(FA, F, hr) do { _Pragma("unroll") for (int r = 0; r < 3; ++r) { const int j = (hr) - r; if (j >= 0 && j < 4) { _Pragma("unroll") for (int sft = 0; sft < 3; ++sft) \
+            if constexpr (!(ABL & 2)) acc[r * 3 + sft] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag4(FA[j]), frag4(F[sft]), acc[r * 3 + sft], 0, 0, 0); } } } while (0)
+#pragma unroll
+        for (int t = 0; t < RING; ++t)
+            if (t < nst && !(ABL & 1)) issue_stage(st_begin + t, t);
+        if (nst >= 3) wait_vm<2 * PER>(); else if (nst == 2) wait_vm<PER>(); else wait_vm<0>();
+        __builtin_amdgcn_s_barrier();
+        unsigned abase, blo0, bhi0;
+        Frag fa[4], f4[3], f50[6], f1[3], f2[3], f3[3];
+        if (nst > 0) {
+            bases(0, abase, blo0, bhi0);
+            READ_A(fa); READ_ROW(f4, 4);
+            WAIT_A(fa); WAIT3(f4);
+        }
+        unsigned long long t_loop = 0, t_bar = 0, t_lgkm = 0, t_dma = 0, tq = 0;
+#define TICK() (ABL & 32 ? __builtin_amdgcn_s_memtime() : 0ull)
+#define TW(stmt) do { if constexpr (ABL & 32) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); stmt; asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); t_lgkm += __builtin_amdgcn_s_memtime() - t_; } else { stmt; } } while (0)
+        if constexpr (ABL & 32) t_loop = __builtin_amdgcn_s_memtime();
+        for (int it = 0; it < nst; ++it) {
+            if (want_bias) { bias_add(fa[0]); bias_add(fa[1]); bias_add(fa[2]); bias_add(fa[3]); }
+            Frag* f5 = f50; Frag* f0 = f50 + 3;
+            READ_ROW(f5, 5); READ_ROW(f0, 0);
+            MMA_ROW(fa, f4, 4);
+            TW(WAIT3(f5); WAIT3(f0));
+            READ_ROW(f1, 1);
+            MMA_ROW(fa, f5, 5); MMA_ROW(fa, f0, 0);
+            TW(WAIT3(f1));
+            READ_ROW(f2, 2);
+            MMA_ROW(fa, f1, 1);
+            TW(WAIT3(f2));
+            READ_ROW(f3, 3);
+            MMA_ROW(fa, f2, 2);
+            TW(WAIT3(f3));
+            // every LDS read of this stage has returned: after the barrier its slot may be refilled.  Stage it+1 must have landed
+            // (one newer stage, it+2, may stay in flight).
+            const bool more = it + 1 < nst;
+            if constexpr (ABL & 32) tq = __builtin_amdgcn_s_memtime();
+            if (more) { if (it + 2 < nst) wait_vm<PER>(); else wait_vm<0>(); }
+            if constexpr (ABL & 32) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long t2 = __builtin_amdgcn_s_memtime(); t_dma += t2 - tq; tq = t2; }
+            if constexpr (!(ABL & 16)) __builtin_amdgcn_s_barrier();
+            if constexpr (ABL & 32) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); t_bar += __builtin_amdgcn_s_memtime() - tq; }
+            Frag na[4], n4[3];
+            if (more) {
+                bases((it + 1) % RING, abase, blo0, bhi0);
+                READ_A(na); READ_ROW(n4, 4);
+            }
+            MMA_ROW(fa, f3, 3);
+            if (it + RING < nst && !(ABL & 1)) issue_stage(st_begin + it + RING, it % RING);
+            if (more) {
+                WAIT_A(na); WAIT3(n4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) fa[j] = na[j];
+#pragma unroll
+                for (int sft = 0; sft < 3; ++sft) f4[sft] = n4[sft];
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (ABL & 32) {
+            if (a.dbg && lane == 0) {
+                unsigned long long* o = a.dbg + ((long long)blockIdx.x * 8 + wave) * 4;
+                o[0] = __builtin_amdgcn_s_memtime() - t_loop; o[1] = t_bar; o[2] = t_lgkm; o[3] = t_dma;
+            }
+        }
+        __syncthreads();
+#undef TW
+#undef TICK
+#undef READ_ROW
+#undef READ_A
+#undef WAIT_A
+#undef MMA_ROW
+    } else {
+    // ---- small images.  Prologue: RING-1 stages in flight, wait for the first
 #pragma unroll
     for (int t = 0; t < RING - 1; ++t)
-        if (t < nst) issue_stage(st_begin + t, t);
+        if (t < nst && !(ABL & 1)) issue_stage(st_begin + t, t);
     wait_inflight(min(RING - 2, nst - 1));
     __builtin_amdgcn_s_barrier();
 
     for (int it = 0; it < nst; ++it) {
         const int slot = it % RING;
         // the stage RING-1 ahead goes into the slot read in iteration it-1 (every wave is past the barrier that ended it)
-        if (it + RING - 1 < nst) issue_stage(st_begin + it + RING - 1, (it + RING - 1) % RING);
-        const char* dyt = smem + slot * STAGE_BYTES;
-        const char* xt = dyt + DY_BYTES;
+        if (it + RING - 1 < nst && !(ABL & 1)) issue_stage(st_begin + it + RING - 1, (it + RING - 1) % RING);
+        const unsigned stage0 = lds0 + slot * STAGE_BYTES;
+        {
+            // a k-step covers 16 / PW patch rows; per k-step one dy fragment and nine halo fragments, read in groups of three
+            // (one tap row) one group ahead of the MFMAs that use them
+            Frag fa[KPW], fb[2][3];
+            unsigned blo[KPW], bhi[KPW];
 #pragma unroll
-        for (int u = 0; u < KPW; ++u) {
-            const int ks = wk + 4 * u;                                   // this wave's k-steps: wk, wk+4, ...
-            // A: dy fragment
-            const char* pa = dyt + ks * 16 * DY_ROW + a_off;
-            const uint2 alo = tr_read(pa), ahi = tr_read(pa + 4 * DY_ROW);
-            const u32x4 fa = u32x4{alo.x, alo.y, ahi.x, ahi.y};
-            if (want_bias) {
-                bsum += __uint_as_float(fa.x << 16) + __uint_as_float(fa.x & 0xffff0000u) + __uint_as_float(fa.y << 16) + __uint_as_float(fa.y & 0xffff0000u)
-                      + __uint_as_float(fa.z << 16) + __uint_as_float(fa.z & 0xffff0000u) + __uint_as_float(fa.w << 16) + __uint_as_float(fa.w & 0xffff0000u);
+            for (int u = 0; u < KPW; ++u) {
+                const int ks = wk + 4 * u;
+                const unsigned pa = stage0 + ks * 16 * DY_ROW + a_off;
+                TR_READ(fa[u].lo, pa, 0); TR_READ(fa[u].hi, pa, 4 * DY_ROW);
+                const int p0 = ks * 16, il = p0 >> a.lPP, pr0 = (p0 & (PP - 1)) / PW;
+                blo[u] = stage0 + DY_BYTES + ((il * HH + pr0) * HW) * X_ROW + b_lo;
+                bhi[u] = stage0 + DY_BYTES + ((il * HH + pr0) * HW) * X_ROW + b_hi;
             }
-            // halo base of the k-step: image il, first patch row pr0 (a k-step covers 16 / PW patch rows)
-            const int p0 = ks * 16, il = p0 >> a.lPP, pr0 = (p0 & (PP - 1)) / PW;
-            const char* pb = xt + ((il * HH + pr0) * HW) * X_ROW;
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const int r = t / 3, s = t - 3 * r;
-                const char* pt = pb + (r * HW + s) * X_ROW;
-                const uint2 blo = tr_read(pt + b_lo), bhi = tr_read(pt + b_hi);
-                const u32x4 fb = u32x4{blo.x, blo.y, bhi.x, bhi.y};
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa), __builtin_bit_cast(bf16x8, fb), acc[t], 0, 0, 0);
+            for (int sft = 0; sft < 3; ++sft) { TR_READ(fb[0][sft].lo, blo[0], sft * X_ROW); TR_READ(fb[0][sft].hi, bhi[0], sft * X_ROW); }
+            if constexpr (KPW == 2)
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0].lo), "+v"(fa[0].hi), "+v"(fa[1].lo), "+v"(fa[1].hi) :: "memory");
+            else
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0].lo), "+v"(fa[0].hi) :: "memory");
+            WAIT3(fb[0]);
+            if (want_bias) {
+#pragma unroll
+                for (int u = 0; u < KPW; ++u) bias_add(fa[u]);
+            }
+#pragma unroll
+            for (int g = 0; g < 3 * KPW; ++g) {                            // group g = (k-step u, tap row r)
+                const int u = g / 3, r = g - 3 * u;
+                auto& cur = fb[g & 1];
+                auto& nxt = fb[(g + 1) & 1];
+                if (g + 1 < 3 * KPW) {
+                    const int u2 = (g + 1) / 3, r2 = (g + 1) - 3 * u2;
+#pragma unroll
+                    for (int sft = 0; sft < 3; ++sft) {
+                        TR_READ(nxt[sft].lo, blo[u2], (r2 * HW + sft) * X_ROW);
+                        TR_READ(nxt[sft].hi, bhi[u2], (r2 * HW + sft) * X_ROW);
+                    }
+                }
+#pragma unroll
+                for (int sft = 0; sft < 3; ++sft)
+                    if constexpr (!(ABL & 2)) acc[r * 3 + sft] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag4(fa[u]), frag4(cur[sft]), acc[r * 3 + sft], 0, 0, 0);
+                if (g + 1 < 3 * KPW) WAIT3(nxt);
             }
         }
         // stage it+1 must have landed before anyone reads it; newer stages may stay in flight across the barrier
         wait_inflight(min(RING - 2, max(nst - 2 - it, 0)));
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     }
-
-    // ---- sum the four k groups through LDS (the ring is idle now): groups 1..3 hand their accumulators to group 0, one at a time
-    float* red = reinterpret_cast<float*>(smem);           // [wn][9 taps][16 regs][64 lanes] = 72 KiB
-    float* rbias = red + 2 * 9 * 16 * 64;                  // [wn][64 lanes]
-    for (int g = 1; g < 4; ++g) {
-        if (wk == g) {
-#pragma unroll
-            for (int t = 0; t < 9; ++t)
-#pragma unroll
-                for (int r4 = 0; r4 < 4; ++r4)
-                    *reinterpret_cast<f32x4*>(red + ((wn * 9 + t) * 4 + r4) * 256 + lane * 4) =
-                        f32x4{acc[t][4 * r4], acc[t][4 * r4 + 1], acc[t][4 * r4 + 2], acc[t][4 * r4 + 3]};
-            if (want_bias) rbias[wn * 64 + lane] = bsum;
-        }
-        __syncthreads();
-        if (wk == 0) {
-#pragma unroll
-            for (int t = 0; t < 9; ++t)
-#pragma unroll
-                for (int r4 = 0; r4 < 4; ++r4) {
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(red + ((wn * 9 + t) * 4 + r4) * 256 + lane * 4);
-                    acc[t][4 * r4] += v.x; acc[t][4 * r4 + 1] += v.y; acc[t][4 * r4 + 2] += v.z; acc[t][4 * r4 + 3] += v.w;
-                }
-            if (want_bias) bsum += rbias[wn * 64 + lane];
-        }
-        __syncthreads();
     }
-    if (wk != 0) return;
+#undef TR_READ
+#undef WAIT3
 
-    // ---- output: packed gradient dw[n][tap][c]; accumulator (reg r, lane l) = row (r&3) + 8*(r>>2) + 4*(l>>5), column l & 31
-    float* out = a.dw + (a.atomic ? 0 : (long long)split * a.slab_stride);
-    const int c = tc * TC + (lane & 31);
-    const int n0 = tn * TN + wn * 32 + 4 * (lane >> 5);
+    // ---- sum the four k groups through LDS (the ring is idle now) as a two-level tree, then hand the finished tile to ALL eight
+    // waves for the write: [n][tap][c] rows of 32 floats leave as 16-byte vectors (one 128-byte line per 8 lanes).
+    float* red = reinterpret_cast<float*>(smem);           // [slot][wn][9 taps][4][64 lanes][4] : one slot = 72 KiB
+    constexpr int SLOT_F = 2 * 9 * 16 * 64;
+    float* rbias = red + 2 * SLOT_F;                       // [4 k groups][wn][64 lanes]
+    auto put = [&](int slot) {
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+        for (int t = 0; t < 9; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int n = n0 + (r & 3) + 8 * (r >> 2);
-            if (n < a.Nreal) {
-                float* o = out + ((long long)n * 9 + t) * a.C + c;
-                if (a.atomic) atomicAdd(o, acc[t][r]); else *o = acc[t][r];
+            for (int r4 = 0; r4 < 4; ++r4)
+                *reinterpret_cast<f32x4*>(red + slot * SLOT_F + ((wn * 9 + t) * 4 + r4) * 256 + lane * 4) =
+                    f32x4{acc[t][4 * r4], acc[t][4 * r4 + 1], acc[t][4 * r4 + 2], acc[t][4 * r4 + 3]};
+    };
+    auto take = [&](int slot) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(red + slot * SLOT_F + ((wn * 9 + t) * 4 + r4) * 256 + lane * 4);
+                acc[t][4 * r4] += v.x; acc[t][4 * r4 + 1] += v.y; acc[t][4 * r4 + 2] += v.z; acc[t][4 * r4 + 3] += v.w;
             }
-        }
-    if (want_bias) {
-        const float tot = bsum + __shfl_xor(bsum, 32, 64);           // the two k halves of the fragment
-        const int n = tn * TN + wn * 32 + (lane & 31);
-        if (lane < 32 && n < a.Nreal) {
+    };
+    if (want_bias) rbias[(wk * 2 + wn) * 64 + lane] = bsum;
+    if (wk >= 2) put(wk - 2);                              // groups 2, 3 -> slots 0, 1
+    __syncthreads();
+    if (wk < 2) take(wk);                                  // group 0 += group 2, group 1 += group 3
+    __syncthreads();
+    if (wk == 1) put(0);
+    __syncthreads();
+    // group 0 finishes the sum and lays the tile out as the output wants it: tile[n (64)][tap (9)][c (32)] fp32 in slot 1
+    float* otile = red + SLOT_F;
+    if (wk == 0) {
+        take(0);
+        const int cc = lane & 31, nb = wn * 32 + 4 * (lane >> 5);
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) otile[((nb + (r & 3) + 8 * (r >> 2)) * 9 + t) * TC + cc] = acc[t][r];
+    }
+    __syncthreads();
+    if constexpr (ABL & 8) return;
+    float* out = a.dw + (a.atomic ? 0 : (long long)split * a.slab_stride);
+    for (int v = tid; v < TN * 9 * (TC / 4); v += 512) {   // 4608 vectors of 4 floats: row = (n, tap), 8 vectors per row
+        const int row = v >> 3, c4 = (v & 7) * 4;
+        const int nl = row / 9, t = row - nl * 9, n = tn * TN + nl;
+        if (n >= a.Nreal) continue;
+        const f32x4 val = *reinterpret_cast<const f32x4*>(otile + row * TC + c4);
+        float* o = out + ((long long)n * 9 + t) * a.C + tc * TC + c4;
+        if (a.atomic) { atomicAdd(o, val.x); atomicAdd(o + 1, val.y); atomicAdd(o + 2, val.z); atomicAdd(o + 3, val.w); }
+        else *reinterpret_cast<f32x4*>(o) = val;
+    }
+    if (want_bias && tid < TN) {
+        const int wnn = tid >> 5, l = tid & 31, n = tn * TN + tid;
+        float tot = 0.f;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) tot += rbias[(g * 2 + wnn) * 64 + l] + rbias[(g * 2 + wnn) * 64 + l + 32];     // fixed order
+        if (n < a.Nreal) {
             if (a.atomic) atomicAdd(a.dbias + n, tot);
             else a.dbias[(long long)split * a.bias_stride + n] = tot;
         }
@@ -279,8 +421,9 @@ static Plan make_plan(int B, int H, int W, int C, int N, int want_splits) {
     const int tiles = p.tiles_n * p.tiles_c;
     int splits = want_splits;
     if (splits <= 0) {
-        // ~2 blocks per CU (512 blocks); keep >= 4 stages per slice so that the block's prologue / final reduction amortise
-        splits = (512 + tiles - 1) / tiles;
+        // one block per CU (the stage ring fills the LDS): slices so that tiles x slices ~ 256, rounded to whole waves of blocks;
+        // keep >= 4 stages per slice so that the block's prologue / final reduction amortise
+        splits = 256 / tiles;                                  // never more blocks than CUs: a second, nearly empty wave of blocks doubles the time
         const int cap = p.stages >= 4 ? p.stages / 4 : 1;
         if (splits > cap) splits = cap;
         if (splits < 1) splits = 1;
@@ -328,6 +471,7 @@ extern "C" int ddpm_conv3x3_wgrad_nhwc(const void* dy, long long dy_ld, const vo
     a.tiles_y = H / p.PH; a.tiles_x = W / p.PW;
     a.stages = p.stages; a.stages_per_split = p.per; a.tiles_n = p.tiles_n; a.tiles_c = p.tiles_c;
     a.atomic = slab_stride == 0;
+    { const char* e = getenv("DDPM_WG_ABLATE"); a.ablate = e ? atoi(e) : 0; const char* d = getenv("DDPM_WG_DBGPTR"); a.dbg = d ? (unsigned long long*)strtoull(d, nullptr, 10) : nullptr; }
     a.d_tiles = make_fastdiv((unsigned)(p.tiles_n * p.tiles_c)); a.d_tiles_c = make_fastdiv((unsigned)p.tiles_c);
     a.d_tpi = make_fastdiv((unsigned)(a.tiles_y * a.tiles_x)); a.d_tiles_x = make_fastdiv((unsigned)a.tiles_x);
     a.d_halo_img = make_fastdiv((unsigned)((p.PH + 2) * (p.PW + 2))); a.d_halo_w = make_fastdiv((unsigned)(p.PW + 2));
@@ -337,7 +481,9 @@ extern "C" int ddpm_conv3x3_wgrad_nhwc(const void* dy, long long dy_ld, const vo
     do {                                                                                                                          \
         constexpr int NIX = ((SPX == 256 ? 324 : (PWV == 8 ? 200 : 288)) * 4 + 511) / 512;                                       \
         constexpr int XB = SPX == 256 ? 336 * 64 : NIX * 128 * 64;                                                                \
-        constexpr int LDS = RINGV * (SPX * 128 + XB) + 1024 > 75 * 1024 ? RINGV * (SPX * 128 + XB) + 1024 : 75 * 1024;          \
+        constexpr int RAW = RINGV * (SPX * 128 + XB) + (SPX == 256 ? 1024 : 0);         /* ring (+ dump): <= 160 KiB */          \
+        constexpr int LDS = RAW > 147 * 1024 ? RAW : 147 * 1024;                        /* the final k-group sum needs 2 x 72 KiB + 2 KiB */ \
+        static_assert(LDS <= 160 * 1024, "LDS budget");                                                                          \
         static bool attr_set = false;                                                                                             \
         if (!attr_set) {                                                                                                          \
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3_kernel<SPX, PWV, RINGV>),                            \
@@ -346,7 +492,14 @@ extern "C" int ddpm_conv3x3_wgrad_nhwc(const void* dy, long long dy_ld, const vo
         }                                                                                                                         \
         hipLaunchKernelGGL((wgrad3x3_kernel<SPX, PWV, RINGV>), grid, dim3(512), LDS, st, a);                                      \
     } while (0)
-    if (p.stage_px == 256) WG_LAUNCH(256, 16, 3);            // 3 x (32 KiB dy + 21 KiB halo) + 1 KiB = 160 KiB
+    if (p.stage_px == 256 && a.ablate) {
+        const int ab = a.ablate;
+        constexpr int LDS = 3 * (256 * 128 + 336 * 64) + 1024;
+#define WG_ABL(V) do { hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3_kernel<256, 16, 3, V>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS); \
+                       hipLaunchKernelGGL((wgrad3x3_kernel<256, 16, 3, V>), grid, dim3(512), LDS, st, a); } while (0)
+        if (ab == 9) WG_ABL(9); else if (ab == 2) WG_ABL(2); else if (ab == 1) WG_ABL(1); else if (ab == 8) WG_ABL(8); else if (ab == 25) WG_ABL(25); else if (ab == 32) WG_ABL(32); else if (ab == 41) WG_ABL(41); else WG_ABL(10);
+#undef WG_ABL
+    } else if (p.stage_px == 256) WG_LAUNCH(256, 16, 3);            // 3 x (32 KiB dy + 21 KiB halo) + 1 KiB = 160 KiB
     else if (p.PW == 8) WG_LAUNCH(128, 8, 4);
     else WG_LAUNCH(128, 4, 4);
 #undef WG_LAUNCH
