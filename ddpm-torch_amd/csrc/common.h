@@ -115,5 +115,17 @@ __device__ __forceinline__ bool dropout_keep(unsigned long long seed, unsigned l
     return (h >> 8) >= thresh24;          // P(keep) = 1 - thresh24 / 2^24
 }
 
+// The same hash for element indices below 2^32 (every tensor of the hot path): the seed-dependent part is loop-invariant.
+//   keep(seed, idx) == dropout_keep32(dropout_h0(seed), (unsigned)idx, thresh)   for idx < 2^32
+__device__ __forceinline__ unsigned dropout_h0(unsigned long long seed) {
+    return mix32((unsigned)seed) ^ ((unsigned)(seed >> 32) * 0x9E3779B9u);
+}
+__device__ __forceinline__ bool dropout_keep32(unsigned h0, unsigned idx, unsigned thresh24) { return (mix32(idx ^ h0) >> 8) >= thresh24; }
+// d/dz [z*sigmoid(z)] with the hardware reciprocal (1 ulp) instead of the IEEE division
+__device__ __forceinline__ float silu_grad_fast_(float z) {
+    const float s = __builtin_amdgcn_rcpf(1.0f + __expf(-z));
+    return s * (1.0f + z * (1.0f - s));
+}
+
 static inline int check_launch() { return hipGetLastError() == hipSuccess ? DDPM_OK : DDPM_ERR_LAUNCH; }
 static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }

@@ -11,9 +11,27 @@
 // coefficients from those sums + dgamma/dbeta atomics by the slab-0 blocks, then dx).  SiLU and the dropout mask are
 // recomputed.
 #include "common.h"
+#include <stdlib.h>
+
+extern "C" int ddpm_colsum(const void* dy, long long ld, float* per_sample, long long ps_ld, float* total, int B, int HW, int C, int dtype, void* stream);
 
 constexpr int GN_THREADS = 256;
 constexpr int GN_MAXC = 2048;
+
+template <int I> struct GnIC { static constexpr int v = I; };
+template <int N, typename F>
+__device__ __forceinline__ void static_for_gn(F&& f) {
+    if constexpr (N > 0) { static_for_gn<N - 1>(f); f(GnIC<N - 1>{}); }
+}
+// s_waitcnt vmcnt(N + extra): `extra` plain loads were issued AFTER the DMA instructions being counted (runtime 0 or NV)
+template <int N>
+__device__ __forceinline__ void gn_wait_vm(int extra) {
+    if (extra == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+    else if (extra == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N + 1) : "memory");
+    else if (extra == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N + 2) : "memory");
+    else if (extra == 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N + 4) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N + 8) : "memory");
+}
 
 struct GnShape {
     int B, HW, C, G, cpg;       // cpg = C / G
@@ -372,12 +390,311 @@ void gn_reg_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __r
     }
 }
 
+// ---- single-launch kernels for the big slices: x staged in LDS, one HBM read of every input
+// Same slicing as the register kernels — a block owns (sample b, a chunk of GPB groups) over all HW pixels, up to 64 KiB —
+// but the x slice is DMA'd straight into LDS (buffer_load ... lds: no VGPRs are spent on it) and, in the backward, only dy
+// (<= 8 vectors per thread) sits in registers: ~100 VGPRs and ~66 KiB of LDS, i.e. TWO blocks per CU, so one block's
+// load phase overlaps the other's arithmetic.  Thread t owns the 16-byte vectors v = t, t + 512, ... (vector column
+// j = t % seg_vecs of pixels prow, prow + R, ...) in every pass, so it only ever reads LDS bytes its own wave fetched: a
+// counted vmcnt per vector orders them, pass 1 starts on the first vectors while the rest of the slice is still in flight,
+// and no barrier is needed between the passes.
+// Block reduction of per-thread channel partials for these kernels: butterfly over the lanes of a wave that hold the same
+// vector column (needs seg_vecs | 64), then a fixed-order sum over the 8 waves — 1 KiB of scratch instead of 16 KiB.
+template <int VEC>
+__device__ __forceinline__ void gn_block_channel_sum_w(const float (&part)[VEC], const GnFused& f, bool active, int j, int prow, int tid,
+                                                       float* sh_row, float* sh_ch) {
+    if (64 % f.seg_vecs) { gn_block_channel_sum<VEC>(part, f, active, j, prow, tid, sh_row, sh_ch); return; }
+    float v[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) v[e] = active ? part[e] : 0.f;
+    for (int off = f.seg_vecs; off < 64; off <<= 1) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) v[e] += __shfl_xor(v[e], off, 64);
+    }
+    __syncthreads();                                  // previous users of the scratch are done
+    if ((tid & 63) < f.seg_vecs) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) sh_row[(tid >> 6) * f.seg_ch + j * VEC + e] = v[e];
+    }
+    __syncthreads();
+    for (int c = tid; c < f.seg_ch; c += 512) {
+        float acc = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) acc += sh_row[w * f.seg_ch + c];
+        sh_ch[c] = acc;
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t gn_slice_rsrc(const void* base, long long bytes) {
+    const unsigned long long ad = (unsigned long long)base;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)ad), hi = __builtin_amdgcn_readfirstlane((unsigned)(ad >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0,
+                                             __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
+}
+
+//   backward pass 1: A1[c] = sum dz*xhat, A2[c] = sum dz -> dgamma / dbeta atomics, group coefficients c1, c2
+//            pass 2: dx = rstd * (dz*gamma - xhat*c1 - c2) (+= when accumulate), optionally the per-(sample, channel) sums of dx
+//                    (the time-bias gradient of the block, ddpm_torch/models/unet.py:86: no separate column-sum launch).
+template <typename T, int NV>
+__global__ __launch_bounds__(512, 4)
+void gn_lds_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx, GnShape s, GnFused f, long long dy_ld,
+                       long long dx_ld, const float* __restrict__ stats, float* __restrict__ dgamma, float* __restrict__ dbeta, GnApply a,
+                       int accumulate, float* __restrict__ dx_colsum, long long colsum_ld) {
+    constexpr int VEC = Elem<T>::VEC, ES = (int)sizeof(T);
+    extern __shared__ __attribute__((aligned(16))) char lsm[];
+    char* xs = lsm;                                               // [NV][512] vectors of x
+    float* sh_row = reinterpret_cast<float*>(lsm + NV * 512 * 16);
+    float* sh_ch = sh_row + ((64 % f.seg_vecs) ? f.rows_per_iter * f.seg_ch : 8 * f.seg_ch);
+    float* sh_c1 = sh_ch + f.seg_ch;
+    float* sh_c2 = sh_c1 + 32;
+    const int b = blockIdx.y, c0 = blockIdx.x * f.seg_ch, tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool active = tid < f.nta;
+    const int j = tid % f.seg_vecs, prow = tid / f.seg_vecs;
+    const __amdgpu_buffer_rsrc_t rx = gn_slice_rsrc(x + ((long long)b * s.HW) * s.x_ld + c0, ((long long)(s.HW - 1) * s.x_ld + f.seg_ch) * ES);
+    // per-channel constants first: ordinary loads issued BEFORE the DMA can be waited for with a counted vmcnt
+    float mean[VEC], rstd[VEC], gm[VEC], bt[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+        const int c = c0 + j * VEC + e, g = active ? c / s.cpg : 0;
+        mean[e] = stats[((long long)b * s.G + g) * 2]; rstd[e] = stats[((long long)b * s.G + g) * 2 + 1];
+        gm[e] = active ? a.gamma[c] : 0.f; bt[e] = active ? a.beta[c] : 0.f;
+    }
+    const T* db = dy + ((long long)b * s.HW) * dy_ld + c0 + j * VEC;
+    u32x4 vd[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {                     // issue order x_0, dy_0, x_1, dy_1, ...: pair i is complete at vmcnt(2 (NV-1-i))
+        const int p = prow + i * f.rows_per_iter;
+        const bool ok = active && p < s.HW;
+        const unsigned ox = ok ? (unsigned)(((long long)p * s.x_ld + j * VEC) * ES) : 0x7ffffff0u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(xs + (i * 512 + wave * 64) * 16), 16, ox, 0, 0, 0);
+        vd[i] = ok ? ldg16(db + (long long)p * dy_ld) : zero16();
+    }
+    const float keep_scale = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
+    const unsigned h0 = dropout_h0(gn_seed(a));
+    const unsigned idx0 = (unsigned)(((unsigned)b * (unsigned)s.HW) * (unsigned)s.C + (unsigned)(c0 + j * VEC));   // < 2^32: checked by the host
+    auto dz_of = [&](int p, int e, float xh, float d) -> float {
+        float dz = d;
+        if (a.drop_p > 0.f) dz = dropout_keep32(h0, idx0 + (unsigned)p * (unsigned)s.C + (unsigned)e, a.thresh24) ? dz * keep_scale : 0.f;
+        if (a.silu) dz *= silu_grad_fast_(gm[e] * xh + bt[e]);
+        return dz;
+    };
+    float a1[VEC], a2[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) a1[e] = a2[e] = 0.f;
+    const u32x4* myx = reinterpret_cast<const u32x4*>(xs) + tid;
+    static_for_gn<NV>([&](auto ic) {
+        constexpr int i = decltype(ic)::v;
+        gn_wait_vm<2 * (NV - 1 - i)>(0);
+        const int p = prow + i * f.rows_per_iter;
+        if (active && p < s.HW) {
+            float fx[VEC], fd[VEC];
+            Elem<T>::unpack(myx[i * 512], fx); Elem<T>::unpack(vd[i], fd);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const float xh = (fx[e] - mean[e]) * rstd[e];
+                const float dz = dz_of(p, e, xh, fd[e]);
+                a1[e] += dz * xh; a2[e] += dz;
+            }
+        }
+    });
+    const float inv_n = 1.0f / ((float)s.HW * s.cpg);
+    gn_block_channel_sum_w<VEC>(a1, f, active, j, prow, tid, sh_row, sh_ch);
+    for (int c = tid; c < f.seg_ch; c += 512) {
+        if (dgamma) atomicAdd(dgamma + c0 + c, sh_ch[c]);
+        sh_ch[c] *= a.gamma[c0 + c];
+    }
+    __syncthreads();
+    if (tid < f.GPB) {
+        float acc = 0.f;
+        for (int c = tid * s.cpg; c < (tid + 1) * s.cpg; ++c) acc += sh_ch[c];
+        sh_c1[tid] = acc * inv_n;
+    }
+    gn_block_channel_sum_w<VEC>(a2, f, active, j, prow, tid, sh_row, sh_ch);
+    for (int c = tid; c < f.seg_ch; c += 512) {
+        if (dbeta) atomicAdd(dbeta + c0 + c, sh_ch[c]);
+        sh_ch[c] *= a.gamma[c0 + c];
+    }
+    __syncthreads();
+    if (tid < f.GPB) {
+        float acc = 0.f;
+        for (int c = tid * s.cpg; c < (tid + 1) * s.cpg; ++c) acc += sh_ch[c];
+        sh_c2[tid] = acc * inv_n;
+    }
+    __syncthreads();
+    float c1[VEC], c2[VEC], cs[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { const int g = active ? (j * VEC + e) / s.cpg : 0; c1[e] = sh_c1[g]; c2[e] = sh_c2[g]; cs[e] = 0.f; }
+    T* ob = dx + ((long long)b * s.HW) * dx_ld + c0 + j * VEC;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int p = prow + i * f.rows_per_iter;
+        if (active && p < s.HW) {
+            float fx[VEC], fd[VEC], o[VEC];
+            Elem<T>::unpack(myx[i * 512], fx); Elem<T>::unpack(vd[i], fd);
+            if (accumulate) Elem<T>::unpack(ldg16(ob + (long long)p * dx_ld), o);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                const float xh = (fx[e] - mean[e]) * rstd[e];
+                const float dz = dz_of(p, e, xh, fd[e]);
+                const float r = rstd[e] * (dz * gm[e] - xh * c1[e] - c2[e]);
+                o[e] = accumulate ? o[e] + r : r;
+            }
+            const u32x4 packed = Elem<T>::pack(o);
+            if (dx_colsum) {                                   // sums of the values as STORED (what a column sum over dx would read)
+                float q[VEC];
+                Elem<T>::unpack(packed, q);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) cs[e] += q[e];
+            }
+            stg16(ob + (long long)p * dx_ld, packed);
+        }
+    }
+    if (dx_colsum) {
+        gn_block_channel_sum_w<VEC>(cs, f, active, j, prow, tid, sh_row, sh_ch);
+        for (int c = tid; c < f.seg_ch; c += 512) dx_colsum[(long long)b * colsum_ld + c0 + c] = sh_ch[c];     // one owner per (b, c): plain store
+    }
+}
+
+// forward twin: x slice in LDS; mean, then the centred variance (second pass over LDS, exact two-pass statistics), then
+// y = drop(silu(x * a_c + b_c)) streamed out.
+template <typename T, int NV>
+__global__ __launch_bounds__(512, 4)
+void gn_lds_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, GnShape s, GnFused f, GnApply a) {
+    constexpr int VEC = Elem<T>::VEC, ES = (int)sizeof(T);
+    extern __shared__ __attribute__((aligned(16))) char lsm[];
+    char* xs = lsm;
+    float* sh_row = reinterpret_cast<float*>(lsm + NV * 512 * 16);
+    float* sh_ch = sh_row + ((64 % f.seg_vecs) ? f.rows_per_iter * f.seg_ch : 8 * f.seg_ch);
+    float* sh_mean = sh_ch + f.seg_ch;
+    float* sh_rstd = sh_mean + 32;
+    const int b = blockIdx.y, c0 = blockIdx.x * f.seg_ch, tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool active = tid < f.nta;
+    const int j = tid % f.seg_vecs, prow = tid / f.seg_vecs;
+    const __amdgpu_buffer_rsrc_t rx = gn_slice_rsrc(x + ((long long)b * s.HW) * s.x_ld + c0, ((long long)(s.HW - 1) * s.x_ld + f.seg_ch) * ES);
+    float gmv[VEC], btv[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { const int c = c0 + j * VEC + e; gmv[e] = active ? a.gamma[c] : 0.f; btv[e] = active ? a.beta[c] : 0.f; }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int p = prow + i * f.rows_per_iter;
+        const unsigned ox = (active && p < s.HW) ? (unsigned)(((long long)p * s.x_ld + j * VEC) * ES) : 0x7ffffff0u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(xs + (i * 512 + wave * 64) * 16), 16, ox, 0, 0, 0);
+    }
+    const u32x4* myx = reinterpret_cast<const u32x4*>(xs) + tid;
+    const float n = (float)s.HW * (float)s.cpg;
+    float part[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) part[e] = 0.f;
+    static_for_gn<NV>([&](auto ic) {
+        constexpr int i = decltype(ic)::v;
+        gn_wait_vm<NV - 1 - i>(0);
+        const int p = prow + i * f.rows_per_iter;
+        if (active && p < s.HW) {
+            float fv[VEC];
+            Elem<T>::unpack(myx[i * 512], fv);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) part[e] += fv[e];
+        }
+    });
+    gn_block_channel_sum_w<VEC>(part, f, active, j, prow, tid, sh_row, sh_ch);
+    if (tid < f.GPB) {
+        float acc = 0.f;
+        for (int c = tid * s.cpg; c < (tid + 1) * s.cpg; ++c) acc += sh_ch[c];
+        sh_mean[tid] = acc / n;
+    }
+    __syncthreads();
+    float mean[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { mean[e] = sh_mean[active ? (j * VEC + e) / s.cpg : 0]; part[e] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int p = prow + i * f.rows_per_iter;
+        if (active && p < s.HW) {
+            float fv[VEC];
+            Elem<T>::unpack(myx[i * 512], fv);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) { const float d = fv[e] - mean[e]; part[e] += d * d; }
+        }
+    }
+    gn_block_channel_sum_w<VEC>(part, f, active, j, prow, tid, sh_row, sh_ch);
+    if (tid < f.GPB) {
+        float acc = 0.f;
+        for (int c = tid * s.cpg; c < (tid + 1) * s.cpg; ++c) acc += sh_ch[c];
+        const float rstd = 1.0f / sqrtf(acc / n + a.eps);
+        sh_rstd[tid] = rstd;
+        if (a.stats) {
+            const long long gi = (long long)b * s.G + blockIdx.x * f.GPB + tid;
+            a.stats[gi * 2] = sh_mean[tid]; a.stats[gi * 2 + 1] = rstd;
+        }
+    }
+    __syncthreads();
+    if (!active) return;
+    float ca[VEC], cb[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+        ca[e] = sh_rstd[(j * VEC + e) / s.cpg] * gmv[e];
+        cb[e] = btv[e] - mean[e] * ca[e];
+    }
+    const float keep_scale = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
+    const unsigned h0 = dropout_h0(gn_seed(a));
+    const unsigned idx0 = (unsigned)(((unsigned)b * (unsigned)s.HW) * (unsigned)s.C + (unsigned)(c0 + j * VEC));
+    T* yb = y + ((long long)b * s.HW) * s.y_ld + c0 + j * VEC;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int p = prow + i * f.rows_per_iter;
+        if (p >= s.HW) break;
+        float fv[VEC];
+        Elem<T>::unpack(myx[i * 512], fv);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            float z = fv[e] * ca[e] + cb[e];
+            if (a.silu) z = silu_fast_(z);
+            if (a.drop_p > 0.f) z = dropout_keep32(h0, idx0 + (unsigned)p * (unsigned)s.C + (unsigned)e, a.thresh24) ? z * keep_scale : 0.f;
+            fv[e] = z;
+        }
+        stg16(yb + (long long)p * s.y_ld, Elem<T>::pack(fv));
+    }
+}
+
 constexpr int GN_FUSED_SLICE = 64 * 1024;     // LDS bytes of activations per block: two blocks per CU
 
 // picks the group chunk; false when no chunk of this geometry fits (falls back to the two-launch path)
 static const long long gn_fused_max_bytes = getenv("DDPM_GN_FUSED_MAX_KB") ? atoll(getenv("DDPM_GN_FUSED_MAX_KB")) * 1024 : GN_FUSED_SLICE;
 // (128 KiB slices = 512-thread blocks work and make the 32^2 x 128-channel forward 10 % faster in isolation, but the training
 //  step measured 0.25 ms slower with them — A/B in one session, scripts/step_jitter.py — so the default stays at 64 KiB.)
+
+// LDS-staged kernels: largest group chunk whose x slice fits 64 KiB with <= 8 vectors per thread; prefers >= 512 blocks
+// (two per CU) as long as a pixel segment stays >= 128 bytes
+static bool gn_lds_plan(const GnShape& s, int esize, GnFused& f, size_t& lds_bytes) {
+    const int vec = 16 / esize;
+    int best = 0;
+    for (int gpb = 1; gpb <= s.G && gpb <= 32; gpb <<= 1) {
+        if (s.G % gpb) continue;
+        const int seg_ch = gpb * s.cpg;
+        if (seg_ch % vec) continue;
+        if ((long long)s.HW * seg_ch * esize > 64 * 1024 || seg_ch / vec > 512) break;
+        best = gpb;
+    }
+    if (!best) return false;
+    while (best > 1 && (long long)s.B * (s.G / best) < 512 && (best / 2) * s.cpg * esize >= 128 && ((best / 2) * s.cpg) % vec == 0) best >>= 1;
+    f.GPB = best; f.seg_ch = best * s.cpg; f.seg_vecs = f.seg_ch / vec;
+    if (f.seg_ch * esize < 48) return false;
+    f.nt = 512;
+    f.nta = (512 / f.seg_vecs) * f.seg_vecs; f.rows_per_iter = f.nta / f.seg_vecs;
+    f.nv = (s.HW + f.rows_per_iter - 1) / f.rows_per_iter;
+    if (f.nv > 8) return false;
+    // measured (scripts/gn_bench.py, B = 128): the staged kernels win from 4 vectors per thread on (32^2 x 128: backward 51 vs 70 us,
+    // 16^2 x 256: 25 vs 44 us); slices whose vector columns do not divide a wave (384 channels: 3 / 12 vectors per pixel) would
+    // need the 16 KiB reduction scratch and one block per CU — slower than the two streaming launches (286 vs 198 us)
+    if (f.nv < 4 || 64 % f.seg_vecs) return false;
+    const int nvt = f.nv <= 1 ? 1 : f.nv <= 2 ? 2 : f.nv <= 4 ? 4 : 8;
+    const size_t scratch = (64 % f.seg_vecs) ? (size_t)f.rows_per_iter * f.seg_ch : (size_t)8 * f.seg_ch;
+    lds_bytes = (size_t)nvt * 512 * 16 + (scratch + f.seg_ch + 64) * sizeof(float);
+    return lds_bytes <= 160 * 1024 && (long long)s.B * s.HW * s.C < (1ll << 32);
+}
 
 static bool gn_fused_plan(const GnShape& s, int esize, GnFused& f, size_t& lds_bytes) {
     const int vec = 16 / esize;
@@ -626,7 +943,20 @@ extern "C" int ddpm_groupnorm_silu_fwd(const void* x, long long x_ld, void* y, l
     hipStream_t st = (hipStream_t)stream;
     GnFused f; size_t lds = 0;
     static const bool no_fused = getenv("DDPM_GN_NO_FUSED") != nullptr;
-    if (!no_fused && gn_fused_plan(s, es, f, lds)) {      // register-resident single launch (1 read + 1 write of HBM)
+    static const bool no_lds = getenv("DDPM_GN_NO_LDS_FWD") != nullptr;
+    GnFused fl; size_t lds_l = 0;
+    const bool reg_ok = !no_fused && gn_fused_plan(s, es, f, lds);
+    if (!no_lds && !(reg_ok && f.nv <= 2) && gn_lds_plan(s, es, fl, lds_l)) {        // x staged in LDS: single launch, 1 read + 1 write of HBM
+        const dim3 fgrid(G / fl.GPB, B);
+#define GN_LF(T, NV) do { static bool attr = false; if (!attr) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_lds_fwd_kernel<T, NV>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return DDPM_ERR_LAUNCH; attr = true; } \
+        hipLaunchKernelGGL((gn_lds_fwd_kernel<T, NV>), fgrid, dim3(512), lds_l, st, (const T*)x, (T*)y, s, fl, a); } while (0)
+#define GN_LF_NV(T) do { if (fl.nv <= 1) GN_LF(T, 1); else if (fl.nv <= 2) GN_LF(T, 2); else if (fl.nv <= 4) GN_LF(T, 4); else GN_LF(T, 8); } while (0)
+        if (dtype == DDPM_BF16) GN_LF_NV(bf16_t); else GN_LF_NV(float);
+#undef GN_LF_NV
+#undef GN_LF
+        return check_launch();
+    }
+    if (reg_ok) {      // register-resident single launch (1 read + 1 write of HBM)
         const dim3 fgrid(G / f.GPB, B);
 #define GN_FWD(T, NV) do { if (f.nt == 512) hipLaunchKernelGGL((gn_reg_fwd_kernel<T, NV, 512>), fgrid, dim3(512), lds, st, (const T*)x, (T*)y, s, f, a); \
                            else hipLaunchKernelGGL((gn_reg_fwd_kernel<T, NV, 256>), fgrid, dim3(256), lds, st, (const T*)x, (T*)y, s, f, a); } while (0)
@@ -649,7 +979,8 @@ extern "C" int ddpm_groupnorm_silu_fwd(const void* x, long long x_ld, void* y, l
 extern "C" int ddpm_groupnorm_silu_bwd(const void* x, long long x_ld, const void* dy, long long dy_ld, void* dx, long long dx_ld,
                                        const float* gamma, const float* beta, const float* stats, float* dgamma, float* dbeta,
                                        float* workspace, int B, int HW, int C, int G, int silu, float drop_p, unsigned long long seed,
-                                       const unsigned long long* seed_dev, int accumulate, int dtype, void* stream) {
+                                       const unsigned long long* seed_dev, int accumulate, float* dx_colsum, long long colsum_ld,
+                                       int dtype, void* stream) {
     if (!x || !dy || !dx || !gamma || !beta || !stats || !workspace) return DDPM_ERR_NULL;
     if (!aligned16(x) || !aligned16(dy) || !aligned16(dx)) return DDPM_ERR_ALIGN;
     if (dtype != DDPM_BF16 && dtype != DDPM_F32) return DDPM_ERR_DTYPE;
@@ -666,7 +997,26 @@ extern "C" int ddpm_groupnorm_silu_bwd(const void* x, long long x_ld, const void
     // registers the kernel needs > 128 VGPRs from 8 vectors per thread on and then cannot share a CU with the weight-gradient
     // blocks of the side stream; measured end to end (6 alternating pairs) the two streaming launches are 0.13 ms per step
     // faster on the 16^2 / 32^2 tensors, while the 4^2 / 8^2 tensors (<= 2 vectors per thread) keep the single launch.
-    if (!no_fused && gn_fused_plan(s, es, f, lds) && f.nv <= 2) {
+    static const bool no_lds = getenv("DDPM_GN_NO_LDS_BWD") != nullptr;
+    // 1) slices too big for two register vectors per thread: (x, dy) staged in LDS, one launch, one HBM read of each input
+    GnFused fl; size_t lds_l = 0;
+    const bool small = !no_fused && gn_fused_plan(s, es, f, lds) && f.nv <= 2;
+    if (!small && !no_lds && gn_lds_plan(s, es, fl, lds_l)) {
+        const dim3 fgrid(G / fl.GPB, B);
+#define GN_LDS(T, NV) do { static bool attr = false; if (!attr) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_lds_bwd_kernel<T, NV>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return DDPM_ERR_LAUNCH; attr = true; } \
+        hipLaunchKernelGGL((gn_lds_bwd_kernel<T, NV>), fgrid, dim3(512), lds_l, st, (const T*)x, (const T*)dy, (T*)dx, s, fl, dy_ld, dx_ld, stats, dgamma, dbeta, a, accumulate, dx_colsum, colsum_ld); } while (0)
+#define GN_LDS_NV(T) do { if (fl.nv <= 1) GN_LDS(T, 1); else if (fl.nv <= 2) GN_LDS(T, 2); else if (fl.nv <= 4) GN_LDS(T, 4); else GN_LDS(T, 8); } while (0)
+        if (dtype == DDPM_BF16) GN_LDS_NV(bf16_t); else GN_LDS_NV(float);
+#undef GN_LDS_NV
+#undef GN_LDS
+        return check_launch();
+    }
+    // every other path leaves the per-sample column sums of dx to the stand-alone kernel
+    struct ColsumAfter {
+        const void* dx; long long dx_ld; float* out; long long ld; int B, HW, C, dtype; void* stream;
+        int run() const { return out ? ddpm_colsum(dx, dx_ld, out, ld, nullptr, B, HW, C, dtype, stream) : DDPM_OK; }
+    } colsum_after{dx, dx_ld, dx_colsum, colsum_ld, B, HW, C, dtype, stream};
+    if (small) {
         const dim3 fgrid(G / f.GPB, B);
 #define GN_BWD(T, NV) do { if (f.nt == 512) hipLaunchKernelGGL((gn_reg_bwd_kernel<T, NV, 512>), fgrid, dim3(512), lds, st, (const T*)x, (const T*)dy, (T*)dx, s, f, dy_ld, dx_ld, stats, dgamma, dbeta, a, accumulate); \
                            else hipLaunchKernelGGL((gn_reg_bwd_kernel<T, NV, 256>), fgrid, dim3(256), lds, st, (const T*)x, (const T*)dy, (T*)dx, s, f, dy_ld, dx_ld, stats, dgamma, dbeta, a, accumulate); } while (0)
@@ -674,7 +1024,8 @@ extern "C" int ddpm_groupnorm_silu_bwd(const void* x, long long x_ld, const void
         if (dtype == DDPM_BF16) GN_BWD_NV(bf16_t); else GN_BWD_NV(float);
 #undef GN_BWD_NV
 #undef GN_BWD
-        return check_launch();
+        const int rc2 = check_launch();
+        return rc2 ? rc2 : colsum_after.run();
     }
     float* partial = workspace;                                   // [B][S][C][2]
     if (dtype == DDPM_BF16)
@@ -685,7 +1036,8 @@ extern "C" int ddpm_groupnorm_silu_bwd(const void* x, long long x_ld, const void
         hipLaunchKernelGGL(gn_bwd_apply_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx, s, dy_ld, dx_ld, stats, partial, dgamma, dbeta, a, accumulate);
     else
         hipLaunchKernelGGL(gn_bwd_apply_kernel<float>, grid, block, 0, st, (const float*)x, (const float*)dy, (float*)dx, s, dy_ld, dx_ld, stats, partial, dgamma, dbeta, a, accumulate);
-    return check_launch();
+    const int rc3 = check_launch();
+    return rc3 ? rc3 : colsum_after.run();
 }
 
 // GroupNorm statistics only: stats[b][g] = (mean, 1/sqrt(var + eps)) of x — nn.GroupNorm's normalisation constants

@@ -166,9 +166,10 @@ def conv3x3_gn(x, stats, gamma, beta, w_ptr, y_ptr, y_ld, N, silu=True, bias=0, 
         f"conv+gn M={x.B * x.H * x.W} N={N} K={9 * x.C} 3x3")
 
 
-def gn_bwd(x, dy, dx, gamma, beta, stats, dgamma_ptr, dbeta_ptr, ws, silu, drop_p=0.0, seed=0, accumulate=0, seed_dev=0):
+def gn_bwd(x, dy, dx, gamma, beta, stats, dgamma_ptr, dbeta_ptr, ws, silu, drop_p=0.0, seed=0, accumulate=0, seed_dev=0, colsum_ptr=0, colsum_ld=0):
+    """colsum_ptr: zero-initialised [B][colsum_ld] fp32 buffer that receives the per-sample channel sums of dx (0 = not wanted)."""
     _hip.call("ddpm_groupnorm_silu_bwd", x.ptr, x.ld, dy.ptr, dy.ld, dx.ptr, dx.ld, _hip.ptr(gamma), _hip.ptr(beta), _hip.ptr(stats), dgamma_ptr, dbeta_ptr,
-         _hip.ptr(ws), x.B, x.H * x.W, x.C, GN_GROUPS, int(silu), float(drop_p), seed, seed_dev, accumulate, x.dtype, _hip.stream())
+         _hip.ptr(ws), x.B, x.H * x.W, x.C, GN_GROUPS, int(silu), float(drop_p), seed, seed_dev, accumulate, colsum_ptr, colsum_ld, x.dtype, _hip.stream())
 
 
 def colsum(dy, per_sample_ptr, ps_ld, total_ptr):

@@ -1003,10 +1003,11 @@ class _Engine:
             self._bias_grad(ctx, dout, [rb.conv2.bias], Cout, slot=("b2", id(rb)) if rb.has_skip else None)
         # GN2 + SiLU + dropout
         dh1 = self._new(B, x.H, x.W, Cout)
+        # ... which also yields the gradient of the time bias (+ conv1 bias): the per-sample column sums of dh1 land in the
+        # block's columns of the concatenated dtb
         ops.gn_bwd(h1, da2, dh1, rb.norm2.weight, rb.norm2.bias, stats2, self._pptr(ctx, rb.norm2.weight), self._pptr(ctx, rb.norm2.bias),
-                   ws, silu=True, drop_p=drop_p, seed=seed, seed_dev=ctx["seed_dev"])
-        # time bias (+conv1 bias): per-sample column sums into the concatenated dtb
-        ops.colsum(dh1, ctx["dtb"].data_ptr() + 4 * self.tb_off[id(rb)], self.tb_total, 0)
+                   ws, silu=True, drop_p=drop_p, seed=seed, seed_dev=ctx["seed_dev"],
+                   colsum_ptr=ctx["dtb"].data_ptr() + 4 * self.tb_off[id(rb)], colsum_ld=self.tb_total)
         # conv1
         da1 = self._new(B, x.H, x.W, Cin)
         ops.conv2d(dh1, c1.wd.data_ptr(), da1.ptr, da1.ld, Cin, 3, 3, x.H, x.W, pad_t=1, pad_l=1, splitk=self.splitk)
