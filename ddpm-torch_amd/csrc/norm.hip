@@ -288,7 +288,7 @@ template <typename T, int NV, int NT>
 __global__ __launch_bounds__(NT)
 void gn_reg_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx, GnShape s, GnFused f, long long dy_ld,
                        long long dx_ld, const float* __restrict__ stats, float* __restrict__ dgamma, float* __restrict__ dbeta, GnApply a,
-                       int accumulate) {
+                       int accumulate, const T* __restrict__ addp, long long add_ld) {
     constexpr int VEC = Elem<T>::VEC;
     extern __shared__ __attribute__((aligned(16))) float gsh[];
     float* sh_row = gsh;
@@ -376,14 +376,16 @@ void gn_reg_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __r
     for (int i = 0; i < NV; ++i) {
         const int p = prow + i * f.rows_per_iter;
         if (p >= s.HW) break;
-        float fx[VEC], fd[VEC], o[VEC];
+        float fx[VEC], fd[VEC], o[VEC], ad[VEC];
         Elem<T>::unpack(vx[i], fx); Elem<T>::unpack(vd[i], fd);
         if (accumulate) Elem<T>::unpack(ldg16(ob + (long long)p * dx_ld), o);
+        if (addp) Elem<T>::unpack(ldg16(addp + ((long long)b * s.HW + p) * add_ld + c0 + j * VEC), ad);
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
             const float xh = (fx[e] - mean[e]) * rstd[e];
             const float dz = dz_of(p, e, xh, fd[e]);
-            const float r = rstd[e] * (dz * gm[e] - xh * c1[e] - c2[e]);
+            float r = rstd[e] * (dz * gm[e] - xh * c1[e] - c2[e]);
+            if (addp) r += ad[e];
             o[e] = accumulate ? o[e] + r : r;
         }
         stg16(ob + (long long)p * dx_ld, Elem<T>::pack(o));
@@ -440,7 +442,7 @@ template <typename T, int NV>
 __global__ __launch_bounds__(512, 4)
 void gn_lds_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx, GnShape s, GnFused f, long long dy_ld,
                        long long dx_ld, const float* __restrict__ stats, float* __restrict__ dgamma, float* __restrict__ dbeta, GnApply a,
-                       int accumulate, float* __restrict__ dx_colsum, long long colsum_ld) {
+                       int accumulate, float* __restrict__ dx_colsum, long long colsum_ld, const T* __restrict__ addp, long long add_ld) {
     constexpr int VEC = Elem<T>::VEC, ES = (int)sizeof(T);
     extern __shared__ __attribute__((aligned(16))) char lsm[];
     char* xs = lsm;                                               // [NV][512] vectors of x
@@ -533,12 +535,15 @@ void gn_lds_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __r
         if (active && p < s.HW) {
             float fx[VEC], fd[VEC], o[VEC];
             Elem<T>::unpack(myx[i * 512], fx); Elem<T>::unpack(vd[i], fd);
+            float ad[VEC];
             if (accumulate) Elem<T>::unpack(ldg16(ob + (long long)p * dx_ld), o);
+            if (addp) Elem<T>::unpack(ldg16(addp + ((long long)b * s.HW + p) * add_ld + c0 + j * VEC), ad);
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
                 const float xh = (fx[e] - mean[e]) * rstd[e];
                 const float dz = dz_of(p, e, xh, fd[e]);
-                const float r = rstd[e] * (dz * gm[e] - xh * c1[e] - c2[e]);
+                float r = rstd[e] * (dz * gm[e] - xh * c1[e] - c2[e]);
+                if (addp) r += ad[e];
                 o[e] = accumulate ? o[e] + r : r;
             }
             const u32x4 packed = Elem<T>::pack(o);
@@ -779,7 +784,8 @@ __global__ void gn_bwd_reduce_kernel(const T* __restrict__ x, const T* __restric
 template <typename T>
 __global__ void gn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx, GnShape s, long long dy_ld,
                                     long long dx_ld, const float* __restrict__ stats, const float* __restrict__ partial,
-                                    float* __restrict__ dgamma, float* __restrict__ dbeta, GnApply a, int accumulate) {
+                                    float* __restrict__ dgamma, float* __restrict__ dbeta, GnApply a, int accumulate,
+                                    const T* __restrict__ addp, long long add_ld) {
     constexpr int VEC = Elem<T>::VEC;
     __shared__ float sh1[GN_MAXC], sh2[GN_MAXC];
     __shared__ float sh_c1[64], sh_c2[64];
@@ -825,10 +831,11 @@ __global__ void gn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict
     const T* db = dy + ((long long)b * s.HW) * dy_ld + cx * VEC;
     T* ob = dx + ((long long)b * s.HW) * dx_ld + cx * VEC;
     for (int p = p0 + py; p < p1; p += PY) {
-        float f[VEC], d[VEC], o[VEC];
+        float f[VEC], d[VEC], o[VEC], ad[VEC];
         Elem<T>::unpack(ldg16(xb + (long long)p * s.x_ld), f);
         Elem<T>::unpack(ldg16(db + (long long)p * dy_ld), d);
         if (accumulate) Elem<T>::unpack(ldg16(ob + (long long)p * dx_ld), o);
+        if (addp) Elem<T>::unpack(ldg16(addp + ((long long)b * s.HW + p) * add_ld + cx * VEC), ad);
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
             const float xh = (f[j] - mean[j]) * rstd[j];
@@ -838,7 +845,8 @@ __global__ void gn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict
                 dz = dropout_keep(seed, idx, a.thresh24) ? dz * keep_scale : 0.f;
             }
             if (a.silu) dz *= silu_gradf_(gm[j] * xh + bt[j]);
-            const float r = rstd[j] * (dz * gm[j] - xh * c1[j] - c2[j]);
+            float r = rstd[j] * (dz * gm[j] - xh * c1[j] - c2[j]);
+            if (addp) r += ad[j];
             o[j] = accumulate ? o[j] + r : r;
         }
         stg16(ob + (long long)p * dx_ld, Elem<T>::pack(o));
@@ -980,7 +988,7 @@ extern "C" int ddpm_groupnorm_silu_bwd(const void* x, long long x_ld, const void
                                        const float* gamma, const float* beta, const float* stats, float* dgamma, float* dbeta,
                                        float* workspace, int B, int HW, int C, int G, int silu, float drop_p, unsigned long long seed,
                                        const unsigned long long* seed_dev, int accumulate, float* dx_colsum, long long colsum_ld,
-                                       int dtype, void* stream) {
+                                       const void* add, long long add_ld, int dtype, void* stream) {
     if (!x || !dy || !dx || !gamma || !beta || !stats || !workspace) return DDPM_ERR_NULL;
     if (!aligned16(x) || !aligned16(dy) || !aligned16(dx)) return DDPM_ERR_ALIGN;
     if (dtype != DDPM_BF16 && dtype != DDPM_F32) return DDPM_ERR_DTYPE;
@@ -988,7 +996,7 @@ extern "C" int ddpm_groupnorm_silu_bwd(const void* x, long long x_ld, const void
     const int es = dtype == DDPM_BF16 ? 2 : 4;
     int rc = gn_geometry(B, HW, C, G, x_ld, x_ld, es, s, block, grid);
     if (rc) return rc;
-    if (dy_ld % (16 / es) || dx_ld % (16 / es)) return DDPM_ERR_ALIGN;
+    if (dy_ld % (16 / es) || dx_ld % (16 / es) || (add && (add_ld % (16 / es) || !aligned16(add)))) return DDPM_ERR_ALIGN;
     GnApply a = make_apply(gamma, beta, 0.f, silu, drop_p, seed, nullptr, seed_dev);
     hipStream_t st = (hipStream_t)stream;
     GnFused f; size_t lds = 0;
@@ -1004,7 +1012,7 @@ extern "C" int ddpm_groupnorm_silu_bwd(const void* x, long long x_ld, const void
     if (!small && !no_lds && gn_lds_plan(s, es, fl, lds_l)) {
         const dim3 fgrid(G / fl.GPB, B);
 #define GN_LDS(T, NV) do { static bool attr = false; if (!attr) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_lds_bwd_kernel<T, NV>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return DDPM_ERR_LAUNCH; attr = true; } \
-        hipLaunchKernelGGL((gn_lds_bwd_kernel<T, NV>), fgrid, dim3(512), lds_l, st, (const T*)x, (const T*)dy, (T*)dx, s, fl, dy_ld, dx_ld, stats, dgamma, dbeta, a, accumulate, dx_colsum, colsum_ld); } while (0)
+        hipLaunchKernelGGL((gn_lds_bwd_kernel<T, NV>), fgrid, dim3(512), lds_l, st, (const T*)x, (const T*)dy, (T*)dx, s, fl, dy_ld, dx_ld, stats, dgamma, dbeta, a, accumulate, dx_colsum, colsum_ld, (const T*)add, add_ld); } while (0)
 #define GN_LDS_NV(T) do { if (fl.nv <= 1) GN_LDS(T, 1); else if (fl.nv <= 2) GN_LDS(T, 2); else if (fl.nv <= 4) GN_LDS(T, 4); else GN_LDS(T, 8); } while (0)
         if (dtype == DDPM_BF16) GN_LDS_NV(bf16_t); else GN_LDS_NV(float);
 #undef GN_LDS_NV
@@ -1018,8 +1026,8 @@ extern "C" int ddpm_groupnorm_silu_bwd(const void* x, long long x_ld, const void
     } colsum_after{dx, dx_ld, dx_colsum, colsum_ld, B, HW, C, dtype, stream};
     if (small) {
         const dim3 fgrid(G / f.GPB, B);
-#define GN_BWD(T, NV) do { if (f.nt == 512) hipLaunchKernelGGL((gn_reg_bwd_kernel<T, NV, 512>), fgrid, dim3(512), lds, st, (const T*)x, (const T*)dy, (T*)dx, s, f, dy_ld, dx_ld, stats, dgamma, dbeta, a, accumulate); \
-                           else hipLaunchKernelGGL((gn_reg_bwd_kernel<T, NV, 256>), fgrid, dim3(256), lds, st, (const T*)x, (const T*)dy, (T*)dx, s, f, dy_ld, dx_ld, stats, dgamma, dbeta, a, accumulate); } while (0)
+#define GN_BWD(T, NV) do { if (f.nt == 512) hipLaunchKernelGGL((gn_reg_bwd_kernel<T, NV, 512>), fgrid, dim3(512), lds, st, (const T*)x, (const T*)dy, (T*)dx, s, f, dy_ld, dx_ld, stats, dgamma, dbeta, a, accumulate, (const T*)add, add_ld); \
+                           else hipLaunchKernelGGL((gn_reg_bwd_kernel<T, NV, 256>), fgrid, dim3(256), lds, st, (const T*)x, (const T*)dy, (T*)dx, s, f, dy_ld, dx_ld, stats, dgamma, dbeta, a, accumulate, (const T*)add, add_ld); } while (0)
 #define GN_BWD_NV(T) do { if (f.nv <= 1) GN_BWD(T, 1); else if (f.nv <= 2) GN_BWD(T, 2); else if (f.nv <= 4) GN_BWD(T, 4); else if (f.nv <= 8) GN_BWD(T, 8); else GN_BWD(T, 16); } while (0)
         if (dtype == DDPM_BF16) GN_BWD_NV(bf16_t); else GN_BWD_NV(float);
 #undef GN_BWD_NV
@@ -1033,9 +1041,9 @@ extern "C" int ddpm_groupnorm_silu_bwd(const void* x, long long x_ld, const void
     else
         hipLaunchKernelGGL(gn_bwd_reduce_kernel<float>, grid, block, 0, st, (const float*)x, (const float*)dy, s, dy_ld, stats, a, partial);
     if (dtype == DDPM_BF16)
-        hipLaunchKernelGGL(gn_bwd_apply_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx, s, dy_ld, dx_ld, stats, partial, dgamma, dbeta, a, accumulate);
+        hipLaunchKernelGGL(gn_bwd_apply_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx, s, dy_ld, dx_ld, stats, partial, dgamma, dbeta, a, accumulate, (const bf16_t*)add, add_ld);
     else
-        hipLaunchKernelGGL(gn_bwd_apply_kernel<float>, grid, block, 0, st, (const float*)x, (const float*)dy, (float*)dx, s, dy_ld, dx_ld, stats, partial, dgamma, dbeta, a, accumulate);
+        hipLaunchKernelGGL(gn_bwd_apply_kernel<float>, grid, block, 0, st, (const float*)x, (const float*)dy, (float*)dx, s, dy_ld, dx_ld, stats, partial, dgamma, dbeta, a, accumulate, (const float*)add, add_ld);
     const int rc3 = check_launch();
     return rc3 ? rc3 : colsum_after.run();
 }

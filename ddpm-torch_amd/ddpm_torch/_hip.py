@@ -31,7 +31,7 @@ PROTOTYPES = {
     "ddpm_wgrad_unpack": [P, P, P, I, F, P],
     "ddpm_gemm": [P, L, L, I, P, L, L, I, P, L, L, P, P, L, L, I, I, I, I, F, I, I, I, I, P],
     "ddpm_groupnorm_silu_fwd": [P, L, P, L, P, P, P, P, I, I, I, I, F, I, F, U, P, I, P],
-    "ddpm_groupnorm_silu_bwd": [P, L, P, L, P, L, P, P, P, P, P, P, I, I, I, I, I, F, U, P, I, P, L, I, P],
+    "ddpm_groupnorm_silu_bwd": [P, L, P, L, P, L, P, P, P, P, P, P, I, I, I, I, I, F, U, P, I, P, L, P, L, I, P],
     "ddpm_gn_workspace_floats": [I, I, I, I, I],
     "ddpm_last_gemm_variant": [I],
     "ddpm_attention_fwd": [P, L, P, L, I, I, I, F, I, P],

@@ -166,10 +166,12 @@ def conv3x3_gn(x, stats, gamma, beta, w_ptr, y_ptr, y_ld, N, silu=True, bias=0, 
         f"conv+gn M={x.B * x.H * x.W} N={N} K={9 * x.C} 3x3")
 
 
-def gn_bwd(x, dy, dx, gamma, beta, stats, dgamma_ptr, dbeta_ptr, ws, silu, drop_p=0.0, seed=0, accumulate=0, seed_dev=0, colsum_ptr=0, colsum_ld=0):
-    """colsum_ptr: zero-initialised [B][colsum_ld] fp32 buffer that receives the per-sample channel sums of dx (0 = not wanted)."""
+def gn_bwd(x, dy, dx, gamma, beta, stats, dgamma_ptr, dbeta_ptr, ws, silu, drop_p=0.0, seed=0, accumulate=0, seed_dev=0, colsum_ptr=0, colsum_ld=0, add=None):
+    """colsum_ptr: zero-initialised [B][colsum_ld] fp32 buffer that receives the per-sample channel sums of dx (0 = not wanted).
+    add: View of a second gradient contribution summed into dx in the same pass (the identity branch of a residual connection)."""
     _hip.call("ddpm_groupnorm_silu_bwd", x.ptr, x.ld, dy.ptr, dy.ld, dx.ptr, dx.ld, _hip.ptr(gamma), _hip.ptr(beta), _hip.ptr(stats), dgamma_ptr, dbeta_ptr,
-         _hip.ptr(ws), x.B, x.H * x.W, x.C, GN_GROUPS, int(silu), float(drop_p), seed, seed_dev, accumulate, colsum_ptr, colsum_ld, x.dtype, _hip.stream())
+         _hip.ptr(ws), x.B, x.H * x.W, x.C, GN_GROUPS, int(silu), float(drop_p), seed, seed_dev, accumulate, colsum_ptr, colsum_ld,
+         add.ptr if add is not None else 0, add.ld if add is not None else 0, x.dtype, _hip.stream())
 
 
 def colsum(dy, per_sample_ptr, ps_ld, total_ptr):

@@ -1014,14 +1014,13 @@ class _Engine:
         self._wgrad(ctx, rb.conv1.weight, dh1, a1, Cin, Cout, 3, 3, pad_t=1, pad_l=1, splits=self._splits(Cout, 9 * Cin, dh1.rows))
         # GN1 + SiLU, then the skip path, into d(x)
         g, acc = self._grad_target(x)
+        # (identity skip: the block's output gradient joins d(x) inside the same kernel)
         ops.gn_bwd(x, da1, g, rb.norm1.weight, rb.norm1.bias, stats1, self._pptr(ctx, rb.norm1.weight), self._pptr(ctx, rb.norm1.bias),
-                   ws, silu=True, accumulate=acc)
+                   ws, silu=True, accumulate=acc, add=None if rb.has_skip else dout)
         if rb.has_skip:
             cs = self.convs[id(rb.skip)]
             ops.conv2d(dout, cs.wd.data_ptr(), g.ptr, g.ld, Cin, 1, 1, x.H, x.W, accumulate=1, splitk=self.splitk)
             self._wgrad(ctx, rb.skip.weight, dout, x, Cin, Cout, 1, 1, splits=self._splits(Cout, Cin, dout.rows))
-        else:
-            ops.add_rows(dout, g, 1)
         if parts is not None:                                 # x was a concat buffer: hand each producer its slice
             c0 = parts[0].C
             for pv, (a, b) in zip(parts, ((0, c0), (c0, x.C))):
@@ -1061,8 +1060,7 @@ class _Engine:
         # GN (no SiLU) + identity residual
         g, acc = self._grad_target(x)
         ops.gn_bwd(x, dhn, g, ab.norm.weight, ab.norm.bias, stats, self._pptr(ctx, ab.norm.weight), self._pptr(ctx, ab.norm.bias),
-                   ws, silu=False, accumulate=acc)
-        ops.add_rows(dout, g, 1)
+                   ws, silu=False, accumulate=acc, add=dout)
 
     def _temb_bwd(self, ctx, st):
         m, gflat, B, dtb, E = self.m, ctx["gflat"], ctx["B"], ctx["dtb"], self.E

@@ -123,12 +123,14 @@ int ddpm_groupnorm_silu_fwd(const void* x, long long x_ld, void* y, long long y_
                             float drop_p, unsigned long long seed, const unsigned long long* seed_dev, int dtype, void* stream);
 /* backward of the above: dx (+= when accumulate), dgamma/dbeta += (fp32 atomics).  dx_colsum (optional): receives the per-sample
  * channel sums of dx, dx_colsum[b*colsum_ld + c] = sum_pixels dx[b,:,c] — the gradient of the per-sample time bias that was added
- * in front of this GroupNorm (ddpm_torch/models/unet.py:86); the buffer must be zero on entry (paths without the fused sum add into it). */
+ * in front of this GroupNorm (ddpm_torch/models/unet.py:86); the buffer must be zero on entry (paths without the fused sum add into it).
+ * add (optional, NHWC with pitch add_ld): a second gradient contribution added to dx in the same pass — the identity branch of the
+ * residual connections (unet.py:60,89): dx = gn_backward(dy) + add  (no separate fan-in add launch). */
 int ddpm_groupnorm_silu_bwd(const void* x, long long x_ld, const void* dy, long long dy_ld, void* dx, long long dx_ld,
                             const float* gamma, const float* beta, const float* stats, float* dgamma, float* dbeta,
                             float* workspace, int B, int HW, int C, int G, int silu, float drop_p, unsigned long long seed,
                             const unsigned long long* seed_dev, int accumulate, float* dx_colsum, long long colsum_ld,
-                            int dtype, void* stream);
+                            const void* add, long long add_ld, int dtype, void* stream);
 long long ddpm_gn_workspace_floats(int B, int HW, int C, int G, int dtype);
 
 /* get_timestep_embedding (ddpm_torch/functions.py:10-26): out[b] = cat(sin(t_b f), cos(t_b f)) (zero pad if dim odd);

@@ -228,7 +228,7 @@ class Emulator:
             s[..., 0] = mean.float().numpy(); s[..., 1] = (1.0 / torch.sqrt(var + eps)).float().numpy()
 
     def ddpm_groupnorm_silu_bwd(self, x, x_ld, dy, dy_ld, dx, dx_ld, gamma, beta, stats, dgamma, dbeta, ws, B, HW, C, G, silu, drop_p,
-                                seed, seed_dev, acc, dx_colsum, colsum_ld, dt, st):
+                                seed, seed_dev, acc, dx_colsum, colsum_ld, add, add_ld, dt, st):
         if seed_dev and drop_p > 0:
             seed = (seed + int(_np(seed_dev, 1, ctypes.c_uint64, np.uint64)[0])) & ((1 << 64) - 1)
         xin = torch.from_numpy(Mat(x, B * HW, C, x_ld, dt).get()).requires_grad_(True)
@@ -238,7 +238,10 @@ class Emulator:
         with torch.enable_grad():                  # we are called from inside an autograd.Function.backward
             self._gn(xin, g, b, G, 1e-6, silu, drop_p, seed, B, HW, C).backward(gy)
         dst = Mat(dx, B * HW, C, dx_ld, dt)
-        dst.set(dst.get() + xin.grad.numpy() if acc else xin.grad.numpy())
+        val = xin.grad.numpy()
+        if add:
+            val = val + Mat(add, B * HW, C, add_ld, dt).get()
+        dst.set(dst.get() + val if acc else val)
         if dx_colsum:
             cs = Mat(dx_colsum, B, C, colsum_ld, F32)
             cs.set(cs.get() + dst.get().reshape(B, HW, C).sum(1))

@@ -267,7 +267,8 @@ def test_groupnorm_fwd_bwd(dt, B, HW, C, silu, drop):
         dx = r(B * HW, ld, seed=7, dt=dt)
         both("ddpm_groupnorm_silu_bwd", A(x), ld, A(dy), ld, A(dx, out=True, name="dx"), ld, A(gamma), A(beta), A(stats),
              A(dgamma.clone(), out=True, name="dgamma"), A(dbeta.clone(), out=True, name="dbeta"), A(ws), B, HW, C, 32, silu, drop, seed, None, acc,
-             A(torch.zeros(B, C + 4), out=True, name="dx_colsum") if acc == 0 else None, C + 4, dt,
+             A(torch.zeros(B, C + 4), out=True, name="dx_colsum") if acc == 0 else None, C + 4,
+             A(r(B * HW, ld, seed=8, dt=dt)) if acc else None, ld, dt,
              tol=2e-4 if dt == 0 else 2e-2, atol=2e-3 if dt else 1e-4)
     if drop:
         # the per-step part of the seed read from a device word (captured training step): seed + *word
@@ -277,7 +278,7 @@ def test_groupnorm_fwd_bwd(dt, B, HW, C, silu, drop):
              B, HW, C, 32, 1e-6, silu, drop, seed, A(word), dt, tol=TOL[dt] * (5 if dt == 0 else 1.5))
         dx = r(B * HW, ld, seed=7, dt=dt)
         both("ddpm_groupnorm_silu_bwd", A(x), ld, A(dy), ld, A(dx, out=True, name="dx_devseed"), ld, A(gamma), A(beta), A(stats),
-             None, None, A(ws), B, HW, C, 32, silu, drop, seed, A(word), 0, None, 0, dt, tol=2e-4 if dt == 0 else 2e-2)
+             None, None, A(ws), B, HW, C, 32, silu, drop, seed, A(word), 0, None, 0, None, 0, dt, tol=2e-4 if dt == 0 else 2e-2)
 
 
 @pytest.mark.parametrize("dt", [0, 1])
