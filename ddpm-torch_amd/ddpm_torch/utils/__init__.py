@@ -4,7 +4,7 @@ import random
 import numpy as np
 import torch
 
-__all__ = ["seed_all", "get_param", "ConfigDict"]
+__all__ = ["seed_all", "get_param", "ConfigDict", "save_image_grid"]
 
 
 def seed_all(seed):
@@ -30,3 +30,24 @@ class ConfigDict(dict):
 
     def __getattr__(self, name):
         return self.get(name, None)
+
+
+def save_image_grid(x, path, nrow=8, pad=2):
+    """Write a batch of images in [-1, 1] ([N, C, H, W]) as one grid picture — the role torchvision's ``save_image(normalize=True,
+    value_range=(-1, 1))`` plays in the reference (utils/train.py:60).  Needs Pillow; without it the tensor is saved next to the
+    requested name as ``.pt``."""
+    x = x.detach().float().cpu().clamp(-1, 1)
+    n, c, h, w = x.shape
+    nrow = max(1, min(nrow, n))
+    rows = (n + nrow - 1) // nrow
+    grid = torch.zeros(c, rows * (h + pad) + pad, nrow * (w + pad) + pad)
+    for i in range(n):
+        r, q = divmod(i, nrow)
+        grid[:, pad + r * (h + pad): pad + r * (h + pad) + h, pad + q * (w + pad): pad + q * (w + pad) + w] = x[i]
+    arr = (grid * 127.5 + 127.5).round().clamp(0, 255).to(torch.uint8).permute(1, 2, 0).numpy()
+    try:
+        from PIL import Image
+    except ImportError:
+        torch.save(x, path.rsplit(".", 1)[0] + ".pt")
+        return
+    Image.fromarray(arr.squeeze(-1) if c == 1 else arr).save(path)

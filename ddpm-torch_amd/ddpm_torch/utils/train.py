@@ -20,6 +20,7 @@ global-norm clip, Adam step, ``zero_grad(set_to_none)``, LR-schedule step, EMA u
 
 Checkpoints keep the reference's on-disk layout ({model, optimizer, ema, scheduler, epoch, ...}, utils/train.py:249-276).
 """
+import math
 import os
 import re
 import warnings
@@ -542,8 +543,8 @@ class Trainer:
         self.model.eval()
         x = self.sample_fn(sample_size=self.num_samples, sample_seed=self.sample_seed).cpu()
         if self.is_leader:
-            # tensors in [-1, 1]; encoding them as an image grid is the data path's job (torchvision is not on the hot path)
-            torch.save(x, os.path.join(image_dir, f"{e + 1}.pt"))
+            from . import save_image_grid
+            save_image_grid(x, os.path.join(image_dir, f"{e + 1}.jpg"), nrow=max(1, math.floor(math.sqrt(self.num_samples))))
 
     def train(self, evaluator=None, chkpt_path=None, image_dir=None):
         if self.num_samples:
