@@ -3,12 +3,17 @@
     python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
 
 One "step" = one full reference training step (ddpm_torch/utils/train.py:148-170: forward, backward, global-norm clip,
-Adam, LR schedule, EMA, loss reduce) on B=128 synthetic 32x32 images PER GPU (weak scaling), bf16 compute with fp32
-master weights / gradients / optimizer state, dropout 0.1 active — configs/cifar10.json of the reference.
-Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line; extra objects:
-  roofline     — the dominant kernel (MFMA implicit-GEMM, operands K-contiguous: all conv forward/dgrad + linears):
-                 algorithmic FLOPs of its launches in one training step / their summed HIP-event durations, vs 2.5 PFLOP/s
-  sampling     — eval-mode ancestral sampling throughput (B=128) from timed p_sample steps, scaled to 1000 steps
+Adam, LR schedule, EMA, loss reduce incl. loss.item()) on B=128 synthetic 32x32 images PER GPU (weak scaling), bf16
+compute with fp32 master weights / gradients / optimizer state, dropout 0.1 active — configs/cifar10.json of the
+reference (BASELINE config 2; config 3 at N > 1).  Inputs are resident in HBM before the timed region.
+Rank 0 prints ONE JSON line.  Beyond the driver's contract it carries:
+  roofline     — the MFMA kernel with the most GPU time in the step: algorithmic FLOPs of its launches / their summed
+                 HIP-event durations (events recorded on the launch stream around every MFMA launch of one extra step),
+                 vs the dense bf16 peak; `isolated` = the same with the two-stream overlap switched off; `traffic` = HBM
+                 bytes per launch of that kernel from separate rocprofv3 --pmc passes (profiles/, see scripts/gpu_pmc_bench.sh)
+  sampling     — eval-mode ancestral sampling (B=128, 1000 steps, hipGraph replay) + a batch sweep
+  other_configs— N = 1 only: the fp32 (parity) mode of the same step / sampler, BASELINE config 4 (CelebA 64x64 UNet,
+                 DDIM-50, B=128) and the per-GPU work of config 5 (CelebA-HQ 256x256 UNet, B=2 training step)
   cpu_baseline — the oracle (CPU restatement, kind "port") timed on this box's host cores on a bounded sample
 """
 import argparse
@@ -25,12 +30,35 @@ import torch.distributed as dist  # noqa: E402
 
 CIFAR = dict(in_channels=3, hid_channels=128, out_channels=3, ch_multipliers=[1, 2, 2, 2], num_res_blocks=2,
              apply_attn=[False, True, False, False], drop_rate=0.1)
-FWD_GFLOP_PER_SAMPLE = 12.443713536      # SURVEY.md §8d (2*MAC over convs, linears, attention matmuls)
-PEAK_BF16_TFLOPS = 2500.0                # dense MFMA peak, MI355X_MICROARCH.md
+CELEBA = dict(CIFAR, apply_attn=[False, False, True, False], drop_rate=0.0)
+CELEBAHQ = dict(in_channels=3, hid_channels=128, out_channels=3, ch_multipliers=[1, 1, 2, 2, 4, 4], num_res_blocks=2,
+                apply_attn=[False, False, False, False, True, False], drop_rate=0.0)
+# forward GFLOP per sample (2*MAC over convs, linears, attention matmuls); a training step counts 3x
+FWD_GFLOP = {"cifar": 12.443713536, "celeba": 46.741, "celebahq": 497.028}
+PEAK = {"bf16": 2500.0, "fp32": 157.3}                    # dense MFMA TFLOP/s, MI355X_MICROARCH.md
 B_PER_GPU = 128
+VARIANT = {1: "gemm_kernel<4 waves,128x128>", 2: "gemm_kernel<8 waves,128x128>", 3: "gemm_kernel<deep ring,128x128>",
+           4: "gemm64_kernel<64x64>", 5: "conv3x3_halo_kernel<256px x 128>", 6: "wgrad3x3_kernel<64x32 x 9 taps>"}
 
 
-def cpu_baseline(seconds_budget=25.0):
+def host_cpu():
+    model, phys = "unknown", set()
+    try:
+        pid = cid = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name") and model == "unknown":
+                model = line.split(":", 1)[1].strip()
+            elif line.startswith("physical id"):
+                pid = line.split(":", 1)[1].strip()
+            elif line.startswith("core id"):
+                cid = line.split(":", 1)[1].strip()
+                phys.add((pid, cid))
+    except OSError:
+        pass
+    return model, len(phys) or (os.cpu_count() or 1)
+
+
+def cpu_baseline(seconds_budget=20.0):
     """Oracle training step (fp32, torch CPU ops) on a bounded sample: B=16, warm-up 1, then steps until ~budget."""
     from oracle import diffusion_ref as D, train_ref, unet_ref as U
     torch.manual_seed(1234)
@@ -48,18 +76,49 @@ def cpu_baseline(seconds_budget=25.0):
         st.step(T, x, t, noise)
         n += 1
     dt = time.perf_counter() - t0
+    model, phys = host_cpu()
     return {"value": round(B * n / dt, 3), "unit": "imgs/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle (CPU restatement of the reference) training step, CIFAR UNet fp32, B={B}, {n} steps after 1 warm-up"}
+            "cpu_model": model, "physical_cores": phys, "logical_cpus": os.cpu_count(),
+            "sample": f"oracle (CPU restatement of the reference) training step, CIFAR UNet fp32, B={B}, {n} steps after 1 warm-up, "
+                      f"{torch.get_num_threads()} torch threads"}
+
+
+def make_trainer(ddpm_torch, cfg, dev, dtype, shape, var_type, distributed=False, rank=0, native=True, local=0, lr=2e-4):
+    model = ddpm_torch.UNet(**cfg).to(dev).set_compute_dtype(dtype)
+    net = model
+    if distributed:
+        if native:
+            model.set_process_group()
+        else:
+            net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local])
+    dif = ddpm_torch.GaussianDiffusion(ddpm_torch.get_beta_schedule("linear", 1e-4, 0.02, 1000), "eps", var_type, "mse")
+    opt = torch.optim.Adam(net.parameters(), lr=lr, betas=(0.9, 0.999))
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lr_lambda=lambda s: min((s + 1) / 5000, 1.0))
+    tr = ddpm_torch.Trainer(net, opt, dif, epochs=1, trainloader=None, sampler=object() if distributed else None, scheduler=sched,
+                            use_ema=True, grad_norm=1.0, shape=shape, device=dev, distributed=distributed, rank=rank)
+    return model, net, dif, tr
+
+
+def timed_steps(tr, x0, steps, warmup, sync):
+    for i in range(warmup):
+        tr.step(x0, global_steps=i + 1)
+    sync()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        tr.step(x0, global_steps=warmup + i + 1)
+    sync()
+    return time.perf_counter() - t0
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--sample-steps", type=int, default=1000, help="length of the timed p_sample chain (1000 = the real thing)")
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--sample-steps", type=int, default=1000, help="length of the timed p_sample chain (1000 = the real thing; 0 = skip sampling and the other configs)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the fp32 / CelebA / CelebA-HQ lines")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -72,24 +131,17 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", init_method="env://", world_size=world, rank=rank)     # "nccl" is RCCL on ROCm
 
+    import ddim
     import ddpm_torch
+    import ddpm_torch.models.unet as unet_mod
+    import ddpm_torch.utils.train as train_mod
     from ddpm_torch import _ops
     ddpm_torch.seed_all(1234)
-    model = ddpm_torch.UNet(**CIFAR).to(dev).set_compute_dtype(args.dtype)
     # Data parallelism: the engine's own reducer (parameters broadcast from rank 0; gradient staging buffer all-reduced over
     # RCCL in chunks from inside the hand-written backward, overlapped with the rest of it).  BENCH_DDP=torch falls back to
     # the reference's DistributedDataParallel wrapper (train.py:110), which also works but only starts reducing after backward.
-    net = model
-    if distributed:
-        if os.environ.get("BENCH_DDP", "native") == "torch":
-            net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local])
-        else:
-            model.set_process_group()
-    dif = ddpm_torch.GaussianDiffusion(ddpm_torch.get_beta_schedule("linear", 1e-4, 0.02, 1000), "eps", "fixed-large", "mse")
-    opt = torch.optim.Adam(net.parameters(), lr=2e-4, betas=(0.9, 0.999))
-    sched = torch.optim.lr_scheduler.LambdaLR(opt, lr_lambda=lambda s: min((s + 1) / 5000, 1.0))
-    tr = ddpm_torch.Trainer(net, opt, dif, epochs=1, trainloader=None, sampler=object() if distributed else None, scheduler=sched,
-                            use_ema=True, grad_norm=1.0, shape=(3, 32, 32), device=dev, distributed=distributed, rank=rank)
+    native = os.environ.get("BENCH_DDP", "native") != "torch"
+    model, net, dif, tr = make_trainer(ddpm_torch, CIFAR, dev, args.dtype, (3, 32, 32), "fixed-large", distributed, rank, native, local)
     g = torch.Generator().manual_seed(1234 + rank)
     x0 = (torch.rand(B_PER_GPU, 3, 32, 32, generator=g) * 2 - 1).to(dev)            # resident before timing
 
@@ -100,14 +152,7 @@ def main():
             torch.cuda.synchronize()
 
     net.train()
-    for i in range(args.warmup):
-        tr.step(x0, global_steps=i + 1)
-    sync()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        tr.step(x0, global_steps=args.warmup + i + 1)
-    sync()
-    elapsed = time.perf_counter() - t0
+    elapsed = timed_steps(tr, x0, args.steps, args.warmup, sync)
     if distributed:
         te = torch.tensor([elapsed], device=dev)
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
@@ -115,23 +160,19 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     imgs_per_s = B_PER_GPU * world * args.steps / elapsed
     loss = tr.current_stats["loss"]
+    step_mode = "direct step, " + ("hipGraph replay" if any(d.graph is not None for d in tr._direct.values()) else "eager launches") \
+        if tr._direct else "autograd step"
 
-    out = None
     # ---- roofline of the dominant kernel: per-launch HIP events (recorded on the stream each kernel is launched on) over
     # one more training step.  The product runs the weight-gradient kernels on a side stream NEXT to the critical path, so
     # a launch's duration includes the slowdown from sharing the chip; `isolated` repeats the measurement with that
     # overlap switched off (every kernel alone on the GPU), which is what says how good each kernel is by itself.
-    import ddpm_torch.models.unet as unet_mod
-    VARIANT = {1: "gemm_kernel<4 waves,128x128>", 2: "gemm_kernel<8 waves,128x128>", 3: "gemm_kernel<deep ring,128x128>",
-               4: "gemm64_kernel<64x64>", 5: "conv3x3_halo_kernel<256px x 128>"}
-    peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3
+    peak = PEAK[args.dtype]
 
-    import ddpm_torch.utils.train as train_mod
-
-    def profile_step(step_no):
+    def profile_step(trainer, x, step_no):
         graph_was, train_mod._TRAIN_GRAPH = train_mod._TRAIN_GRAPH, False       # per-launch events need the eager form of the step
         _ops.PROFILE = []
-        tr.step(x0, global_steps=step_no)
+        trainer.step(x, global_steps=step_no)
         torch.cuda.synchronize()
         prof, _ops.PROFILE = _ops.PROFILE, None
         train_mod._TRAIN_GRAPH = graph_was
@@ -145,77 +186,132 @@ def main():
             e2[0] += 1; e2[1] += flops; e2[2] += dt_s
         return agg, shapes
 
-    def table(agg):
+    def table(agg, pk):
         return {k: {"launches": v[0], "gflop": round(v[1] / 1e9, 1), "ms": round(v[2] * 1e3, 3), "tflops": round(v[1] / v[2] / 1e12, 1),
-                    "avg_launch_us": round(v[2] / v[0] * 1e6, 2), "frac": round(v[1] / v[2] / 1e12 / peak, 4)}
+                    "avg_launch_us": round(v[2] / v[0] * 1e6, 2), "frac": round(v[1] / v[2] / 1e12 / pk, 4)}
                 for k, v in sorted(agg.items(), key=lambda kv: -kv[1][2])}
 
-    agg, shapes = profile_step(args.warmup + args.steps + 1)
+    def total(agg, pk):
+        f, t = sum(v[1] for v in agg.values()), sum(v[2] for v in agg.values())
+        return {"tflops": round(f / t / 1e12, 1), "ms": round(t * 1e3, 3), "frac": round(f / t / 1e12 / pk, 4)}
+
+    agg, shapes = profile_step(tr, x0, args.warmup + args.steps + 1)
     side_was = unet_mod._SIDE_STREAM
     unet_mod._SIDE_STREAM = False
-    agg_iso, shapes_iso = profile_step(args.warmup + args.steps + 2)
+    agg_iso, shapes_iso = profile_step(tr, x0, args.warmup + args.steps + 2)
     unet_mod._SIDE_STREAM = side_was
     # (every rank ran the two extra steps above: with N > 1 they contain the gradient all-reduce and the loss reduce)
+    out = None
     if rank == 0:
         if os.environ.get("BENCH_SHAPES"):
             with open(os.environ["BENCH_SHAPES"], "w") as f:
                 for k, v in sorted(shapes_iso.items(), key=lambda kv: -kv[1][2]):
                     f.write(f"{v[2] * 1e3:8.3f} ms  n={v[0]:3d}  {v[1] / v[2] / 1e12:7.1f} TF  {k}\n")
-        # dominant kernel = the one with the most GPU time in the step
-        dom_name, dom = max(agg.items(), key=lambda kv: kv[1][2])
+        dom_name, dom = max(agg.items(), key=lambda kv: kv[1][2])          # dominant kernel = the one with the most GPU time in the step
         achieved = dom[1] / dom[2] / 1e12
-        tot_f, tot_t = sum(v[1] for v in agg.values()), sum(v[2] for v in agg.values())
-        iso_f, iso_t = sum(v[1] for v in agg_iso.values()), sum(v[2] for v in agg_iso.values())
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")
+        if os.path.exists(tpath):
+            for rec in json.load(open(tpath)).get("kernels", []):
+                if rec["match"] in dom_name:
+                    traffic = {"hbm_bytes_per_launch": rec["fetch_bytes_per_launch"] + rec["write_bytes_per_launch"],
+                               "fetch_bytes_per_launch": rec["fetch_bytes_per_launch"], "write_bytes_per_launch": rec["write_bytes_per_launch"],
+                               "source": rec.get("source", "profiles/r02_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; FETCH_SIZE x2 per the gfx950 guide)")}
         roofline = {"bound": "mfma", "kernel": dom_name, "achieved": round(achieved, 1), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(achieved / peak, 4), "traffic": None,
+                    "frac": round(achieved / peak, 4), "traffic": traffic,
                     "launches_per_step": dom[0], "avg_launch_us": round(dom[2] / dom[0] * 1e6, 2),
                     "note": "durations as they occur in the product step (two HIP streams share the GPU); `isolated` = same step, one stream",
-                    "all_mfma_kernels": {"tflops": round(tot_f / tot_t / 1e12, 1), "ms": round(tot_t * 1e3, 3), "frac": round(tot_f / tot_t / 1e12 / peak, 4)},
-                    "per_kernel": table(agg),
-                    "isolated": {"all_mfma_kernels": {"tflops": round(iso_f / iso_t / 1e12, 1), "ms": round(iso_t * 1e3, 3), "frac": round(iso_f / iso_t / 1e12 / peak, 4)},
-                                 "per_kernel": table(agg_iso)}}
-        # ---- sampling: the reference's p_sample (EMA weights are what generate.py samples with; same cost), B=128,
-        # eval mode, fixed-large, seed 131071.  --sample-steps 1000 (default) runs the real 1000-step chain end to end;
-        # a smaller S times an S-step chain (identical per-step work) and scales to 1000 steps.
-        net.eval()
-        S = args.sample_steps
-        if S <= 0:
-            raise SystemExit(json.dumps({"train_only_ms_per_step": ms_per_step, "roofline": roofline}))
-        sdif = dif if S == 1000 else ddpm_torch.GaussianDiffusion(ddpm_torch.get_beta_schedule("linear", 1e-4, 0.02, S), "eps", "fixed-large", "mse")
-        sdif.p_sample(model, shape=(8, 3, 32, 32), device=dev, seed=1)          # warm-up (small batch, same kernels)
-        torch.cuda.synchronize()
-        s0 = time.perf_counter()
-        xs = sdif.p_sample(model, shape=(B_PER_GPU, 3, 32, 32), device=dev, seed=131071)
-        torch.cuda.synchronize()
-        s_el = time.perf_counter() - s0
-        assert xs.shape == (B_PER_GPU, 3, 32, 32) and bool(torch.isfinite(xs).all())
-        samp = {"batch": B_PER_GPU, "steps_timed": S, "seconds": round(s_el, 3), "ms_per_step": round(s_el / S * 1e3, 3),
-                "samples_per_s_1000_steps": round(B_PER_GPU / (s_el / S * 1000), 4),
-                "model_tflops": round(B_PER_GPU * FWD_GFLOP_PER_SAMPLE / (s_el / S) / 1e3, 1),
-                "mode": "hipGraph replay of the captured step" if os.environ.get("DDPM_TORCH_AMD_GRAPH", "1") != "0" else "eager"}
-        # batch sweep (SURVEY.md §8d "M2: B=128 and a sweep"): 50-step chains (identical per-step work), scaled to 1000 steps
-        sweep = {}
-        if S == 1000 and not os.environ.get("BENCH_NO_SWEEP"):
-            swdif = ddpm_torch.GaussianDiffusion(ddpm_torch.get_beta_schedule("linear", 1e-4, 0.02, 50), "eps", "fixed-large", "mse")
-            for sb in (32, 256, 512):
-                swdif.p_sample(model, shape=(sb, 3, 32, 32), device=dev, seed=3)      # capture / warm-up for this batch size
-                torch.cuda.synchronize()
-                w0 = time.perf_counter()
-                swdif.p_sample(model, shape=(sb, 3, 32, 32), device=dev, seed=4)
-                torch.cuda.synchronize()
-                w_el = (time.perf_counter() - w0) / 50
-                sweep[str(sb)] = {"ms_per_step": round(w_el * 1e3, 3), "samples_per_s_1000_steps": round(sb / (w_el * 1000), 3)}
-            samp["batch_sweep"] = sweep
+                    "all_mfma_kernels": total(agg, peak), "per_kernel": table(agg, peak),
+                    "isolated": {"all_mfma_kernels": total(agg_iso, peak), "per_kernel": table(agg_iso, peak)}}
         out = {"metric": "training imgs/s/GPU + 1000-step DDPM samples/s, CIFAR-10 UNet @1/2/4/8 MI355X",
                "value": round(imgs_per_s, 2), "unit": "imgs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": args.dtype, "data": "synthetic",
                "config": {"workload": "configs/cifar10.json UNet (35.7M params), full Trainer.step, B=128 per GPU, 32x32, T=1000, dropout 0.1, Adam+clip+EMA",
-                          "global_batch": B_PER_GPU * world, "parallelism": f"dp{world}" + ("" if world == 1 else (" (torch DDP)" if os.environ.get("BENCH_DDP") == "torch" else " (native chunked RCCL all-reduce inside backward)")), "imgs_per_s_per_gpu": round(imgs_per_s / world, 2),
-                          "train_model_tflops_per_gpu": round(imgs_per_s / world * 3 * FWD_GFLOP_PER_SAMPLE / 1e3, 1), "final_loss": round(loss, 4)},
-               "roofline": roofline, "sampling": samp}
-        if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+                          "global_batch": B_PER_GPU * world,
+                          "parallelism": f"dp{world}" + ("" if world == 1 else (" (native chunked RCCL all-reduce inside backward)" if native else " (torch DDP)")),
+                          "step_execution": step_mode, "imgs_per_s_per_gpu": round(imgs_per_s / world, 2),
+                          "train_model_tflops_per_gpu": round(imgs_per_s / world * 3 * FWD_GFLOP["cifar"] / 1e3, 1),
+                          "train_model_frac_of_peak": round(imgs_per_s / world * 3 * FWD_GFLOP["cifar"] / 1e3 / peak, 4), "final_loss": round(loss, 4)},
+               "roofline": roofline}
+
+    # ---- sampling + the other BASELINE configurations (rank 0 only: independent work, no collectives)
+    S = args.sample_steps
+    if rank == 0 and S > 0:
+        net.eval()
+        # the reference's p_sample (EMA weights are what generate.py samples with; same cost), B=128, eval mode, fixed-large,
+        # seed 131071.  --sample-steps 1000 (default) runs the real 1000-step chain end to end; a smaller S times an S-step
+        # chain (identical per-step work) and scales to 1000 steps.
+        def chain(process, mdl, shape, seed, steps):
+            process.prepare_sampler(mdl, shape, dev)          # capture of the step graph for this shape (a serving process does it once)
+            torch.cuda.synchronize()
+            s0 = time.perf_counter()
+            xs = process.p_sample(mdl, shape=shape, device=dev, seed=seed)
+            torch.cuda.synchronize()
+            el = time.perf_counter() - s0
+            assert xs.shape == shape and bool(torch.isfinite(xs).all())
+            return el
+
+        sdif = dif if S == 1000 else ddpm_torch.GaussianDiffusion(ddpm_torch.get_beta_schedule("linear", 1e-4, 0.02, S), "eps", "fixed-large", "mse")
+        s_el = chain(sdif, model, (B_PER_GPU, 3, 32, 32), 131071, S)
+        samp = {"batch": B_PER_GPU, "steps_timed": S, "seconds": round(s_el, 3), "ms_per_step": round(s_el / S * 1e3, 3),
+                "samples_per_s_1000_steps": round(B_PER_GPU / (s_el / S * 1000), 4),
+                "model_tflops": round(B_PER_GPU * FWD_GFLOP["cifar"] / (s_el / S) / 1e3, 1),
+                "frac_of_peak": round(B_PER_GPU * FWD_GFLOP["cifar"] / (s_el / S) / 1e3 / peak, 4),
+                "mode": "hipGraph replay of the captured step" if os.environ.get("DDPM_TORCH_AMD_GRAPH", "1") != "0" else "eager"}
+        if S == 1000 and not os.environ.get("BENCH_NO_SWEEP"):
+            # batch sweep (SURVEY.md §8d "M2: B=128 and a sweep"): 50-step chains (identical per-step work), scaled to 1000 steps
+            swdif = ddpm_torch.GaussianDiffusion(ddpm_torch.get_beta_schedule("linear", 1e-4, 0.02, 50), "eps", "fixed-large", "mse")
+            sweep = {}
+            for sb in (32, 256, 512):
+                w_el = chain(swdif, model, (sb, 3, 32, 32), 4, 50) / 50
+                sweep[str(sb)] = {"ms_per_step": round(w_el * 1e3, 3), "samples_per_s_1000_steps": round(sb / (w_el * 1000), 3)}
+            samp["batch_sweep"] = sweep
+        out["sampling"] = samp
+
+        if world == 1 and not args.no_extras:
+            extras = {}
+            # (1) the exact-fp32 MFMA mode (the mode that meets the 1e-3 parity bar) on the same step and sampler
+            if args.dtype == "bf16":
+                m32, n32, d32, t32 = make_trainer(ddpm_torch, CIFAR, dev, "fp32", (3, 32, 32), "fixed-large")
+                n32.train()
+                el = timed_steps(t32, x0, 6, 2, torch.cuda.synchronize)
+                f32_train = B_PER_GPU * 6 / el
+                n32.eval()
+                d50 = ddpm_torch.GaussianDiffusion(ddpm_torch.get_beta_schedule("linear", 1e-4, 0.02, 50), "eps", "fixed-large", "mse")
+                s32 = chain(d50, m32, (B_PER_GPU, 3, 32, 32), 131071, 50) / 50
+                extras["cifar10_fp32_mode"] = {
+                    "train_imgs_per_s": round(f32_train, 1), "train_ms_per_step": round(el / 6 * 1e3, 2),
+                    "train_frac_of_fp32_peak": round(f32_train * 3 * FWD_GFLOP["cifar"] / 1e3 / PEAK["fp32"], 4),
+                    "sampling_ms_per_step": round(s32 * 1e3, 3), "samples_per_s_1000_steps": round(B_PER_GPU / (s32 * 1000), 3),
+                    "sampling_frac_of_fp32_peak": round(B_PER_GPU * FWD_GFLOP["cifar"] / s32 / 1e3 / PEAK["fp32"], 4),
+                    "note": "exact-fp32 MFMA (v_mfma_f32_32x32x2_f32), peak 157.3 TFLOP/s; forward error vs the fp32 oracle 4e-6 (bf16 mode: 1.7e-2)"}
+                del m32, n32, t32
+            # (2) BASELINE config 4: CelebA 64x64 UNet, DDIM 50 steps (linear sub-sequence, eta 0), B=128, seed 131071
+            mc = ddpm_torch.UNet(**CELEBA).to(dev).set_compute_dtype(args.dtype).eval()
+            dd = ddim.DDIM(ddpm_torch.get_beta_schedule("linear", 1e-4, 0.02, 1000), "eps", "fixed-small", "mse", eta=0.0,
+                           subsequence=ddim.get_selection_schedule("linear", 50, 1000))
+            c_el = chain(dd, mc, (B_PER_GPU, 3, 64, 64), 131071, 50)
+            extras["celeba64_ddim50"] = {
+                "batch": B_PER_GPU, "seconds_per_chain": round(c_el, 3), "samples_per_s": round(B_PER_GPU / c_el, 2), "ms_per_step": round(c_el / 50 * 1e3, 3),
+                "model_tflops": round(B_PER_GPU * FWD_GFLOP["celeba"] / (c_el / 50) / 1e3, 1),
+                "frac_of_peak": round(B_PER_GPU * FWD_GFLOP["celeba"] / (c_el / 50) / 1e3 / peak, 4), "dtype": args.dtype}
+            del mc
+            # (3) BASELINE config 5, per-GPU work: CelebA-HQ 256x256 UNet (113.7M params), B=2, full Trainer.step
+            torch.cuda.empty_cache()
+            mh, nh, dh, th = make_trainer(ddpm_torch, CELEBAHQ, dev, args.dtype, (3, 256, 256), "fixed-small", lr=2e-5)
+            nh.train()
+            xh = (torch.rand(2, 3, 256, 256, generator=torch.Generator().manual_seed(7)) * 2 - 1).to(dev)
+            h_el = timed_steps(th, xh, 10, 3, torch.cuda.synchronize)
+            extras["celebahq256_train_b2"] = {
+                "batch_per_gpu": 2, "imgs_per_s_per_gpu": round(2 * 10 / h_el, 2), "ms_per_step": round(h_el / 10 * 1e3, 2),
+                "model_tflops": round(2 * 10 / h_el * 3 * FWD_GFLOP["celebahq"] / 1e3, 1),
+                "frac_of_peak": round(2 * 10 / h_el * 3 * FWD_GFLOP["celebahq"] / 1e3 / peak, 4), "dtype": args.dtype,
+                "final_loss": round(th.current_stats["loss"], 4)}
+            del mh, nh, th
+            out["other_configs"] = extras
+    if rank == 0 and not args.no_cpu_baseline and world == 1:
+        out["cpu_baseline"] = cpu_baseline()
     if distributed:
         dist.barrier()
         dist.destroy_process_group()

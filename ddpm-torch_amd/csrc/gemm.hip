@@ -1271,15 +1271,17 @@ template __global__ void attn_fwd_kernel<8>(MatDesc, MatDesc, MatDesc, bf16_t*, 
 
 // ---------------------------------------------------------------------------------------------- host side
 
-// which kernel the most recent conv / GEMM call of this thread dispatched to (bench.py attributes its per-launch timings
-// with it): 1 gemm_kernel 4-wave, 2 gemm_kernel 8-wave, 3 gemm_kernel deep ring, 4 gemm64_kernel, 5 conv3x3_halo_kernel
-static thread_local int g_last_variant = 0;
+// Kernel ids reported by the ddpm_*_variant queries (bench.py attributes its per-launch timings with them):
+// 1 gemm_kernel 4-wave, 2 gemm_kernel 8-wave, 3 gemm_kernel deep ring, 4 gemm64_kernel, 5 conv3x3_halo_kernel.
+// The queries run the SAME dispatch code with `dry` set (nothing is launched): the library keeps no mutable state.
 static const int g_xcd_swizzle = getenv("DDPM_NO_XCD_SWIZZLE") ? 0 : 1;
+static thread_local int g_variant_query = 0, g_variant_result = 0;      // scoped to ONE ddpm_*_variant call (set and cleared inside it)
 
 struct GemmArgs {          // plain-C mirror filled by the extern "C" entry points
     MatDesc A, B;
     Epilogue ep;
     int M, N, K, batch, splits, dtype;
+    int dry, variant;      // dry: decide the kernel (-> variant) but launch nothing
 };
 
 struct GnFold { const float* stats; const float* gamma; const float* beta; int G, silu; };     // GroupNorm folded into the conv's input
@@ -1321,7 +1323,8 @@ static int conv3x3_halo_launch(GemmArgs& g, const void* x, long long x_ld, const
         }                                                                                                                \
         hipLaunchKernelGGL((conv3x3_halo_kernel<RING, HROWS>), grid, dim3(512), LDS, st, a, tiles_n, g_xcd_swizzle);                    \
     } while (0)
-    g_last_variant = 5;
+    g.variant = 5;
+    if (g.dry) return (gn && (NB != 1 || HP > 324)) ? -1 : DDPM_OK;
     if (gn) {                              // GroupNorm + SiLU applied to the resident halo: single-patch geometry only
         if (NB != 1 || HP > 324) return -1;
         a.gn_stats = gn->stats; a.gn_gamma = gn->gamma; a.gn_beta = gn->beta; a.gn_G = gn->G; a.gn_cpg = C / gn->G; a.gn_silu = gn->silu;
@@ -1331,7 +1334,6 @@ static int conv3x3_halo_launch(GemmArgs& g, const void* x, long long x_ld, const
             attr_set = true;
         }
         hipLaunchKernelGGL((conv3x3_halo_kernel<4, 384, true>), grid, dim3(512), LDS, st, a, tiles_n, g_xcd_swizzle);
-        g_last_variant = 5;
         return check_launch();
     }
     if (HP <= 384) C3_LAUNCH(4, 384);      // one 16x16 patch: 2 x 48 KiB halo + 4 x 16 KiB weight ring
@@ -1387,9 +1389,10 @@ static int launch_t(GemmArgs& g, hipStream_t st) {
         }                                                                                                                \
         hipLaunchKernelGGL((gemm64_kernel<T, NG>), grid64, dim3(256), LDS64, st, g.A, g.B, g.ep, g.M, g.N, g.K, t64n, g_xcd_swizzle);   \
     } while (0)
+        g.variant = 4;
+        if (g.dry) return DDPM_OK;
         if ((long long)grid64.x * grid64.z <= 256) LAUNCH64(3); else LAUNCH64(2);
 #undef LAUNCH64
-        g_last_variant = 4;
         return check_launch();
     }
     const size_t lds2 = TILE * CS_LD * sizeof(float);     // 4 operand tiles (64 KiB) <= fp32 epilogue staging (66 KiB)
@@ -1400,6 +1403,8 @@ static int launch_t(GemmArgs& g, hipStream_t st) {
 
 #define LAUNCH(TA, TB, NB, NWV, LDS)                                                                                     \
     do {                                                                                                                 \
+        g.variant = NB != 2 ? 3 : (NWV == 8 ? 2 : 1);                                                                    \
+        if (g.dry) break;                                                                                                \
         static bool attr_set = false;   /* > 64 KiB of dynamic LDS needs the opt-in once per instantiation */            \
         if (!attr_set) {                                                                                                 \
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, TA, TB, NB, NWV>),                     \
@@ -1408,7 +1413,6 @@ static int launch_t(GemmArgs& g, hipStream_t st) {
             attr_set = true;                                                                                             \
         }                                                                                                                \
         hipLaunchKernelGGL((gemm_kernel<T, TA, TB, NB, NWV>), grid, dim3(NWV * 64), (LDS), st, g.A, g.B, g.ep, g.M, g.N, g.K, kps, tiles_n, g_xcd_swizzle); \
-        g_last_variant = NB != 2 ? 3 : (NWV == 8 ? 2 : 1);                                                               \
     } while (0)
     // 8-wave blocks whenever both operands take the DMA path (all bf16 products, fp32 with k-contiguous operands)
     constexpr bool BF = sizeof(T) == 2;
@@ -1426,6 +1430,8 @@ static int launch_t(GemmArgs& g, hipStream_t st) {
         if constexpr (BF) {
             static const bool no_scat = getenv("DDPM_GEMM_NO_SCAT") != nullptr;
             if (w8 && g.ep.mode >= 2 && !no_scat) {          // weight gradients: the scatter-only instantiation
+                g.variant = 2;
+                if (g.dry) return DDPM_OK;
                 static bool attr_set = false;
                 if (!attr_set) {
                     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, true, true, 2, 8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2) != hipSuccess)
@@ -1433,13 +1439,12 @@ static int launch_t(GemmArgs& g, hipStream_t st) {
                     attr_set = true;
                 }
                 hipLaunchKernelGGL((gemm_kernel<T, true, true, 2, 8, true>), grid, dim3(512), lds2, st, g.A, g.B, g.ep, g.M, g.N, g.K, kps, tiles_n, g_xcd_swizzle);
-                g_last_variant = 2;
             } else if (w8) LAUNCH(true, true, 2, 8, lds2);
             else LAUNCH(true, true, 2, 4, lds2);
         } else LAUNCH(true, true, 2, 4, lds2);
     }
 #undef LAUNCH
-    return check_launch();
+    return g.dry ? DDPM_OK : check_launch();
 }
 
 static int validate(const MatDesc& d, int esize) {
@@ -1470,11 +1475,13 @@ int ddpm_gemm_launch(GemmArgs& g, hipStream_t st) {
     if ((rc = finish_desc(g.A, es)) != DDPM_OK) return rc;
     if ((rc = finish_desc(g.B, es)) != DDPM_OK) return rc;
     set_vec_ok(g, es);
-    return g.dtype == DDPM_BF16 ? launch_t<bf16_t>(g, st) : launch_t<float>(g, st);
+    rc = g.dtype == DDPM_BF16 ? launch_t<bf16_t>(g, st) : launch_t<float>(g, st);
+    if (g.dry) g_variant_result = g.variant;
+    return rc;
 }
 
 // ---------------------------------------------------------------------------------------------- C ABI
-static void zero_args(GemmArgs& g) { memset(&g, 0, sizeof(g)); g.batch = 1; g.splits = 1; g.ep.alpha = 1.f; }
+static void zero_args(GemmArgs& g) { memset(&g, 0, sizeof(g)); g.batch = 1; g.splits = 1; g.ep.alpha = 1.f; g.dry = g_variant_query; }
 
 static void conv_desc(MatDesc& d, const void* x, long long x_ld, int npix_out, int H, int W, int C, int Ho, int Wo, int R, int S,
                       int stride, int pad_t, int pad_l, int upsample, int dilate) {
@@ -1519,7 +1526,7 @@ extern "C" int ddpm_conv2d_nhwc(const void* x, long long x_ld, const void* w, vo
         out_mode == 0 && splits <= 1 && C % 64 == 0 && Ho == H && Wo == W && g.M >= 16384 && aligned16(x) && aligned16(w) && x_ld % 8 == 0) {
         set_vec_ok(g, 2);
         const int rc = conv3x3_halo_launch(g, x, x_ld, w, B, H, W, C, N, (hipStream_t)stream);
-        if (rc >= 0) return rc;              // -1: geometry not covered, fall through to the generic kernel
+        if (rc >= 0) { if (g.dry) g_variant_result = g.variant; return rc; }     // -1: geometry not covered, fall through to the generic kernel
     }
     return ddpm_gemm_launch(g, (hipStream_t)stream);
 }
@@ -1634,8 +1641,35 @@ extern "C" int ddpm_attention_fwd(const void* qkv, long long ld, void* out, long
     return check_launch();
 }
 
-extern "C" int ddpm_last_gemm_variant(int reset) {
-    const int v = g_last_variant;
-    if (reset) g_last_variant = 0;
-    return v;
+// ---- which kernel would serve this call?  Same argument meaning as the launching entry points, no pointers, nothing launched,
+// no state: returns the kernel id (see the top of the host section) or -(error code).
+static const void* const FAKE = reinterpret_cast<const void*>(0x1000);
+
+extern "C" int ddpm_conv2d_variant(long long x_ld, long long y_ld, int B, int H, int W, int C, int Ho, int Wo, int N, int R, int S,
+                                   int stride, int pad_t, int pad_l, int upsample, int dilate, int out_mode, int splits, int dtype) {
+    g_variant_query = 1;
+    const int rc = ddpm_conv2d_nhwc(FAKE, x_ld, FAKE, const_cast<void*>(FAKE), y_ld, nullptr, nullptr, 0, nullptr, 0, B, H, W, C, Ho, Wo, N, R, S, stride, pad_t, pad_l,
+                                    upsample, dilate, 0, out_mode, splits, splits > 1 ? reinterpret_cast<float*>(0x1000) : nullptr,
+                                    splits > 1 ? reinterpret_cast<unsigned*>(0x1000) : nullptr, dtype, nullptr);
+    const int v = g_variant_result;
+    g_variant_query = 0;
+    return rc ? -rc : v;
+}
+extern "C" int ddpm_conv2d_wgrad_variant(long long dy_ld, long long x_ld, int B, int H, int W, int C, int Creal, int Ho, int Wo, int N, int Nreal,
+                                         int R, int S, int stride, int pad_t, int pad_l, int upsample, int splits, int dtype) {
+    g_variant_query = 1;
+    const int rc = ddpm_conv2d_wgrad_nhwc(FAKE, dy_ld, FAKE, x_ld, reinterpret_cast<float*>(0x1000), 0, B, H, W, C, Creal, Ho, Wo, N, Nreal, R, S, stride, pad_t, pad_l,
+                                          upsample, splits, dtype, nullptr);
+    const int v = g_variant_result;
+    g_variant_query = 0;
+    return rc ? -rc : v;
+}
+extern "C" int ddpm_gemm_variant(long long a_ld, int a_trans, long long b_ld, int b_trans, long long c_ld, int M, int N, int K, int batch,
+                                 int out_mode, int splits, int dtype) {
+    g_variant_query = 1;
+    const int rc = ddpm_gemm(FAKE, a_ld, 0, a_trans, FAKE, b_ld, 0, b_trans, const_cast<void*>(FAKE), c_ld, 0, nullptr, nullptr, 0, 0, M, N, K, batch, 1.f, 0, out_mode,
+                             splits, dtype, nullptr);
+    const int v = g_variant_result;
+    g_variant_query = 0;
+    return rc ? -rc : v;
 }

@@ -20,7 +20,7 @@ _ERR = {1: "bad shape / divisibility", 2: "unsupported dtype", 3: "misaligned po
 P, I, L, F, U = c_void_p, c_int, c_longlong, c_float, c_ulonglong
 
 # name -> argtypes; every function returns int status (0 = OK) except ddpm_gn_workspace_floats and
-# ddpm_last_gemm_variant / ddpm_wgrad_effective_splits / ddpm_conv3x3_wgrad_splits (plain values).
+# the ddpm_*_variant queries / ddpm_wgrad_effective_splits / ddpm_conv3x3_wgrad_splits (plain values).
 PROTOTYPES = {
     "ddpm_conv2d_nhwc": [P, L, P, P, L, P, P, L, P, L] + [I] * 14 + [I, I, I, P, P, I, P],
     "ddpm_conv2d_wgrad_nhwc": [P, L, P, L, P, L] + [I] * 17 + [P],
@@ -33,7 +33,9 @@ PROTOTYPES = {
     "ddpm_groupnorm_silu_fwd": [P, L, P, L, P, P, P, P, I, I, I, I, F, I, F, U, P, I, P],
     "ddpm_groupnorm_silu_bwd": [P, L, P, L, P, L, P, P, P, P, P, P, I, I, I, I, I, F, U, P, I, P, L, P, L, I, P],
     "ddpm_gn_workspace_floats": [I, I, I, I, I],
-    "ddpm_last_gemm_variant": [I],
+    "ddpm_conv2d_variant": [L, L] + [I] * 17,
+    "ddpm_conv2d_wgrad_variant": [L, L] + [I] * 17,
+    "ddpm_gemm_variant": [L, I, L, I, L, I, I, I, I, I, I, I],
     "ddpm_attention_fwd": [P, L, P, L, I, I, I, F, I, P],
     "ddpm_groupnorm_stats": [P, L, P, I, I, I, I, F, I, P],
     "ddpm_conv3x3_gn_silu_nhwc": [P, L, P, P, P, I, I, P, P, L, P, P, L, P, L, I, I, I, I, I, I, P],

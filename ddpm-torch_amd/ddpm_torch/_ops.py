@@ -18,7 +18,8 @@ GN_EPS = 1e-6
 PROFILE = None
 
 
-def _timed(kind, flops, fn, shape=""):
+def _timed(kind, flops, fn, shape="", variant=None):
+    """variant: callable returning the id of the kernel the library dispatches this call to (a stateless query)."""
     if PROFILE is None:
         fn()
         return
@@ -26,7 +27,7 @@ def _timed(kind, flops, fn, shape=""):
     a.record()
     fn()
     b.record()
-    PROFILE.append((kind, flops, a, b, shape, _hip.lib().ddpm_last_gemm_variant(1)))
+    PROFILE.append((kind, flops, a, b, shape, variant() if variant is not None else 0))
 
 
 class View:
@@ -75,7 +76,8 @@ def conv2d(x, w_ptr, y_ptr, y_ld, N, R, S, Ho, Wo, stride=1, pad_t=0, pad_l=0, u
         "ddpm_conv2d_nhwc", x.ptr, x.ld, w_ptr, y_ptr, y_ld, bias, rowbias, rowbias_ld, res_ptr, res_ld,
         x.B, x.H, x.W, x.C, Ho, Wo, N, R, S, stride, pad_t, pad_l, upsample, dilate, accumulate, out_mode, splits, ws, cnt,
         x.dtype, _hip.stream()),
-        f"conv M={x.B * Ho * Wo} N={N} K={R * S * x.C} {R}x{S} s{stride} u{upsample} d{dilate}")
+        f"conv M={x.B * Ho * Wo} N={N} K={R * S * x.C} {R}x{S} s{stride} u{upsample} d{dilate}",
+        lambda: _hip.lib().ddpm_conv2d_variant(x.ld, y_ld, x.B, x.H, x.W, x.C, Ho, Wo, N, R, S, stride, pad_t, pad_l, upsample, dilate, out_mode, splits, x.dtype))
 
 
 _USE_SPLITK = bool(os.environ.get("DDPM_SPLITK"))
@@ -113,7 +115,8 @@ def conv2d_wgrad(dy, x, dw_ptr, Creal, Nreal, R, S, stride=1, pad_t=0, pad_l=0, 
     """slab_stride = 0: atomics into dw_ptr; > 0: split s stores its partial at dw_ptr + 4*s*slab_stride (see ddpm_wgrad_reduce)."""
     _timed("gemm_tt", 2.0 * dy.rows * Nreal * R * S * x.C, lambda: _hip.call(
         "ddpm_conv2d_wgrad_nhwc", dy.ptr, dy.ld, x.ptr, x.ld, dw_ptr, slab_stride, x.B, x.H, x.W, x.C, Creal, dy.H, dy.W, dy.C, Nreal, R, S,
-        stride, pad_t, pad_l, upsample, splits, x.dtype, _hip.stream()), f"wgrad M={Nreal} N={R * S * x.C} K={dy.rows} splits={splits}")
+        stride, pad_t, pad_l, upsample, splits, x.dtype, _hip.stream()), f"wgrad M={Nreal} N={R * S * x.C} K={dy.rows} splits={splits}",
+        lambda: _hip.lib().ddpm_conv2d_wgrad_variant(dy.ld, x.ld, x.B, x.H, x.W, x.C, Creal, dy.H, dy.W, dy.C, Nreal, R, S, stride, pad_t, pad_l, upsample, splits, x.dtype))
 
 
 def conv3x3_wgrad_splits(B, H, W, C, N, splits=0):
@@ -125,7 +128,7 @@ def conv3x3_wgrad(dy, x, dw_ptr, slab_stride, dbias_ptr, bias_stride, Nreal, spl
     """dw[n][3][3][c] (+ dbias) of a 3x3 / stride 1 / pad 1 conv by the patch-stationary kernel (bf16)."""
     _timed("wgrad3x3", 2.0 * dy.rows * Nreal * 9 * x.C, lambda: _hip.call(
         "ddpm_conv3x3_wgrad_nhwc", dy.ptr, dy.ld, x.ptr, x.ld, dw_ptr, slab_stride, dbias_ptr, bias_stride, x.B, x.H, x.W, x.C, dy.C, Nreal,
-        splits, x.dtype, _hip.stream()), f"wgrad3x3 M={Nreal} N={9 * x.C} K={dy.rows} splits={splits}")
+        splits, x.dtype, _hip.stream()), f"wgrad3x3 M={Nreal} N={9 * x.C} K={dy.rows} splits={splits}", lambda: 6)
 
 
 def wgrad_effective_splits(K, splits, dtype):
@@ -136,7 +139,8 @@ def gemm(a_ptr, a_ld, a_bs, a_trans, b_ptr, b_ld, b_bs, b_trans, c_ptr, c_ld, c_
          bias=0, res_ptr=0, res_ld=0, res_bs=0, accumulate=0, out_mode=0, splits=1):
     _timed("gemm_" + "nt"[a_trans] + "nt"[b_trans], 2.0 * batch * M * N * K, lambda: _hip.call(
         "ddpm_gemm", a_ptr, a_ld, a_bs, a_trans, b_ptr, b_ld, b_bs, b_trans, c_ptr, c_ld, c_bs, bias, res_ptr, res_ld, res_bs,
-        M, N, K, batch, alpha, accumulate, out_mode, splits, dtype, _hip.stream()), f"gemm b={batch} M={M} N={N} K={K} dt={dtype}")
+        M, N, K, batch, alpha, accumulate, out_mode, splits, dtype, _hip.stream()), f"gemm b={batch} M={M} N={N} K={K} dt={dtype}",
+        lambda: _hip.lib().ddpm_gemm_variant(a_ld, a_trans, b_ld, b_trans, c_ld, M, N, K, batch, out_mode, splits, dtype))
 
 
 def gn_workspace_floats(B, HW, C, dtype):
@@ -163,7 +167,7 @@ def conv3x3_gn(x, stats, gamma, beta, w_ptr, y_ptr, y_ld, N, silu=True, bias=0, 
     _timed("gemm_nn", 2.0 * x.B * x.H * x.W * N * 9 * x.C, lambda: _hip.call(
         "ddpm_conv3x3_gn_silu_nhwc", x.ptr, x.ld, _hip.ptr(stats), _hip.ptr(gamma), _hip.ptr(beta), GN_GROUPS, int(silu), w_ptr, y_ptr, y_ld,
         bias, rowbias, rowbias_ld, res_ptr, res_ld, x.B, x.H, x.W, x.C, N, x.dtype, _hip.stream()),
-        f"conv+gn M={x.B * x.H * x.W} N={N} K={9 * x.C} 3x3")
+        f"conv+gn M={x.B * x.H * x.W} N={N} K={9 * x.C} 3x3", lambda: 5)
 
 
 def gn_bwd(x, dy, dx, gamma, beta, stats, dgamma_ptr, dbeta_ptr, ws, silu, drop_p=0.0, seed=0, accumulate=0, seed_dev=0, colsum_ptr=0, colsum_ld=0, add=None):

@@ -262,28 +262,33 @@ class GaussianDiffusion:
             return None
         return [m.engine() for m in denoise_fn.modules() if isinstance(m, UNet)]
 
-    def _graph_loop(self, denoise_fn, shape, device, noise, seed, steps):
-        """Replay the captured sampling step ``steps`` times; returns None if capture is not possible (the caller then
-        runs the eager loop; no RNG state has been consumed)."""
+    def _graph_entry(self, denoise_fn, shape, device, default_rng):
+        """Cached captured step for (denoiser, shape), capturing it on first use; None when capture is not possible."""
         cache = self.__dict__.setdefault("_sample_graphs", {})
         engines = self._engines_of(denoise_fn)
-        key = (id(denoise_fn), shape, str(device), seed is None, getattr(denoise_fn, "training", None),
+        key = (id(denoise_fn), shape, str(device), default_rng, getattr(denoise_fn, "training", None),
                tuple(e.T for e in engines) if engines else None)
         ent = cache.get(key)
         if ent is not None and ent["ref"]() is not denoise_fn:
             ent = None                                            # the id was recycled by another object
         if ent is None:
-            ent = self._capture_sample_step(denoise_fn, shape, device, seed is None)
-            if ent is None:
-                return None
-            if engines is not None:                               # arbitrary callables are captured per call: nothing tells us when their weights change
+            ent = self._capture_sample_step(denoise_fn, shape, device, default_rng)
+            if ent is not None and engines is not None:           # arbitrary callables are captured per call: nothing tells us when their weights change
                 import weakref
                 ent["ref"] = weakref.ref(denoise_fn)
                 if len(cache) >= 8:
                     cache.pop(next(iter(cache)))
                 cache[key] = ent
+        return ent
+
+    def _graph_loop(self, denoise_fn, shape, device, noise, seed, steps):
+        """Replay the captured sampling step ``steps`` times; returns None if capture is not possible (the caller then
+        runs the eager loop; no RNG state has been consumed)."""
+        ent = self._graph_entry(denoise_fn, shape, device, default_rng=seed is None)
+        if ent is None:
+            return None
         x_t, t, rng, graph = ent["x_t"], ent["t"], ent["rng"], ent["graph"]
-        for e in engines or ():
+        for e in self._engines_of(denoise_fn) or ():
             e.ensure_fresh()
         if rng is not None:
             rng.manual_seed(seed)
@@ -295,6 +300,16 @@ class GaussianDiffusion:
         for _ in range(steps):
             graph.replay()
         return x_t.clone()
+
+    def prepare_sampler(self, denoise_fn, shape, device, seeded=True):
+        """Capture (and cache) the hipGraph of one sampling step for ``(denoise_fn, shape)`` without running a chain, so that the
+        first ``p_sample`` of a serving process does not pay for it.  Returns True when a captured step is ready.  Not in the
+        reference (its loop is eager)."""
+        device = torch.device(device)
+        if device.type != "cuda" or os.environ.get("DDPM_TORCH_AMD_GRAPH", "1") == "0" or self._num_steps() < 4:
+            return False
+        with torch.inference_mode():
+            return self._graph_entry(denoise_fn, tuple(shape), device, default_rng=not seeded) is not None
 
     def _capture_sample_step(self, denoise_fn, shape, device, default_rng):
         dev = device

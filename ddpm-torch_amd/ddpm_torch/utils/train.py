@@ -23,6 +23,7 @@ Checkpoints keep the reference's on-disk layout ({model, optimizer, ema, schedul
 import math
 import os
 import re
+import time
 import warnings
 import weakref
 from contextlib import nullcontext
@@ -37,7 +38,8 @@ from .._graphs import SegmentedGraph
 
 __all__ = ["Trainer", "EMA", "ModelWrapper", "DummyScheduler", "RunningStatistics"]
 
-_TRAIN_GRAPH = os.environ.get("DDPM_TORCH_AMD_TRAIN_GRAPH", "1") != "0"
+# "auto" (default): the captured step is used when it measures faster than the eager one on this workload; "1" / "0" force it
+_TRAIN_GRAPH = {"0": False, "1": True}.get(os.environ.get("DDPM_TORCH_AMD_TRAIN_GRAPH", "auto"), "auto")
 
 
 class DummyScheduler:
@@ -328,6 +330,9 @@ class _DirectStep:
         self.calls = 0
         self.graph = None
         self.graph_failed = False
+        # auto mode: wall times (Trainer.step reports them) of a few eager and a few replayed steps decide which one stays
+        self.times = {"eager": [], "graph": []}
+        self.last_kind, self.choice = None, None
 
     @staticmethod
     def _pinned(t):
@@ -365,6 +370,28 @@ class _DirectStep:
         tr._fused.launch(tr.grad_norm, hyper_dev=self.hyper_dev.data_ptr())
         eng.refresh_unconditionally()                                          # the next forward reads the re-derived copies
 
+    PROBE = 3
+
+    def _wants_graph(self):
+        if _TRAIN_GRAPH != "auto":
+            return bool(_TRAIN_GRAPH)
+        if self.choice is not None:
+            return self.choice == "graph"
+        if len(self.times["eager"]) < self.PROBE:
+            return False
+        if len(self.times["graph"]) < self.PROBE:
+            return True
+        med = lambda v: sorted(v)[len(v) // 2]
+        # On one GPU the replayed graph loses the overlap of the weight-gradient stream with the critical path (the graph executor
+        # serialises the two branches), so it only wins where the step is bound by launch overhead (small batches, small images)
+        self.choice = "graph" if med(self.times["graph"]) < 0.97 * med(self.times["eager"]) else "eager"
+        return self.choice == "graph"
+
+    def observe(self, seconds):
+        """Wall time of the Trainer.step that just ran this object (auto mode bookkeeping)."""
+        if self.last_kind is not None and self.choice is None and len(self.times[self.last_kind]) < self.PROBE:
+            self.times[self.last_kind].append(seconds)
+
     def run(self, x):
         tr, eng = self.tr, self.unet.engine()
         self.x0.copy_(x, non_blocking=True)
@@ -374,8 +401,10 @@ class _DirectStep:
         params = tr._fused.prepare(grad_ptrs=self.grad_ptrs, stable_grads=True)
         assert len(params) == len(eng.params)
         self._write_hyper()
-        use_graph = (_TRAIN_GRAPH and not self.graph_failed and self.x0.is_cuda and self.calls >= 1 and tr.input_source is None
+        can_graph = (not self.graph_failed and self.x0.is_cuda and self.calls >= 1 and tr.input_source is None
                      and not torch.cuda.is_current_stream_capturing())
+        use_graph = can_graph and self._wants_graph()
+        self.last_kind = None
         if use_graph and self.graph is None:
             g = SegmentedGraph(self.x0.device)
             g.register_generator(tr.generator)
@@ -385,10 +414,15 @@ class _DirectStep:
                 warnings.warn(f"hipGraph capture of the training step failed ({type(e).__name__}: {e}); running it eagerly")
                 torch.cuda.synchronize()
                 self.graph_failed, self.graph = True, None
+            captured_now = True
+        else:
+            captured_now = False
         if use_graph and self.graph is not None:
             self.graph.replay()
+            self.last_kind = None if captured_now else "graph"          # the step that paid for the capture is not a sample
         else:
             self.body()
+            self.last_kind = "eager" if self.calls >= 1 else None        # nor is the very first step (lazy initialisation)
         self.calls += 1
         tr._fused.committed()
         eng.mark_fresh()
@@ -478,13 +512,16 @@ class Trainer:
         return m
 
     def step(self, x, global_steps=1):
+        t_begin = time.perf_counter()
         x = x.to(self.device)
         unet = self._direct_unet() if os.environ.get("DDPM_TORCH_AMD_DIRECT_STEP", "1") != "0" else None
+        direct = None
         if unet is not None and x.dtype == torch.float32:
             key = (tuple(x.shape), bool(unet.training))
             if key not in self._direct:
                 self._direct[key] = _DirectStep(self, unet, key[0])
-            loss = self._direct[key].run(x).clone()
+            direct = self._direct[key]
+            loss = direct.run(x).clone()
             if self._ema_on:
                 self.ema.num_updates += 1
             self.scheduler.step()
@@ -507,7 +544,9 @@ class Trainer:
         if self.distributed:
             dist.reduce(loss, dst=0, op=dist.ReduceOp.SUM)
             loss.div_(self.world_size)
-        self.stats.update(x.shape[0], loss=loss.item() * x.shape[0])
+        self.stats.update(x.shape[0], loss=loss.item() * x.shape[0])         # .item(): the host waits for the step here, as in the reference
+        if direct is not None:
+            direct.observe(time.perf_counter() - t_begin)
 
     # ------------------------------------------------------------------ sampling with the (EMA) weights
     def sample_fn(self, sample_size=None, noise=None, diffusion=None, sample_seed=None):

@@ -106,11 +106,17 @@ int ddpm_conv3x3_gn_silu_nhwc(const void* x, long long x_ld, const float* gn_sta
 int ddpm_attention_fwd(const void* qkv, long long ld, void* out, long long out_ld, int B, int L, int C, float scale,
                        int dtype, void* stream);
 
-/* Instrumentation (no upstream counterpart): which kernel the most recent ddpm_conv2d_nhwc / ddpm_conv2d_wgrad_nhwc /
- * ddpm_gemm call of the calling thread dispatched to — 1 gemm_kernel (4 waves), 2 gemm_kernel (8 waves), 3 gemm_kernel
- * (deep LDS ring), 4 gemm64_kernel (64x64 tiles), 5 conv3x3_halo_kernel; 0 = none since the last reset.  bench.py uses it
- * to attribute its per-launch HIP-event timings to the kernel that actually ran.  Not a status code. */
-int ddpm_last_gemm_variant(int reset);
+/* Instrumentation (no upstream counterpart): which kernel ddpm_conv2d_nhwc / ddpm_conv2d_wgrad_nhwc / ddpm_gemm would dispatch a
+ * call with these arguments to — 1 gemm_kernel (4 waves), 2 gemm_kernel (8 waves), 3 gemm_kernel (deep LDS ring), 4 gemm64_kernel
+ * (64x64 tiles), 5 conv3x3_halo_kernel; a negative value is -(status code) for arguments the launching call would reject.
+ * Pure functions of their arguments: the same dispatch code runs with launching switched off, nothing is retained between calls.
+ * bench.py uses them to attribute its per-launch HIP-event timings to the kernel that ran. */
+int ddpm_conv2d_variant(long long x_ld, long long y_ld, int B, int H, int W, int C, int Ho, int Wo, int N, int R, int S,
+                        int stride, int pad_t, int pad_l, int upsample, int dilate, int out_mode, int splits, int dtype);
+int ddpm_conv2d_wgrad_variant(long long dy_ld, long long x_ld, int B, int H, int W, int C, int Creal, int Ho, int Wo, int N, int Nreal,
+                              int R, int S, int stride, int pad_t, int pad_l, int upsample, int splits, int dtype);
+int ddpm_gemm_variant(long long a_ld, int a_trans, long long b_ld, int b_trans, long long c_ld, int M, int N, int K, int batch,
+                      int out_mode, int splits, int dtype);
 
 /* nn.GroupNorm(32, C, eps=1e-6) -> SiLU -> Dropout(p) (unet.py:18-20,15,81,85-87,139-140; :57 without SiLU):
  *   y = drop(silu((x - mean_g) * rstd_g * gamma_c + beta_c)),  biased variance over (C/G)*HW elements.

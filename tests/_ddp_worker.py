@@ -59,9 +59,8 @@ def run(rank, world, port, mode, out_dir, kind="cpu"):
     if native:
         # full distributed Trainer.steps on top (loss reduce to rank 0 included).  "native": the direct step, captured into
         # graph segments on a GPU (the all-reduces run between the segments); "native_eager": same step without capture
-        if mode == "native_eager":
-            from ddpm_torch.utils import train as train_mod
-            train_mod._TRAIN_GRAPH = False
+        from ddpm_torch.utils import train as train_mod
+        train_mod._TRAIN_GRAPH = mode != "native_eager"             # force the captured / the eager form (the default picks by measurement)
         dif = ddpm_torch.GaussianDiffusion(ddpm_torch.get_beta_schedule("linear", 1e-4, 0.02, 1000), "eps", "fixed-large", "mse")
         opt = torch.optim.Adam(model.parameters(), lr=1e-3)
         tr = ddpm_torch.Trainer(model, opt, dif, epochs=1, trainloader=None, sampler=object(), use_ema=True, shape=(3, 8, 8),

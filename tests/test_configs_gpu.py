@@ -247,3 +247,27 @@ def test_ddim50_celeba_quadratic_eta1_vs_eager(monkeypatch):
         monkeypatch.setenv("DDPM_TORCH_AMD_GRAPH", "0")
         b = dd.p_sample(m, shape=(2, 3, 64, 64), device=DEV, seed=131071)
         assert torch.isfinite(a).all() and torch.equal(a, b), (sched, float((a - b).abs().max()))
+
+
+def test_auto_mode_picks_a_step_execution_and_keeps_training(monkeypatch):
+    """Default (auto): a few eager and a few replayed steps are timed, one form is kept; the loss keeps decreasing through the
+    hand-over and both probes were real training steps."""
+    from tests.test_unet_gpu import TINY3
+    monkeypatch.setattr(train_mod, "_TRAIN_GRAPH", "auto")
+    torch.manual_seed(3)
+    m, _ = make(TINY3, dtype=torch.float32)
+    m.train()
+    dif = ddpm_torch.GaussianDiffusion(ddpm_torch.get_beta_schedule("linear", 1e-4, 0.02, 1000), "eps", "fixed-large", "mse")
+    opt = torch.optim.Adam(m.parameters(), lr=2e-3)
+    tr = ddpm_torch.Trainer(m, opt, dif, epochs=1, trainloader=None, use_ema=True, shape=(3, 16, 16), device=torch.device(DEV))
+    x = (torch.rand(4, 3, 16, 16, generator=torch.Generator().manual_seed(1)) * 2 - 1).to(DEV)
+    losses = []
+    for i in range(14):
+        tr.stats.reset()
+        tr.step(x, global_steps=i + 1)
+        losses.append(tr.current_stats["loss"])
+    ds = next(iter(tr._direct.values()))
+    assert ds.choice in ("eager", "graph") and len(ds.times["eager"]) == 3 and len(ds.times["graph"]) == 3
+    assert ds.graph is not None and not ds.graph_failed
+    assert int(opt.state[next(iter(m.parameters()))]["step"]) == 14 and tr.ema.num_updates == 13
+    assert sum(losses[-4:]) < sum(losses[:4])
