@@ -37,6 +37,8 @@ PROTOTYPES = {
     "ddpm_conv2d_wgrad_variant": [L, L] + [I] * 17,
     "ddpm_gemm_variant": [L, I, L, I, L, I, I, I, I, I, I, I],
     "ddpm_attention_fwd": [P, L, P, L, I, I, I, F, I, P],
+    "ddpm_attention_fwd_lse": [P, L, P, L, P, I, I, I, F, I, P],
+    "ddpm_attention_bwd": [P, L, P, L, P, L, P, P, P, L, I, I, I, F, I, P],
     "ddpm_groupnorm_stats": [P, L, P, I, I, I, I, F, I, P],
     "ddpm_conv3x3_gn_silu_nhwc": [P, L, P, P, P, I, I, P, P, L, P, P, L, P, L, I, I, I, I, I, I, P],
     "ddpm_timestep_embedding": [P, P, P, I, I, P],

@@ -242,6 +242,7 @@ class _ConvW:
 
 _WGRAD_TARGET_BLOCKS = int(os.environ.get("DDPM_WGRAD_BLOCKS", "512"))
 _FUSED_ATTENTION = os.environ.get("DDPM_FUSED_ATTENTION", "1") != "0"
+_FLASH_ATTENTION = os.environ.get("DDPM_FLASH_ATTENTION", "1") != "0"     # 0: the five-product path with L x L tensors (A/B only)
 _UP_DGRAD_FUSED = os.environ.get("DDPM_UP_DGRAD_FUSED", "1") != "0"    # upsample convs: dgrad as one 4x4 stride-2 conv
 _FOLD_MAX_CHANNELS = 128
 _FOLD_MIN_PIXELS = 16384            # below this the small-grid kernels serve the layer better than the 256-pixel-tile conv
@@ -830,15 +831,23 @@ class _Engine:
         ops.conv2d(hn, ci.wf.data_ptr(), qkv.ptr, qkv.ld, 3 * C, 1, 1, x.H, x.W, bias=ab.project_in.bias.data_ptr(), splitk=self.splitk)
         es, bs = self.es, Lk * 3 * C
         o = self._new(B, x.H, x.W, C)
-        prob = None
+        prob = lse = None
+        scale = 1.0 / math.sqrt(C)
+        flash = _FLASH_ATTENTION and self.T == torch.bfloat16 and Lk <= 256 and Lk % 16 == 0 and C <= 512 and C % 32 == 0
         if not save and _FUSED_ATTENTION and self.T == torch.bfloat16 and Lk % 128 == 0 and C in (128, 256):
             # inference: one kernel, the L x L logits / probabilities stay in LDS and registers (unet.py:41-52)
-            _hip.call("ddpm_attention_fwd", qkv.ptr, qkv.ld, o.ptr, o.ld, B, Lk, C, 1.0 / math.sqrt(C), self.dcode, _hip.stream())
+            _hip.call("ddpm_attention_fwd", qkv.ptr, qkv.ld, o.ptr, o.ld, B, Lk, C, scale, self.dcode, _hip.stream())
+        elif flash:
+            # training (and the geometries the kernel above does not serve): same, plus the row log-sum-exp the backward
+            # kernels rebuild the probabilities from — no L x L tensor exists in memory
+            lse = self._f32(B, Lk) if save else None
+            _hip.call("ddpm_attention_fwd_lse", qkv.ptr, qkv.ld, o.ptr, o.ld, lse.data_ptr() if save else 0, B, Lk, C, scale,
+                      self.dcode, _hip.stream())
         else:
             q, kk, v = qkv.ptr, qkv.ptr + C * es, qkv.ptr + 2 * C * es
             logits = self._f32(B, Lk, Lk)                       # S = Q K^T / sqrt(C)   (unet.py:46-48)
             ops.gemm(q, 3 * C, bs, 0, kk, 3 * C, bs, 0, logits.data_ptr(), Lk, Lk * Lk, Lk, Lk, C, self.dcode, batch=B,
-                     alpha=1.0 / math.sqrt(C), out_mode=1)
+                     alpha=scale, out_mode=1)
             prob = torch.empty((B, Lk, Lk), dtype=self.T, device=self.device)
             _hip.call("ddpm_softmax_fwd", logits.data_ptr(), prob.data_ptr(), B * Lk, Lk, self.dcode, _hip.stream())
             ops.gemm(prob.data_ptr(), Lk, Lk * Lk, 0, v, 3 * C, bs, 1, o.ptr, C, Lk * C, Lk, C, Lk, self.dcode, batch=B)   # O = P V (unet.py:50)
@@ -846,7 +855,7 @@ class _Engine:
         ops.conv2d(o, co.wf.data_ptr(), out.ptr, out.ld, C, 1, 1, x.H, x.W, bias=ab.project_out.bias.data_ptr(),
                    res_ptr=x.ptr, res_ld=x.ld, splitk=self.splitk)
         if save:
-            st["tape"].append(("attn", ab, x, out, hn, stats, qkv, prob, o))
+            st["tape"].append(("attn", ab, x, out, hn, stats, qkv, prob, o, lse))
 
     # ================================================================ backward
     def _open_backward(self, st, gflat=None, cut=None):
@@ -1027,7 +1036,7 @@ class _Engine:
                 pv.grad, pv.ginit = g.chan_slice(a, b), True
 
     def _attn_bwd(self, ctx, rec):
-        _, ab, x, out, hn, stats, qkv, prob, o = rec
+        _, ab, x, out, hn, stats, qkv, prob, o, lse = rec
         gflat, ws, B = ctx["gflat"], ctx["ws"], ctx["B"]
         C, Lk = ab.in_channels, x.H * x.W
         dout = out.grad
@@ -1043,15 +1052,21 @@ class _Engine:
         q, kk, v = qkv.ptr, qkv.ptr + C * es, qkv.ptr + 2 * C * es
         dqkv = self._new(B, x.H, x.W, 3 * C)
         dq, dk, dv = dqkv.ptr, dqkv.ptr + C * es, dqkv.ptr + 2 * C * es
-        dp = self._f32(B, Lk, Lk)                            # dP = dO V^T
-        ops.gemm(do.ptr, C, Lk * C, 0, v, 3 * C, bs, 0, dp.data_ptr(), Lk, Lk * Lk, Lk, Lk, C, self.dcode, batch=B, out_mode=1)
-        # dV = P^T dO
-        ops.gemm(prob.data_ptr(), Lk, Lk * Lk, 1, do.ptr, C, Lk * C, 1, dv, 3 * C, bs, Lk, C, Lk, self.dcode, batch=B)
-        ds = torch.empty((B, Lk, Lk), dtype=self.T, device=self.device)
-        _hip.call("ddpm_softmax_bwd", prob.data_ptr(), dp.data_ptr(), ds.data_ptr(), B * Lk, Lk, self.dcode, _hip.stream())
         scale = 1.0 / math.sqrt(C)
-        ops.gemm(ds.data_ptr(), Lk, Lk * Lk, 0, kk, 3 * C, bs, 1, dq, 3 * C, bs, Lk, C, Lk, self.dcode, batch=B, alpha=scale)   # dQ = dS K
-        ops.gemm(ds.data_ptr(), Lk, Lk * Lk, 1, q, 3 * C, bs, 1, dk, 3 * C, bs, Lk, C, Lk, self.dcode, batch=B, alpha=scale)    # dK = dS^T Q
+        if lse is not None:
+            # flash-style: P is rebuilt from q, k and the saved log-sum-exp inside the kernels (dQ; then dK and dV)
+            dvec = self._f32(B, Lk)
+            _hip.call("ddpm_attention_bwd", qkv.ptr, qkv.ld, o.ptr, o.ld, do.ptr, do.ld, lse.data_ptr(), dvec.data_ptr(),
+                      dqkv.ptr, dqkv.ld, B, Lk, C, scale, self.dcode, _hip.stream())
+        else:
+            dp = self._f32(B, Lk, Lk)                            # dP = dO V^T
+            ops.gemm(do.ptr, C, Lk * C, 0, v, 3 * C, bs, 0, dp.data_ptr(), Lk, Lk * Lk, Lk, Lk, C, self.dcode, batch=B, out_mode=1)
+            # dV = P^T dO
+            ops.gemm(prob.data_ptr(), Lk, Lk * Lk, 1, do.ptr, C, Lk * C, 1, dv, 3 * C, bs, Lk, C, Lk, self.dcode, batch=B)
+            ds = torch.empty((B, Lk, Lk), dtype=self.T, device=self.device)
+            _hip.call("ddpm_softmax_bwd", prob.data_ptr(), dp.data_ptr(), ds.data_ptr(), B * Lk, Lk, self.dcode, _hip.stream())
+            ops.gemm(ds.data_ptr(), Lk, Lk * Lk, 0, kk, 3 * C, bs, 1, dq, 3 * C, bs, Lk, C, Lk, self.dcode, batch=B, alpha=scale)   # dQ = dS K
+            ops.gemm(ds.data_ptr(), Lk, Lk * Lk, 1, q, 3 * C, bs, 1, dk, 3 * C, bs, Lk, C, Lk, self.dcode, batch=B, alpha=scale)    # dK = dS^T Q
         # project_in
         dhn = self._new(B, x.H, x.W, C)
         ops.conv2d(dqkv, ci.wd.data_ptr(), dhn.ptr, dhn.ld, C, 1, 1, x.H, x.W, splitk=self.splitk)

@@ -106,6 +106,18 @@ int ddpm_conv3x3_gn_silu_nhwc(const void* x, long long x_ld, const float* gn_sta
 int ddpm_attention_fwd(const void* qkv, long long ld, void* out, long long out_ld, int B, int L, int C, float scale,
                        int dtype, void* stream);
 
+/* Attention for training, and for every geometry ddpm_attention_fwd does not serve (ddpm_torch/models/unet.py:41-52 and its autograd
+ * backward): same packed qkv layout.  The forward also writes lse[b][i] = log sum_j exp(q_i . k_j * scale) (fp32, [B][L]; may be NULL
+ * for inference); the backward rebuilds the probabilities from q, k and lse on chip — no L x L tensor is ever written — and produces
+ *     dV = P^T dO      dS = P o (dO V^T - D),  D[i] = sum_c dO[i][c] O[i][c]      dQ = dS K * scale      dK = dS^T Q * scale
+ * into the packed gradient buffer dqkv[B][L][dqkv_ld] (dq at channel 0, dk at C, dv at 2C).  dvec: [B][L] fp32 workspace (receives D).
+ * bf16 only; L <= 256 with L % 16 == 0 (the reference attends at 16x16 and below); C <= 512 with C % 32 == 0; else DDPM_ERR_SHAPE. */
+int ddpm_attention_fwd_lse(const void* qkv, long long ld, void* out, long long out_ld, float* lse, int B, int L, int C, float scale,
+                           int dtype, void* stream);
+int ddpm_attention_bwd(const void* qkv, long long ld, const void* o, long long o_ld, const void* d_o, long long do_ld,
+                       const float* lse, float* dvec, void* dqkv, long long dqkv_ld, int B, int L, int C, float scale,
+                       int dtype, void* stream);
+
 /* Instrumentation (no upstream counterpart): which kernel ddpm_conv2d_nhwc / ddpm_conv2d_wgrad_nhwc / ddpm_gemm would dispatch a
  * call with these arguments to — 1 gemm_kernel (4 waves), 2 gemm_kernel (8 waves), 3 gemm_kernel (deep LDS ring), 4 gemm64_kernel
  * (64x64 tiles), 5 conv3x3_halo_kernel; a negative value is -(status code) for arguments the launching call would reject.

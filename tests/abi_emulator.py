@@ -424,6 +424,29 @@ class Emulator:
         p_ = s / s.sum(-1, keepdims=True)
         Mat(out, B * L, C, out_ld, dt).set(np.einsum("bij,bjc->bic", p_, v).reshape(B * L, C).astype(np.float32))
 
+    def ddpm_attention_fwd_lse(self, qkv, ld, out, out_ld, lse, B, L, C, scale, dt, st):
+        x = Mat(qkv, B * L, 3 * C, ld, dt).get().reshape(B, L, 3 * C).astype(np.float64)
+        q, k, v = x[..., :C], x[..., C:2 * C], x[..., 2 * C:]
+        s = np.einsum("bic,bjc->bij", q, k) * scale
+        m = s.max(-1, keepdims=True)
+        e = np.exp(s - m)
+        if lse:
+            f32(lse, B * L)[...] = (m[..., 0] + np.log(e.sum(-1))).reshape(-1)
+        p_ = e / e.sum(-1, keepdims=True)
+        Mat(out, B * L, C, out_ld, dt).set(np.einsum("bij,bjc->bic", p_, v).reshape(B * L, C).astype(np.float32))
+
+    def ddpm_attention_bwd(self, qkv, ld, o, o_ld, d_o, do_ld, lse, dvec, dqkv, dqkv_ld, B, L, C, scale, dt, st):
+        x = Mat(qkv, B * L, 3 * C, ld, dt).get().reshape(B, L, 3 * C).astype(np.float64)
+        q, k, v = x[..., :C], x[..., C:2 * C], x[..., 2 * C:]
+        O = Mat(o, B * L, C, o_ld, dt).get().reshape(B, L, C).astype(np.float64)
+        dO = Mat(d_o, B * L, C, do_ld, dt).get().reshape(B, L, C).astype(np.float64)
+        p_ = np.exp(np.einsum("bic,bjc->bij", q, k) * scale - f32(lse, B * L).reshape(B, L, 1))
+        D = (dO * O).sum(-1)
+        f32(dvec, B * L)[...] = D.reshape(-1)
+        ds = p_ * (np.einsum("bic,bjc->bij", dO, v) - D[..., None]) * scale
+        g = np.concatenate([np.einsum("bij,bjc->bic", ds, k), np.einsum("bij,bic->bjc", ds, q), np.einsum("bij,bic->bjc", p_, dO)], -1)
+        Mat(dqkv, B * L, 3 * C, dqkv_ld, dt).set(g.reshape(B * L, 3 * C).astype(np.float32))
+
     def ddpm_softmax_bwd(self, p, dp, ds, rows, L, dt, st):
         P = Mat(p, rows, L, L, dt).get()
         d = f32(dp, rows * L).reshape(rows, L)

@@ -325,6 +325,45 @@ def test_attention_fwd_fused(B, L, C):
     both("ddpm_attention_fwd", A(qkv2.to(torch.bfloat16)), ld, A(out, out=True, name="o_peaked"), old, B, L, C, 1.0 / math.sqrt(C), 1, tol=TOL[1])
 
 
+FLASH_CASES = [(3, 256, 256), (2, 256, 512), (2, 16, 256), (2, 64, 128), (2, 256, 128), (1, 64, 512), (2, 16, 64), (2, 128, 96), (1, 48, 32)]
+
+
+@pytest.mark.parametrize("B,L,C", FLASH_CASES)
+def test_attention_training_pair_keeps_no_LxL_tensor(B, L, C):
+    """ddpm_attention_fwd_lse + ddpm_attention_bwd against the float64 restatement: output, log-sum-exp, D and the packed
+    dq | dk | dv — at the reference's attention geometries (16x16 at C = 256 / 512, the 8x8 / 4x4 middle blocks) and ragged ones."""
+    ld, old, gld = 3 * C + 16, C + 8, 3 * C + 24
+    scale = 1.0 / math.sqrt(C)
+    for peak in (1.0, 5.0):
+        qkv = r(B * L, ld, seed=21, dt=1, scale=1.2).float()
+        qkv[:, :C] *= peak
+        qkv = qkv.to(torch.bfloat16)
+        out = torch.zeros(B * L, old, dtype=torch.bfloat16)
+        lse = torch.zeros(B * L)
+        both("ddpm_attention_fwd_lse", A(qkv), ld, A(out, out=True, name="o"), old, A(lse, out=True, name="lse"), B, L, C, scale, 1, tol=TOL[1])
+        both("ddpm_attention_fwd_lse", A(qkv), ld, A(out, out=True, name="o_nolse"), old, None, B, L, C, scale, 1, tol=TOL[1])
+        d_o = torch.zeros(B * L, old, dtype=torch.bfloat16)
+        d_o[:, :C] = r(B * L, C, seed=22, dt=1)
+        dvec = torch.zeros(B * L)
+        dqkv = torch.zeros(B * L, gld, dtype=torch.bfloat16)
+        both("ddpm_attention_bwd", A(qkv), ld, A(out), old, A(d_o), old, A(lse), A(dvec, out=True, name="D"), A(dqkv, out=True, name="dqkv"), gld,
+             B, L, C, scale, 1, tol=2e-2)
+        g = dqkv.float()
+        assert float(g[:, 3 * C:].abs().max()) == 0.0                        # the pitch padding is never written
+        for nm, sl in (("dq", g[:, :C]), ("dk", g[:, C:2 * C]), ("dv", g[:, 2 * C:3 * C])):
+            assert float(sl.abs().max()) > 0, nm
+
+
+def test_attention_training_pair_rejects_what_it_cannot_serve():
+    x = torch.zeros(512, 3 * 64, dtype=torch.bfloat16).cuda()
+    o = torch.zeros(512, 64, dtype=torch.bfloat16).cuda()
+    f = _hip.lib().ddpm_attention_fwd_lse
+    assert f(x.data_ptr(), 192, o.data_ptr(), 64, 0, 1, 512, 64, 0.125, 1, _hip.stream()) == 1        # L > 256
+    assert f(x.data_ptr(), 192, o.data_ptr(), 64, 0, 1, 24, 64, 0.125, 1, _hip.stream()) == 1         # L % 16
+    assert f(x.data_ptr(), 192, o.data_ptr(), 64, 0, 1, 16, 48, 0.125, 1, _hip.stream()) == 1         # C % 32
+    assert f(x.data_ptr(), 192, o.data_ptr(), 64, 0, 1, 16, 64, 0.125, 0, _hip.stream()) == 2         # fp32
+
+
 def test_attention_fwd_rejects_unsupported_geometry():
     x = torch.zeros(16, 3 * 64, dtype=torch.bfloat16).cuda()
     o = torch.zeros(16, 64, dtype=torch.bfloat16).cuda()
