@@ -104,23 +104,31 @@ static inline FastDiv make_fastdiv(unsigned d) {
 }
 
 // Counter-based dropout RNG shared by forward and backward (and by the test hook that dumps the mask):
-// keep(seed, idx) is a pure function, so backward regenerates the mask instead of storing it.
+// keep(seed, idx) is a pure function, so backward regenerates the mask instead of storing it.  One 32-bit hash word serves the
+// PAIR of adjacent elements (2q, 2q + 1) — 16 bits each, P(keep) = 1 - thresh16 / 65536 — because the two 32-bit integer
+// multiplies of the mixer are quarter-rate VALU instructions and the GroupNorm kernels that draw the masks are VALU-bound.
 __device__ __forceinline__ unsigned mix32(unsigned x) {
     x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
     return x;
 }
-__device__ __forceinline__ bool dropout_keep(unsigned long long seed, unsigned long long idx, unsigned thresh24) {
-    unsigned lo = (unsigned)idx, hi = (unsigned)(idx >> 32);
-    unsigned h = mix32(lo ^ mix32(hi + (unsigned)seed) ^ (unsigned)(seed >> 32) * 0x9E3779B9u);
-    return (h >> 8) >= thresh24;          // P(keep) = 1 - thresh24 / 2^24
+__device__ __forceinline__ unsigned dropout_word(unsigned long long seed, unsigned long long pair) {
+    const unsigned lo = (unsigned)pair, hi = (unsigned)(pair >> 32);
+    return mix32(lo ^ mix32(hi + (unsigned)seed) ^ (unsigned)(seed >> 32) * 0x9E3779B9u);
 }
-
-// The same hash for element indices below 2^32 (every tensor of the hot path): the seed-dependent part is loop-invariant.
-//   keep(seed, idx) == dropout_keep32(dropout_h0(seed), (unsigned)idx, thresh)   for idx < 2^32
+__device__ __forceinline__ bool dropout_keep(unsigned long long seed, unsigned long long idx, unsigned thresh16) {
+    const unsigned w = dropout_word(seed, idx >> 1);
+    return ((idx & 1) ? (w >> 16) : (w & 0xffffu)) >= thresh16;
+}
+// The same word for pair indices below 2^32 (every tensor of the hot path): the seed-dependent part is loop-invariant.
+//   dropout_word(seed, q) == dropout_word32(dropout_h0(seed), (unsigned)q)   for q < 2^32
 __device__ __forceinline__ unsigned dropout_h0(unsigned long long seed) {
     return mix32((unsigned)seed) ^ ((unsigned)(seed >> 32) * 0x9E3779B9u);
 }
-__device__ __forceinline__ bool dropout_keep32(unsigned h0, unsigned idx, unsigned thresh24) { return (mix32(idx ^ h0) >> 8) >= thresh24; }
+__device__ __forceinline__ unsigned dropout_word32(unsigned h0, unsigned pair) { return mix32(pair ^ h0); }
+static inline unsigned dropout_thresh16(float p) {
+    const double th = (double)p * 65536.0;
+    return th <= 0 ? 0u : (th >= 65536.0 ? 65536u : (unsigned)(th + 0.5));
+}
 // d/dz [z*sigmoid(z)] with the hardware reciprocal (1 ulp) instead of the IEEE division
 __device__ __forceinline__ float silu_grad_fast_(float z) {
     const float s = __builtin_amdgcn_rcpf(1.0f + __expf(-z));

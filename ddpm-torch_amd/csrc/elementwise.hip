@@ -553,14 +553,12 @@ extern "C" int ddpm_softmax_bwd(const void* p, const float* dp, void* ds, long l
 }
 
 // ------------------------------------------------------------------ test hook: the dropout keep-mask the GN kernels regenerate
-__global__ void dropout_mask_kernel(float* __restrict__ mask, long long n, unsigned long long seed, unsigned thresh24) {
+__global__ void dropout_mask_kernel(float* __restrict__ mask, long long n, unsigned long long seed, unsigned thresh16) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
-        mask[i] = dropout_keep(seed, (unsigned long long)i, thresh24) ? 1.f : 0.f;
+        mask[i] = dropout_keep(seed, (unsigned long long)i, thresh16) ? 1.f : 0.f;
 }
 extern "C" int ddpm_dropout_mask(float* mask, long long n, float p, unsigned long long seed, void* stream) {
     if (!mask) return DDPM_ERR_NULL;
-    double th = (double)p * 16777216.0;
-    unsigned t24 = th <= 0 ? 0u : (th >= 16777216.0 ? 16777216u : (unsigned)(th + 0.5));
-    hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, mask, n, seed, t24);
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, mask, n, seed, dropout_thresh16(p));
     return check_launch();
 }

@@ -89,7 +89,7 @@ __global__ void gn_stats_kernel(const T* __restrict__ x, GnShape s, float* __res
 struct GnApply {
     const float* gamma; const float* beta;
     float eps; int silu;
-    float drop_p; unsigned thresh24; unsigned long long seed;   // dropout after SiLU (unet.py:87); p = 0 disables
+    float drop_p; unsigned thresh16; unsigned long long seed;   // dropout after SiLU (unet.py:87); p = 0 disables
     const unsigned long long* seed_dev;                         // optional device word added to `seed` (hipGraph replays: the per-step part of the seed lives in memory)
     float* stats;              // [B][G][2] (mean, rstd) saved for backward, or null
 };
@@ -145,7 +145,7 @@ __global__ void gn_apply_kernel(const T* __restrict__ x, T* __restrict__ y, GnSh
             if (a.silu) z = siluf_(z);
             if (a.drop_p > 0.f) {
                 unsigned long long idx = ((unsigned long long)b * s.HW + p) * s.C + cx * VEC + j;
-                z = dropout_keep(seed, idx, a.thresh24) ? z * keep_scale : 0.f;
+                z = dropout_keep(seed, idx, a.thresh16) ? z * keep_scale : 0.f;
             }
             f[j] = z;
         }
@@ -164,6 +164,7 @@ struct GnFused {
     int nta;                       // active threads: largest multiple of seg_vecs <= nt (a thread keeps one vector column)
     int rows_per_iter;             // R = nta / seg_vecs pixels per sweep of the block
     int nv;                        // vectors per thread = ceil(HW / R)
+    int xcd_remap;                 // LDS kernels: keep the channel chunks of a sample on one XCD (see gn_block_slice)
 };
 
 // Ordered block reduction of per-thread channel partials: part[e] belongs to channel j*VEC + e of the segment.  On return
@@ -274,7 +275,7 @@ void gn_reg_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, GnShape s, Gn
             if (a.silu) z = siluf_(z);
             if (a.drop_p > 0.f) {
                 const unsigned long long idx = ((unsigned long long)b * s.HW + p) * s.C + c0 + j * VEC + e;
-                z = dropout_keep(seed, idx, a.thresh24) ? z * keep_scale : 0.f;
+                z = dropout_keep(seed, idx, a.thresh16) ? z * keep_scale : 0.f;
             }
             fv[e] = z;
         }
@@ -321,7 +322,7 @@ void gn_reg_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __r
         float dz = d;
         if (a.drop_p > 0.f) {
             const unsigned long long idx = ((unsigned long long)b * s.HW + p) * s.C + c0 + j * VEC + e;
-            dz = dropout_keep(seed, idx, a.thresh24) ? dz * keep_scale : 0.f;
+            dz = dropout_keep(seed, idx, a.thresh16) ? dz * keep_scale : 0.f;
         }
         if (a.silu) dz *= silu_gradf_(gm[e] * xh + bt[e]);
         return dz;
@@ -405,16 +406,21 @@ void gn_reg_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __r
 template <int VEC>
 __device__ __forceinline__ void gn_block_channel_sum_w(const float (&part)[VEC], const GnFused& f, bool active, int j, int prow, int tid,
                                                        float* sh_row, float* sh_ch) {
-    if (64 % f.seg_vecs) { gn_block_channel_sum<VEC>(part, f, active, j, prow, tid, sh_row, sh_ch); return; }
+    // lanes l, l + seg_vecs, l + 2 seg_vecs, ... of a wave hold the same vector column: strided tree (any seg_vecs <= 32, also the
+    // 3 / 6 / 12 vectors per pixel of the 384-channel tensors), after which lanes < seg_vecs hold their column's wave total
     float v[VEC];
 #pragma unroll
     for (int e = 0; e < VEC; ++e) v[e] = active ? part[e] : 0.f;
-    for (int off = f.seg_vecs; off < 64; off <<= 1) {
+    const int lane = tid & 63;
+    int top = f.seg_vecs;
+    while (top * 2 < 64) top *= 2;
+    for (int off = top; off >= f.seg_vecs; off >>= 1) {
+        const bool in = lane + off < 64;
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) v[e] += __shfl_xor(v[e], off, 64);
+        for (int e = 0; e < VEC; ++e) { const float o = __shfl_down(v[e], off, 64); v[e] += in ? o : 0.f; }
     }
     __syncthreads();                                  // previous users of the scratch are done
-    if ((tid & 63) < f.seg_vecs) {
+    if (lane < f.seg_vecs) {
 #pragma unroll
         for (int e = 0; e < VEC; ++e) sh_row[(tid >> 6) * f.seg_ch + j * VEC + e] = v[e];
     }
@@ -435,6 +441,19 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t gn_slice_rsrc(const void* base
                                              __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
 }
 
+// Block -> (sample, channel chunk) for the LDS kernels.  The chunks of one sample split every 128-byte line of its rows between
+// them; consecutive workgroup ids go round-robin over the 8 XCDs (one L2 each), so with the plain (chunk, sample) grid the parts
+// of a line are fetched by different L2s.  Remapped, the chunks of a sample are ids 8 apart: same XCD, dispatched back to back —
+// the line comes from HBM once and the partners hit in L2.
+__device__ __forceinline__ void gn_block_slice(const GnFused& f, int& b, int& chunk) {
+    const int gx = gridDim.x, gy = gridDim.y;
+    if ((gy & 7) == 0 && f.xcd_remap) {
+        const int L = blockIdx.y * gx + blockIdx.x, k = L >> 3;
+        chunk = k % gx;
+        b = (k / gx) * 8 + (L & 7);
+    } else { b = blockIdx.y; chunk = blockIdx.x; }
+}
+
 //   backward pass 1: A1[c] = sum dz*xhat, A2[c] = sum dz -> dgamma / dbeta atomics, group coefficients c1, c2
 //            pass 2: dx = rstd * (dz*gamma - xhat*c1 - c2) (+= when accumulate), optionally the per-(sample, channel) sums of dx
 //                    (the time-bias gradient of the block, ddpm_torch/models/unet.py:86: no separate column-sum launch).
@@ -447,10 +466,12 @@ void gn_lds_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __r
     extern __shared__ __attribute__((aligned(16))) char lsm[];
     char* xs = lsm;                                               // [NV][512] vectors of x
     float* sh_row = reinterpret_cast<float*>(lsm + NV * 512 * 16);
-    float* sh_ch = sh_row + ((64 % f.seg_vecs) ? f.rows_per_iter * f.seg_ch : 8 * f.seg_ch);
+    float* sh_ch = sh_row + 8 * f.seg_ch;
     float* sh_c1 = sh_ch + f.seg_ch;
     float* sh_c2 = sh_c1 + 32;
-    const int b = blockIdx.y, c0 = blockIdx.x * f.seg_ch, tid = threadIdx.x;
+    int b, chunk;
+    gn_block_slice(f, b, chunk);
+    const int c0 = chunk * f.seg_ch, tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool active = tid < f.nta;
     const int j = tid % f.seg_vecs, prow = tid / f.seg_vecs;
@@ -476,11 +497,21 @@ void gn_lds_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __r
     const float keep_scale = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
     const unsigned h0 = dropout_h0(gn_seed(a));
     const unsigned idx0 = (unsigned)(((unsigned)b * (unsigned)s.HW) * (unsigned)s.C + (unsigned)(c0 + j * VEC));   // < 2^32: checked by the host
-    auto dz_of = [&](int p, int e, float xh, float d) -> float {
-        float dz = d;
-        if (a.drop_p > 0.f) dz = dropout_keep32(h0, idx0 + (unsigned)p * (unsigned)s.C + (unsigned)e, a.thresh24) ? dz * keep_scale : 0.f;
-        if (a.silu) dz *= silu_grad_fast_(gm[e] * xh + bt[e]);
-        return dz;
+    // dz = dy * dropout mask * silu'(z) for one vector: one hash word per pair of channels
+    auto dz_vec = [&](int p, const float (&xh)[VEC], float (&d)[VEC]) {
+        if (a.drop_p > 0.f) {
+            const unsigned q0 = (idx0 + (unsigned)p * (unsigned)s.C) >> 1;
+#pragma unroll
+            for (int e = 0; e < VEC; e += 2) {
+                const unsigned w = dropout_word32(h0, q0 + (e >> 1));
+                d[e] = (w & 0xffffu) >= a.thresh16 ? d[e] * keep_scale : 0.f;
+                d[e + 1] = (w >> 16) >= a.thresh16 ? d[e + 1] * keep_scale : 0.f;
+            }
+        }
+        if (a.silu) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) d[e] *= silu_grad_fast_(gm[e] * xh[e] + bt[e]);
+        }
     };
     float a1[VEC], a2[VEC];
 #pragma unroll
@@ -491,14 +522,14 @@ void gn_lds_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __r
         gn_wait_vm<2 * (NV - 1 - i)>(0);
         const int p = prow + i * f.rows_per_iter;
         if (active && p < s.HW) {
-            float fx[VEC], fd[VEC];
+            float fx[VEC], fd[VEC], xh[VEC];
             Elem<T>::unpack(myx[i * 512], fx); Elem<T>::unpack(vd[i], fd);
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) {
-                const float xh = (fx[e] - mean[e]) * rstd[e];
-                const float dz = dz_of(p, e, xh, fd[e]);
-                a1[e] += dz * xh; a2[e] += dz;
-            }
+            for (int e = 0; e < VEC; ++e) xh[e] = (fx[e] - mean[e]) * rstd[e];
+            dz_vec(p, xh, fd);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) { a1[e] += fd[e] * xh[e]; a2[e] += fd[e]; }
+            vd[i] = Elem<T>::pack(fd);                         // pass 2 reuses dz (stored at the tensor dtype, as an autograd graph would) instead of redoing the mask and silu'
         }
     });
     const float inv_n = 1.0f / ((float)s.HW * s.cpg);
@@ -541,8 +572,7 @@ void gn_lds_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __r
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
                 const float xh = (fx[e] - mean[e]) * rstd[e];
-                const float dz = dz_of(p, e, xh, fd[e]);
-                float r = rstd[e] * (dz * gm[e] - xh * c1[e] - c2[e]);
+                float r = rstd[e] * (fd[e] * gm[e] - xh * c1[e] - c2[e]);          // fd holds dz here
                 if (addp) r += ad[e];
                 o[e] = accumulate ? o[e] + r : r;
             }
@@ -571,10 +601,12 @@ void gn_lds_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, GnShape s, Gn
     extern __shared__ __attribute__((aligned(16))) char lsm[];
     char* xs = lsm;
     float* sh_row = reinterpret_cast<float*>(lsm + NV * 512 * 16);
-    float* sh_ch = sh_row + ((64 % f.seg_vecs) ? f.rows_per_iter * f.seg_ch : 8 * f.seg_ch);
+    float* sh_ch = sh_row + 8 * f.seg_ch;
     float* sh_mean = sh_ch + f.seg_ch;
     float* sh_rstd = sh_mean + 32;
-    const int b = blockIdx.y, c0 = blockIdx.x * f.seg_ch, tid = threadIdx.x;
+    int b, chunk;
+    gn_block_slice(f, b, chunk);
+    const int c0 = chunk * f.seg_ch, tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool active = tid < f.nta;
     const int j = tid % f.seg_vecs, prow = tid / f.seg_vecs;
@@ -631,7 +663,7 @@ void gn_lds_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, GnShape s, Gn
         const float rstd = 1.0f / sqrtf(acc / n + a.eps);
         sh_rstd[tid] = rstd;
         if (a.stats) {
-            const long long gi = (long long)b * s.G + blockIdx.x * f.GPB + tid;
+            const long long gi = (long long)b * s.G + chunk * f.GPB + tid;
             a.stats[gi * 2] = sh_mean[tid]; a.stats[gi * 2 + 1] = rstd;
         }
     }
@@ -657,8 +689,16 @@ void gn_lds_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, GnShape s, Gn
         for (int e = 0; e < VEC; ++e) {
             float z = fv[e] * ca[e] + cb[e];
             if (a.silu) z = silu_fast_(z);
-            if (a.drop_p > 0.f) z = dropout_keep32(h0, idx0 + (unsigned)p * (unsigned)s.C + (unsigned)e, a.thresh24) ? z * keep_scale : 0.f;
             fv[e] = z;
+        }
+        if (a.drop_p > 0.f) {
+            const unsigned q0 = (idx0 + (unsigned)p * (unsigned)s.C) >> 1;
+#pragma unroll
+            for (int e = 0; e < VEC; e += 2) {
+                const unsigned w = dropout_word32(h0, q0 + (e >> 1));
+                fv[e] = (w & 0xffffu) >= a.thresh16 ? fv[e] * keep_scale : 0.f;
+                fv[e + 1] = (w >> 16) >= a.thresh16 ? fv[e + 1] * keep_scale : 0.f;
+            }
         }
         stg16(yb + (long long)p * s.y_ld, Elem<T>::pack(fv));
     }
@@ -692,12 +732,14 @@ static bool gn_lds_plan(const GnShape& s, int esize, GnFused& f, size_t& lds_byt
     f.nv = (s.HW + f.rows_per_iter - 1) / f.rows_per_iter;
     if (f.nv > 8) return false;
     // measured (scripts/gn_bench.py, B = 128): the staged kernels win from 4 vectors per thread on (32^2 x 128: backward 51 vs 70 us,
-    // 16^2 x 256: 25 vs 44 us); slices whose vector columns do not divide a wave (384 channels: 3 / 12 vectors per pixel) would
-    // need the 16 KiB reduction scratch and one block per CU — slower than the two streaming launches (286 vs 198 us)
-    if (f.nv < 4 || 64 % f.seg_vecs) return false;
+    // 16^2 x 256: 25 vs 44 us).  Vector columns that do not divide a wave (384 channels: 3 / 12 vectors per pixel) are fine: the
+    // wave reduction is a strided tree (gn_block_channel_sum_w)
+    if (f.nv < 4 || f.seg_vecs > 32) return false;
     const int nvt = f.nv <= 1 ? 1 : f.nv <= 2 ? 2 : f.nv <= 4 ? 4 : 8;
-    const size_t scratch = (64 % f.seg_vecs) ? (size_t)f.rows_per_iter * f.seg_ch : (size_t)8 * f.seg_ch;
+    const size_t scratch = (size_t)8 * f.seg_ch;
     lds_bytes = (size_t)nvt * 512 * 16 + (scratch + f.seg_ch + 64) * sizeof(float);
+    static const bool no_remap = getenv("DDPM_GN_NO_XCD_REMAP") != nullptr;
+    f.xcd_remap = no_remap ? 0 : 1;
     return lds_bytes <= 160 * 1024 && (long long)s.B * s.HW * s.C < (1ll << 32);
 }
 
@@ -761,7 +803,7 @@ __global__ void gn_bwd_reduce_kernel(const T* __restrict__ x, const T* __restric
             float dz = d[j];
             if (a.drop_p > 0.f) {
                 unsigned long long idx = ((unsigned long long)b * s.HW + p) * s.C + cx * VEC + j;
-                dz = dropout_keep(seed, idx, a.thresh24) ? dz * keep_scale : 0.f;
+                dz = dropout_keep(seed, idx, a.thresh16) ? dz * keep_scale : 0.f;
             }
             if (a.silu) dz *= silu_gradf_(gm[j] * xh + bt[j]);
             a1[j] += dz * xh; a2[j] += dz;
@@ -842,7 +884,7 @@ __global__ void gn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict
             float dz = d[j];
             if (a.drop_p > 0.f) {
                 unsigned long long idx = ((unsigned long long)b * s.HW + p) * s.C + cx * VEC + j;
-                dz = dropout_keep(seed, idx, a.thresh24) ? dz * keep_scale : 0.f;
+                dz = dropout_keep(seed, idx, a.thresh16) ? dz * keep_scale : 0.f;
             }
             if (a.silu) dz *= silu_gradf_(gm[j] * xh + bt[j]);
             float r = rstd[j] * (dz * gm[j] - xh * c1[j] - c2[j]);
@@ -925,8 +967,7 @@ static int gn_geometry(int B, int HW, int C, int G, long long x_ld, long long y_
 static GnApply make_apply(const float* gamma, const float* beta, float eps, int silu, float drop_p, unsigned long long seed, float* stats,
                           const unsigned long long* seed_dev = nullptr) {
     GnApply a; a.seed_dev = seed_dev; a.gamma = gamma; a.beta = beta; a.eps = eps; a.silu = silu; a.drop_p = drop_p; a.seed = seed; a.stats = stats;
-    double th = (double)drop_p * 16777216.0;
-    a.thresh24 = th <= 0 ? 0u : (th >= 16777216.0 ? 16777216u : (unsigned)(th + 0.5));
+    a.thresh16 = dropout_thresh16(drop_p);
     return a;
 }
 

@@ -42,8 +42,6 @@ struct Wg3Args {
     int stages, stages_per_split;
     int tiles_n, tiles_c;
     int atomic;                      // 1: atomicAdd into dw / dbias; 0: plain stores into slab copy `split`
-    unsigned long long* dbg;         // ABL & 32 builds: per-wave cycle totals [block][wave][4] = {loop, barrier wait, lgkm waits, dma wait}
-    int ablate;                      // timing experiments only (DDPM_WG_ABLATE): 1 no DMA, 2 no MFMA, 4 no fragment reads, 8 no output
     FastDiv d_tiles, d_tiles_c, d_tpi, d_tiles_x, d_halo_img, d_halo_w;
 };
 
@@ -68,7 +66,7 @@ __device__ __forceinline__ uint2 tr_read(const char* p) {
 // RING: LDS stages in flight + 1.  NI_DY / NI_X: DMA instructions per thread per stage for the dy tile / the halo.
 // Wave w = (k group w >> 1, out-channel half w & 1).  16-wide patches: k group g owns patch rows 4g .. 4g+3 of the stage;
 // smaller images: k-steps g, g + 4, ...
-template <int STAGE_PX, int PW, int RING, int ABL = 0>      // ABL: compile-time ablations for timing experiments (4 no fragment reads, 16 no barrier)
+template <int STAGE_PX, int PW, int RING>
 __global__ __launch_bounds__(512, 2)
 void wgrad3x3_kernel(Wg3Args a) {
     constexpr int KSTEPS = STAGE_PX / 16;                  // 16-pixel k-steps per stage
@@ -183,7 +181,7 @@ void wgrad3x3_kernel(Wg3Args a) {
     // first version of this kernel spent 4.5 us per stage against 1.1 us of MFMA work).  With asm reads the LGKM counter is
     // ours to manage: a group of reads is issued one MFMA group ahead of its use and retired by `s_waitcnt lgkmcnt(0)` tied to
     // the destination registers (in/out operands), so no MFMA can be scheduled above the wait that covers its operands.
-#define TR_READ(dst, addr, off) do { if constexpr (!(ABL & 4)) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off)); else dst = uint2{addr, (unsigned)(off)}; } while (0)
+#define TR_READ(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
     struct Frag { uint2 lo, hi; };
     auto frag4 = [](const Frag& f) { return __builtin_bit_cast(bf16x8, u32x4{f.lo.x, f.lo.y, f.hi.x, f.hi.y}); };
     auto bias_add = [&](const Frag& f) {
@@ -209,10 +207,10 @@ void wgrad3x3_kernel(Wg3Args a) {
 #define READ_A(FA) do { _Pragma("unroll") for (int j = 0; j < 4; ++j) { TR_READ(FA[j].lo, abase, j * 16 * DY_ROW); TR_READ(FA[j].hi, abase, j * 16 * DY_ROW + 4 * DY_ROW); } } while (0)
 #define WAIT_A(FA) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(FA[0].lo), "+v"(FA[0].hi), "+v"(FA[1].lo), "+v"(FA[1].hi), "+v"(FA[2].lo), "+v"(FA[2].hi), "+v"(FA[3].lo), "+v"(FA[3].hi) :: "memory")
 #define MMA_ROW(FA, F, hr) do { _Pragma("unroll") for (int r = 0; r < 3; ++r) { const int j = (hr) - r; if (j >= 0 && j < 4) { _Pragma("unroll") for (int sft = 0; sft < 3; ++sft) \
-            if constexpr (!(ABL & 2)) acc[r * 3 + sft] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag4(FA[j]), frag4(F[sft]), acc[r * 3 + sft], 0, 0, 0); } } } while (0)
+            acc[r * 3 + sft] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag4(FA[j]), frag4(F[sft]), acc[r * 3 + sft], 0, 0, 0); } } } while (0)
 #pragma unroll
         for (int t = 0; t < RING; ++t)
-            if (t < nst && !(ABL & 1)) issue_stage(st_begin + t, t);
+            if (t < nst) issue_stage(st_begin + t, t);
         if (nst >= 3) wait_vm<2 * PER>(); else if (nst == 2) wait_vm<PER>(); else wait_vm<0>();
         __builtin_amdgcn_s_barrier();
         unsigned abase, blo0, bhi0;
@@ -222,40 +220,33 @@ void wgrad3x3_kernel(Wg3Args a) {
             READ_A(fa); READ_ROW(f4, 4);
             WAIT_A(fa); WAIT3(f4);
         }
-        unsigned long long t_loop = 0, t_bar = 0, t_lgkm = 0, t_dma = 0, tq = 0;
-#define TICK() (ABL & 32 ? __builtin_amdgcn_s_memtime() : 0ull)
-#define TW(stmt) do { if constexpr (ABL & 32) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); stmt; asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); t_lgkm += __builtin_amdgcn_s_memtime() - t_; } else { stmt; } } while (0)
-        if constexpr (ABL & 32) t_loop = __builtin_amdgcn_s_memtime();
         for (int it = 0; it < nst; ++it) {
             if (want_bias) { bias_add(fa[0]); bias_add(fa[1]); bias_add(fa[2]); bias_add(fa[3]); }
             Frag* f5 = f50; Frag* f0 = f50 + 3;
             READ_ROW(f5, 5); READ_ROW(f0, 0);
             MMA_ROW(fa, f4, 4);
-            TW(WAIT3(f5); WAIT3(f0));
+            WAIT3(f5); WAIT3(f0);
             READ_ROW(f1, 1);
             MMA_ROW(fa, f5, 5); MMA_ROW(fa, f0, 0);
-            TW(WAIT3(f1));
+            WAIT3(f1);
             READ_ROW(f2, 2);
             MMA_ROW(fa, f1, 1);
-            TW(WAIT3(f2));
+            WAIT3(f2);
             READ_ROW(f3, 3);
             MMA_ROW(fa, f2, 2);
-            TW(WAIT3(f3));
+            WAIT3(f3);
             // every LDS read of this stage has returned: after the barrier its slot may be refilled.  Stage it+1 must have landed
             // (one newer stage, it+2, may stay in flight).
             const bool more = it + 1 < nst;
-            if constexpr (ABL & 32) tq = __builtin_amdgcn_s_memtime();
             if (more) { if (it + 2 < nst) wait_vm<PER>(); else wait_vm<0>(); }
-            if constexpr (ABL & 32) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long t2 = __builtin_amdgcn_s_memtime(); t_dma += t2 - tq; tq = t2; }
-            if constexpr (!(ABL & 16)) __builtin_amdgcn_s_barrier();
-            if constexpr (ABL & 32) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); t_bar += __builtin_amdgcn_s_memtime() - tq; }
+            __builtin_amdgcn_s_barrier();
             Frag na[4], n4[3];
             if (more) {
                 bases((it + 1) % RING, abase, blo0, bhi0);
                 READ_A(na); READ_ROW(n4, 4);
             }
             MMA_ROW(fa, f3, 3);
-            if (it + RING < nst && !(ABL & 1)) issue_stage(st_begin + it + RING, it % RING);
+            if (it + RING < nst) issue_stage(st_begin + it + RING, it % RING);
             if (more) {
                 WAIT_A(na); WAIT3(n4);
 #pragma unroll
@@ -265,15 +256,7 @@ void wgrad3x3_kernel(Wg3Args a) {
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if constexpr (ABL & 32) {
-            if (a.dbg && lane == 0) {
-                unsigned long long* o = a.dbg + ((long long)blockIdx.x * 8 + wave) * 4;
-                o[0] = __builtin_amdgcn_s_memtime() - t_loop; o[1] = t_bar; o[2] = t_lgkm; o[3] = t_dma;
-            }
-        }
         __syncthreads();
-#undef TW
-#undef TICK
 #undef READ_ROW
 #undef READ_A
 #undef WAIT_A
@@ -282,14 +265,14 @@ void wgrad3x3_kernel(Wg3Args a) {
     // ---- small images.  Prologue: RING-1 stages in flight, wait for the first
 #pragma unroll
     for (int t = 0; t < RING - 1; ++t)
-        if (t < nst && !(ABL & 1)) issue_stage(st_begin + t, t);
+        if (t < nst) issue_stage(st_begin + t, t);
     wait_inflight(min(RING - 2, nst - 1));
     __builtin_amdgcn_s_barrier();
 
     for (int it = 0; it < nst; ++it) {
         const int slot = it % RING;
         // the stage RING-1 ahead goes into the slot read in iteration it-1 (every wave is past the barrier that ended it)
-        if (it + RING - 1 < nst && !(ABL & 1)) issue_stage(st_begin + it + RING - 1, (it + RING - 1) % RING);
+        if (it + RING - 1 < nst) issue_stage(st_begin + it + RING - 1, (it + RING - 1) % RING);
         const unsigned stage0 = lds0 + slot * STAGE_BYTES;
         {
             // a k-step covers 16 / PW patch rows; per k-step one dy fragment and nine halo fragments, read in groups of three
@@ -331,7 +314,7 @@ void wgrad3x3_kernel(Wg3Args a) {
                 }
 #pragma unroll
                 for (int sft = 0; sft < 3; ++sft)
-                    if constexpr (!(ABL & 2)) acc[r * 3 + sft] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag4(fa[u]), frag4(cur[sft]), acc[r * 3 + sft], 0, 0, 0);
+                    acc[r * 3 + sft] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag4(fa[u]), frag4(cur[sft]), acc[r * 3 + sft], 0, 0, 0);
                 if (g + 1 < 3 * KPW) WAIT3(nxt);
             }
         }
@@ -383,7 +366,6 @@ void wgrad3x3_kernel(Wg3Args a) {
             for (int r = 0; r < 16; ++r) otile[((nb + (r & 3) + 8 * (r >> 2)) * 9 + t) * TC + cc] = acc[t][r];
     }
     __syncthreads();
-    if constexpr (ABL & 8) return;
     float* out = a.dw + (a.atomic ? 0 : (long long)split * a.slab_stride);
     for (int v = tid; v < TN * 9 * (TC / 4); v += 512) {   // 4608 vectors of 4 floats: row = (n, tap), 8 vectors per row
         const int row = v >> 3, c4 = (v & 7) * 4;
@@ -471,7 +453,6 @@ extern "C" int ddpm_conv3x3_wgrad_nhwc(const void* dy, long long dy_ld, const vo
     a.tiles_y = H / p.PH; a.tiles_x = W / p.PW;
     a.stages = p.stages; a.stages_per_split = p.per; a.tiles_n = p.tiles_n; a.tiles_c = p.tiles_c;
     a.atomic = slab_stride == 0;
-    { const char* e = getenv("DDPM_WG_ABLATE"); a.ablate = e ? atoi(e) : 0; const char* d = getenv("DDPM_WG_DBGPTR"); a.dbg = d ? (unsigned long long*)strtoull(d, nullptr, 10) : nullptr; }
     a.d_tiles = make_fastdiv((unsigned)(p.tiles_n * p.tiles_c)); a.d_tiles_c = make_fastdiv((unsigned)p.tiles_c);
     a.d_tpi = make_fastdiv((unsigned)(a.tiles_y * a.tiles_x)); a.d_tiles_x = make_fastdiv((unsigned)a.tiles_x);
     a.d_halo_img = make_fastdiv((unsigned)((p.PH + 2) * (p.PW + 2))); a.d_halo_w = make_fastdiv((unsigned)(p.PW + 2));
@@ -492,14 +473,7 @@ extern "C" int ddpm_conv3x3_wgrad_nhwc(const void* dy, long long dy_ld, const vo
         }                                                                                                                         \
         hipLaunchKernelGGL((wgrad3x3_kernel<SPX, PWV, RINGV>), grid, dim3(512), LDS, st, a);                                      \
     } while (0)
-    if (p.stage_px == 256 && a.ablate) {
-        const int ab = a.ablate;
-        constexpr int LDS = 3 * (256 * 128 + 336 * 64) + 1024;
-#define WG_ABL(V) do { hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3_kernel<256, 16, 3, V>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS); \
-                       hipLaunchKernelGGL((wgrad3x3_kernel<256, 16, 3, V>), grid, dim3(512), LDS, st, a); } while (0)
-        if (ab == 9) WG_ABL(9); else if (ab == 2) WG_ABL(2); else if (ab == 1) WG_ABL(1); else if (ab == 8) WG_ABL(8); else if (ab == 25) WG_ABL(25); else if (ab == 32) WG_ABL(32); else if (ab == 41) WG_ABL(41); else WG_ABL(10);
-#undef WG_ABL
-    } else if (p.stage_px == 256) WG_LAUNCH(256, 16, 3);            // 3 x (32 KiB dy + 21 KiB halo) + 1 KiB = 160 KiB
+    if (p.stage_px == 256) WG_LAUNCH(256, 16, 3);            // 3 x (32 KiB dy + 21 KiB halo) + 1 KiB = 160 KiB
     else if (p.PW == 8) WG_LAUNCH(128, 8, 4);
     else WG_LAUNCH(128, 4, 4);
 #undef WG_LAUNCH

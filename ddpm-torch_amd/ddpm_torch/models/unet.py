@@ -248,6 +248,7 @@ _FOLD_MAX_CHANNELS = 128
 _FOLD_MIN_PIXELS = 16384            # below this the small-grid kernels serve the layer better than the 256-pixel-tile conv
 _FOLD_GN = os.environ.get("DDPM_FOLD_GN", "1") != "0"               # inference: GroupNorm+SiLU folded into the 3x3 convs
 _SIDE_STREAM = os.environ.get("DDPM_SIDE_STREAM", "1") != "0"      # weight / bias gradients on a second HIP stream
+_WGRAD_MINSTEPS = int(os.environ.get("DDPM_WGRAD_MINSTEPS", "20"))
 _WGRAD_SLABS = os.environ.get("DDPM_WGRAD_SLABS", "0") != "0"      # deterministic slab reduction instead of atomics
 _WGRAD3 = os.environ.get("DDPM_WGRAD3", "1") != "0"                # patch-stationary kernel for the 3x3 / stride-1 weight gradients
 _WGRAD3_ATOMIC = os.environ.get("DDPM_WGRAD3_ATOMIC", "0") != "0"  # ... with fp32 atomics instead of slab copies
@@ -957,7 +958,7 @@ class _Engine:
         K-steps to amortise them: >= 20 when K allows it, >= 8 on the short reductions (scripts/microbench.py sweeps)."""
         tiles = -(-M // 128) * -(-N // 128)
         ksteps = -(-K // (8 * self.vec))
-        return max(1, min(_WGRAD_TARGET_BLOCKS // tiles, ksteps // (20 if ksteps >= 100 else 8)))
+        return max(1, min(_WGRAD_TARGET_BLOCKS // tiles, ksteps // (_WGRAD_MINSTEPS if ksteps >= 100 else min(8, _WGRAD_MINSTEPS))))
 
     def _bias_grad(self, ctx, dy, biases, creal, slot=None):
         """db[c] = sum over pixels and batch of dy.  One owner: atomics straight into its gradient.  Several owners or a

@@ -21,6 +21,8 @@ def timeit(fn, n=20):
 
 
 tot_f = tot_b = 0.0
+if os.environ.get('GN_ONLY'):
+    SHAPES = SHAPES[:int(os.environ['GN_ONLY'])]
 for H, C, cnt in SHAPES:
     x = View(torch.randn(B, H, H, C, device="cuda").bfloat16(), B, H, H, C)
     y, dy, dx = (View(torch.randn(B, H, H, C, device="cuda").bfloat16(), B, H, H, C) for _ in range(3))
@@ -32,6 +34,7 @@ for H, C, cnt in SHAPES:
     tf = timeit(lambda: ops.gn_fwd(x, y, g, bt, stats, ws, silu=SILU, drop_p=DROP, seed=123))
     tb = timeit(lambda: ops.gn_bwd(x, dy, dx, g, bt, stats, dg.data_ptr(), db.data_ptr(), ws, silu=SILU, drop_p=DROP, seed=123, colsum_ptr=cs.data_ptr(), colsum_ld=C))
     mb = B * H * H * C * 2 / 1e6
-    print(f"{H:2d}^2 x {C:3d} x{cnt:2d}: fwd {tf:6.1f} us ({2 * mb / tf:5.2f} TB/s)  bwd {tb:6.1f} us ({3 * mb / tb:5.2f} TB/s)", flush=True)
+    tc = timeit(lambda: y.base.copy_(x.base))
+    print(f"{H:2d}^2 x {C:3d} x{cnt:2d}: fwd {tf:6.1f} us ({2 * mb / tf:5.2f} TB/s)  bwd {tb:6.1f} us ({3 * mb / tb:5.2f} TB/s)   [copy_ {tc:5.1f} us {2 * mb / tc:5.2f} TB/s]", flush=True)
     tot_f += tf * cnt; tot_b += tb * cnt
 print(f"network totals: fwd {tot_f / 1e3:.3f} ms  bwd {tot_b / 1e3:.3f} ms")

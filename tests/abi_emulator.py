@@ -56,8 +56,8 @@ class Mat:
         self.view[...] = _f32_to_bf16(values).reshape(self.rows, self.cols) if self.dcode == BF16 else values
 
 
-def _keep_mask(seed, idx, thresh24):
-    """numpy mirror of dropout_keep() in csrc/common.h."""
+def _keep_mask(seed, idx, thresh16):
+    """numpy mirror of dropout_keep() in csrc/common.h: one hash word per pair of adjacent elements, 16 bits each."""
     def mix32(x):
         x = x.astype(np.uint32)
         x ^= x >> np.uint32(16); x = (x * np.uint32(0x7FEB352D)).astype(np.uint32)
@@ -65,17 +65,19 @@ def _keep_mask(seed, idx, thresh24):
         x ^= x >> np.uint32(16)
         return x
     idx = idx.astype(np.uint64)
-    lo = (idx & np.uint64(0xFFFFFFFF)).astype(np.uint32)
-    hi = (idx >> np.uint64(32)).astype(np.uint32)
+    pair = idx >> np.uint64(1)
+    lo = (pair & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+    hi = (pair >> np.uint64(32)).astype(np.uint32)
     s_lo, s_hi = np.uint32(seed & 0xFFFFFFFF), np.uint32((seed >> 32) & 0xFFFFFFFF)
     with np.errstate(over="ignore"):
-        h = mix32(lo ^ mix32((hi + s_lo).astype(np.uint32)) ^ np.uint32((int(s_hi) * 0x9E3779B9) & 0xFFFFFFFF))
-    return (h >> np.uint32(8)) >= np.uint32(thresh24)
+        w = mix32(lo ^ mix32((hi + s_lo).astype(np.uint32)) ^ np.uint32((int(s_hi) * 0x9E3779B9) & 0xFFFFFFFF))
+    field = np.where((idx & np.uint64(1)) == 1, w >> np.uint32(16), w & np.uint32(0xFFFF))
+    return field >= np.uint32(thresh16)
 
 
 def _thresh(p):
-    th = p * 16777216.0
-    return 0 if th <= 0 else (16777216 if th >= 16777216.0 else int(th + 0.5))
+    th = p * 65536.0
+    return 0 if th <= 0 else (65536 if th >= 65536.0 else int(th + 0.5))
 
 
 def _canvas(x_nchw, Ho, Wo, R, S, stride, pad_t, pad_l, upsample, dilate):
