@@ -153,6 +153,43 @@ __global__ void gn_apply_kernel(const T* __restrict__ x, T* __restrict__ y, GnSh
     }
 }
 
+// ---- per-channel / per-group constants of a thread's vector column, fetched with as few VMEM instructions as possible: an
+// instruction occupies the CU's address path for 16 clk whatever its width, and with 16 resident waves the 24-32 scalar loads
+// these constants used to cost (one per element for gamma, beta, mean, rstd) took longer than the data loads themselves.
+// group of channel c: a shift for the power-of-two group widths (everything but the 384-channel tensors)
+__device__ __forceinline__ int gn_gidx(int c, int cpg) { return (cpg & (cpg - 1)) == 0 ? c >> (__ffs(cpg) - 1) : c / cpg; }
+typedef float gn_f32x4 __attribute__((ext_vector_type(4)));
+typedef float gn_f32x2 __attribute__((ext_vector_type(2)));
+template <int VEC>
+__device__ __forceinline__ void gn_ld_channels(const float* __restrict__ p, bool ok, float (&o)[VEC]) {
+#pragma unroll
+    for (int q = 0; q < VEC; q += 4) {
+        gn_f32x4 v = (gn_f32x4)(0.f);
+        if (ok) v = *reinterpret_cast<const gn_f32x4*>(p + q);
+        o[q] = v.x; o[q + 1] = v.y; o[q + 2] = v.z; o[q + 3] = v.w;
+    }
+}
+// one load per GROUP the vector touches (1 when cpg is a multiple of the vector width, VEC / cpg when it divides it)
+template <int VEC, typename L>
+__device__ __forceinline__ void gn_per_group(int c_first, int cpg, bool ok, L&& at_group_start) {
+    const bool p2 = (cpg & (cpg - 1)) == 0;
+    const int sh = __ffs(cpg) - 1;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+        const int c = c_first + e;
+        const bool first = e == 0 || (p2 ? (c & (cpg - 1)) == 0 : c % cpg == 0);
+        at_group_start(e, first && ok, p2 ? c >> sh : c / cpg);
+    }
+}
+template <int VEC>
+__device__ __forceinline__ void gn_group_stats(const float* __restrict__ stats, long long b_G, int c_first, int cpg, bool ok, float (&mean)[VEC], float (&rstd)[VEC]) {
+    gn_f32x2 cur; cur.x = 0.f; cur.y = 1.f;
+    gn_per_group<VEC>(c_first, cpg, ok, [&](int e, bool load, int g) {
+        if (load) cur = *reinterpret_cast<const gn_f32x2*>(stats + (b_G + g) * 2);
+        mean[e] = cur.x; rstd[e] = cur.y;
+    });
+}
+
 // ---- single-launch kernels: one block owns (sample b, a chunk of GPB groups) = all HW pixels x seg_ch = GPB*cpg channels,
 // and keeps that slice (<= 64 KiB) IN REGISTERS: thread (j, prow) holds the 16-byte vector column j of pixels prow,
 // prow + R, ... (NV of them, all requested before the first is used).  Statistics and group coefficients come from an
@@ -226,7 +263,7 @@ void gn_reg_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, GnShape s, Gn
     __syncthreads();
     float mean[VEC];
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) mean[e] = sh_mean[(j * VEC + e) / s.cpg];
+    for (int e = 0; e < VEC; ++e) mean[e] = sh_mean[gn_gidx(j * VEC + e, s.cpg)];
     // centred variance
 #pragma unroll
     for (int e = 0; e < VEC; ++e) part[e] = 0.f;
@@ -254,11 +291,12 @@ void gn_reg_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, GnShape s, Gn
     __syncthreads();
     if (!active) return;
     float ca[VEC], cb[VEC];
+    gn_ld_channels<VEC>(a.gamma + c0 + j * VEC, true, ca);
+    gn_ld_channels<VEC>(a.beta + c0 + j * VEC, true, cb);
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
-        const int c = j * VEC + e;
-        ca[e] = sh_rstd[c / s.cpg] * a.gamma[c0 + c];
-        cb[e] = a.beta[c0 + c] - mean[e] * ca[e];
+        ca[e] *= sh_rstd[gn_gidx(j * VEC + e, s.cpg)];
+        cb[e] -= mean[e] * ca[e];
     }
     const float keep_scale = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
     const unsigned long long seed = gn_seed(a);
@@ -310,12 +348,9 @@ void gn_reg_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __r
         vd[i] = ok ? ldg16(db + (long long)p * dy_ld) : zero16();
     }
     float mean[VEC], rstd[VEC], gm[VEC], bt[VEC];
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) {
-        const int c = c0 + j * VEC + e, g = c / s.cpg;
-        mean[e] = stats[((long long)b * s.G + g) * 2]; rstd[e] = stats[((long long)b * s.G + g) * 2 + 1];
-        gm[e] = active ? a.gamma[c] : 0.f; bt[e] = active ? a.beta[c] : 0.f;
-    }
+    gn_group_stats<VEC>(stats, (long long)b * s.G, c0 + j * VEC, s.cpg, active, mean, rstd);
+    gn_ld_channels<VEC>(a.gamma + c0 + j * VEC, active, gm);
+    gn_ld_channels<VEC>(a.beta + c0 + j * VEC, active, bt);
     const float keep_scale = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
     const unsigned long long seed = gn_seed(a);
     auto dz_of = [&](int p, int e, float xh, float d) -> float {
@@ -371,7 +406,7 @@ void gn_reg_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __r
     if (!active) return;
     float c1[VEC], c2[VEC];
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) { const int g = (j * VEC + e) / s.cpg; c1[e] = sh_c1[g]; c2[e] = sh_c2[g]; }
+    for (int e = 0; e < VEC; ++e) { const int g = gn_gidx(j * VEC + e, s.cpg); c1[e] = sh_c1[g]; c2[e] = sh_c2[g]; }
     T* ob = dx + ((long long)b * s.HW) * dx_ld + c0 + j * VEC;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -403,35 +438,87 @@ void gn_reg_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __r
 // and no barrier is needed between the passes.
 // Block reduction of per-thread channel partials for these kernels: butterfly over the lanes of a wave that hold the same
 // vector column (needs seg_vecs | 64), then a fixed-order sum over the 8 waves — 1 KiB of scratch instead of 16 KiB.
-template <int VEC>
-__device__ __forceinline__ void gn_block_channel_sum_w(const float (&part)[VEC], const GnFused& f, bool active, int j, int prow, int tid,
-                                                       float* sh_row, float* sh_ch) {
-    // lanes l, l + seg_vecs, l + 2 seg_vecs, ... of a wave hold the same vector column: strided tree (any seg_vecs <= 32, also the
-    // 3 / 6 / 12 vectors per pixel of the 384-channel tensors), after which lanes < seg_vecs hold their column's wave total
-    float v[VEC];
+// Wave stage for power-of-two seg_vecs: a butterfly that HALVES the payload at every step — the lane whose bit `OFF` is set keeps
+// the upper half of its values and sends the lower half to its partner (and vice versa), so 16 values cross the wave in
+// 8 + 4 + 2 + 1 exchanges instead of 4 x 16 (the exchanges go through the LDS crossbar; with 16 resident waves they were the
+// most expensive part of the statistics).  Each lane ends with the wave totals of the values base .. base + CNT - 1.
+template <int CNT, int OFF, typename W>
+__device__ __forceinline__ void gn_lane_reduce(float (&v)[CNT], int sv, int lane, int base, W&& write) {
+    if constexpr (OFF == 0) {
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) v[e] = active ? part[e] : 0.f;
-    const int lane = tid & 63;
-    int top = f.seg_vecs;
-    while (top * 2 < 64) top *= 2;
-    for (int off = top; off >= f.seg_vecs; off >>= 1) {
-        const bool in = lane + off < 64;
+        for (int k = 0; k < CNT; ++k) write(base + k, v[k]);
+    } else {
+        if (OFF < sv) {
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) { const float o = __shfl_down(v[e], off, 64); v[e] += in ? o : 0.f; }
+            for (int k = 0; k < CNT; ++k) write(base + k, v[k]);
+            return;
+        }
+        if constexpr (CNT > 1) {
+            const bool bit = (lane & OFF) != 0;
+            float o[CNT / 2];
+#pragma unroll
+            for (int k = 0; k < CNT / 2; ++k) {
+                const float send = bit ? v[k] : v[k + CNT / 2], keep = bit ? v[k + CNT / 2] : v[k];
+                o[k] = keep + __shfl_xor(send, OFF, 64);
+            }
+            gn_lane_reduce<CNT / 2, OFF / 2>(o, sv, lane, base + (bit ? CNT / 2 : 0), write);
+        } else {
+            v[0] += __shfl_xor(v[0], OFF, 64);
+            gn_lane_reduce<1, OFF / 2>(v, sv, lane, base, write);
+        }
     }
+}
+
+// NARR partial vectors at once (same barriers): sh_row holds NARR x [8 waves][seg_ch], sh_ch NARR x [seg_ch]
+template <int VEC, int NARR>
+__device__ __forceinline__ void gn_block_sum_w(float (&v)[NARR * VEC], const GnFused& f, int j, int tid, float* sh_row, float* sh_ch) {
+    const int lane = tid & 63, wave = tid >> 6;
     __syncthreads();                                  // previous users of the scratch are done
-    if (lane < f.seg_vecs) {
+    if ((f.seg_vecs & (f.seg_vecs - 1)) == 0) {
+        gn_lane_reduce<NARR * VEC, 32>(v, f.seg_vecs, lane, 0, [&](int gi, float val) {
+            const int m = gi / VEC, e = gi - m * VEC;        // VEC is a compile-time power of two
+            sh_row[(m * 8 + wave) * f.seg_ch + j * VEC + e] = val;      // lanes holding copies of a total store the same value
+        });
+    } else {
+        // lanes l, l + seg_vecs, l + 2 seg_vecs, ... hold the same vector column (3 / 6 / 12 vectors per pixel of the 384-channel
+        // tensors): strided tree, after which lanes < seg_vecs hold their column's wave total
+        int top = f.seg_vecs;
+        while (top * 2 < 64) top *= 2;
+        for (int off = top; off >= f.seg_vecs; off >>= 1) {
+            const bool in = lane + off < 64;
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) sh_row[(tid >> 6) * f.seg_ch + j * VEC + e] = v[e];
+            for (int e = 0; e < NARR * VEC; ++e) { const float o = __shfl_down(v[e], off, 64); v[e] += in ? o : 0.f; }
+        }
+        if (lane < f.seg_vecs) {
+#pragma unroll
+            for (int gi = 0; gi < NARR * VEC; ++gi) sh_row[((gi / VEC) * 8 + wave) * f.seg_ch + j * VEC + (gi % VEC)] = v[gi];
+        }
     }
     __syncthreads();
-    for (int c = tid; c < f.seg_ch; c += 512) {
+    for (int c = tid; c < NARR * f.seg_ch; c += 512) {
+        const int m = c / f.seg_ch, cc = c - m * f.seg_ch;
         float acc = 0.f;
 #pragma unroll
-        for (int w = 0; w < 8; ++w) acc += sh_row[w * f.seg_ch + c];
+        for (int w = 0; w < 8; ++w) acc += sh_row[(m * 8 + w) * f.seg_ch + cc];
         sh_ch[c] = acc;
     }
     __syncthreads();
+}
+template <int VEC>
+__device__ __forceinline__ void gn_block_channel_sum_w(const float (&part)[VEC], const GnFused& f, bool active, int j, int prow, int tid,
+                                                       float* sh_row, float* sh_ch) {
+    float v[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) v[e] = active ? part[e] : 0.f;
+    gn_block_sum_w<VEC, 1>(v, f, j, tid, sh_row, sh_ch);
+}
+template <int VEC>
+__device__ __forceinline__ void gn_block_channel_sum2_w(const float (&pa)[VEC], const float (&pb)[VEC], const GnFused& f, bool active, int j, int tid,
+                                                        float* sh_row, float* sh_ch) {
+    float v[2 * VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { v[e] = active ? pa[e] : 0.f; v[VEC + e] = active ? pb[e] : 0.f; }
+    gn_block_sum_w<VEC, 2>(v, f, j, tid, sh_row, sh_ch);
 }
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t gn_slice_rsrc(const void* base, long long bytes) {
@@ -440,6 +527,14 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t gn_slice_rsrc(const void* base
     return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0,
                                              __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
 }
+
+#ifdef GN_TIMING
+__device__ unsigned long long* g_gn_timing = nullptr;          // debug builds only (scripts/gn_timeline.sh): [block][8] stamps
+#define GN_STAMP(slot) do { if (g_gn_timing && threadIdx.x == 0) g_gn_timing[(blockIdx.y * gridDim.x + blockIdx.x) * 8 + (slot)] = (slot) == 0 || (slot) == 7 ? wall_clock64() : clock64(); } while (0)
+extern "C" int ddpm_debug_set_gn_timing(void* p) { return hipMemcpyToSymbol(HIP_SYMBOL(g_gn_timing), &p, sizeof(p)) == hipSuccess ? 0 : -1; }
+#else
+#define GN_STAMP(slot)
+#endif
 
 // Block -> (sample, channel chunk) for the LDS kernels.  The chunks of one sample split every 128-byte line of its rows between
 // them; consecutive workgroup ids go round-robin over the 8 XCDs (one L2 each), so with the plain (chunk, sample) grid the parts
@@ -466,8 +561,8 @@ void gn_lds_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __r
     extern __shared__ __attribute__((aligned(16))) char lsm[];
     char* xs = lsm;                                               // [NV][512] vectors of x
     float* sh_row = reinterpret_cast<float*>(lsm + NV * 512 * 16);
-    float* sh_ch = sh_row + 8 * f.seg_ch;
-    float* sh_c1 = sh_ch + f.seg_ch;
+    float* sh_ch = sh_row + 16 * f.seg_ch;
+    float* sh_c1 = sh_ch + 2 * f.seg_ch;
     float* sh_c2 = sh_c1 + 32;
     int b, chunk;
     gn_block_slice(f, b, chunk);
@@ -478,12 +573,9 @@ void gn_lds_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __r
     const __amdgpu_buffer_rsrc_t rx = gn_slice_rsrc(x + ((long long)b * s.HW) * s.x_ld + c0, ((long long)(s.HW - 1) * s.x_ld + f.seg_ch) * ES);
     // per-channel constants first: ordinary loads issued BEFORE the DMA can be waited for with a counted vmcnt
     float mean[VEC], rstd[VEC], gm[VEC], bt[VEC];
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) {
-        const int c = c0 + j * VEC + e, g = active ? c / s.cpg : 0;
-        mean[e] = stats[((long long)b * s.G + g) * 2]; rstd[e] = stats[((long long)b * s.G + g) * 2 + 1];
-        gm[e] = active ? a.gamma[c] : 0.f; bt[e] = active ? a.beta[c] : 0.f;
-    }
+    gn_group_stats<VEC>(stats, (long long)b * s.G, c0 + j * VEC, s.cpg, active, mean, rstd);
+    gn_ld_channels<VEC>(a.gamma + c0 + j * VEC, active, gm);
+    gn_ld_channels<VEC>(a.beta + c0 + j * VEC, active, bt);
     const T* db = dy + ((long long)b * s.HW) * dy_ld + c0 + j * VEC;
     u32x4 vd[NV];
 #pragma unroll
@@ -533,32 +625,25 @@ void gn_lds_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __r
         }
     });
     const float inv_n = 1.0f / ((float)s.HW * s.cpg);
-    gn_block_channel_sum_w<VEC>(a1, f, active, j, prow, tid, sh_row, sh_ch);
-    for (int c = tid; c < f.seg_ch; c += 512) {
-        if (dgamma) atomicAdd(dgamma + c0 + c, sh_ch[c]);
-        sh_ch[c] *= a.gamma[c0 + c];
+    gn_block_channel_sum2_w<VEC>(a1, a2, f, active, j, tid, sh_row, sh_ch);        // sh_ch = [A1 | A2]
+    for (int c = tid; c < 2 * f.seg_ch; c += 512) {
+        const bool second = c >= f.seg_ch;
+        const int cc = second ? c - f.seg_ch : c;
+        float* dst = second ? dbeta : dgamma;
+        if (dst) atomicAdd(dst + c0 + cc, sh_ch[c]);
+        sh_ch[c] *= a.gamma[c0 + cc];
     }
     __syncthreads();
-    if (tid < f.GPB) {
+    if (tid < 2 * f.GPB) {
+        const int second = tid >= f.GPB, g = tid - second * f.GPB;
         float acc = 0.f;
-        for (int c = tid * s.cpg; c < (tid + 1) * s.cpg; ++c) acc += sh_ch[c];
-        sh_c1[tid] = acc * inv_n;
-    }
-    gn_block_channel_sum_w<VEC>(a2, f, active, j, prow, tid, sh_row, sh_ch);
-    for (int c = tid; c < f.seg_ch; c += 512) {
-        if (dbeta) atomicAdd(dbeta + c0 + c, sh_ch[c]);
-        sh_ch[c] *= a.gamma[c0 + c];
-    }
-    __syncthreads();
-    if (tid < f.GPB) {
-        float acc = 0.f;
-        for (int c = tid * s.cpg; c < (tid + 1) * s.cpg; ++c) acc += sh_ch[c];
-        sh_c2[tid] = acc * inv_n;
+        for (int c = g * s.cpg; c < (g + 1) * s.cpg; ++c) acc += sh_ch[second * f.seg_ch + c];
+        (second ? sh_c2 : sh_c1)[g] = acc * inv_n;
     }
     __syncthreads();
     float c1[VEC], c2[VEC], cs[VEC];
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) { const int g = active ? (j * VEC + e) / s.cpg : 0; c1[e] = sh_c1[g]; c2[e] = sh_c2[g]; cs[e] = 0.f; }
+    for (int e = 0; e < VEC; ++e) { const int g = active ? gn_gidx(j * VEC + e, s.cpg) : 0; c1[e] = sh_c1[g]; c2[e] = sh_c2[g]; cs[e] = 0.f; }
     T* ob = dx + ((long long)b * s.HW) * dx_ld + c0 + j * VEC;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -592,7 +677,7 @@ void gn_lds_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __r
     }
 }
 
-// forward twin: x slice in LDS; mean, then the centred variance (second pass over LDS, exact two-pass statistics), then
+// forward twin: x slice in LDS; pivot-shifted moments accumulated while the slice lands (one pass), then
 // y = drop(silu(x * a_c + b_c)) streamed out.
 template <typename T, int NV>
 __global__ __launch_bounds__(512, 4)
@@ -601,9 +686,10 @@ void gn_lds_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, GnShape s, Gn
     extern __shared__ __attribute__((aligned(16))) char lsm[];
     char* xs = lsm;
     float* sh_row = reinterpret_cast<float*>(lsm + NV * 512 * 16);
-    float* sh_ch = sh_row + 8 * f.seg_ch;
-    float* sh_mean = sh_ch + f.seg_ch;
+    float* sh_ch = sh_row + 16 * f.seg_ch;
+    float* sh_mean = sh_ch + 2 * f.seg_ch;
     float* sh_rstd = sh_mean + 32;
+    GN_STAMP(0); GN_STAMP(1);
     int b, chunk;
     gn_block_slice(f, b, chunk);
     const int c0 = chunk * f.seg_ch, tid = threadIdx.x;
@@ -611,9 +697,17 @@ void gn_lds_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, GnShape s, Gn
     const bool active = tid < f.nta;
     const int j = tid % f.seg_vecs, prow = tid / f.seg_vecs;
     const __amdgpu_buffer_rsrc_t rx = gn_slice_rsrc(x + ((long long)b * s.HW) * s.x_ld + c0, ((long long)(s.HW - 1) * s.x_ld + f.seg_ch) * ES);
-    float gmv[VEC], btv[VEC];
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) { const int c = c0 + j * VEC + e; gmv[e] = active ? a.gamma[c] : 0.f; btv[e] = active ? a.beta[c] : 0.f; }
+    float gmv[VEC], btv[VEC], piv[VEC];
+    const float piv_g = tid < f.GPB ? gn_pivot(x, s.x_ld, s.HW, b, chunk * f.GPB + tid, s.cpg) : 0.f;     // used by the threads that finalise a group
+    gn_ld_channels<VEC>(a.gamma + c0 + j * VEC, active, gmv);
+    gn_ld_channels<VEC>(a.beta + c0 + j * VEC, active, btv);
+    {
+        float cur = 0.f;
+        gn_per_group<VEC>(c0 + j * VEC, s.cpg, active, [&](int e, bool load, int g) {
+            if (load) cur = gn_pivot(x, s.x_ld, s.HW, b, g, s.cpg);
+            piv[e] = cur;
+        });
+    }
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int p = prow + i * f.rows_per_iter;
@@ -622,9 +716,11 @@ void gn_lds_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, GnShape s, Gn
     }
     const u32x4* myx = reinterpret_cast<const u32x4*>(xs) + tid;
     const float n = (float)s.HW * (float)s.cpg;
-    float part[VEC];
+    // single pass over the slice while it lands: moments of (x - pivot), pivot = the group's first element (gn_pivot) — accurate
+    // when |mean| >> std, and the statistics cost nothing beyond the load phase
+    float s1[VEC], s2[VEC];
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) part[e] = 0.f;
+    for (int e = 0; e < VEC; ++e) s1[e] = s2[e] = 0.f;
     static_for_gn<NV>([&](auto ic) {
         constexpr int i = decltype(ic)::v;
         gn_wait_vm<NV - 1 - i>(0);
@@ -633,46 +729,40 @@ void gn_lds_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, GnShape s, Gn
             float fv[VEC];
             Elem<T>::unpack(myx[i * 512], fv);
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) part[e] += fv[e];
+            for (int e = 0; e < VEC; ++e) { const float d = fv[e] - piv[e]; s1[e] += d; s2[e] += d * d; }
         }
     });
-    gn_block_channel_sum_w<VEC>(part, f, active, j, prow, tid, sh_row, sh_ch);
+    GN_STAMP(2);
+#ifdef GN_TIMING
+    __syncthreads();          // timing builds: separate 'waiting for the slowest wave' from the reduction proper
+#endif
+    GN_STAMP(3);
+    gn_block_channel_sum2_w<VEC>(s1, s2, f, active, j, tid, sh_row, sh_ch);
     if (tid < f.GPB) {
-        float acc = 0.f;
-        for (int c = tid * s.cpg; c < (tid + 1) * s.cpg; ++c) acc += sh_ch[c];
-        sh_mean[tid] = acc / n;
+        float acc = 0.f, sq = 0.f;
+        for (int c = tid * s.cpg; c < (tid + 1) * s.cpg; ++c) { acc += sh_ch[c]; sq += sh_ch[f.seg_ch + c]; }
+        // fp32 is enough here: the moments are of (x - pivot) with the pivot inside the data, so E[d^2] - E[d]^2 does not cancel
+        const float inv_n = 1.0f / n, dmean = acc * inv_n;
+        const float var = fmaxf(sq * inv_n - dmean * dmean, 0.f);
+        const float mean_g = piv_g + dmean;
+        float rstd = __builtin_amdgcn_rsqf(var + a.eps);
+        rstd = rstd * (1.5f - 0.5f * (var + a.eps) * rstd * rstd);          // one Newton step on the hardware estimate
+        sh_mean[tid] = mean_g; sh_rstd[tid] = rstd;
+        if (a.stats) {
+            const long long gi = (long long)b * s.G + chunk * f.GPB + tid;
+            a.stats[gi * 2] = mean_g; a.stats[gi * 2 + 1] = rstd;
+        }
     }
     __syncthreads();
     float mean[VEC];
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) { mean[e] = sh_mean[active ? (j * VEC + e) / s.cpg : 0]; part[e] = 0.f; }
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int p = prow + i * f.rows_per_iter;
-        if (active && p < s.HW) {
-            float fv[VEC];
-            Elem<T>::unpack(myx[i * 512], fv);
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) { const float d = fv[e] - mean[e]; part[e] += d * d; }
-        }
-    }
-    gn_block_channel_sum_w<VEC>(part, f, active, j, prow, tid, sh_row, sh_ch);
-    if (tid < f.GPB) {
-        float acc = 0.f;
-        for (int c = tid * s.cpg; c < (tid + 1) * s.cpg; ++c) acc += sh_ch[c];
-        const float rstd = 1.0f / sqrtf(acc / n + a.eps);
-        sh_rstd[tid] = rstd;
-        if (a.stats) {
-            const long long gi = (long long)b * s.G + chunk * f.GPB + tid;
-            a.stats[gi * 2] = sh_mean[tid]; a.stats[gi * 2 + 1] = rstd;
-        }
-    }
-    __syncthreads();
+    for (int e = 0; e < VEC; ++e) mean[e] = sh_mean[active ? gn_gidx(j * VEC + e, s.cpg) : 0];
+    GN_STAMP(4);
     if (!active) return;
     float ca[VEC], cb[VEC];
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
-        ca[e] = sh_rstd[(j * VEC + e) / s.cpg] * gmv[e];
+        ca[e] = sh_rstd[gn_gidx(j * VEC + e, s.cpg)] * gmv[e];
         cb[e] = btv[e] - mean[e] * ca[e];
     }
     const float keep_scale = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
@@ -702,6 +792,11 @@ void gn_lds_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, GnShape s, Gn
         }
         stg16(yb + (long long)p * s.y_ld, Elem<T>::pack(fv));
     }
+    GN_STAMP(5);
+#ifdef GN_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    GN_STAMP(6); GN_STAMP(7);
 }
 
 constexpr int GN_FUSED_SLICE = 64 * 1024;     // LDS bytes of activations per block: two blocks per CU
@@ -737,7 +832,7 @@ static bool gn_lds_plan(const GnShape& s, int esize, GnFused& f, size_t& lds_byt
     if (f.nv < 4 || f.seg_vecs > 32) return false;
     const int nvt = f.nv <= 1 ? 1 : f.nv <= 2 ? 2 : f.nv <= 4 ? 4 : 8;
     const size_t scratch = (size_t)8 * f.seg_ch;
-    lds_bytes = (size_t)nvt * 512 * 16 + (scratch + f.seg_ch + 64) * sizeof(float);
+    lds_bytes = (size_t)nvt * 512 * 16 + (2 * scratch + 2 * f.seg_ch + 64) * sizeof(float);
     static const bool no_remap = getenv("DDPM_GN_NO_XCD_REMAP") != nullptr;
     f.xcd_remap = no_remap ? 0 : 1;
     return lds_bytes <= 160 * 1024 && (long long)s.B * s.HW * s.C < (1ll << 32);
