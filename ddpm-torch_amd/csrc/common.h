@@ -137,3 +137,7 @@ __device__ __forceinline__ float silu_grad_fast_(float z) {
 
 static inline int check_launch() { return hipGetLastError() == hipSuccess ? DDPM_OK : DDPM_ERR_LAUNCH; }
 static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+// pointwise.hip: launcher of the persistent 1x1-conv kernel (-1: geometry not covered)
+int ddpm_pointwise_launch(const void* x, long long x_ld, const void* w, void* y, long long y_ld, const float* bias, const void* residual,
+                          long long res_ld, int accumulate, int M, int N, int K, int dry, void* stream);

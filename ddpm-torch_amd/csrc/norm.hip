@@ -564,6 +564,8 @@ void gn_lds_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __r
     float* sh_ch = sh_row + 16 * f.seg_ch;
     float* sh_c1 = sh_ch + 2 * f.seg_ch;
     float* sh_c2 = sh_c1 + 32;
+    float* sh_gam = sh_c2 + 32;                                  // gamma of the block's channels: the finalising threads index it by channel
+    GN_STAMP(0); GN_STAMP(1);
     int b, chunk;
     gn_block_slice(f, b, chunk);
     const int c0 = chunk * f.seg_ch, tid = threadIdx.x;
@@ -576,6 +578,7 @@ void gn_lds_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __r
     gn_group_stats<VEC>(stats, (long long)b * s.G, c0 + j * VEC, s.cpg, active, mean, rstd);
     gn_ld_channels<VEC>(a.gamma + c0 + j * VEC, active, gm);
     gn_ld_channels<VEC>(a.beta + c0 + j * VEC, active, bt);
+    const float gam_c = tid < f.seg_ch ? a.gamma[c0 + tid] : 0.f;      // (seg_ch <= 512) requested before the DMA, parked in LDS after pass 1
     const T* db = dy + ((long long)b * s.HW) * dy_ld + c0 + j * VEC;
     u32x4 vd[NV];
 #pragma unroll
@@ -624,6 +627,8 @@ void gn_lds_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __r
             vd[i] = Elem<T>::pack(fd);                         // pass 2 reuses dz (stored at the tensor dtype, as an autograd graph would) instead of redoing the mask and silu'
         }
     });
+    GN_STAMP(2);
+    if (tid < f.seg_ch) sh_gam[tid] = gam_c;                      // published by the first barrier of the reduction
     const float inv_n = 1.0f / ((float)s.HW * s.cpg);
     gn_block_channel_sum2_w<VEC>(a1, a2, f, active, j, tid, sh_row, sh_ch);        // sh_ch = [A1 | A2]
     for (int c = tid; c < 2 * f.seg_ch; c += 512) {
@@ -631,7 +636,7 @@ void gn_lds_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __r
         const int cc = second ? c - f.seg_ch : c;
         float* dst = second ? dbeta : dgamma;
         if (dst) atomicAdd(dst + c0 + cc, sh_ch[c]);
-        sh_ch[c] *= a.gamma[c0 + cc];
+        sh_ch[c] *= sh_gam[cc];
     }
     __syncthreads();
     if (tid < 2 * f.GPB) {
@@ -641,6 +646,7 @@ void gn_lds_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __r
         (second ? sh_c2 : sh_c1)[g] = acc * inv_n;
     }
     __syncthreads();
+    GN_STAMP(3);
     float c1[VEC], c2[VEC], cs[VEC];
 #pragma unroll
     for (int e = 0; e < VEC; ++e) { const int g = active ? gn_gidx(j * VEC + e, s.cpg) : 0; c1[e] = sh_c1[g]; c2[e] = sh_c2[g]; cs[e] = 0.f; }
@@ -671,10 +677,16 @@ void gn_lds_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __r
             stg16(ob + (long long)p * dx_ld, packed);
         }
     }
+    GN_STAMP(4);
     if (dx_colsum) {
         gn_block_channel_sum_w<VEC>(cs, f, active, j, prow, tid, sh_row, sh_ch);
         for (int c = tid; c < f.seg_ch; c += 512) dx_colsum[(long long)b * colsum_ld + c0 + c] = sh_ch[c];     // one owner per (b, c): plain store
     }
+    GN_STAMP(5);
+#ifdef GN_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    GN_STAMP(6); GN_STAMP(7);
 }
 
 // forward twin: x slice in LDS; pivot-shifted moments accumulated while the slice lands (one pass), then
@@ -832,7 +844,7 @@ static bool gn_lds_plan(const GnShape& s, int esize, GnFused& f, size_t& lds_byt
     if (f.nv < 4 || f.seg_vecs > 32) return false;
     const int nvt = f.nv <= 1 ? 1 : f.nv <= 2 ? 2 : f.nv <= 4 ? 4 : 8;
     const size_t scratch = (size_t)8 * f.seg_ch;
-    lds_bytes = (size_t)nvt * 512 * 16 + (2 * scratch + 2 * f.seg_ch + 64) * sizeof(float);
+    lds_bytes = (size_t)nvt * 512 * 16 + (2 * scratch + 3 * f.seg_ch + 64) * sizeof(float);
     static const bool no_remap = getenv("DDPM_GN_NO_XCD_REMAP") != nullptr;
     f.xcd_remap = no_remap ? 0 : 1;
     return lds_bytes <= 160 * 1024 && (long long)s.B * s.HW * s.C < (1ll << 32);

@@ -113,6 +113,27 @@ def test_conv3x3_stationary_halo_path(B, H, C, N):
          B, H, H, C, H, H, N, 3, 3, 1, 1, 1, 0, 0, 0, 0, 1, None, None, dt, tol=TOL[dt])
 
 
+PW_CASES = [(32, 32, 128, 256), (64, 32, 128, 256), (35, 31, 64, 192), (128, 16, 256, 768), (130, 16, 320, 384), (70, 31, 192, 104), (128, 16, 768, 256)]
+
+
+@pytest.mark.parametrize("B,H,C,N", PW_CASES)
+def test_conv1x1_streaming_path(B, H, C, N):
+    """bf16 1x1 / stride 1 with >= 32768 pixels takes the persistent streaming kernel (csrc/pointwise.hip): both tile heights, ragged
+    pixel / channel tails, one to twelve K-steps, pitched operands, and the bias / residual / accumulate epilogues."""
+    dt = 1
+    M = B * H * H
+    assert M >= 32768 and _hip.lib().ddpm_conv2d_variant(C + 16, N + 32, B, H, H, C, H, H, N, 1, 1, 1, 0, 0, 0, 0, 0, 1, dt) == 7
+    ld, yld = C + 16, N + 32
+    x = r(M, ld, seed=1, dt=dt)
+    w = r(N, C, seed=2, dt=dt, scale=1.0 / math.sqrt(C))
+    bias = r(N, seed=3)
+    res, y = r(M, yld, seed=5, dt=dt), r(M, yld, seed=6, dt=dt)
+    for acc, with_res, with_bias in ((0, 0, 1), (0, 1, 1), (1, 0, 1), (1, 1, 0), (0, 0, 0)):
+        both("ddpm_conv2d_nhwc", A(x), ld, A(w), A(y.clone(), out=True, name=f"y acc={acc} res={with_res} bias={with_bias}"), yld,
+             A(bias) if with_bias else None, None, 0, A(res) if with_res else None, yld if with_res else 0,
+             B, H, H, C, H, H, N, 1, 1, 1, 0, 0, 0, 0, acc, 0, 1, None, None, dt, tol=TOL[dt])
+
+
 @pytest.mark.parametrize("B,H,C,N,silu", [(16, 32, 128, 128, 1), (65, 16, 256, 192, 1), (5, 64, 64, 128, 0), (17, 32, 192, 256, 1)])
 def test_conv3x3_with_folded_groupnorm(B, H, C, N, silu):
     """Inference path: statistics in one launch, then GroupNorm(+SiLU) applied to the LDS-resident halo inside the conv."""
