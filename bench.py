@@ -38,7 +38,7 @@ FWD_GFLOP = {"cifar": 12.443713536, "celeba": 46.741, "celebahq": 497.028}
 PEAK = {"bf16": 2500.0, "fp32": 157.3}                    # dense MFMA TFLOP/s, MI355X_MICROARCH.md
 B_PER_GPU = 128
 VARIANT = {1: "gemm_kernel<4 waves,128x128>", 2: "gemm_kernel<8 waves,128x128>", 3: "gemm_kernel<deep ring,128x128>",
-           4: "gemm64_kernel<64x64>", 5: "conv3x3_halo_kernel<256px x 128>", 6: "wgrad3x3_kernel<64x32 x 9 taps>", 7: "pw_conv_kernel<persistent 1x1>"}
+           4: "gemm64_kernel<64x64>", 5: "conv3x3_halo_kernel<256px x 128>", 6: "wgrad3x3_kernel<64x32 x 9 taps>", 7: "pw_conv_kernel<persistent 1x1>", 8: "conv3x3_stream_kernel<persistent, 256px x 128>"}
 
 
 def host_cpu():

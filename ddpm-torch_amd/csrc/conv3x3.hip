@@ -1,0 +1,403 @@
+// 3x3 / stride 1 / pad 1 convolution, bf16 — the hot conv of the UNet, forward and data gradient (ddpm_torch/modules.py:60-101 `Conv2d`
+// inside ddpm_torch/models/unet.py:21-34 `ResidualBlock`) — as a PERSISTENT stationary-halo kernel for images of 16x16 pixels and up.
+//
+// Same K-loop as conv3x3_halo_kernel (gemm.hip): a block owns one 16 x 16 output patch x 128 output channels and walks K as
+// (64-channel chunk, tap); the 18 x 18 input halo of a chunk is DMA'd into LDS once and serves all nine taps, only the 128 x 64 weight
+// tile streams per tap.  What changes is everything around the loop, which was 9.4 us of a 24.9 us block on the 128 -> 128 @ 32 x 32
+// layers (prologue 4.9: nothing to multiply until the first halo and weight tile have crossed the chip; epilogue 4.5: the whole fp32
+// tile staged through LDS, then written) and ran with every block of the launch in the same phase:
+//   * one block per CU loops over its tiles; the step sequence (tile, chunk, tap) is flat: the halo of the NEXT tile's first chunk and
+//     its first weight tiles are requested during the last taps of the current tile, so a tile's K-loop starts the moment the
+//     previous one ends;
+//   * the MFMA operands are swapped (rows = output channels, columns = pixels): an accumulator lane owns ONE pixel and runs of four
+//     consecutive channels, adds bias / time-embedding bias / residual itself, trades halves with its partner lane (v_permlane32_swap)
+//     and stores 16-byte pieces of the NHWC row straight from registers.  No LDS staging, no epilogue barrier — the LDS holds nothing
+//     but the pipeline, and the stores drain under the next tile's MFMAs;
+//   * the per-channel bias row and the per-image time-embedding row of a tile ride into LDS with its first weight tile: an ordinary
+//     load in the epilogue would have to wait for every LDS-DMA issued before it (loads retire in order) and drain the ring.
+#include "common.h"
+#include <string.h>
+#include <stdlib.h>
+
+namespace {
+
+constexpr unsigned OOB = 0x7ffffff0u;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+struct CsArgs {
+    const bf16_t* x; long long x_ld; unsigned x_extent;
+    const bf16_t* w; unsigned w_extent;                   // packed [N][9][C]: k = tap * C + c
+    bf16_t* out; long long out_ld;
+    const float* bias; const float* rowbias; long long rowbias_ld; unsigned rowbias_extent;
+    const bf16_t* res; long long res_ld;
+    int accumulate;
+    int B, H, W, C, N, K;
+    int tiles_y, tiles_x, tiles_n, total_tiles, xcd;
+    FastDiv d_tiles_n, d_tpi, d_tiles_x;
+};
+
+constexpr int HWD = 18, HP = 324;                         // halo of a 16 x 16 patch
+constexpr int NI = 6;                                     // halo DMA parts: 5 x 512 vectors + 32
+constexpr int RING = 4;                                   // weight tiles in the ring (RING - 1 in flight)
+constexpr int HALO_BYTES = 5 * 512 * 16 + 1024;           // 41,984: parts 0-4 by all waves, part 5 by wave 0
+constexpr int WT_BYTES = 128 * 128;
+constexpr int DUMP_AT = 2 * HALO_BYTES + RING * WT_BYTES; // 1 KiB the other waves' (all out-of-range) part-5 lanes write their zeros to
+constexpr int ROWS_AT = DUMP_AT + 1024;                   // 2 slots x (bias row 1 KiB | time-bias row 1 KiB)
+constexpr int LDS_BYTES = ROWS_AT + 4096;
+static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+
+template <int N> __device__ __forceinline__ void wait_vm() {
+    static_assert(N >= 0 && N < 64, "vmcnt immediate");
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory");
+}
+
+__device__ __forceinline__ int logical_tile(int id, int total, int xcd) {       // see xcd_logical_id in gemm.hip
+    if (!xcd) return id;
+    const int per = total >> 3;
+    return id < (per << 3) ? (id & 7) * per + (id >> 3) : id;
+}
+
+struct TilePos { int img, py0, px0, tn; };
+
+#ifdef C3_TIMING
+__device__ unsigned long long* g_c3_timing = nullptr;        // debug builds only (scripts/c3_timeline.py): [block][8] stamps
+#define C3_STAMP(slot) do { if (g_c3_timing && threadIdx.x == 0) g_c3_timing[blockIdx.x * 8 + (slot)] = (slot) == 0 || (slot) == 7 ? wall_clock64() : clock64(); } while (0)
+#else
+#define C3_STAMP(slot)
+#endif
+
+__global__ __launch_bounds__(512, 2)
+void conv3x3_stream_kernel(CsArgs a) {
+    C3_STAMP(0); C3_STAMP(1);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* halo = smem;
+    char* wring = smem + 2 * HALO_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave >> 2, wm = wave & 3;              // wave = 64 channels x 64 pixels (4 patch rows)
+
+    auto rsrc_of = [&](const void* p, unsigned extent) {
+        const unsigned long long ad = (unsigned long long)p;
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)ad), hi = __builtin_amdgcn_readfirstlane((unsigned)(ad >> 32));
+        return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0,
+                                                 __builtin_amdgcn_readfirstlane((int)extent), 0x00020000);
+    };
+    const __amdgpu_buffer_rsrc_t rx = rsrc_of(a.x, a.x_extent), rw = rsrc_of(a.w, a.w_extent);
+    const __amdgpu_buffer_rsrc_t rbias = rsrc_of(a.bias ? (const void*)a.bias : (const void*)a.w, a.bias ? (unsigned)(a.N * 4) : 0u);
+    const __amdgpu_buffer_rsrc_t rrow = rsrc_of(a.rowbias ? (const void*)a.rowbias : (const void*)a.w, a.rowbias ? a.rowbias_extent : 0u);
+
+    // "+ residual" or "+= out": one extra bf16 tensor added in the epilogue
+    const bool extra = a.res || a.accumulate;
+    const int G = gridDim.x;
+    const int my_tiles = a.total_tiles > (int)blockIdx.x ? (a.total_tiles - 1 - (int)blockIdx.x) / G + 1 : 0;
+    if (my_tiles == 0) return;
+    auto tile_pos = [&](int k) {
+        const int lid = logical_tile(blockIdx.x + k * G, a.total_tiles, a.xcd);
+        const int tmi = (int)fdiv((unsigned)lid, a.d_tiles_n);
+        const int tpi = a.tiles_y * a.tiles_x;
+        const int img = (int)fdiv((unsigned)tmi, a.d_tpi), pt = tmi - img * tpi;
+        const int ty = (int)fdiv((unsigned)pt, a.d_tiles_x);
+        TilePos t; t.img = img; t.py0 = ty * 16; t.px0 = (pt - ty * a.tiles_x) * 16; t.tn = lid - tmi * a.tiles_n;
+        return t;
+    };
+    // halo DMA plan of a tile: vector v = tid + 512 i -> halo pixel hp = v >> 3 (row hy, column hx of the 18 x 18 halo), physical chunk
+    // v & 7 = logical chunk ^ ((hx >> 1) & 7): the 16 pixels one ds_read_b128 lane group touches land on 16 distinct (bank half, chunk)
+    // pairs for every tap shift.  Pixels outside the image (and the 480 vectors past the halo in part 5) get an out-of-range offset.
+    auto halo_plan = [&](const TilePos& t, unsigned (&ho)[NI]) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int v = tid + 512 * i, hp = v >> 3;
+            const int hy = hp / HWD, hx = hp - hy * HWD;
+            const int iy = t.py0 + hy - 1, ix = t.px0 + hx - 1;
+            const bool ok = hp < HP && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+            const int lc = (v & 7) ^ ((hx >> 1) & 7);
+            ho[i] = ok ? ((unsigned)((t.img * a.H + iy) * a.W + ix) * (unsigned)a.x_ld + (unsigned)(lc * 8)) * 2u : OOB;     // < 2^31: checked by the launcher
+        }
+    };
+    auto issue_halo_part = [&](unsigned ho, int i, int cc, char* dst) {
+        const unsigned o = ho == OOB ? OOB : ho + (unsigned)(cc * 128);
+        char* d = i < 5 ? dst + (wave * 64 + 512 * i) * 16 : (wave == 0 ? dst + 5 * 512 * 16 : smem + DUMP_AT);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)d, 16, o, 0, 0, 0);
+    };
+    // weight DMA plan: vector v = tid + 512 i -> row n = v >> 3 of the 128-row tile, physical chunk v & 7 = logical ^ ((row >> 1) & 7)
+    unsigned wrow[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int v = tid + 512 * i, row = v >> 3, lc = (v & 7) ^ ((row >> 1) & 7);
+        wrow[i] = (unsigned)(((long long)row * a.K + lc * 8) * 2);
+    }
+    const unsigned w_tile_bytes = (unsigned)((long long)128 * a.K * 2);
+    const int nchunks = a.C >> 6;
+    const int steps_per_tile = nchunks * 9, total = my_tiles * steps_per_tile;
+
+    // ---- weight ring.  The tile requested in step (cc, tap) is the one RING - 1 = 3 steps ahead: tap + 3 of the same chunk, or tap - 6 of
+    // the next chunk, or — in the last chunk — of chunk 0 of the NEXT tile.  With the tap loop unrolled all of that is static except the
+    // chunk / tile switch, which keeps the per-step scalar work (the loop is issue-bound between its barriers) to a few instructions.
+    auto issue_w = [&](int tn, int cc, int tap, int slot) {
+        char* dst = wring + slot * WT_BYTES;
+        const unsigned base = (unsigned)tn * w_tile_bytes + (unsigned)((tap * a.C + cc * 64) * 2);      // rows beyond N: past the extent -> zeros
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(dst + (wave * 64 + 512 * i) * 16), 16, base + wrow[i], 0, 0, 0);
+    };
+    // first stage of a tile: its bias row (wave 0) and the time-embedding row of its image (wave 1) ride along — issued BEFORE the stage's
+    // loads, so they have landed when the stage has.  Lanes >= 32 are out of range and write zeros into the slot's padding.
+    auto issue_rows = [&](const TilePos& t, int parity) {
+        char* slot = smem + ROWS_AT + parity * 2048;
+        if (wave == 0 && a.bias)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rbias, (__attribute__((address_space(3))) void*)slot, 16,
+                                                     lane < 32 ? (unsigned)((t.tn * 128 + lane * 4) * 4) : OOB, 0, 0, 0);
+        if (wave == 1 && a.rowbias)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rrow, (__attribute__((address_space(3))) void*)(slot + 1024), 16,
+                                                     lane < 32 ? (unsigned)(((long long)t.img * a.rowbias_ld + t.tn * 128 + lane * 4) * 4) : OOB, 0, 0, 0);
+    };
+
+    // this lane's pixels (columns of its two 32-pixel accumulator blocks) -> halo index of tap (0, 0)
+    int hp0[2], pxl[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int p = wm * 64 + j * 32 + (lane & 31);
+        hp0[j] = (p >> 4) * HWD + (p & 15);
+        pxl[j] = p & 15;
+    }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x16)(0.f);
+
+    // ---- prologue: halo of (tile 0, chunk 0), the tile's rows, then the first RING - 1 weight tiles; wait for the halo + tile 0 only
+    TilePos cur = tile_pos(0);
+    unsigned hoff[NI];
+    halo_plan(cur, hoff);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) issue_halo_part(hoff[i], i, 0, halo);
+    issue_rows(cur, 0);
+#pragma unroll
+    for (int t = 0; t < RING - 1; ++t) issue_w(cur.tn, 0, t, t);
+    wait_vm<4>();
+    __builtin_amdgcn_s_barrier();
+
+    C3_STAMP(2);
+    const int sw = (lane >> 5) ^ ((lane >> 1) & 7);
+    const int hi = lane >> 5;
+    int slot = 0, hb = 0;                                  // ring slot of the step being consumed; halo buffer in use
+    bool st8 = false;                                      // this wave's 8 epilogue stores of the previous tile may still be in flight
+    for (int k = 0; k < my_tiles; ++k) {
+        const bool more_tiles = k + 1 < my_tiles;
+        TilePos nxt = cur;
+        if (more_tiles) nxt = tile_pos(k + 1);
+        for (int cc = 0; cc < nchunks; ++cc) {
+            if (cc + 1 == nchunks && more_tiles) halo_plan(nxt, hoff);           // the last chunk prefetches the NEXT tile's halo: its plan replaces this tile's
+            const char* hcur = halo + hb * HALO_BYTES;
+            char* hnxt = halo + (hb ^ 1) * HALO_BYTES;
+            const bool same_tile = cc + 1 < nchunks;
+            const bool prefetch = same_tile || more_tiles;  // is there a chunk after this one?
+            const bool last_chunk = !same_tile;
+            const int ncc = same_tile ? cc + 1 : 0;          // ... its chunk index and its tile's channel tile
+            const int ntn = same_tile ? cur.tn : nxt.tn;
+            u32x2 rv[2][2][4];                               // residual OR previous output (the launcher admits one of them)
+            bool pre = false;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {              // fully unrolled: the halo-part index and the ring arithmetic are constants
+                const char* wcur = wring + slot * WT_BYTES;
+                // in program order: a part of the next halo (next chunk of this tile, or chunk 0 of the next tile), then the weight tile
+                // RING - 1 steps ahead (its slot was read in the previous step; every wave is past that barrier).  Loads retire in order, so
+                // once the first weight tile of the next chunk has landed its whole halo has too (all six parts are requested in taps 0-5,
+                // that weight tile in tap 6).
+                if (tap < NI && prefetch) issue_halo_part(hoff[tap < NI ? tap : 0], tap, ncc, hnxt);
+                if (tap == 8 && last_chunk && extra) {
+                    // last step of the tile with a residual / "+=" epilogue: request those rows NOW, ahead of this step's weight tile.
+                    // INLINE ASM: a C++ load would make hipcc drain every pending LDS-DMA first; the wait is issued by hand below.
+                    pre = true;
+                    const int n0 = cur.tn * 128 + wn * 64 + 4 * (lane >> 5);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int p = wm * 64 + j * 32 + (lane & 31);
+                        // one address per pixel, the 4-channel runs at constant byte offsets.  UNCONDITIONAL loads (a load under `if` makes the
+                        // result a phi that the compiler fills right after the asm, before the data is back): waves whose 64 channels lie beyond
+                        // N (N % 64 == 0) read the start of their row instead and are zeroed after the wait.
+                        const bf16_t* base = (a.res ? a.res : a.out) + ((long long)(cur.img * a.H + cur.py0 + (p >> 4)) * a.W + cur.px0 + (p & 15)) * (a.res ? a.res_ld : a.out_ld)
+                                             + (n0 < a.N ? n0 : 0);
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+#pragma unroll
+                            for (int g = 0; g < 4; ++g)
+                                asm volatile("global_load_dwordx2 %0, %1, off offset:%2" : "=v"(rv[j][i][g]) : "v"(base), "n"((i * 32 + 8 * g) * 2) : "memory");
+                    }
+                }
+                const int wslot = (slot + RING - 1) & (RING - 1);
+                if (tap + RING - 1 < 9) issue_w(cur.tn, cc, tap + RING - 1, wslot);
+                else if (prefetch) {
+                    if (tap == 9 - (RING - 1) && last_chunk) issue_rows(nxt, (k + 1) & 1);     // first stage of the next tile
+                    issue_w(ntn, ncc, tap + RING - 1 - 9, wslot);
+                }
+                const int r = tap / 3, s = tap - 3 * r;
+                const int shift = r * HWD + s;
+#pragma unroll
+                for (int kc = 0; kc < 4; ++kc) {
+                    u32x4 fw[2], fx[2];
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) fw[i] = *reinterpret_cast<const u32x4*>(wcur + (wn * 64 + i * 32 + (lane & 31)) * 128 + (((2 * kc) ^ sw) << 4));
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int key = ((pxl[j] + s) >> 1) & 7;
+                        fx[j] = *reinterpret_cast<const u32x4*>(hcur + (hp0[j] + shift) * 128 + ((((2 * kc) | hi) ^ key) << 4));
+                    }
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fw[i]), __builtin_bit_cast(bf16x8, fx[j]), acc[i][j], 0, 0, 0);
+                }
+#ifdef C3_STEPTIMING
+                if (g_c3_timing && threadIdx.x == 0 && blockIdx.x == 0 && k == 0) g_c3_timing[2048 + cc * 9 + tap] = clock64();
+#endif
+                slot = (slot + 1) & (RING - 1);
+                if (tap == 8 && last_chunk) break;          // the tile's last step: epilogue first, then this step's wait + barrier (below)
+                // the next step's weight tile must have landed; the RING - 2 newer tiles (2 DMA instructions each) may stay in flight.  The
+                // count ignores newer halo parts: waiting for more to retire is always safe.  Only the last chunk of the block's last tile
+                // has fewer than two newer tiles (taps 6, 7).
+                if (tap >= 6 && !prefetch) { if (tap == 6) wait_vm<2>(); else wait_vm<0>(); }
+                else if (tap < 2 && cc == 0 && st8) wait_vm<12>();      // + the previous tile's stores: they sit between the tile waited for
+                else wait_vm<4>();                                      //   and the newer ones in the (in-order) queue for two more steps
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+            if (last_chunk) {
+                if (k == 0) C3_STAMP(3); else if (k == 1) C3_STAMP(5);
+                // ---- tile done (the unrolled loop was left before the step's wait): out = acc + bias + time bias (+ residual | + out).
+                // accumulator (i, j), register r, lane l: channel n0 + i*32 + 8 (r >> 2) + 4 (l >> 5) + (r & 3), pixel j*32 + (l & 31) of the wave
+                const char* rows = smem + ROWS_AT + (k & 1) * 2048;
+                // bias + time bias of this lane's 4-channel runs: INLINE-ASM LDS reads (hipcc puts `s_waitcnt vmcnt(0)` in front of a C++ LDS
+                // read it cannot prove disjoint from the pending LDS-DMA: that would drain the ring at every tile), eight in flight per wait.
+                // ... and the rows requested in the last step: everything older than the weight tile requested after them has to be back
+                // (no register operands on the waits: "+v" ties make hipcc copy the registers in front of the asm; the scheduling barriers
+                // keep every use below them instead)
+                if (pre) {
+                    if (prefetch) wait_vm<2>(); else wait_vm<0>();
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (!(cur.tn * 128 + wn * 64 < a.N)) {
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+#pragma unroll
+                            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                                for (int g = 0; g < 4; ++g) rv[j][i][g] = (u32x2)(0u);
+                    }
+                }
+                const int n0 = cur.tn * 128 + wn * 64;
+                bf16_t* orow[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int p = wm * 64 + j * 32 + (lane & 31);
+                    orow[j] = a.out + ((long long)(cur.img * a.H + cur.py0 + (p >> 4)) * a.W + cur.px0 + (p & 15)) * a.out_ld;
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    f32x4v bsum[4], brow[4];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const unsigned ad = (unsigned)(size_t)(rows + (wn * 64 + i * 32 + 8 * g + 4 * (lane >> 5)) * 4);
+                        // (unconditional: a read under `if (a.bias)` makes the result a phi, and the compiler copies an asm output into
+                        // its phi register right after the asm — before the data has arrived; absent rows are zeroed after the wait)
+                        asm volatile("ds_read_b128 %0, %1" : "=v"(bsum[g]) : "v"(ad) : "memory");
+                        asm volatile("ds_read_b128 %0, %1 offset:1024" : "=v"(brow[g]) : "v"(ad) : "memory");
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        if (!a.bias) bsum[g] = (f32x4v)(0.f);
+                        if (!a.rowbias) brow[g] = (f32x4v)(0.f);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        uint2 pk[4];
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            float v[4] = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                            v[0] += bsum[g].x + brow[g].x; v[1] += bsum[g].y + brow[g].y;
+                            v[2] += bsum[g].z + brow[g].z; v[3] += bsum[g].w + brow[g].w;
+                            if (extra) {
+                                const u32x2 r2 = rv[j][i][g];
+                                v[0] += __uint_as_float(r2.x << 16); v[1] += __uint_as_float(r2.x & 0xffff0000u);
+                                v[2] += __uint_as_float(r2.y << 16); v[3] += __uint_as_float(r2.y & 0xffff0000u);
+                            }
+                            pk[g].x = pack_bf2(v[0], v[1]); pk[g].y = pack_bf2(v[2], v[3]);
+                        }
+                        // lanes l and l + 32 hold channels +0..3 / +4..7 of every 8-channel group of pixel l: the lower lane takes both halves of
+                        // the even groups, the upper lane both halves of the odd groups -> every lane stores 16 contiguous bytes, a pair 32
+#pragma unroll
+                        for (int q2 = 0; q2 < 2; ++q2) {
+                            const u32x2 sx = __builtin_amdgcn_permlane32_swap(pk[2 * q2].x, pk[2 * q2 + 1].x, false, false);
+                            const u32x2 sy = __builtin_amdgcn_permlane32_swap(pk[2 * q2].y, pk[2 * q2 + 1].y, false, false);
+                            const int n = n0 + i * 32 + 16 * q2 + 8 * (lane >> 5);
+                            if (n < a.N) {
+                                u32x4 o; o.x = sx.x; o.y = sy.x; o.z = sx.y; o.w = sy.y;
+                                *reinterpret_cast<u32x4*>(orow[j] + n) = o;
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = (f32x16)(0.f);
+                if (k == 0) C3_STAMP(4); else if (k == 1) C3_STAMP(6);
+                // the wait + barrier of the tile's last step.  Loads and stores retire in issue order, so the stores just issued (eight per
+                // lane, none when the wave's 64 channels lie beyond N) count among the newer operations: waiting them out here would park the
+                // block for the whole write burst of the chip.
+                st8 = n0 < a.N;
+                if (!more_tiles) wait_vm<0>(); else if (st8) wait_vm<12>(); else wait_vm<4>();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+            hb ^= 1;
+        }
+        cur = nxt;
+    }
+    C3_STAMP(7);
+}
+
+}  // namespace
+
+#ifdef C3_TIMING
+extern "C" int ddpm_debug_set_c3_timing(void* p) { return hipMemcpyToSymbol(HIP_SYMBOL(g_c3_timing), &p, sizeof(p)) == hipSuccess ? 0 : -1; }
+#endif
+
+// Launcher behind conv3x3_halo_launch (gemm.hip): 16 x 16 patches, bf16 -> bf16.  -1: geometry / epilogue not covered (the caller keeps
+// conv3x3_halo_kernel), else a status code.  dry: decide only.
+int ddpm_conv3x3_stream_launch(const void* x, long long x_ld, const void* w, void* y, long long y_ld, const float* bias, const float* rowbias,
+                               long long rowbias_ld, const void* residual, long long res_ld, int accumulate, int B, int H, int W, int C, int N,
+                               int xcd, int dry, void* stream) {
+    static const bool off = getenv("DDPM_CONV_NO_STREAM3") != nullptr;
+    if (off || (residual && accumulate) || H % 16 || W % 16 || C % 64 || N % 64 || x_ld % 8 || y_ld % 8 || (residual && res_ld % 4) || (rowbias && rowbias_ld % 4)) return -1;
+    if (!aligned16(x) || !aligned16(w) || !aligned16(y) || (residual && (((uintptr_t)residual) & 7)) || (bias && !aligned16(bias)) || (rowbias && !aligned16(rowbias))) return -1;
+    const long long xbytes = ((long long)B * H * W * x_ld - (x_ld - C)) * 2, wbytes = (long long)N * 9 * C * 2;
+    const long long rbbytes = rowbias ? ((long long)(B - 1) * rowbias_ld + N) * 4 : 0;
+    if (xbytes > 0x7ffffff0ll || wbytes > 0x7ffffff0ll || rbbytes > 0x7ffffff0ll) return -1;
+    if (dry) return DDPM_OK;
+    CsArgs a; memset(&a, 0, sizeof(a));
+    a.x = (const bf16_t*)x; a.x_ld = x_ld; a.x_extent = (unsigned)xbytes;
+    a.w = (const bf16_t*)w; a.w_extent = (unsigned)wbytes;
+    a.out = (bf16_t*)y; a.out_ld = y_ld;
+    a.bias = bias; a.rowbias = rowbias; a.rowbias_ld = rowbias_ld; a.rowbias_extent = (unsigned)rbbytes;
+    a.res = (const bf16_t*)residual; a.res_ld = res_ld; a.accumulate = accumulate;
+    a.B = B; a.H = H; a.W = W; a.C = C; a.N = N; a.K = 9 * C;
+    a.tiles_y = H / 16; a.tiles_x = W / 16; a.tiles_n = (N + 127) / 128;
+    a.total_tiles = B * a.tiles_y * a.tiles_x * a.tiles_n;
+    a.xcd = xcd;
+    a.d_tiles_n = make_fastdiv((unsigned)a.tiles_n); a.d_tpi = make_fastdiv((unsigned)(a.tiles_y * a.tiles_x)); a.d_tiles_x = make_fastdiv((unsigned)a.tiles_x);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_stream_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) return DDPM_ERR_LAUNCH;
+        attr_set = true;
+    }
+    static const int max_grid = getenv("DDPM_C3_GRID") ? atoi(getenv("DDPM_C3_GRID")) : 256;      // (timing experiments: > 256 = fewer tiles per block)
+    const int grid = a.total_tiles < max_grid ? a.total_tiles : max_grid;
+    hipLaunchKernelGGL(conv3x3_stream_kernel, dim3(grid), dim3(512), LDS_BYTES, (hipStream_t)stream, a);
+    return check_launch();
+}

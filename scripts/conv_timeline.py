@@ -9,7 +9,7 @@ DEV = "cuda:0"
 lib = ctypes.CDLL(os.path.join(ROOT, "ddpm-torch_amd", "csrc", "libddpm_hip.so"))
 dt = torch.bfloat16
 B = 128
-for (H, C, N, R) in ((32, 128, 256, 1), (16, 256, 256, 1), (16, 256, 768, 1), (16, 768, 256, 1), (8, 256, 256, 3), (4, 256, 256, 3), (8, 512, 256, 1)):
+for (H, C, N, R) in ((32, 128, 128, 3), (16, 256, 256, 3), (32, 256, 128, 3), (16, 512, 256, 3), (32, 128, 256, 1), (16, 256, 256, 1), (16, 256, 768, 1), (16, 768, 256, 1), (8, 256, 256, 3), (4, 256, 256, 3), (8, 512, 256, 1)):
     x = View(torch.randn(B, H, H, C, device=DEV).to(dt), B, H, H, C)
     w = (torch.randn(N, R * R * C, device=DEV) / math.sqrt(R * R * C)).to(dt)
     y = View(torch.empty(B, H, H, N, device=DEV, dtype=dt), B, H, H, N)

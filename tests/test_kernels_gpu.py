@@ -111,6 +111,13 @@ def test_conv3x3_stationary_halo_path(B, H, C, N):
     y2 = torch.zeros(M, N, dtype=DT[dt])
     both("ddpm_conv2d_nhwc", A(x), ld, A(w), A(y2, out=True, name="y_plain"), N, None, None, 0, None, 0,
          B, H, H, C, H, H, N, 3, 3, 1, 1, 1, 0, 0, 0, 0, 1, None, None, dt, tol=TOL[dt])
+    # "+=" without a residual (the data-gradient epilogue), bias only, time-embedding bias only
+    both("ddpm_conv2d_nhwc", A(x), ld, A(w), A(y.clone(), out=True, name="y_accumulate"), yld, A(bias), None, 0, None, 0,
+         B, H, H, C, H, H, N, 3, 3, 1, 1, 1, 0, 0, 1, 0, 1, None, None, dt, tol=TOL[dt])
+    both("ddpm_conv2d_nhwc", A(x), ld, A(w), A(y.clone(), out=True, name="y_rowbias"), yld, None, A(rowb), N + 8, None, 0,
+         B, H, H, C, H, H, N, 3, 3, 1, 1, 1, 0, 0, 0, 0, 1, None, None, dt, tol=TOL[dt])
+    # 16-pixel-aligned images take the persistent kernel (conv3x3.hip), the 8 x 8 ones the four-patch halo kernel (gemm.hip)
+    assert _hip.lib().ddpm_conv2d_variant(ld, yld, B, H, H, C, H, H, N, 3, 3, 1, 1, 1, 0, 0, 0, 1, dt) == (8 if H % 16 == 0 else 5)
 
 
 PW_CASES = [(32, 32, 128, 256), (64, 32, 128, 256), (35, 31, 64, 192), (128, 16, 256, 768), (130, 16, 320, 384), (70, 31, 192, 104), (128, 16, 768, 256)]
