@@ -120,12 +120,20 @@ void pw_conv_kernel(PwArgs a) {
 
     const int sw = (lane >> 5) ^ ((lane >> 1) & 7);
     int c_mt = blockIdx.x, c_nt = 0, c_ks = 0, c_tile = 0;     // consume cursor
+    constexpr int ST = 4 * MJ;                                 // 16-byte stores per lane in a tile's epilogue
+    int st_window = 0;
     for (int q = 0; q < total; ++q) {
-        // stage q has landed when at most the stages issued after it are outstanding.  The count deliberately ignores the
-        // epilogue's stores (they are newer than the loads waited for, loads retire in issue order: waiting for MORE to retire is
-        // always safe, whatever order stores retire in).
+        // stage q has landed when at most the operations issued after it are outstanding: the newer stages and — loads and stores
+        // retire in issue order — for the RING - 1 stages after a tile's epilogue also its ST stores (waiting those out would park the
+        // block for the write burst of the whole chip at every tile).  Waiting for MORE to retire is always safe: the stores are left
+        // out when the windows of two epilogues would overlap or the wave stored a partial channel range.
         const int newer = min(RING - 2, total - 1 - q);
-        if (newer >= 2) wait_vm<2 * PER>(); else if (newer == 1) wait_vm<PER>(); else wait_vm<0>();
+        if (st_window > 0) {
+            --st_window;
+            if (newer >= 2) wait_vm<2 * PER + ST>(); else if (newer == 1) wait_vm<PER + ST>(); else wait_vm<ST>();
+        } else {
+            if (newer >= 2) wait_vm<2 * PER>(); else if (newer == 1) wait_vm<PER>(); else wait_vm<0>();
+        }
         __builtin_amdgcn_s_barrier();                          // ... for every wave; and every wave is done reading stage q-1
         // last K-step of a tile with a residual / "+=" epilogue: request those rows NOW, ahead of the next stage's LDS-DMA — loads
         // retire in order, so requested in the epilogue they would wait for every stage in flight (and the compiler's wait for them
@@ -228,6 +236,8 @@ void pw_conv_kernel(PwArgs a) {
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < MJ; ++j) acc[i][j] = (f32x16)(0.f);
+            // (full 64-channel range stored by this wave -> exactly ST stores; epilogues at least RING - 1 stages apart -> one window at a time)
+            st_window = (a.ksteps >= RING - 1 && c_nt * 128 + wn * 64 + 64 <= a.N && !(a.ablate & 1)) ? RING - 1 : 0;
             c_ks = 0; ++c_tile;
             if (++c_nt == a.tiles_n) { c_nt = 0; c_mt += gridDim.x; }
         } else ++c_ks;
