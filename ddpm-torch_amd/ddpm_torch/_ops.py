@@ -131,6 +131,18 @@ def conv3x3_wgrad(dy, x, dw_ptr, slab_stride, dbias_ptr, bias_stride, Nreal, spl
         splits, x.dtype, _hip.stream()), f"wgrad3x3 M={Nreal} N={9 * x.C} K={dy.rows} splits={splits}", lambda: 6)
 
 
+def conv1x1_wgrad_splits(P, C, N):
+    """Slab copies the 1x1 weight-gradient kernel writes for this geometry; 0 = not covered."""
+    return int(_hip.lib().ddpm_conv1x1_wgrad_splits(P, C, N))
+
+
+def conv1x1_wgrad(dy, x, dw_ptr, slab_stride, dbias_ptr, bias_stride, Nreal, splits):
+    """dw[n][c] (+ dbias) of a 1x1 / stride 1 conv by the slab kernel (bf16)."""
+    _timed("wgrad1x1", 2.0 * dy.rows * Nreal * x.C, lambda: _hip.call(
+        "ddpm_conv1x1_wgrad_nhwc", dy.ptr, dy.ld, x.ptr, x.ld, dw_ptr, slab_stride, dbias_ptr, bias_stride, dy.rows, x.C, Nreal,
+        splits, x.dtype, _hip.stream()), f"wgrad1x1 M={Nreal} N={x.C} K={dy.rows} splits={splits}", lambda: 9)
+
+
 def wgrad_effective_splits(K, splits, dtype):
     return int(_hip.lib().ddpm_wgrad_effective_splits(K, splits, dtype))
 

@@ -251,6 +251,7 @@ _SIDE_STREAM = os.environ.get("DDPM_SIDE_STREAM", "1") != "0"      # weight / bi
 _WGRAD_MINSTEPS = int(os.environ.get("DDPM_WGRAD_MINSTEPS", "20"))
 _WGRAD_SLABS = os.environ.get("DDPM_WGRAD_SLABS", "0") != "0"      # deterministic slab reduction instead of atomics
 _WGRAD3 = os.environ.get("DDPM_WGRAD3", "1") != "0"                # patch-stationary kernel for the 3x3 / stride-1 weight gradients
+_WGRAD1 = os.environ.get("DDPM_WGRAD1", "1") != "0"                # slab kernel for the 1x1 weight gradients
 _WGRAD3_ATOMIC = os.environ.get("DDPM_WGRAD3_ATOMIC", "0") != "0"  # ... with fp32 atomics instead of slab copies
 
 
@@ -539,7 +540,30 @@ class _Engine:
             patch = self._eff_splits.get(pkey)
             if patch is None:
                 patch = self._eff_splits[pkey] = ops.conv3x3_wgrad_splits(x.B, x.H, x.W, x.C, dy.C)
-        if patch:
+        point = 0
+        if (not patch and _WGRAD1 and self.T == torch.bfloat16 and R == 1 and S == 1 and not kw.get("upsample") and kw.get("stride", 1) == 1
+                and not kw.get("pad_t") and not kw.get("pad_l") and Creal == x.C and Nreal == dy.C):
+            pkey = ("w1", dy.rows, x.C, dy.C)
+            point = self._eff_splits.get(pkey)
+            if point is None:
+                point = self._eff_splits[pkey] = ops.conv1x1_wgrad_splits(dy.rows, x.C, dy.C)
+        if point:
+            # 1x1: slab kernel (csrc/wgrad1x1.hip) — one block per CU, partial tiles stored from registers, bias gradient folded in
+            bias_ptr = self._pptr(ctx, bias) if bias is not None else 0
+            with self._leaf(ctx, dy, x):
+                n = Nreal * Creal
+                stride = (n + 3) // 4 * 4
+                bstride = (Nreal + 3) // 4 * 4
+                slab = self._slabs.get(id(weight))
+                if slab is None or slab.numel() < point * (stride + bstride):
+                    slab = self._slabs[id(weight)] = torch.empty(point * (stride + bstride), dtype=torch.float32, device=self.device)
+                bslab = slab.data_ptr() + 4 * point * stride
+                ops.conv1x1_wgrad(dy, x, slab.data_ptr(), stride, bslab if bias is not None else 0, bstride, Nreal, point)
+                ctx["slab_rows"].append((slab.data_ptr(), self._pptr(ctx, weight), n, point, stride))
+                if bias is not None:
+                    ctx["slab_rows"].append((bslab, bias_ptr, Nreal, point, bstride))
+            did_bias = bias is not None
+        elif patch:
             bias_ptr = self._pptr(ctx, bias) if bias is not None else 0
             with self._leaf(ctx, dy, x):
                 if _WGRAD3_ATOMIC:
@@ -1047,8 +1071,8 @@ class _Engine:
         # project_out
         do = self._new(B, x.H, x.W, C)
         ops.conv2d(dout, co.wd.data_ptr(), do.ptr, do.ld, C, 1, 1, x.H, x.W, splitk=self.splitk)
-        self._wgrad(ctx, ab.project_out.weight, dout, o, C, C, 1, 1, splits=self._splits(C, C, dout.rows))
-        self._bias_grad(ctx, dout, [ab.project_out.bias], C)
+        if not self._wgrad(ctx, ab.project_out.weight, dout, o, C, C, 1, 1, splits=self._splits(C, C, dout.rows), bias=ab.project_out.bias):
+            self._bias_grad(ctx, dout, [ab.project_out.bias], C)
         # attention core
         q, kk, v = qkv.ptr, qkv.ptr + C * es, qkv.ptr + 2 * C * es
         dqkv = self._new(B, x.H, x.W, 3 * C)
@@ -1071,8 +1095,8 @@ class _Engine:
         # project_in
         dhn = self._new(B, x.H, x.W, C)
         ops.conv2d(dqkv, ci.wd.data_ptr(), dhn.ptr, dhn.ld, C, 1, 1, x.H, x.W, splitk=self.splitk)
-        self._wgrad(ctx, ab.project_in.weight, dqkv, hn, C, 3 * C, 1, 1, splits=self._splits(3 * C, C, dqkv.rows))
-        self._bias_grad(ctx, dqkv, [ab.project_in.bias], 3 * C)
+        if not self._wgrad(ctx, ab.project_in.weight, dqkv, hn, C, 3 * C, 1, 1, splits=self._splits(3 * C, C, dqkv.rows), bias=ab.project_in.bias):
+            self._bias_grad(ctx, dqkv, [ab.project_in.bias], 3 * C)
         # GN (no SiLU) + identity residual
         g, acc = self._grad_target(x)
         ops.gn_bwd(x, dhn, g, ab.norm.weight, ab.norm.bias, stats, self._pptr(ctx, ab.norm.weight), self._pptr(ctx, ab.norm.bias),

@@ -70,6 +70,16 @@ int ddpm_conv3x3_wgrad_nhwc(const void* dy, long long dy_ld, const void* x, long
                             float* dbias, long long bias_stride, int B, int H, int W, int C, int N, int Nreal, int splits,
                             int dtype, void* stream);
 
+/* Weight (and bias) gradient of a 1x1 / stride-1 convolution — autograd of F.conv2d (ddpm_torch/modules.py:120-123) at the attention
+ * projections and skip connections (ddpm_torch/models/unet.py:27-29, :38-39) — by the slab kernel of csrc/wgrad1x1.hip (bf16):
+ *     dW[n][c] = sum_p dy[p][n] * x[p][c]      db[n] = sum_p dy[p][n]      p over the P = B*H*W pixels
+ * ddpm_conv1x1_wgrad_splits returns the number of slab copies the kernel writes for this geometry (0: not covered, use
+ * ddpm_conv2d_wgrad_nhwc); slice s STORES its partials at dw + s*slab_stride ([N][C] fp32) and dbias + s*bias_stride (dbias may be
+ * NULL); ddpm_wgrad_reduce sums the copies in a fixed order. */
+int ddpm_conv1x1_wgrad_splits(int P, int C, int N);
+int ddpm_conv1x1_wgrad_nhwc(const void* dy, long long dy_ld, const void* x, long long x_ld, float* dw, long long slab_stride,
+                            float* dbias, long long bias_stride, int P, int C, int N, int splits, int dtype, void* stream);
+
 int ddpm_wgrad_reduce(const long long* table, int n_tensors, void* stream);
 
 int ddpm_wgrad_unpack(const float* gpack, float* gflat, const long long* descs, int n_tensors, float scale, void* stream);

@@ -165,6 +165,15 @@ class Emulator:
                 for c in range(copies):
                     f32(dbias + 4 * c * bias_stride, Nreal)[...] = v if c == copies - 1 else 0.0
 
+    def ddpm_conv1x1_wgrad_nhwc(self, dy, dy_ld, x, x_ld, dw, slab_stride, dbias, bias_stride, P, C, N, splits, dt, st):
+        g = Mat(dy, P, N, dy_ld, dt).get().astype(np.float64)
+        v = Mat(x, P, C, x_ld, dt).get().astype(np.float64)
+        full = (g.T @ v).astype(np.float32).reshape(-1)                 # [N][C]; the slab copies sum to it (here: all in the last one)
+        for c in range(splits):
+            f32(dw + 4 * c * slab_stride, N * C)[...] = full if c == splits - 1 else 0.0
+            if dbias:
+                f32(dbias + 4 * c * bias_stride, N)[...] = g.sum(0).astype(np.float32) if c == splits - 1 else 0.0
+
     def ddpm_wgrad_reduce(self, table, n, st):
         for src, dst, length, copies, stride in i64(table, 5 * n).reshape(n, 5):
             acc = np.zeros(int(length), dtype=np.float32)

@@ -120,6 +120,37 @@ def test_conv3x3_stationary_halo_path(B, H, C, N):
     assert _hip.lib().ddpm_conv2d_variant(ld, yld, B, H, H, C, H, H, N, 3, 3, 1, 1, 1, 0, 0, 0, 1, dt) == (8 if H % 16 == 0 else 5)
 
 
+WG1_CASES = [(32768, 256, 256), (32768, 256, 768), (131072, 128, 256), (33635, 192, 104), (32768, 768, 256), (16384, 64, 64), (40000, 384, 128)]
+
+
+@pytest.mark.parametrize("P,C,N", WG1_CASES)
+def test_conv1x1_wgrad_slab_kernel(P, C, N):
+    """dW = dy^T x and db = colsum(dy) of a 1x1 conv by the slab kernel (csrc/wgrad1x1.hip): the slab copies, summed in order as
+    ddpm_wgrad_reduce does, against float64 — full and ragged channel tiles, a pixel count that is not a multiple of the K-step,
+    pitched operands."""
+    splits = _hip.lib().ddpm_conv1x1_wgrad_splits(P, C, N)
+    assert splits > 0
+    ld_y, ld_x = N + 8, C + 16
+    dy = r(P, ld_y, seed=3, dt=1, scale=0.5)
+    x = r(P, ld_x, seed=4, dt=1)
+    stride, bstride = N * C + 4, N + 4
+    dyd, xd = dy.cuda(), x.cuda()
+    slabs = torch.full((splits * stride,), float("nan"), device="cuda")
+    bslabs = torch.full((splits * bstride,), float("nan"), device="cuda")
+    _hip.call("ddpm_conv1x1_wgrad_nhwc", dyd.data_ptr(), ld_y, xd.data_ptr(), ld_x, slabs.data_ptr(), stride, bslabs.data_ptr(), bstride,
+              P, C, N, splits, 1, _hip.stream())
+    torch.cuda.synchronize()
+    got = slabs.view(splits, stride)[:, :N * C].double().sum(0).view(N, C).cpu()
+    gotb = bslabs.view(splits, bstride)[:, :N].double().sum(0).cpu()
+    ref = dy[:, :N].double().t() @ x[:, :C].double()
+    refb = dy[:, :N].double().sum(0)
+    assert torch.isfinite(got).all() and torch.isfinite(gotb).all()
+    assert float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) + 1e-3, float((got - ref).abs().max())
+    assert float((gotb - refb).abs().max()) <= 2e-5 * float(refb.abs().max()) + 1e-3
+    # the geometry query refuses what the kernel does not serve
+    assert _hip.lib().ddpm_conv1x1_wgrad_splits(8192, C, N) == 0 and _hip.lib().ddpm_conv1x1_wgrad_splits(P, C + 4, N) == 0
+
+
 PW_CASES = [(32, 32, 128, 256), (64, 32, 128, 256), (35, 31, 64, 192), (128, 16, 256, 768), (130, 16, 320, 384), (70, 31, 192, 104), (128, 16, 768, 256)]
 
 
