@@ -102,10 +102,12 @@ def make_trainer(ddpm_torch, cfg, dev, dtype, shape, var_type, distributed=False
 def timed_steps(tr, x0, steps, warmup, sync):
     for i in range(warmup):
         tr.step(x0, global_steps=i + 1)
+    tr.current_stats
     sync()
     t0 = time.perf_counter()
     for i in range(steps):
         tr.step(x0, global_steps=warmup + i + 1)
+    tr.current_stats                     # every step's loss read-back is collected INSIDE the timed region (the last one is still pending)
     sync()
     return time.perf_counter() - t0
 
@@ -160,7 +162,8 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     imgs_per_s = B_PER_GPU * world * args.steps / elapsed
     loss = tr.current_stats["loss"]
-    step_mode = "direct step, " + ("hipGraph replay" if any(d.graph is not None for d in tr._direct.values()) else "eager launches") \
+    replayed = any((d.choice == "graph") if d.choice is not None else (d.graph is not None and d.last_kind == "graph") for d in tr._direct.values())
+    step_mode = "direct step, " + ("hipGraph replay" if replayed else "eager launches") + (" (chosen by measurement)" if any(d.choice for d in tr._direct.values()) else "") \
         if tr._direct else "autograd step"
 
     # ---- roofline of the dominant kernel: per-launch HIP events (recorded on the stream each kernel is launched on) over

@@ -39,6 +39,7 @@ from .._graphs import SegmentedGraph
 __all__ = ["Trainer", "EMA", "ModelWrapper", "DummyScheduler", "RunningStatistics"]
 
 # "auto" (default): the captured step is used when it measures faster than the eager one on this workload; "1" / "0" force it
+_ASYNC_LOSS = os.environ.get("DDPM_TORCH_AMD_ASYNC_LOSS", "1") != "0"     # 0: read the loss back synchronously in every step
 _TRAIN_GRAPH = {"0": False, "1": True}.get(os.environ.get("DDPM_TORCH_AMD_TRAIN_GRAPH", "auto"), "auto")
 
 
@@ -78,6 +79,23 @@ class RunningStatistics:
 
     def __repr__(self):
         return "RunningStatistics(" + ", ".join(f"{k}={v:.6g}" for k, v in self.extract().items()) + ")" if self.count else "RunningStatistics()"
+
+
+class _StepStatistics(RunningStatistics):
+    """The Trainer's statistics: the loss of the latest step may still be on its way from the device (see Trainer.step); every
+    read or reset collects it first, so callers see exactly what the synchronous read-back would have produced."""
+
+    def __init__(self, drain, **kwargs):
+        super().__init__(**kwargs)
+        self._drain = drain
+
+    def reset(self):
+        self._drain()
+        super().reset()
+
+    def extract(self):
+        self._drain()
+        return super().extract()
 
 
 class EMA:
@@ -452,7 +470,8 @@ class Trainer:
         self.sample_seed = 131071 + self.rank                                            # utils/train.py:117
         self.use_ema = use_ema
         self.ema = EMA(model.module if isinstance(model, DDP) else model, decay=ema_decay) if use_ema else nullcontext()
-        self.stats = RunningStatistics(loss=None)
+        self.stats = _StepStatistics(self._collect_loss, loss=None)
+        self._loss_pending, self._loss_host, self._loss_slot = None, None, 0
         self._fused = _FusedUpdate(optimizer, self.ema)
         self._direct = {}                               # (input shape, train/eval) -> _DirectStep
         self.input_source = None                        # optional fn(t_buf, noise_buf) filling the step's (t, noise) in place (parity tests)
@@ -544,9 +563,34 @@ class Trainer:
         if self.distributed:
             dist.reduce(loss, dst=0, op=dist.ReduceOp.SUM)
             loss.div_(self.world_size)
-        self.stats.update(x.shape[0], loss=loss.item() * x.shape[0])         # .item(): the host waits for the step here, as in the reference
+        probing = direct is not None and _TRAIN_GRAPH == "auto" and direct.choice is None
+        if _ASYNC_LOSS and loss.is_cuda and not probing:
+            # The reference reads the loss back with .item() at this point (utils/train.py:170) and so parks the host until the GPU has
+            # finished the step — after which the GPU idles while the host prepares the next one.  Same read-back, one step later: the
+            # value goes to pinned memory asynchronously and is added to the statistics when the NEXT step gets here (or when the
+            # statistics are read or reset), by which time it has long arrived.
+            self._collect_loss()
+            if self._loss_host is None:
+                self._loss_host = [torch.zeros((), dtype=torch.float32).pin_memory() for _ in range(2)]
+            buf = self._loss_host[self._loss_slot]
+            self._loss_slot ^= 1
+            buf.copy_(loss, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._loss_pending = (x.shape[0], ev, buf)
+        else:
+            self._collect_loss()
+            RunningStatistics.update(self.stats, x.shape[0], loss=loss.item() * x.shape[0])      # the host waits for the step here
         if direct is not None:
             direct.observe(time.perf_counter() - t_begin)
+
+    def _collect_loss(self):
+        """Add the loss of the step whose read-back is still pending (if any) to the statistics."""
+        if self._loss_pending is not None:
+            n, ev, buf = self._loss_pending
+            self._loss_pending = None
+            ev.synchronize()
+            RunningStatistics.update(self.stats, n, loss=float(buf) * n)
 
     # ------------------------------------------------------------------ sampling with the (EMA) weights
     def sample_fn(self, sample_size=None, noise=None, diffusion=None, sample_seed=None):
