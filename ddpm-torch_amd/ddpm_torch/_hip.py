@@ -100,8 +100,22 @@ def call(name, *args):
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 
 
+_routed = None
+
+
+def route_stream(handle):
+    """Make stream() return `handle` (a raw hipStream_t) until route_stream(previous) — for code that launches a few kernels on
+    another stream without switching torch's current stream.  Returns the previous routing."""
+    global _routed
+    prev, _routed = _routed, handle
+    return prev
+
+
 def stream():
-    """hipStream_t of torch's current stream (the raw getter skips building a torch.cuda.Stream per launch)."""
+    """hipStream_t the next launch goes to: the routed one if any, else torch's current stream (the raw getter skips building a
+    torch.cuda.Stream per launch)."""
+    if _routed is not None:
+        return _routed
     if _raw_stream is not None:
         return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream

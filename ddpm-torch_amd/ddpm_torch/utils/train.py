@@ -384,7 +384,7 @@ class _DirectStep:
         torch.sum(losses * self.gloss, dim=0, out=self.loss)                   # mean over the batch
         gout = torch.empty_like(out)
         _hip.call("ddpm_mse_bwd", out.data_ptr(), target.data_ptr(), self.gloss.data_ptr(), gout.data_ptr(), B, n, s())
-        eng.backward(tape, gout, gflat=self.gflat, cut=cut)
+        eng.backward(tape, gout, gflat=self.gflat, cut=cut, want_views=False)
         tr._fused.launch(tr.grad_norm, hyper_dev=self.hyper_dev.data_ptr())
         eng.refresh_unconditionally()                                          # the next forward reads the re-derived copies
 
