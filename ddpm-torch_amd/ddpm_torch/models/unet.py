@@ -251,6 +251,7 @@ _SIDE_STREAM = os.environ.get("DDPM_SIDE_STREAM", "1") != "0"      # weight / bi
 _WGRAD_MINSTEPS = int(os.environ.get("DDPM_WGRAD_MINSTEPS", "20"))
 _WGRAD_SLABS = os.environ.get("DDPM_WGRAD_SLABS", "0") != "0"      # deterministic slab reduction instead of atomics
 _WGRAD3 = os.environ.get("DDPM_WGRAD3", "1") != "0"                # patch-stationary kernel for the 3x3 / stride-1 weight gradients
+_SLAB_FLUSH_ROWS = int(os.environ.get("DDPM_SLAB_FLUSH_ROWS", "6"))   # slab reductions queued on the side stream every so many rows
 _WGRAD1 = os.environ.get("DDPM_WGRAD1", "1") != "0"                # slab kernel for the 1x1 weight gradients
 _WGRAD3_ATOMIC = os.environ.get("DDPM_WGRAD3_ATOMIC", "0") != "0"  # ... with fp32 atomics instead of slab copies
 
@@ -614,16 +615,21 @@ class _Engine:
                 self._comm(ctx, lambda works=works, chunk=chunk: works.append(self._all_reduce(chunk)))
         return did_bias
 
-    def _flush_slabs(self, ctx):
-        """Sum the slab copies recorded since the last flush into the staging buffer (one launch)."""
+    def _flush_slabs(self, ctx, on_side=False):
+        """Sum the slab copies recorded since the last flush into the staging buffer (one launch).  ``on_side``: queue it on the side
+        stream, behind the kernels that wrote the copies, without making the main stream wait — the backward flushes like this every
+        few layers, so that the ~0.25 ms of slab traffic runs under the critical path instead of after it."""
         rows = tuple(ctx["slab_rows"])
         if not rows:
             return
         ctx["slab_rows"] = []
-        self._join_side(ctx)
         table = self._slab_tables.get(rows)
         if table is None:                                    # addresses are stable (persistent buffers): built once per geometry
             table = self._slab_tables[rows] = torch.tensor(rows, dtype=torch.int64, device=self.device)
+        if on_side and ctx.get("side") is not None:
+            _hip.call("ddpm_wgrad_reduce", table.data_ptr(), len(rows), ctx["side_handle"])
+            return
+        self._join_side(ctx)
         _hip.call("ddpm_wgrad_reduce", table.data_ptr(), len(rows), _hip.stream())
 
     def _comm(self, ctx, fn):
@@ -965,6 +971,8 @@ class _Engine:
         # ---- the rest of the tape in reverse
         for rec in reversed(tape[:-1]):
             kind = rec[0]
+            if ctx["pending"] is None and len(ctx["slab_rows"]) >= _SLAB_FLUSH_ROWS:
+                self._flush_slabs(ctx, on_side=True)
             if kind == "res":
                 self._res_bwd(ctx, rec)
             elif kind == "attn":

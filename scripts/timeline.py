@@ -10,8 +10,8 @@ from collections import defaultdict
 
 
 def short(name):
-    name = re.sub(r"\(.*", "", name)
     name = re.sub(r"void |at::native::|\(anonymous namespace\)::", "", name)
+    name = re.sub(r"\(.*", "", name)
     return name[:70]
 
 
@@ -55,6 +55,10 @@ def main(d, marker="mt_adam_ema_kernel"):
     for g, x, y in gaps[:12]:
         print(f"   {1e-3 * g:7.1f}  {x}  ->  {y}")
     print(f"   total gap {1e-6 * sum(g for g, _, _ in gaps if g > 0):.3f} ms over {len(gaps)} boundaries")
+    # the tail of the step: what runs (and what waits) between the end of the backward's critical path and the optimiser
+    print("last 28 dispatches (start, end in us before the end of the step; queue; kernel):")
+    for s_, e_, n, q_ in sorted(step, key=lambda r: r[0])[-28:]:
+        print(f"   {1e-3 * (t1 - s_):8.1f} {1e-3 * (t1 - e_):8.1f}  q{q_}  {short(n) or '(anonymous-namespace kernel)'}")
 
 
 if __name__ == "__main__":
