@@ -1127,19 +1127,24 @@ class _Engine:
         F = _hip.F32
         # fc (all blocks at once): dW = dtb^T s_t ; db = colsum(dtb) ; d(s_t) = dtb W.  dW / db land in gpack slots that the
         # unpack table fans out to every fc.weight / fc.bias / conv1.bias.
-        ops.gemm(dtb.data_ptr(), Ct, 0, 1, s_t.data_ptr(), E, 0, 1, self._pptr(ctx, "fc_w"), E, 0, Ct, E, B, F, out_mode=1)
-        ops.colsum(View(dtb, 1, B, 1, Ct), 0, 0, self._pptr(ctx, "fc_b"))
+        # (parameter gradients are leaves: on the side stream, next to the chain d(s_t) -> d(t_emb) -> d(s1) -> d(e1) that is the very
+        #  end of the backward's critical path)
+        with self._leaf(ctx, dtb, s_t):
+            ops.gemm(dtb.data_ptr(), Ct, 0, 1, s_t.data_ptr(), E, 0, 1, self._pptr(ctx, "fc_w"), E, 0, Ct, E, B, F, out_mode=1)
+            ops.colsum(View(dtb, 1, B, 1, Ct), 0, 0, self._pptr(ctx, "fc_b"))
         ds_t = torch.zeros((B, E), dtype=torch.float32, device=self.device)     # K = sum Cout (~5000): split-K with fp32 atomics
         ops.gemm(dtb.data_ptr(), Ct, 0, 0, fc_w.data_ptr(), E, 0, 1, ds_t.data_ptr(), E, 0, B, E, Ct, F, out_mode=2, splits=max(1, Ct // 256))
         dt_emb = self._f32(B, E)
         _hip.call("ddpm_silu_bwd", t_emb.data_ptr(), ds_t.data_ptr(), dt_emb.data_ptr(), B * E, 0, _hip.stream())
         ctx["dt_emb"] = dt_emb                                  # d/d(t_emb): what the reference's ResidualBlock hands back to the embedding MLP
         lin2, lin1 = m.embed[2], m.embed[0]
-        ops.gemm(dt_emb.data_ptr(), E, 0, 1, s1.data_ptr(), E, 0, 1, self._pptr(ctx, lin2.weight), E, 0, E, E, B, F, out_mode=1)
-        ops.colsum(View(dt_emb, 1, B, 1, E), 0, 0, self._pptr(ctx, lin2.bias))
+        with self._leaf(ctx, dt_emb, s1):
+            ops.gemm(dt_emb.data_ptr(), E, 0, 1, s1.data_ptr(), E, 0, 1, self._pptr(ctx, lin2.weight), E, 0, E, E, B, F, out_mode=1)
+            ops.colsum(View(dt_emb, 1, B, 1, E), 0, 0, self._pptr(ctx, lin2.bias))
         ds1 = self._f32(B, E)
         ops.gemm(dt_emb.data_ptr(), E, 0, 0, lin2.weight.data_ptr(), E, 0, 1, ds1.data_ptr(), E, 0, B, E, E, F, out_mode=1)
         de1 = self._f32(B, E)
         _hip.call("ddpm_silu_bwd", e1.data_ptr(), ds1.data_ptr(), de1.data_ptr(), B * E, 0, _hip.stream())
-        ops.gemm(de1.data_ptr(), E, 0, 1, temb.data_ptr(), self.hid, 0, 1, self._pptr(ctx, lin1.weight), self.hid, 0, E, self.hid, B, F, out_mode=1)
-        ops.colsum(View(de1, 1, B, 1, E), 0, 0, self._pptr(ctx, lin1.bias))
+        with self._leaf(ctx, de1, temb):
+            ops.gemm(de1.data_ptr(), E, 0, 1, temb.data_ptr(), self.hid, 0, 1, self._pptr(ctx, lin1.weight), self.hid, 0, E, self.hid, B, F, out_mode=1)
+            ops.colsum(View(de1, 1, B, 1, E), 0, 0, self._pptr(ctx, lin1.bias))
