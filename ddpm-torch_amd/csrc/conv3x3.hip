@@ -38,15 +38,32 @@ struct CsArgs {
     FastDiv d_tiles_n, d_tpi, d_tiles_x;
 };
 
-constexpr int HWD = 18, HP = 324;                         // halo of a 16 x 16 patch
-constexpr int NI = 6;                                     // halo DMA parts: 5 x 512 vectors + 32
-constexpr int RING = 4;                                   // weight tiles in the ring (RING - 1 in flight)
-constexpr int HALO_BYTES = 5 * 512 * 16 + 1024;           // 41,984: parts 0-4 by all waves, part 5 by wave 0
+// Patch geometry.  16 x 16 patches (images of 16 x 16 and up): tile = 256 pixels x 128 channels, 8 waves as 2 (channels) x 4 (pixels) of
+// 64 x 64.  8 x 8 patches (the 8 x 8 level, where 256-pixel tiles would leave three quarters of the CUs idle): tile = 64 pixels x 128
+// channels, 8 waves as 4 x 2 of 32 x 32 — a K-step is then only four MFMAs per wave, so the ring is deeper (5 tiles in flight) to
+// cover the same DMA latency with shorter steps.
+template <int PATCH> struct Geo;
+template <> struct Geo<16> {
+    static constexpr int HWD = 18, HP = 324, LP = 4;           // halo width, halo pixels, log2(patch)
+    static constexpr int NI = 6;                                // halo DMA parts: 5 x 512 vectors + 32
+    static constexpr int RING = 4;                              // weight tiles in the ring (RING - 1 in flight)
+    static constexpr int WM = 4, NIB = 2, NJ = 2;               // pixel waves; 32-channel / 32-pixel accumulator blocks per wave
+    static constexpr int HALO_BYTES = 5 * 512 * 16 + 1024;      // 41,984: parts 0-4 by all waves, part 5 by wave 0
+};
+template <> struct Geo<8> {
+    static constexpr int HWD = 10, HP = 100, LP = 3;
+    static constexpr int NI = 2;                                // 800 vectors: two parts (the lanes past the halo fetch zeros into the tail)
+    static constexpr int RING = 6;
+    static constexpr int WM = 2, NIB = 1, NJ = 1;
+    static constexpr int HALO_BYTES = 2 * 512 * 16;
+};
 constexpr int WT_BYTES = 128 * 128;
-constexpr int DUMP_AT = 2 * HALO_BYTES + RING * WT_BYTES; // 1 KiB the other waves' (all out-of-range) part-5 lanes write their zeros to
-constexpr int ROWS_AT = DUMP_AT + 1024;                   // 2 slots x (bias row 1 KiB | time-bias row 1 KiB)
-constexpr int LDS_BYTES = ROWS_AT + 4096;
-static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+template <int PATCH> struct Lds {
+    static constexpr int DUMP_AT = 2 * Geo<PATCH>::HALO_BYTES + Geo<PATCH>::RING * WT_BYTES;   // 1 KiB the other waves' (all out-of-range) part-5 lanes write zeros to
+    static constexpr int ROWS_AT = DUMP_AT + 1024;                                               // 2 slots x (bias row 1 KiB | time-bias row 1 KiB)
+    static constexpr int BYTES = ROWS_AT + 4096;
+    static_assert(BYTES <= 160 * 1024, "LDS");
+};
 
 template <int N> __device__ __forceinline__ void wait_vm() {
     static_assert(N >= 0 && N < 64, "vmcnt immediate");
@@ -68,15 +85,19 @@ __device__ unsigned long long* g_c3_timing = nullptr;        // debug builds onl
 #define C3_STAMP(slot)
 #endif
 
+template <int PATCH>
 __global__ __launch_bounds__(512, 2)
 void conv3x3_stream_kernel(CsArgs a) {
+    typedef Geo<PATCH> G_;
+    constexpr int HWD = G_::HWD, HP = G_::HP, LP = G_::LP, NI = G_::NI, RING = G_::RING, WM = G_::WM, NIB = G_::NIB, NJ = G_::NJ;
+    constexpr int HALO_BYTES = G_::HALO_BYTES, DUMP_AT = Lds<PATCH>::DUMP_AT, ROWS_AT = Lds<PATCH>::ROWS_AT;
     C3_STAMP(0); C3_STAMP(1);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* halo = smem;
     char* wring = smem + 2 * HALO_BYTES;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wn = wave >> 2, wm = wave & 3;              // wave = 64 channels x 64 pixels (4 patch rows)
+    const int wn = wave / WM, wm = wave % WM;             // wave = 32 NIB channels x 32 NJ pixels
 
     auto rsrc_of = [&](const void* p, unsigned extent) {
         const unsigned long long ad = (unsigned long long)p;
@@ -99,12 +120,12 @@ void conv3x3_stream_kernel(CsArgs a) {
         const int tpi = a.tiles_y * a.tiles_x;
         const int img = (int)fdiv((unsigned)tmi, a.d_tpi), pt = tmi - img * tpi;
         const int ty = (int)fdiv((unsigned)pt, a.d_tiles_x);
-        TilePos t; t.img = img; t.py0 = ty * 16; t.px0 = (pt - ty * a.tiles_x) * 16; t.tn = lid - tmi * a.tiles_n;
+        TilePos t; t.img = img; t.py0 = ty * PATCH; t.px0 = (pt - ty * a.tiles_x) * PATCH; t.tn = lid - tmi * a.tiles_n;
         return t;
     };
     // halo DMA plan of a tile: vector v = tid + 512 i -> halo pixel hp = v >> 3 (row hy, column hx of the 18 x 18 halo), physical chunk
-    // v & 7 = logical chunk ^ ((hx >> 1) & 7): the 16 pixels one ds_read_b128 lane group touches land on 16 distinct (bank half, chunk)
-    // pairs for every tap shift.  Pixels outside the image (and the 480 vectors past the halo in part 5) get an out-of-range offset.
+    // v & 7 = logical chunk ^ key, key = (hx >> 1) for 16-wide patches, (hx >> 1) ^ ((hy & 1) << 2) for 8-wide ones: the 16 pixels one
+    // ds_read_b128 lane group touches (two half patch rows / four quarter rows) land on 16 distinct (bank half, chunk) pairs for every tap shift.  Pixels outside the image (and the 480 vectors past the halo in part 5) get an out-of-range offset.
     auto halo_plan = [&](const TilePos& t, unsigned (&ho)[NI]) {
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
@@ -112,13 +133,13 @@ void conv3x3_stream_kernel(CsArgs a) {
             const int hy = hp / HWD, hx = hp - hy * HWD;
             const int iy = t.py0 + hy - 1, ix = t.px0 + hx - 1;
             const bool ok = hp < HP && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-            const int lc = (v & 7) ^ ((hx >> 1) & 7);
+            const int lc = (v & 7) ^ (PATCH == 16 ? (hx >> 1) & 7 : ((hx >> 1) ^ ((hy & 1) << 2)) & 7);
             ho[i] = ok ? ((unsigned)((t.img * a.H + iy) * a.W + ix) * (unsigned)a.x_ld + (unsigned)(lc * 8)) * 2u : OOB;     // < 2^31: checked by the launcher
         }
     };
     auto issue_halo_part = [&](unsigned ho, int i, int cc, char* dst) {
         const unsigned o = ho == OOB ? OOB : ho + (unsigned)(cc * 128);
-        char* d = i < 5 ? dst + (wave * 64 + 512 * i) * 16 : (wave == 0 ? dst + 5 * 512 * 16 : smem + DUMP_AT);
+        char* d = (PATCH == 8 || i < 5) ? dst + (wave * 64 + 512 * i) * 16 : (wave == 0 ? dst + 5 * 512 * 16 : smem + DUMP_AT);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)d, 16, o, 0, 0, 0);
     };
     // weight DMA plan: vector v = tid + 512 i -> row n = v >> 3 of the 128-row tile, physical chunk v & 7 = logical ^ ((row >> 1) & 7)
@@ -155,18 +176,18 @@ void conv3x3_stream_kernel(CsArgs a) {
     };
 
     // this lane's pixels (columns of its two 32-pixel accumulator blocks) -> halo index of tap (0, 0)
-    int hp0[2], pxl[2];
+    int hp0[NJ], pxl[NJ], pyl[NJ];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int p = wm * 64 + j * 32 + (lane & 31);
-        hp0[j] = (p >> 4) * HWD + (p & 15);
-        pxl[j] = p & 15;
+    for (int j = 0; j < NJ; ++j) {
+        const int p = wm * (32 * NJ) + j * 32 + (lane & 31);
+        hp0[j] = (p >> LP) * HWD + (p & (PATCH - 1));
+        pxl[j] = p & (PATCH - 1); pyl[j] = (p >> LP) & 1;
     }
-    f32x16 acc[2][2];
+    f32x16 acc[NIB][NJ];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NIB; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x16)(0.f);
+        for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x16)(0.f);
 
     // ---- prologue: halo of (tile 0, chunk 0), the tile's rows, then the first RING - 1 weight tiles; wait for the halo + tile 0 only
     TilePos cur = tile_pos(0);
@@ -177,14 +198,15 @@ void conv3x3_stream_kernel(CsArgs a) {
     issue_rows(cur, 0);
 #pragma unroll
     for (int t = 0; t < RING - 1; ++t) issue_w(cur.tn, 0, t, t);
-    wait_vm<4>();
+    wait_vm<2 * (RING - 2)>();
     __builtin_amdgcn_s_barrier();
 
     C3_STAMP(2);
     const int sw = (lane >> 5) ^ ((lane >> 1) & 7);
     const int hi = lane >> 5;
     int slot = 0, hb = 0;                                  // ring slot of the step being consumed; halo buffer in use
-    bool st8 = false;                                      // this wave's 8 epilogue stores of the previous tile may still be in flight
+    constexpr int ST = 2 * NIB * NJ;                       // 16-byte stores per lane in a tile's epilogue
+    bool st8 = false;                                      // ... of the previous tile: may still be in flight
     for (int k = 0; k < my_tiles; ++k) {
         const bool more_tiles = k + 1 < my_tiles;
         TilePos nxt = cur;
@@ -198,7 +220,7 @@ void conv3x3_stream_kernel(CsArgs a) {
             const bool last_chunk = !same_tile;
             const int ncc = same_tile ? cc + 1 : 0;          // ... its chunk index and its tile's channel tile
             const int ntn = same_tile ? cur.tn : nxt.tn;
-            u32x2 rv[2][2][4];                               // residual OR previous output (the launcher admits one of them)
+            u32x2 rv[NJ][NIB][4];                            // residual OR previous output (the launcher admits one of them)
             bool pre = false;
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {              // fully unrolled: the halo-part index and the ring arithmetic are constants
@@ -212,23 +234,23 @@ void conv3x3_stream_kernel(CsArgs a) {
                     // last step of the tile with a residual / "+=" epilogue: request those rows NOW, ahead of this step's weight tile.
                     // INLINE ASM: a C++ load would make hipcc drain every pending LDS-DMA first; the wait is issued by hand below.
                     pre = true;
-                    const int n0 = cur.tn * 128 + wn * 64 + 4 * (lane >> 5);
+                    const int n0 = cur.tn * 128 + wn * (32 * NIB) + 4 * (lane >> 5);
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        const int p = wm * 64 + j * 32 + (lane & 31);
+                    for (int j = 0; j < NJ; ++j) {
+                        const int p = wm * (32 * NJ) + j * 32 + (lane & 31);
                         // one address per pixel, the 4-channel runs at constant byte offsets.  UNCONDITIONAL loads (a load under `if` makes the
                         // result a phi that the compiler fills right after the asm, before the data is back): waves whose 64 channels lie beyond
                         // N (N % 64 == 0) read the start of their row instead and are zeroed after the wait.
-                        const bf16_t* base = (a.res ? a.res : a.out) + ((long long)(cur.img * a.H + cur.py0 + (p >> 4)) * a.W + cur.px0 + (p & 15)) * (a.res ? a.res_ld : a.out_ld)
+                        const bf16_t* base = (a.res ? a.res : a.out) + ((long long)(cur.img * a.H + cur.py0 + (p >> LP)) * a.W + cur.px0 + (p & (PATCH - 1))) * (a.res ? a.res_ld : a.out_ld)
                                              + (n0 < a.N ? n0 : 0);
 #pragma unroll
-                        for (int i = 0; i < 2; ++i)
+                        for (int i = 0; i < NIB; ++i)
 #pragma unroll
                             for (int g = 0; g < 4; ++g)
                                 asm volatile("global_load_dwordx2 %0, %1, off offset:%2" : "=v"(rv[j][i][g]) : "v"(base), "n"((i * 32 + 8 * g) * 2) : "memory");
                     }
                 }
-                const int wslot = (slot + RING - 1) & (RING - 1);
+                const int wslot = slot + RING - 1 >= RING ? slot - 1 : slot + RING - 1;
                 if (tap + RING - 1 < 9) issue_w(cur.tn, cc, tap + RING - 1, wslot);
                 else if (prefetch) {
                     if (tap == 9 - (RING - 1) && last_chunk) issue_rows(nxt, (k + 1) & 1);     // first stage of the next tile
@@ -238,31 +260,31 @@ void conv3x3_stream_kernel(CsArgs a) {
                 const int shift = r * HWD + s;
 #pragma unroll
                 for (int kc = 0; kc < 4; ++kc) {
-                    u32x4 fw[2], fx[2];
+                    u32x4 fw[NIB], fx[NJ];
 #pragma unroll
-                    for (int i = 0; i < 2; ++i) fw[i] = *reinterpret_cast<const u32x4*>(wcur + (wn * 64 + i * 32 + (lane & 31)) * 128 + (((2 * kc) ^ sw) << 4));
+                    for (int i = 0; i < NIB; ++i) fw[i] = *reinterpret_cast<const u32x4*>(wcur + (wn * (32 * NIB) + i * 32 + (lane & 31)) * 128 + (((2 * kc) ^ sw) << 4));
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        const int key = ((pxl[j] + s) >> 1) & 7;
+                    for (int j = 0; j < NJ; ++j) {
+                        const int key = PATCH == 16 ? ((pxl[j] + s) >> 1) & 7 : (((pxl[j] + s) >> 1) ^ (((pyl[j] + r) & 1) << 2)) & 7;
                         fx[j] = *reinterpret_cast<const u32x4*>(hcur + (hp0[j] + shift) * 128 + ((((2 * kc) | hi) ^ key) << 4));
                     }
 #pragma unroll
-                    for (int i = 0; i < 2; ++i)
+                    for (int i = 0; i < NIB; ++i)
 #pragma unroll
-                        for (int j = 0; j < 2; ++j)
+                        for (int j = 0; j < NJ; ++j)
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fw[i]), __builtin_bit_cast(bf16x8, fx[j]), acc[i][j], 0, 0, 0);
                 }
-#ifdef C3_STEPTIMING
-                if (g_c3_timing && threadIdx.x == 0 && blockIdx.x == 0 && k == 0) g_c3_timing[2048 + cc * 9 + tap] = clock64();
-#endif
-                slot = (slot + 1) & (RING - 1);
+                slot = slot + 1 == RING ? 0 : slot + 1;
                 if (tap == 8 && last_chunk) break;          // the tile's last step: epilogue first, then this step's wait + barrier (below)
                 // the next step's weight tile must have landed; the RING - 2 newer tiles (2 DMA instructions each) may stay in flight.  The
                 // count ignores newer halo parts: waiting for more to retire is always safe.  Only the last chunk of the block's last tile
                 // has fewer than two newer tiles (taps 6, 7).
-                if (tap >= 6 && !prefetch) { if (tap == 6) wait_vm<2>(); else wait_vm<0>(); }
-                else if (tap < 2 && cc == 0 && st8) wait_vm<12>();      // + the previous tile's stores: they sit between the tile waited for
-                else wait_vm<4>();                                      //   and the newer ones in the (in-order) queue for two more steps
+                // (without a next chunk the tiles run out: after step `tap` only taps tap + 2 .. 8 are newer than the one waited for)
+                if (!prefetch && 7 - tap < RING - 2) {
+                    if (7 - tap >= 3) wait_vm<6>(); else if (7 - tap == 2) wait_vm<4>(); else if (7 - tap == 1) wait_vm<2>(); else wait_vm<0>();
+                }
+                else if (tap < RING - 2 && cc == 0 && st8) wait_vm<2 * (RING - 2) + ST>();   // + the previous tile's stores: they sit between the tile
+                else wait_vm<2 * (RING - 2)>();                                               //   waited for and the newer ones in the (in-order) queue
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
             }
@@ -279,28 +301,28 @@ void conv3x3_stream_kernel(CsArgs a) {
                 if (pre) {
                     if (prefetch) wait_vm<2>(); else wait_vm<0>();
                     __builtin_amdgcn_sched_barrier(0);
-                    if (!(cur.tn * 128 + wn * 64 < a.N)) {
+                    if (!(cur.tn * 128 + wn * (32 * NIB) < a.N)) {
 #pragma unroll
-                        for (int j = 0; j < 2; ++j)
+                        for (int j = 0; j < NJ; ++j)
 #pragma unroll
-                            for (int i = 0; i < 2; ++i)
+                            for (int i = 0; i < NIB; ++i)
 #pragma unroll
                                 for (int g = 0; g < 4; ++g) rv[j][i][g] = (u32x2)(0u);
                     }
                 }
-                const int n0 = cur.tn * 128 + wn * 64;
-                bf16_t* orow[2];
+                const int n0 = cur.tn * 128 + wn * (32 * NIB);
+                bf16_t* orow[NJ];
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int p = wm * 64 + j * 32 + (lane & 31);
-                    orow[j] = a.out + ((long long)(cur.img * a.H + cur.py0 + (p >> 4)) * a.W + cur.px0 + (p & 15)) * a.out_ld;
+                for (int j = 0; j < NJ; ++j) {
+                    const int p = wm * (32 * NJ) + j * 32 + (lane & 31);
+                    orow[j] = a.out + ((long long)(cur.img * a.H + cur.py0 + (p >> LP)) * a.W + cur.px0 + (p & (PATCH - 1))) * a.out_ld;
                 }
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
+                for (int i = 0; i < NIB; ++i) {
                     f32x4v bsum[4], brow[4];
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
-                        const unsigned ad = (unsigned)(size_t)(rows + (wn * 64 + i * 32 + 8 * g + 4 * (lane >> 5)) * 4);
+                        const unsigned ad = (unsigned)(size_t)(rows + (wn * (32 * NIB) + i * 32 + 8 * g + 4 * (lane >> 5)) * 4);
                         // (unconditional: a read under `if (a.bias)` makes the result a phi, and the compiler copies an asm output into
                         // its phi register right after the asm — before the data has arrived; absent rows are zeroed after the wait)
                         asm volatile("ds_read_b128 %0, %1" : "=v"(bsum[g]) : "v"(ad) : "memory");
@@ -314,7 +336,7 @@ void conv3x3_stream_kernel(CsArgs a) {
                         if (!a.rowbias) brow[g] = (f32x4v)(0.f);
                     }
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) {
+                    for (int j = 0; j < NJ; ++j) {
                         uint2 pk[4];
 #pragma unroll
                         for (int g = 0; g < 4; ++g) {
@@ -343,15 +365,15 @@ void conv3x3_stream_kernel(CsArgs a) {
                     }
                 }
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < NIB; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) acc[i][j] = (f32x16)(0.f);
+                    for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x16)(0.f);
                 if (k == 0) C3_STAMP(4); else if (k == 1) C3_STAMP(6);
                 // the wait + barrier of the tile's last step.  Loads and stores retire in issue order, so the stores just issued (eight per
                 // lane, none when the wave's 64 channels lie beyond N) count among the newer operations: waiting them out here would park the
                 // block for the whole write burst of the chip.
                 st8 = n0 < a.N;
-                if (!more_tiles) wait_vm<0>(); else if (st8) wait_vm<12>(); else wait_vm<4>();
+                if (!more_tiles) wait_vm<0>(); else if (st8) wait_vm<2 * (RING - 2) + ST>(); else wait_vm<2 * (RING - 2)>();
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
             }
@@ -368,13 +390,16 @@ void conv3x3_stream_kernel(CsArgs a) {
 extern "C" int ddpm_debug_set_c3_timing(void* p) { return hipMemcpyToSymbol(HIP_SYMBOL(g_c3_timing), &p, sizeof(p)) == hipSuccess ? 0 : -1; }
 #endif
 
-// Launcher behind conv3x3_halo_launch (gemm.hip): 16 x 16 patches, bf16 -> bf16.  -1: geometry / epilogue not covered (the caller keeps
-// conv3x3_halo_kernel), else a status code.  dry: decide only.
+// Launcher behind ddpm_conv2d_nhwc (gemm.hip) for 3x3 / stride 1 / pad 1, bf16 -> bf16: 16 x 16 patches for images of 16 x 16 and up with
+// >= 16384 pixels, 8 x 8 patches for 8 x 8-divisible images with >= 4096 pixels.  -1: geometry / epilogue not covered (the caller keeps
+// its other kernels), else a status code.  dry: decide only.
 int ddpm_conv3x3_stream_launch(const void* x, long long x_ld, const void* w, void* y, long long y_ld, const float* bias, const float* rowbias,
                                long long rowbias_ld, const void* residual, long long res_ld, int accumulate, int B, int H, int W, int C, int N,
                                int xcd, int dry, void* stream) {
-    static const bool off = getenv("DDPM_CONV_NO_STREAM3") != nullptr;
-    if (off || (residual && accumulate) || H % 16 || W % 16 || C % 64 || N % 64 || x_ld % 8 || y_ld % 8 || (residual && res_ld % 4) || (rowbias && rowbias_ld % 4)) return -1;
+    static const bool off = getenv("DDPM_CONV_NO_STREAM3") != nullptr, off8 = getenv("DDPM_CONV_NO_STREAM3_8") != nullptr;
+    const long long M = (long long)B * H * W;
+    const int patch = (H % 16 == 0 && W % 16 == 0 && M >= 16384) ? 16 : ((H % 8 == 0 && W % 8 == 0 && M >= 4096 && !off8) ? 8 : 0);
+    if (off || !patch || (residual && accumulate) || C % 64 || N % 64 || x_ld % 8 || y_ld % 8 || (residual && res_ld % 4) || (rowbias && rowbias_ld % 4)) return -1;
     if (!aligned16(x) || !aligned16(w) || !aligned16(y) || (residual && (((uintptr_t)residual) & 7)) || (bias && !aligned16(bias)) || (rowbias && !aligned16(rowbias))) return -1;
     const long long xbytes = ((long long)B * H * W * x_ld - (x_ld - C)) * 2, wbytes = (long long)N * 9 * C * 2;
     const long long rbbytes = rowbias ? ((long long)(B - 1) * rowbias_ld + N) * 4 : 0;
@@ -387,17 +412,23 @@ int ddpm_conv3x3_stream_launch(const void* x, long long x_ld, const void* w, voi
     a.bias = bias; a.rowbias = rowbias; a.rowbias_ld = rowbias_ld; a.rowbias_extent = (unsigned)rbbytes;
     a.res = (const bf16_t*)residual; a.res_ld = res_ld; a.accumulate = accumulate;
     a.B = B; a.H = H; a.W = W; a.C = C; a.N = N; a.K = 9 * C;
-    a.tiles_y = H / 16; a.tiles_x = W / 16; a.tiles_n = (N + 127) / 128;
+    a.tiles_y = H / patch; a.tiles_x = W / patch; a.tiles_n = (N + 127) / 128;
     a.total_tiles = B * a.tiles_y * a.tiles_x * a.tiles_n;
     a.xcd = xcd;
     a.d_tiles_n = make_fastdiv((unsigned)a.tiles_n); a.d_tpi = make_fastdiv((unsigned)(a.tiles_y * a.tiles_x)); a.d_tiles_x = make_fastdiv((unsigned)a.tiles_x);
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_stream_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) return DDPM_ERR_LAUNCH;
-        attr_set = true;
-    }
     static const int max_grid = getenv("DDPM_C3_GRID") ? atoi(getenv("DDPM_C3_GRID")) : 256;      // (timing experiments: > 256 = fewer tiles per block)
     const int grid = a.total_tiles < max_grid ? a.total_tiles : max_grid;
-    hipLaunchKernelGGL(conv3x3_stream_kernel, dim3(grid), dim3(512), LDS_BYTES, (hipStream_t)stream, a);
+#define C3_LAUNCH(PATCHV)                                                                                                              \
+    do {                                                                                                                               \
+        static bool attr_set = false;                                                                                                  \
+        if (!attr_set) {                                                                                                               \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_stream_kernel<PATCHV>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                    Lds<PATCHV>::BYTES) != hipSuccess) return DDPM_ERR_LAUNCH;                                         \
+            attr_set = true;                                                                                                           \
+        }                                                                                                                              \
+        hipLaunchKernelGGL(conv3x3_stream_kernel<PATCHV>, dim3(grid), dim3(512), Lds<PATCHV>::BYTES, (hipStream_t)stream, a);           \
+    } while (0)
+    if (patch == 16) C3_LAUNCH(16); else C3_LAUNCH(8);
+#undef C3_LAUNCH
     return check_launch();
 }

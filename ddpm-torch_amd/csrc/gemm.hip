@@ -1328,11 +1328,6 @@ static int conv3x3_halo_launch(GemmArgs& g, const void* x, long long x_ld, const
         }                                                                                                                \
         hipLaunchKernelGGL((conv3x3_halo_kernel<RING, HROWS>), grid, dim3(512), LDS, st, a, tiles_n, g_xcd_swizzle);                    \
     } while (0)
-    if (!gn && NB == 1 && PH == 16 && PW == 16 && g.ep.mode == 0) {      // persistent form with the register epilogue (conv3x3.hip)
-        const int rc = ddpm_conv3x3_stream_launch(x, x_ld, w, g.ep.out, g.ep.ldc, g.ep.bias, g.ep.rowbias, g.ep.rowbias_ld, g.ep.residual, g.ep.res_ld,
-                                                  g.ep.accumulate, B, H, W, C, N, g_xcd_swizzle, g.dry, st);
-        if (rc >= 0) { g.variant = 8; return rc; }
-    }
     g.variant = 5;
     if (g.dry) return (gn && (NB != 1 || HP > 324)) ? -1 : DDPM_OK;
     if (gn) {                              // GroupNorm + SiLU applied to the resident halo: single-patch geometry only
@@ -1529,7 +1524,14 @@ extern "C" int ddpm_conv2d_nhwc(const void* x, long long x_ld, const void* w, vo
     g.ep.residual = residual; g.ep.res_ld = res_ld; g.ep.accumulate = accumulate;
     g.ep.HW = Ho * Wo; g.ep.dHW = make_fastdiv((unsigned)(Ho * Wo));
     g.splits = splits; g.ep.splitk_ws = splitk_ws; g.ep.splitk_cnt = splitk_cnt;
-    // hot case: 3x3 / stride 1 / pad 1 on bf16 with enough pixels to fill the chip -> stationary-halo kernel
+    // hot case: 3x3 / stride 1 / pad 1 on bf16 -> persistent stationary-halo kernel (conv3x3.hip: 16 x 16 patches, or 8 x 8 for the 8 x 8 level)
+    if (dtype == DDPM_BF16 && R == 3 && S == 3 && stride == 1 && pad_t == 1 && pad_l == 1 && !upsample && !dilate && out_mode == 0 && splits <= 1 &&
+        Ho == H && Wo == W) {
+        const int rc = ddpm_conv3x3_stream_launch(x, x_ld, w, y, y_ld, bias, rowbias, rowbias_ld, residual, res_ld, accumulate, B, H, W, C, N,
+                                                  g_xcd_swizzle, g.dry, stream);
+        if (rc >= 0) { if (g.dry) g_variant_result = 8; return rc; }
+    }
+    // ... or the one-tile-per-block form (what conv3x3.hip does not cover)
     static const bool no_halo = getenv("DDPM_CONV_NO_HALO") != nullptr;
     static const int halo_min_c = getenv("DDPM_CONV_HALO_MINC") ? atoi(getenv("DDPM_CONV_HALO_MINC")) : 64;
     if (!no_halo && C >= halo_min_c && dtype == DDPM_BF16 && R == 3 && S == 3 && stride == 1 && pad_t == 1 && pad_l == 1 && !upsample && !dilate &&
