@@ -349,8 +349,8 @@ class _DirectStep:
         self.graph = None
         self.graph_failed = False
         # auto mode: wall times (Trainer.step reports them) of a few eager and a few replayed steps decide which one stays
-        self.times = {"eager": [], "graph": []}
-        self.last_kind, self.choice = None, None
+        self.times = {}                      # auto mode: seconds per step of the "eager" / "graph" probe phases
+        self.last_kind, self.choice, self._phase = None, None, None
 
     @staticmethod
     def _pinned(t):
@@ -388,27 +388,40 @@ class _DirectStep:
         tr._fused.launch(tr.grad_norm, hyper_dev=self.hyper_dev.data_ptr())
         eng.refresh_unconditionally()                                          # the next forward reads the re-derived copies
 
-    PROBE = 3
+    PROBE = 4
 
+    # ---- auto mode: which form of the step is faster HERE?  Both are timed the way they will run — launches pipelined, the loss read
+    # back a step late — over PROBE consecutive steps bracketed by device synchronisations: eager launches keep the overlap of the
+    # weight-gradient stream but cost ~7 ms of host time per step (on a slow or busy host that is the bound), the replayed graph
+    # costs the host next to nothing but its executor overlaps the two branches less well.
     def _wants_graph(self):
         if _TRAIN_GRAPH != "auto":
             return bool(_TRAIN_GRAPH)
         if self.choice is not None:
             return self.choice == "graph"
-        if len(self.times["eager"]) < self.PROBE:
-            return False
-        if len(self.times["graph"]) < self.PROBE:
-            return True
-        med = lambda v: sorted(v)[len(v) // 2]
-        # On one GPU the replayed graph loses the overlap of the weight-gradient stream with the critical path (the graph executor
-        # serialises the two branches), so it only wins where the step is bound by launch overhead (small batches, small images)
-        self.choice = "graph" if med(self.times["graph"]) < 0.97 * med(self.times["eager"]) else "eager"
-        return self.choice == "graph"
+        return "eager" in self.times                       # eager phase measured: the graph phase is next (or running)
+
+    def _probe_begin(self, kind):
+        if _TRAIN_GRAPH == "auto" and self.choice is None and not self.x0.is_cuda:
+            self.choice = "eager"                           # (host-emulated runs: nothing to capture)
+        if _TRAIN_GRAPH == "auto" and self.choice is None and kind not in self.times and self._phase is None:
+            torch.cuda.synchronize()
+            self._phase = [kind, 0, time.perf_counter()]
+
+    def _probe_end(self, kind):
+        ph = self._phase
+        if ph is None or ph[0] != kind:
+            return
+        ph[1] += 1
+        if ph[1] == self.PROBE:
+            torch.cuda.synchronize()
+            self.times[kind] = (time.perf_counter() - ph[2]) / self.PROBE
+            self._phase = None
+            if "graph" in self.times:
+                self.choice = "graph" if self.times["graph"] < 0.98 * self.times["eager"] else "eager"
 
     def observe(self, seconds):
-        """Wall time of the Trainer.step that just ran this object (auto mode bookkeeping)."""
-        if self.last_kind is not None and self.choice is None and len(self.times[self.last_kind]) < self.PROBE:
-            self.times[self.last_kind].append(seconds)
+        """Kept for callers of the earlier interface: the probe now times whole phases itself."""
 
     def run(self, x):
         tr, eng = self.tr, self.unet.engine()
@@ -432,15 +445,25 @@ class _DirectStep:
                 warnings.warn(f"hipGraph capture of the training step failed ({type(e).__name__}: {e}); running it eagerly")
                 torch.cuda.synchronize()
                 self.graph_failed, self.graph = True, None
+                if _TRAIN_GRAPH == "auto":
+                    self.choice = "eager"
             captured_now = True
         else:
             captured_now = False
         if use_graph and self.graph is not None:
+            if not captured_now:
+                self._probe_begin("graph")                  # (the step that paid for the capture is not a sample)
             self.graph.replay()
-            self.last_kind = None if captured_now else "graph"          # the step that paid for the capture is not a sample
+            self.last_kind = "graph"
+            if not captured_now:
+                self._probe_end("graph")
         else:
+            if self.calls >= 1:
+                self._probe_begin("eager")                  # (nor is the very first step: lazy initialisation)
             self.body()
-            self.last_kind = "eager" if self.calls >= 1 else None        # nor is the very first step (lazy initialisation)
+            self.last_kind = "eager"
+            if self.calls >= 1:
+                self._probe_end("eager")
         self.calls += 1
         tr._fused.committed()
         eng.mark_fresh()
@@ -563,8 +586,7 @@ class Trainer:
         if self.distributed:
             dist.reduce(loss, dst=0, op=dist.ReduceOp.SUM)
             loss.div_(self.world_size)
-        probing = direct is not None and _TRAIN_GRAPH == "auto" and direct.choice is None
-        if _ASYNC_LOSS and loss.is_cuda and not probing:
+        if _ASYNC_LOSS and loss.is_cuda:
             # The reference reads the loss back with .item() at this point (utils/train.py:170) and so parks the host until the GPU has
             # finished the step — after which the GPU idles while the host prepares the next one.  Same read-back, one step later: the
             # value goes to pinned memory asynchronously and is added to the statistics when the NEXT step gets here (or when the

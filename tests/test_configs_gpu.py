@@ -267,7 +267,7 @@ def test_auto_mode_picks_a_step_execution_and_keeps_training(monkeypatch):
         tr.step(x, global_steps=i + 1)
         losses.append(tr.current_stats["loss"])
     ds = next(iter(tr._direct.values()))
-    assert ds.choice in ("eager", "graph") and len(ds.times["eager"]) == 3 and len(ds.times["graph"]) == 3
+    assert ds.choice in ("eager", "graph") and set(ds.times) == {"eager", "graph"} and min(ds.times.values()) > 0
     assert ds.graph is not None and not ds.graph_failed
     assert int(opt.state[next(iter(m.parameters()))]["step"]) == 14 and tr.ema.num_updates == 13
     assert sum(losses[-4:]) < sum(losses[:4])
