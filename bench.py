@@ -7,10 +7,11 @@ Adam, LR schedule, EMA, loss reduce incl. loss.item()) on B=128 synthetic 32x32 
 compute with fp32 master weights / gradients / optimizer state, dropout 0.1 active — configs/cifar10.json of the
 reference (BASELINE config 2; config 3 at N > 1).  Inputs are resident in HBM before the timed region.
 Rank 0 prints ONE JSON line.  Beyond the driver's contract it carries:
-  roofline     — the MFMA kernel with the most GPU time in the step: algorithmic FLOPs of its launches / their summed
-                 HIP-event durations (events recorded on the launch stream around every MFMA launch of one extra step),
-                 vs the dense bf16 peak; `isolated` = the same with the two-stream overlap switched off; `traffic` = HBM
-                 bytes per launch of that kernel from separate rocprofv3 --pmc passes (profiles/, see scripts/gpu_pmc_bench.sh)
+  roofline     — the MFMA kernel with the most GPU time per step (ranked with every kernel alone on the chip): algorithmic
+                 FLOPs of its launches / their summed HIP-event durations in the product step (events recorded on the launch
+                 stream — main or side — around every MFMA launch of one extra step), vs the dense bf16 peak; `isolated` = the
+                 same with the two-stream overlap switched off; `runner_up` = the next kernel by in-product time; `traffic` =
+                 HBM bytes per launch from separate rocprofv3 --pmc passes (profiles/, see scripts/gpu_profile.sh)
   sampling     — eval-mode ancestral sampling (B=128, 1000 steps, hipGraph replay) + a batch sweep
   other_configs— N = 1 only: the fp32 (parity) mode of the same step / sampler, BASELINE config 4 (CelebA 64x64 UNet,
                  DDIM-50, B=128) and the per-GPU work of config 5 (CelebA-HQ 256x256 UNet, B=2 training step)
@@ -38,7 +39,8 @@ FWD_GFLOP = {"cifar": 12.443713536, "celeba": 46.741, "celebahq": 497.028}
 PEAK = {"bf16": 2500.0, "fp32": 157.3}                    # dense MFMA TFLOP/s, MI355X_MICROARCH.md
 B_PER_GPU = 128
 VARIANT = {1: "gemm_kernel<4 waves,128x128>", 2: "gemm_kernel<8 waves,128x128>", 3: "gemm_kernel<deep ring,128x128>",
-           4: "gemm64_kernel<64x64>", 5: "conv3x3_halo_kernel<256px x 128>", 6: "wgrad3x3_kernel<64x32 x 9 taps>", 7: "pw_conv_kernel<persistent 1x1>", 8: "conv3x3_stream_kernel<persistent, 256px x 128>"}
+           4: "gemm64_kernel<64x64>", 5: "conv3x3_halo_kernel<256px x 128>", 6: "wgrad3x3_kernel<64x32 x 9 taps>", 7: "pw_conv_kernel<persistent 1x1>", 8: "conv3x3_stream_kernel<16> (persistent, 256px x 128)",
+           9: "wgrad1x1_kernel<128c x 128n slabs>", 10: "conv3x3_stream_kernel<8> (persistent, 64px x 128)"}
 
 
 def host_cpu():
@@ -210,20 +212,31 @@ def main():
             with open(os.environ["BENCH_SHAPES"], "w") as f:
                 for k, v in sorted(shapes_iso.items(), key=lambda kv: -kv[1][2]):
                     f.write(f"{v[2] * 1e3:8.3f} ms  n={v[0]:3d}  {v[1] / v[2] / 1e12:7.1f} TF  {k}\n")
-        dom_name, dom = max(agg.items(), key=lambda kv: kv[1][2])          # dominant kernel = the one with the most GPU time in the step
+        # dominant kernel = the one with the most GPU time per step when every kernel has the chip to itself (the isolated pass:
+        # stable from run to run, and the order rocprofv3's kernel-trace of the product step gives); its `achieved` below is the
+        # in-product figure.  The event-bracketed durations of the side stream's weight-gradient kernels include queueing behind
+        # main-stream workgroups, which is why the runner-up is listed with them.
+        dom_name = max(agg_iso.items(), key=lambda kv: kv[1][2])[0]
+        dom = agg[dom_name]
         achieved = dom[1] / dom[2] / 1e12
+        ru_name, ru = max(((k, v) for k, v in agg.items() if k != dom_name), key=lambda kv: kv[1][2])
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")
         if os.path.exists(tpath):
-            for rec in json.load(open(tpath)).get("kernels", []):
-                if rec["match"] in dom_name:
+            recs = json.load(open(tpath)).get("kernels", [])
+            exact = [r for r in recs if dom_name.split(" ")[0] in r["kernel"]]          # same template instance when the name carries it
+            for rec in (exact or recs):
+                if traffic is None and rec["match"] in dom_name:
                     traffic = {"hbm_bytes_per_launch": rec["fetch_bytes_per_launch"] + rec["write_bytes_per_launch"],
                                "fetch_bytes_per_launch": rec["fetch_bytes_per_launch"], "write_bytes_per_launch": rec["write_bytes_per_launch"],
                                "source": rec.get("source", "profiles/r02_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; FETCH_SIZE x2 per the gfx950 guide)")}
         roofline = {"bound": "mfma", "kernel": dom_name, "achieved": round(achieved, 1), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(achieved / peak, 4), "traffic": traffic,
                     "launches_per_step": dom[0], "avg_launch_us": round(dom[2] / dom[0] * 1e6, 2),
-                    "note": "durations as they occur in the product step (two HIP streams share the GPU); `isolated` = same step, one stream",
+                    "note": "durations as they occur in the product step (two HIP streams share the GPU); `isolated` = same step, one stream; "
+                            "dominant = most GPU time in the isolated pass",
+                    "runner_up": {"kernel": ru_name, "achieved": round(ru[1] / ru[2] / 1e12, 1), "frac": round(ru[1] / ru[2] / 1e12 / peak, 4),
+                                  "launches_per_step": ru[0], "avg_launch_us": round(ru[2] / ru[0] * 1e6, 2)},
                     "all_mfma_kernels": total(agg, peak), "per_kernel": table(agg, peak),
                     "isolated": {"all_mfma_kernels": total(agg_iso, peak), "per_kernel": table(agg_iso, peak)}}
         out = {"metric": "training imgs/s/GPU + 1000-step DDPM samples/s, CIFAR-10 UNet @1/2/4/8 MI355X",

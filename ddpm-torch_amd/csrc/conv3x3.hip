@@ -392,7 +392,7 @@ extern "C" int ddpm_debug_set_c3_timing(void* p) { return hipMemcpyToSymbol(HIP_
 
 // Launcher behind ddpm_conv2d_nhwc (gemm.hip) for 3x3 / stride 1 / pad 1, bf16 -> bf16: 16 x 16 patches for images of 16 x 16 and up with
 // >= 16384 pixels, 8 x 8 patches for 8 x 8-divisible images with >= 4096 pixels.  -1: geometry / epilogue not covered (the caller keeps
-// its other kernels), else a status code.  dry: decide only.
+// its other kernels), else a status code.  dry: decide only, and return the patch edge (16 / 8) that would run.
 int ddpm_conv3x3_stream_launch(const void* x, long long x_ld, const void* w, void* y, long long y_ld, const float* bias, const float* rowbias,
                                long long rowbias_ld, const void* residual, long long res_ld, int accumulate, int B, int H, int W, int C, int N,
                                int xcd, int dry, void* stream) {
@@ -404,7 +404,7 @@ int ddpm_conv3x3_stream_launch(const void* x, long long x_ld, const void* w, voi
     const long long xbytes = ((long long)B * H * W * x_ld - (x_ld - C)) * 2, wbytes = (long long)N * 9 * C * 2;
     const long long rbbytes = rowbias ? ((long long)(B - 1) * rowbias_ld + N) * 4 : 0;
     if (xbytes > 0x7ffffff0ll || wbytes > 0x7ffffff0ll || rbbytes > 0x7ffffff0ll) return -1;
-    if (dry) return DDPM_OK;
+    if (dry) return patch;
     CsArgs a; memset(&a, 0, sizeof(a));
     a.x = (const bf16_t*)x; a.x_ld = x_ld; a.x_extent = (unsigned)xbytes;
     a.w = (const bf16_t*)w; a.w_extent = (unsigned)wbytes;

@@ -1529,7 +1529,7 @@ extern "C" int ddpm_conv2d_nhwc(const void* x, long long x_ld, const void* w, vo
         Ho == H && Wo == W) {
         const int rc = ddpm_conv3x3_stream_launch(x, x_ld, w, y, y_ld, bias, rowbias, rowbias_ld, residual, res_ld, accumulate, B, H, W, C, N,
                                                   g_xcd_swizzle, g.dry, stream);
-        if (rc >= 0) { if (g.dry) g_variant_result = 8; return rc; }
+        if (rc >= 0) { if (g.dry) { g_variant_result = rc == 8 ? 10 : 8; return DDPM_OK; } return rc; }
     }
     // ... or the one-tile-per-block form (what conv3x3.hip does not cover)
     static const bool no_halo = getenv("DDPM_CONV_NO_HALO") != nullptr;

@@ -24,9 +24,11 @@ def _timed(kind, flops, fn, shape="", variant=None):
         fn()
         return
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    a.record()
+    # the events go on the stream the kernel goes to: a routed side stream is not torch's current stream
+    st = torch.cuda.ExternalStream(_hip._routed) if _hip._routed is not None else torch.cuda.current_stream()
+    a.record(st)
     fn()
-    b.record()
+    b.record(st)
     PROFILE.append((kind, flops, a, b, shape, variant() if variant is not None else 0))
 
 

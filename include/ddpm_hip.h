@@ -130,7 +130,7 @@ int ddpm_attention_bwd(const void* qkv, long long ld, const void* o, long long o
 
 /* Instrumentation (no upstream counterpart): which kernel ddpm_conv2d_nhwc / ddpm_conv2d_wgrad_nhwc / ddpm_gemm would dispatch a
  * call with these arguments to — 1 gemm_kernel (4 waves), 2 gemm_kernel (8 waves), 3 gemm_kernel (deep LDS ring), 4 gemm64_kernel
- * (64x64 tiles), 5 conv3x3_halo_kernel, 7 pw_conv_kernel (persistent streaming 1x1 conv), 8 conv3x3_stream_kernel (persistent stationary-halo 3x3 conv); a negative value is -(status code) for arguments the launching call would reject.
+ * (64x64 tiles), 5 conv3x3_halo_kernel, 7 pw_conv_kernel (persistent streaming 1x1 conv), 8 / 10 conv3x3_stream_kernel (persistent stationary-halo 3x3 conv, 16x16 / 8x8 patches), 9 wgrad1x1_kernel; a negative value is -(status code) for arguments the launching call would reject.
  * Pure functions of their arguments: the same dispatch code runs with launching switched off, nothing is retained between calls.
  * bench.py uses them to attribute its per-launch HIP-event timings to the kernel that ran. */
 int ddpm_conv2d_variant(long long x_ld, long long y_ld, int B, int H, int W, int C, int Ho, int Wo, int N, int R, int S,

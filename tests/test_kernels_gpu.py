@@ -118,7 +118,7 @@ def test_conv3x3_stationary_halo_path(B, H, C, N):
     both("ddpm_conv2d_nhwc", A(x), ld, A(w), A(y.clone(), out=True, name="y_rowbias"), yld, None, A(rowb), N + 8, None, 0,
          B, H, H, C, H, H, N, 3, 3, 1, 1, 1, 0, 0, 0, 0, 1, None, None, dt, tol=TOL[dt])
     # the persistent kernel (conv3x3.hip) serves both patch geometries; too few pixels (3 x 24 x 24) fall through to the tile GEMMs
-    assert (_hip.lib().ddpm_conv2d_variant(ld, yld, B, H, H, C, H, H, N, 3, 3, 1, 1, 1, 0, 0, 0, 1, dt) == 8) == (M >= 4096)
+    assert (_hip.lib().ddpm_conv2d_variant(ld, yld, B, H, H, C, H, H, N, 3, 3, 1, 1, 1, 0, 0, 0, 1, dt) in (8, 10)) == (M >= 4096)
 
 
 WG1_CASES = [(32768, 256, 256), (32768, 256, 768), (131072, 128, 256), (33635, 192, 104), (32768, 768, 256), (16384, 64, 64), (40000, 384, 128)]
