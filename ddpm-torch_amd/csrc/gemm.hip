@@ -126,6 +126,7 @@ struct Loader {
     __amdgpu_buffer_rsrc_t rsrc;
     int tile0;
     int kv, wave, row0;           // !TRANS: logical k-chunk, wave id, first tile row
+    int kvoff, kuni;              // !TRANS conv: byte offset of this lane's chunk inside a K-step; 1 when a K-step never straddles two taps (C % BK == 0)
     int kq, ng;                   // TRANS
     int roff[NV];               // !TRANS: byte offset of the row (plain; OOB when the row is outside) or of pixel (b, y0, x0) (conv)
     unsigned tapmask[NV];       // !TRANS conv without up/down-scaling: bit (r*S+s) set when the tap is inside the image
@@ -144,6 +145,8 @@ struct Loader {
             row0 = tid >> 3;
             wave = __builtin_amdgcn_readfirstlane(tid >> 6);
             kv = (tid & 7) ^ ((row0 >> 1) & 7);
+            kvoff = kv * VEC * ES;
+            kuni = (d.conv && d.sh == 0 && d.C % BK == 0) ? 1 : 0;
 #pragma unroll
             for (int i = 0; i < NV; ++i) {
                 const int m = tile0 + row0 + (NT / 8) * i;
@@ -202,7 +205,19 @@ struct Loader {
         const int k = k0 + kv * VEC;
         const bool kok = k < k_end;
         unsigned off[NV];
-        if (d.conv) {
+        if (kuni) {
+            // C is a multiple of the K-step: the step lies inside ONE tap, so tap, channel and tap offset are wave-uniform
+            // (SALU) and a lane is left with the mask test and one add per row — the per-lane divisions below cost ~250 clk
+            // per call, fully exposed with one wave per SIMD (scripts/g64_timeline.py).
+            const int k0u = __builtin_amdgcn_readfirstlane(k0);
+            const unsigned tapu = fdiv((unsigned)k0u, d.dC);
+            const int cu = k0u - (int)tapu * d.C;
+            const int ru = (int)fdiv(tapu, d.dS), su = (int)tapu - ru * d.S;
+            const int tapoff = ((ru * d.W + su) * (int)d.ld + cu) * ES;
+            const unsigned tb = k0u < k_end ? tapu : 31u;           // K is a multiple of the step here: no partial tail
+#pragma unroll
+            for (int i = 0; i < NV; ++i) off[i] = ((tapmask[i] >> tb) & 1u) ? (unsigned)(roff[i] + kvoff + tapoff) : OOB;
+        } else if (d.conv) {
             unsigned tap = fdiv((unsigned)k, d.dC);
             const int c = k - (int)tap * d.C;
             const int r = (int)fdiv(tap, d.dS), s = (int)tap - r * d.S;
@@ -757,73 +772,99 @@ constexpr int G64 = 2;            // K-steps per barrier group
 
 // NG = groups in the LDS ring: 3 (96 KiB, one block per CU, two groups in flight) for grids of <= 256 blocks, 2 (64 KiB, two
 // blocks per CU, one group in flight) for larger ones where the second resident block hides what the shallower ring exposes.
+// EIGHT waves: a wave can only put one LDS-DMA instruction on its way every ~128 clk (scripts/g64_timeline.py: 1024 clk for the
+// 8 instructions of a group with 4 waves, against 630 clk for the group's fragment reads + MFMAs, the two strictly one after the
+// other with a single wave per SIMD), so the DMA issue is spread over twice the waves and the two waves of a SIMD overlap one's
+// DMA issue with the other's math: waves 0-3 take the first K-step of every group, waves 4-7 the second (same 2 x 2 quadrants),
+// and the two partial tiles are added through LDS before the epilogue.
 template <typename T, int NG>
-__global__ __launch_bounds__(256, NG == 2 ? 2 : 1)
+__global__ __launch_bounds__(512, NG == 2 ? 2 : 1)
 void gemm64_kernel(MatDesc A, MatDesc B, Epilogue ep, int M, int N, int K, int tiles_n, int xcd) {
     HALO_WALL(0); HALO_STAMP(1);
-    constexpr int BK = 8 * Elem<T>::VEC, KF = Mma<T>::KF, NT = 256;
+    constexpr int BK = 8 * Elem<T>::VEC, KF = Mma<T>::KF, NT = 512;
+    static_assert(G64 == 2, "one K-step of a group per wave quartet");
     constexpr int OP_BYTES = T64 * ROW_BYTES;             // one operand tile (8 KiB); stage = [A | B]
     constexpr int GROUP_BYTES = G64 * 2 * OP_BYTES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int kh = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;
     const int lid = xcd_logical_id(blockIdx.x, gridDim.x, xcd);
     const int tm = lid / tiles_n, tn = lid - tm * tiles_n;
     const int batch = blockIdx.z;
-    Loader<T, false, 4, T64> la(A, batch, tm * T64, tid);
-    Loader<T, false, 4, T64> lb(B, batch, tn * T64, tid);
+    const int nsplit = gridDim.y, by = blockIdx.y;        // in-launch split-K: each tile's K range in nsplit runs of whole groups
+    Loader<T, false, 8, T64> la(A, batch, tm * T64, tid);
+    Loader<T, false, 8, T64> lb(B, batch, tn * T64, tid);
     f32x16 acc0 = (f32x16)(0.f), acc1 = (f32x16)(0.f);   // two accumulators: consecutive MFMAs do not wait on each other
     float bias_t[Elem<T>::VEC], bias_f[4];                // requested now, consumed in the epilogue
     if (ep.mode == 0) epilogue_bias<T, NT, T64>(ep, tn * T64, N, tid, bias_t);
     else epilogue_bias<float, NT, T64>(ep, tn * T64, N, tid, bias_f);
-    const int ngroups = ((K + BK - 1) / BK + G64 - 1) / G64;
-    // one group = G64 stages = 8 LDS-DMA instructions per wave (K-steps past the end fetch zeros: out-of-range offsets)
+    const int ngroups_all = ((K + BK - 1) / BK + G64 - 1) / G64;
+    const int gps = (ngroups_all + nsplit - 1) / nsplit, g0 = by * gps;
+    const int ngroups = min(gps, ngroups_all - g0);       // >= 1: the launcher splits only when every run gets groups
+    // one group = G64 stages = 4 LDS-DMA instructions per wave (K-steps past the end fetch zeros: out-of-range offsets)
     auto issue_group = [&](int grp, int slot) {
 #pragma unroll
         for (int u = 0; u < G64; ++u) {
-            la.issue((grp * G64 + u) * BK, K, smem + slot * GROUP_BYTES + u * 2 * OP_BYTES);
-            lb.issue((grp * G64 + u) * BK, K, smem + slot * GROUP_BYTES + u * 2 * OP_BYTES + OP_BYTES);
+            la.issue(((g0 + grp) * G64 + u) * BK, K, smem + slot * GROUP_BYTES + u * 2 * OP_BYTES);
+            lb.issue(((g0 + grp) * G64 + u) * BK, K, smem + slot * GROUP_BYTES + u * 2 * OP_BYTES + OP_BYTES);
         }
     };
     issue_group(0, 0);
     if (NG > 2 && ngroups > 1) issue_group(1, 1);
-    wait_tiles_in_flight<8>(NG > 2 && ngroups > 1 ? 1 : 0);
+    wait_tiles_in_flight<4>(NG > 2 && ngroups > 1 ? 1 : 0);
     __builtin_amdgcn_s_barrier();
     HALO_STAMP(2);
     int slot = 0;
+#ifdef HALO_TIMING
+    unsigned long long tq0 = 0, tq1 = 0, tq2 = 0, tq3 = 0, tq4 = 0;      // phases of group 8: fragment reads + MFMA issue | DMA issue | vmcnt wait | barrier
+#define G64_T(v) do { if (gi == 8) v = clock64(); } while (0)
+#else
+#define G64_T(v)
+#endif
     for (int gi = 0; gi < ngroups; ++gi) {
-        const char* base = smem + slot * GROUP_BYTES;
-        // One wave per SIMD: nothing else hides latencies, and a K-step of this tile is short — so ONE barrier covers two
-        // K-steps.  All fragments of the group are requested first, the MFMAs queue on two independent accumulators, then
-        // comes the address arithmetic + LDS-DMA issue of the group NG-1 ahead (its slot, the one of group gi-1, is free
-        // since the last barrier): it runs under the MFMAs.
-        u32x4 fa[G64][BK / KF], fb[G64][BK / KF];
+        const char* base = smem + slot * GROUP_BYTES + kh * 2 * OP_BYTES;
+        G64_T(tq0);
+        // All fragments of the wave's K-step are requested first, the MFMAs queue on two independent accumulators, then comes
+        // the LDS-DMA issue of the group NG-1 ahead (its slot, the one of group gi-1, is free since the last barrier).
+        u32x4 fa[BK / KF], fb[BK / KF];
 #pragma unroll
-        for (int u = 0; u < G64; ++u)
-#pragma unroll
-            for (int kc = 0; kc < BK / KF; ++kc) {
-                fa[u][kc] = read_frag<T, false>(base + u * 2 * OP_BYTES, wm * 32, kc, lane);
-                fb[u][kc] = read_frag<T, false>(base + u * 2 * OP_BYTES + OP_BYTES, wn * 32, kc, lane);
-            }
+        for (int kc = 0; kc < BK / KF; ++kc) {
+            fa[kc] = read_frag<T, false>(base, wm * 32, kc, lane);
+            fb[kc] = read_frag<T, false>(base + OP_BYTES, wn * 32, kc, lane);
+        }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int u = 0; u < G64; ++u)
-#pragma unroll
-            for (int kc = 0; kc < BK / KF; ++kc) {
-                if (kc & 1) Mma<T>::run(fa[u][kc], fb[u][kc], acc1); else Mma<T>::run(fa[u][kc], fb[u][kc], acc0);
-            }
+        for (int kc = 0; kc < BK / KF; ++kc) {
+            if (kc & 1) Mma<T>::run(fa[kc], fb[kc], acc1); else Mma<T>::run(fa[kc], fb[kc], acc0);
+        }
         __builtin_amdgcn_sched_barrier(0);
+        G64_T(tq1);
         if (gi + NG - 1 < ngroups) issue_group(gi + NG - 1, slot == 0 ? NG - 1 : slot - 1);
-        wait_tiles_in_flight<8>(NG > 2 && gi + 2 < ngroups ? 1 : 0);   // group gi+1 has landed; group gi+2 may stay in flight
+        G64_T(tq2);
+        wait_tiles_in_flight<4>(NG > 2 && gi + 2 < ngroups ? 1 : 0);   // group gi+1 has landed; group gi+2 may stay in flight
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        G64_T(tq3);
         __builtin_amdgcn_s_barrier();
+        G64_T(tq4);
         slot = slot == NG - 1 ? 0 : slot + 1;
     }
     HALO_STAMP(3);
+#ifdef HALO_TIMING
+    if (g_halo_timing && threadIdx.x == 0)
+        g_halo_timing[((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + 7] =
+            ((tq1 - tq0) & 0xffff) | (((tq2 - tq1) & 0xffff) << 16) | (((tq3 - tq2) & 0xffff) << 32) | (((tq4 - tq3) & 0xffff) << 48);
+#endif
+#undef G64_T
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = acc0[r] + acc1[r];
+    // the second K-step's partial tile joins the first's through LDS (the ring is idle: the loop ended on a barrier with no DMA pending)
+    float* red = reinterpret_cast<float*>(smem) + (wave & 3) * (16 * 64) + lane;
+    if (kh) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[r * 64] = acc[r];
+    }
     // epilogue: fp32 staging [64][68]
     constexpr int LD64 = T64 + 4;
     float* cs = reinterpret_cast<float*>(smem);
@@ -831,7 +872,15 @@ void gemm64_kernel(MatDesc A, MatDesc B, Epilogue ep, int M, int N, int K, int t
     RowEpilogue<T, T, NT, T64, T64, decltype(rowmap)> re_t(ep, batch, rowmap, tn * T64, N, tid);
     RowEpilogue<T, float, NT, T64, T64, decltype(rowmap)> re_f(ep, batch, rowmap, tn * T64, N, tid);
     if (ep.mode == 0) re_t.load(0); else re_f.load(0);
-    {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (!kh) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] += red[r * 64];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();              // every partial has been read before the staging overwrites it
+    if (!kh) {
         const int rb = wm * 32 + 4 * (lane >> 5), cb = wn * 32 + (lane & 31);
         static_for<16>([&](auto ic) {
             constexpr int r = decltype(ic)::v;
@@ -841,6 +890,37 @@ void gemm64_kernel(MatDesc A, MatDesc B, Epilogue ep, int M, int N, int K, int t
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     HALO_STAMP(6);
+    if (nsplit > 1) {
+        // Every run publishes its fp32 partial tile as a slab, takes an arrival ticket, and the LAST arriver adds the slabs in run
+        // order (bit-deterministic whoever arrives last) and carries on into the epilogue; the counter goes back to zero (no memset
+        // between launches).  The slabs move with agent-scope (write-through / L2-bypassing) accesses, dword by dword, instead of
+        // plain stores bracketed by release / acquire fences: a fence writes back and invalidates the XCD's whole L2 — 5 us here,
+        // more with a step's worth of dirty activations in it.
+        const long long tile_id = (long long)batch * gridDim.x + lid;
+        float* slabs = ep.splitk_ws + tile_id * nsplit * (T64 * T64);
+        float* mine = slabs + (long long)by * (T64 * T64);
+        for (int v = tid; v < T64 * T64; v += NT)
+            __hip_atomic_store(mine + v, cs[(v >> 6) * LD64 + (v & 63)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        float* flag = cs + T64;                      // row 0, first padding column
+        if (tid == 0) {
+            const unsigned ticket = __hip_atomic_fetch_add(ep.splitk_cnt + tile_id, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *flag = (ticket == (unsigned)(nsplit - 1)) ? 1.f : 0.f;
+            if (ticket == (unsigned)(nsplit - 1)) __hip_atomic_store(ep.splitk_cnt + tile_id, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        if (*flag == 0.f) return;
+        for (int v = tid; v < T64 * T64; v += NT) {
+            float* c = cs + (v >> 6) * LD64 + (v & 63);
+            const float own = *c;
+            float a = (by == 0) ? own : __hip_atomic_load(slabs + v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int sp = 1; sp < nsplit; ++sp)
+                a += (sp == by) ? own : __hip_atomic_load(slabs + (long long)sp * (T64 * T64) + v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *c = a;
+        }
+        __syncthreads();
+    }
     if (ep.mode == 0) re_t.finish_all(cs, bias_t);
     else re_f.finish_all(cs, bias_f);
     HALO_STAMP(4); HALO_WALL(5);
@@ -1379,10 +1459,14 @@ static int launch_t(GemmArgs& g, hipStream_t st) {
     dim3 grid(tiles_m * tiles_n, splits, g.batch);
     // small grids of k-contiguous products: 64x64 tiles put 4x as many CUs to work (see gemm64_kernel)
     static const bool no_t64 = getenv("DDPM_GEMM_NO_T64") != nullptr;
-    if (!no_t64 && !g.A.trans && !g.B.trans && splits == 1 && (g.ep.mode == 0 || g.ep.mode == 1) &&
-        (long long)tiles_m * tiles_n * g.batch <= 128) {
+    if (!no_t64 && !g.A.trans && !g.B.trans && (splits == 1 || (splits == 2 && g.ep.splitk_ws && g.ep.splitk_cnt)) &&
+        (g.ep.mode == 0 || g.ep.mode == 1) && (long long)tiles_m * tiles_n * g.batch <= 128) {
         const int t64n = (g.N + T64 - 1) / T64;
-        const dim3 grid64(((g.M + T64 - 1) / T64) * t64n, 1, g.batch);
+        // two K runs per tile when the caller offers the workspace (splits == 2), the tiles alone leave half the CUs idle and every
+        // run still gets >= 4 groups: the loop is bound by what ONE CU can move into its LDS (scripts/g64_timeline.py)
+        const int groups64 = ((g.K + BK - 1) / BK + G64 - 1) / G64;
+        const int sp64 = (splits == 2 && (long long)((g.M + T64 - 1) / T64) * t64n * g.batch <= 128 && groups64 >= 8) ? 2 : 1;
+        const dim3 grid64(((g.M + T64 - 1) / T64) * t64n, sp64, g.batch);
 #define LAUNCH64(NG)                                                                                                     \
     do {                                                                                                                 \
         constexpr int LDS64 = NG * G64 * 2 * T64 * ROW_BYTES;                                                            \
@@ -1392,11 +1476,11 @@ static int launch_t(GemmArgs& g, hipStream_t st) {
                 return DDPM_ERR_LAUNCH;                                                                                  \
             attr_set = true;                                                                                             \
         }                                                                                                                \
-        hipLaunchKernelGGL((gemm64_kernel<T, NG>), grid64, dim3(256), LDS64, st, g.A, g.B, g.ep, g.M, g.N, g.K, t64n, g_xcd_swizzle);   \
+        hipLaunchKernelGGL((gemm64_kernel<T, NG>), grid64, dim3(512), LDS64, st, g.A, g.B, g.ep, g.M, g.N, g.K, t64n, g_xcd_swizzle);   \
     } while (0)
         g.variant = 4;
         if (g.dry) return DDPM_OK;
-        if ((long long)grid64.x * grid64.z <= 256) LAUNCH64(3); else LAUNCH64(2);
+        if ((long long)grid64.x * grid64.y * grid64.z <= 256) LAUNCH64(3); else LAUNCH64(2);
 #undef LAUNCH64
         return check_launch();
     }

@@ -83,13 +83,16 @@ def conv2d(x, w_ptr, y_ptr, y_ld, N, R, S, Ho, Wo, stride=1, pad_t=0, pad_l=0, u
 
 
 _USE_SPLITK = bool(os.environ.get("DDPM_SPLITK"))
+_SPLITK64 = os.environ.get("DDPM_SPLITK64", "1") != "0"
 
 
 class SplitK:
     """Workspace for the in-launch split-K of layers with few output tiles: fp32 slabs + per-tile arrival counters (zero
-    between launches: the last arriver of every tile resets its counter).  Off by default since the 64x64-tile kernel took
-    over the small grids (it beats 128x128 tiles + split-K on every 8x8 / 4x4 layer, scripts/smallm_sweep.py); set
-    DDPM_SPLITK=1 to get the old behaviour for comparisons."""
+    between launches: the last arriver of every tile resets its counter).  Launches that use it must be stream-ordered (the
+    engine issues every conv forward / data gradient on the main stream).
+    Default: TWO K runs per tile for the layers whose 64x64-tile grid has <= 128 blocks (the 4x4 level): the loop of that
+    kernel is bound by what one CU can move into its LDS, so the second half of the chip halves it (scripts/g64_timeline.py;
+    DDPM_SPLITK64=0 switches it off).  DDPM_SPLITK=1 additionally brings back the old 128x128-tile split-K for comparisons."""
     TARGET_BLOCKS = 128
 
     def __init__(self, device):
@@ -97,20 +100,26 @@ class SplitK:
         self.ws = None
         self.cnt = None
 
+    def _reserve(self, floats, tiles):
+        if self.ws is None or self.ws.numel() < floats:
+            self.ws = torch.empty(floats, dtype=torch.float32, device=self.device)
+        if self.cnt is None or self.cnt.numel() < tiles:
+            self.cnt = torch.zeros(max(tiles, 1024), dtype=torch.int32, device=self.device)
+        return self.ws.data_ptr(), self.cnt.data_ptr()
+
     def plan(self, M, N, K, dtype):
+        ksteps = -(-K // (64 if dtype == _hip.BF16 else 32))
+        tiles = -(-M // 128) * -(-N // 128)
+        tiles64 = -(-M // 64) * -(-N // 64)
+        if _SPLITK64 and tiles64 <= 128 and ksteps >= 16:
+            # sized for either kernel the library may pick for these arguments (64x64 or 128x128 tiles)
+            return (2,) + self._reserve(max(tiles64 * 2 * 4096, tiles * 2 * 16384), max(tiles64, tiles))
         if not _USE_SPLITK:
             return 1, 0, 0
-        tiles = -(-M // 128) * -(-N // 128)
-        ksteps = -(-K // (64 if dtype == _hip.BF16 else 32))
         splits = min(self.TARGET_BLOCKS // tiles, ksteps // 8)
         if splits < 2:
             return 1, 0, 0
-        need = tiles * splits * 16384
-        if self.ws is None or self.ws.numel() < need:
-            self.ws = torch.empty(need, dtype=torch.float32, device=self.device)
-        if self.cnt is None or self.cnt.numel() < tiles:
-            self.cnt = torch.zeros(max(tiles, 1024), dtype=torch.int32, device=self.device)
-        return splits, self.ws.data_ptr(), self.cnt.data_ptr()
+        return (splits,) + self._reserve(tiles * splits * 16384, tiles)
 
 
 def conv2d_wgrad(dy, x, dw_ptr, Creal, Nreal, R, S, stride=1, pad_t=0, pad_l=0, upsample=0, splits=1, slab_stride=0):

@@ -29,7 +29,9 @@ extern "C" {
  * of a stride-2 conv).  w is packed [N][R][S][C] in dtype (ddpm_pack_weight).  dgrad = same call on dy with the
  * flipped/transposed pack and pad = R-1-pad.  out_mode: 0 NHWC dtype (pitch y_ld) | 1 NHWC fp32 | 3 NCHW fp32.
  * splits > 1 splits K over blocks and reduces in-launch (for layers with few output tiles): splitk_ws holds
- * ceil(M/128)*ceil(N/128)*splits*16384 floats, splitk_cnt one zero-initialised counter per tile (left zero). */
+ * max(ceil(M/128)*ceil(N/128)*16384, ceil(M/64)*ceil(N/64)*4096)*splits floats and splitk_cnt one zero-initialised counter
+ * per 64x64 output tile (left zero) — the library picks the tile size; with splits == 2 and at most 128 tiles of 64x64 it is the
+ * small-grid kernel with two K runs per tile. */
 int ddpm_conv2d_nhwc(const void* x, long long x_ld, const void* w, void* y, long long y_ld,
                      const float* bias, const float* rowbias, long long rowbias_ld,
                      const void* residual, long long res_ld,

@@ -121,6 +121,38 @@ def test_conv3x3_stationary_halo_path(B, H, C, N):
     assert (_hip.lib().ddpm_conv2d_variant(ld, yld, B, H, H, C, H, H, N, 3, 3, 1, 1, 1, 0, 0, 0, 1, dt) in (8, 10)) == (M >= 4096)
 
 
+@pytest.mark.parametrize("dt", [0, 1])
+@pytest.mark.parametrize("B,H,C,N,R", [(128, 4, 256, 256, 3), (128, 4, 512, 256, 3), (100, 4, 256, 192, 3), (16, 8, 1024, 64, 1), (128, 4, 64, 256, 3)])
+def test_conv_small_grid_split_k(B, H, C, N, R, dt):
+    """Layers whose 64x64-tile grid has <= 128 blocks take two K runs per tile when the caller offers the workspace (splits = 2):
+    slabs + arrival counters, summed in run order by the last arriver.  Results match the emulator, the counters are back at zero,
+    two launches agree bit for bit; the last case (9 K-steps of bf16: too short to split, 18 of fp32: split) covers the launcher's >= 8-groups rule both ways."""
+    M = B * H * H
+    ld, yld = C + 16, N + 32
+    x = r(M, ld, seed=1, dt=dt)
+    w = r(N, R * R * C, seed=2, dt=dt, scale=1.0 / math.sqrt(R * R * C))
+    bias, rowb = r(N, seed=3), r(B, N + 8, seed=4)
+    res, y = r(M, yld, seed=5, dt=dt), r(M, yld, seed=6, dt=dt)
+    tiles = -(-M // 64) * -(-N // 64)
+    assert tiles <= 128
+    ws = torch.zeros(max(tiles * 2 * 4096, -(-M // 128) * -(-N // 128) * 2 * 16384))
+    cnt = torch.zeros(1024, dtype=torch.int32)
+    pad = R // 2
+    for acc in (0, 1):
+        both("ddpm_conv2d_nhwc", A(x), ld, A(w), A(y.clone(), out=True, name="y"), yld, A(bias), A(rowb), N + 8, A(res), yld,
+             B, H, H, C, H, H, N, R, R, 1, pad, pad, 0, 0, acc, 0, 2, A(ws), A(cnt, out=True, name="counters"), dt, tol=TOL[dt])
+    assert _hip.lib().ddpm_conv2d_variant(ld, yld, B, H, H, C, H, H, N, R, R, 1, pad, pad, 0, 0, 0, 2, dt) == 4
+    xd, wd, wsd, cntd = x.cuda(), w.cuda(), ws.cuda(), cnt.cuda()
+    outs = []
+    for _ in range(2):
+        yd = torch.zeros(M, N, dtype=DT[dt], device="cuda")
+        _hip.call("ddpm_conv2d_nhwc", xd.data_ptr(), ld, wd.data_ptr(), yd.data_ptr(), N, 0, 0, 0, 0, 0,
+                  B, H, H, C, H, H, N, R, R, 1, pad, pad, 0, 0, 0, 0, 2, wsd.data_ptr(), cntd.data_ptr(), dt, _hip.stream())
+        outs.append(yd)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1]) and int(cntd.abs().sum()) == 0
+
+
 WG1_CASES = [(32768, 256, 256), (32768, 256, 768), (131072, 128, 256), (33635, 192, 104), (32768, 768, 256), (16384, 64, 64), (40000, 384, 128)]
 
 
@@ -213,7 +245,7 @@ def test_conv_fwd_inlaunch_splitk(dt, splits):
     x, w = r(M, C, seed=1, dt=dt), r(N, 9 * C, seed=2, dt=dt, scale=0.02)
     bias, rowb, res = r(N, seed=3), r(B, N, seed=4), r(M, N, seed=5, dt=dt)
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
-    ws, cnt = torch.zeros(tiles * splits * 16384), torch.zeros(tiles, dtype=torch.int32)
+    ws, cnt = torch.zeros(tiles * splits * 16384), torch.zeros(tiles * 4, dtype=torch.int32)     # one counter per 64x64 tile
     for rep in range(2):
         y = r(M, N, seed=6, dt=dt)
         wsd, cntd = ws.cuda(), cnt.cuda()
