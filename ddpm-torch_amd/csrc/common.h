@@ -144,4 +144,4 @@ int ddpm_pointwise_launch(const void* x, long long x_ld, const void* w, void* y,
 // conv3x3.hip: launcher of the persistent stationary-halo 3x3 kernel (-1: geometry not covered)
 int ddpm_conv3x3_stream_launch(const void* x, long long x_ld, const void* w, void* y, long long y_ld, const float* bias, const float* rowbias,
                                long long rowbias_ld, const void* residual, long long res_ld, int accumulate, int B, int H, int W, int C, int N,
-                               int xcd, int dry, void* stream);
+                               int upsample, int xcd, int dry, void* stream);

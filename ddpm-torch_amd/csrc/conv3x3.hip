@@ -33,7 +33,8 @@ struct CsArgs {
     const float* bias; const float* rowbias; long long rowbias_ld; unsigned rowbias_extent;
     const bf16_t* res; long long res_ld;
     int accumulate;
-    int B, H, W, C, N, K;
+    int B, H, W, C, N, K;                                 // H, W: OUTPUT (= virtual input) image; ups = 1: x is stored at half that size (nearest 2x)
+    int ups;
     int tiles_y, tiles_x, tiles_n, total_tiles, xcd;
     FastDiv d_tiles_n, d_tpi, d_tiles_x;
 };
@@ -134,7 +135,9 @@ void conv3x3_stream_kernel(CsArgs a) {
             const int iy = t.py0 + hy - 1, ix = t.px0 + hx - 1;
             const bool ok = hp < HP && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
             const int lc = (v & 7) ^ (PATCH == 16 ? (hx >> 1) & 7 : ((hx >> 1) ^ ((hy & 1) << 2)) & 7);
-            ho[i] = ok ? ((unsigned)((t.img * a.H + iy) * a.W + ix) * (unsigned)a.x_ld + (unsigned)(lc * 8)) * 2u : OOB;     // < 2^31: checked by the launcher
+            // nearest-neighbour 2x up-sampling folded into the gather: virtual pixel (iy, ix) is stored pixel (iy >> 1, ix >> 1)
+            const int sy = iy >> a.ups, sx = ix >> a.ups;
+            ho[i] = ok ? ((unsigned)((t.img * (a.H >> a.ups) + sy) * (a.W >> a.ups) + sx) * (unsigned)a.x_ld + (unsigned)(lc * 8)) * 2u : OOB;     // < 2^31: checked by the launcher
         }
     };
     auto issue_halo_part = [&](unsigned ho, int i, int cc, char* dst) {
@@ -390,18 +393,19 @@ void conv3x3_stream_kernel(CsArgs a) {
 extern "C" int ddpm_debug_set_c3_timing(void* p) { return hipMemcpyToSymbol(HIP_SYMBOL(g_c3_timing), &p, sizeof(p)) == hipSuccess ? 0 : -1; }
 #endif
 
-// Launcher behind ddpm_conv2d_nhwc (gemm.hip) for 3x3 / stride 1 / pad 1, bf16 -> bf16: 16 x 16 patches for images of 16 x 16 and up with
+// Launcher behind ddpm_conv2d_nhwc (gemm.hip) for 3x3 / stride 1 / pad 1, bf16 -> bf16 (H, W = output image; upsample: x stored at H/2 x W/2): 16 x 16 patches for images of 16 x 16 and up with
 // >= 16384 pixels, 8 x 8 patches for 8 x 8-divisible images with >= 4096 pixels.  -1: geometry / epilogue not covered (the caller keeps
 // its other kernels), else a status code.  dry: decide only, and return the patch edge (16 / 8) that would run.
 int ddpm_conv3x3_stream_launch(const void* x, long long x_ld, const void* w, void* y, long long y_ld, const float* bias, const float* rowbias,
                                long long rowbias_ld, const void* residual, long long res_ld, int accumulate, int B, int H, int W, int C, int N,
-                               int xcd, int dry, void* stream) {
+                               int upsample, int xcd, int dry, void* stream) {
     static const bool off = getenv("DDPM_CONV_NO_STREAM3") != nullptr, off8 = getenv("DDPM_CONV_NO_STREAM3_8") != nullptr;
     const long long M = (long long)B * H * W;
     const int patch = (H % 16 == 0 && W % 16 == 0 && M >= 16384) ? 16 : ((H % 8 == 0 && W % 8 == 0 && M >= 4096 && !off8) ? 8 : 0);
     if (off || !patch || (residual && accumulate) || C % 64 || N % 64 || x_ld % 8 || y_ld % 8 || (residual && res_ld % 4) || (rowbias && rowbias_ld % 4)) return -1;
     if (!aligned16(x) || !aligned16(w) || !aligned16(y) || (residual && (((uintptr_t)residual) & 7)) || (bias && !aligned16(bias)) || (rowbias && !aligned16(rowbias))) return -1;
-    const long long xbytes = ((long long)B * H * W * x_ld - (x_ld - C)) * 2, wbytes = (long long)N * 9 * C * 2;
+    if (upsample && ((H | W) & 1)) return -1;
+    const long long xbytes = ((long long)B * (H >> upsample) * (W >> upsample) * x_ld - (x_ld - C)) * 2, wbytes = (long long)N * 9 * C * 2;
     const long long rbbytes = rowbias ? ((long long)(B - 1) * rowbias_ld + N) * 4 : 0;
     if (xbytes > 0x7ffffff0ll || wbytes > 0x7ffffff0ll || rbbytes > 0x7ffffff0ll) return -1;
     if (dry) return patch;
@@ -411,7 +415,7 @@ int ddpm_conv3x3_stream_launch(const void* x, long long x_ld, const void* w, voi
     a.out = (bf16_t*)y; a.out_ld = y_ld;
     a.bias = bias; a.rowbias = rowbias; a.rowbias_ld = rowbias_ld; a.rowbias_extent = (unsigned)rbbytes;
     a.res = (const bf16_t*)residual; a.res_ld = res_ld; a.accumulate = accumulate;
-    a.B = B; a.H = H; a.W = W; a.C = C; a.N = N; a.K = 9 * C;
+    a.B = B; a.H = H; a.W = W; a.C = C; a.N = N; a.K = 9 * C; a.ups = upsample ? 1 : 0;
     a.tiles_y = H / patch; a.tiles_x = W / patch; a.tiles_n = (N + 127) / 128;
     a.total_tiles = B * a.tiles_y * a.tiles_x * a.tiles_n;
     a.xcd = xcd;

@@ -1609,10 +1609,11 @@ extern "C" int ddpm_conv2d_nhwc(const void* x, long long x_ld, const void* w, vo
     g.ep.HW = Ho * Wo; g.ep.dHW = make_fastdiv((unsigned)(Ho * Wo));
     g.splits = splits; g.ep.splitk_ws = splitk_ws; g.ep.splitk_cnt = splitk_cnt;
     // hot case: 3x3 / stride 1 / pad 1 on bf16 -> persistent stationary-halo kernel (conv3x3.hip: 16 x 16 patches, or 8 x 8 for the 8 x 8 level)
-    if (dtype == DDPM_BF16 && R == 3 && S == 3 && stride == 1 && pad_t == 1 && pad_l == 1 && !upsample && !dilate && out_mode == 0 && splits <= 1 &&
-        Ho == H && Wo == W) {
-        const int rc = ddpm_conv3x3_stream_launch(x, x_ld, w, y, y_ld, bias, rowbias, rowbias_ld, residual, res_ld, accumulate, B, H, W, C, N,
-                                                  g_xcd_swizzle, g.dry, stream);
+    // (`splits` is an offer, not a demand: this kernel needs no split; the nearest-2x up-sampled input of the Upsample blocks is gathered in place)
+    if (dtype == DDPM_BF16 && R == 3 && S == 3 && stride == 1 && pad_t == 1 && pad_l == 1 && !dilate && out_mode == 0 &&
+        Ho == (H << (upsample ? 1 : 0)) && Wo == (W << (upsample ? 1 : 0))) {
+        const int rc = ddpm_conv3x3_stream_launch(x, x_ld, w, y, y_ld, bias, rowbias, rowbias_ld, residual, res_ld, accumulate, B, Ho, Wo, C, N,
+                                                  upsample ? 1 : 0, g_xcd_swizzle, g.dry, stream);
         if (rc >= 0) { if (g.dry) { g_variant_result = rc == 8 ? 10 : 8; return DDPM_OK; } return rc; }
     }
     // ... or the one-tile-per-block form (what conv3x3.hip does not cover)

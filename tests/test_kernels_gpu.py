@@ -121,6 +121,22 @@ def test_conv3x3_stationary_halo_path(B, H, C, N):
     assert (_hip.lib().ddpm_conv2d_variant(ld, yld, B, H, H, C, H, H, N, 3, 3, 1, 1, 1, 0, 0, 0, 1, dt) in (8, 10)) == (M >= 4096)
 
 
+@pytest.mark.parametrize("B,Hs,C,N", [(16, 16, 128, 128), (130, 4, 128, 192), (5, 16, 256, 64), (33, 8, 64, 256)])
+def test_conv3x3_upsampled_input_persistent_path(B, Hs, C, N):
+    """Upsample block: nearest 2x + 3x3 / s1 / p1 in ONE launch of the persistent kernel (the gather reads stored pixel (y >> 1, x >> 1));
+    both patch geometries, ragged channel tiles, pitched operands, the bias and "+=" epilogues."""
+    dt, H = 1, 2 * Hs
+    M = B * H * H
+    ld, yld = C + 16, N + 32
+    x = r(B * Hs * Hs, ld, seed=1, dt=dt)
+    w = r(N, 9 * C, seed=2, dt=dt, scale=1.0 / math.sqrt(9 * C))
+    bias, y = r(N, seed=3), r(M, yld, seed=6, dt=dt)
+    for acc in (0, 1):
+        both("ddpm_conv2d_nhwc", A(x), ld, A(w), A(y.clone(), out=True, name="y"), yld, A(bias), None, 0, None, 0,
+             B, Hs, Hs, C, H, H, N, 3, 3, 1, 1, 1, 1, 0, acc, 0, 1, None, None, dt, tol=TOL[dt])
+    assert _hip.lib().ddpm_conv2d_variant(ld, yld, B, Hs, Hs, C, H, H, N, 3, 3, 1, 1, 1, 1, 0, 0, 1, dt) in (8, 10)
+
+
 @pytest.mark.parametrize("dt", [0, 1])
 @pytest.mark.parametrize("B,H,C,N,R", [(128, 4, 256, 256, 3), (128, 4, 512, 256, 3), (100, 4, 256, 192, 3), (16, 8, 1024, 64, 1), (128, 4, 64, 256, 3)])
 def test_conv_small_grid_split_k(B, H, C, N, R, dt):
