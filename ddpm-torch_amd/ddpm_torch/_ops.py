@@ -100,10 +100,16 @@ class SplitK:
         self.ws = None
         self.cnt = None
 
+    # every two-run plan fits: <= 128 tiles x 2 runs x one 128x128 fp32 tile.  Reserved in one piece at first use so that the
+    # pointers a captured graph holds stay valid; a buffer that does get outgrown (DDPM_SPLITK=1 only) is retired, never freed.
+    FLOATS64 = 128 * 2 * 16384
+
     def _reserve(self, floats, tiles):
         if self.ws is None or self.ws.numel() < floats:
-            self.ws = torch.empty(floats, dtype=torch.float32, device=self.device)
+            self._retired = getattr(self, "_retired", []) + [self.ws]
+            self.ws = torch.empty(max(floats, self.FLOATS64), dtype=torch.float32, device=self.device)
         if self.cnt is None or self.cnt.numel() < tiles:
+            self._retired = getattr(self, "_retired", []) + [self.cnt]
             self.cnt = torch.zeros(max(tiles, 1024), dtype=torch.int32, device=self.device)
         return self.ws.data_ptr(), self.cnt.data_ptr()
 
