@@ -266,3 +266,20 @@ def test_backward_routes_3x3_weight_gradients_through_the_patch_kernel(emu, monk
     assert grads[0][1] < grads[1][1]                             # folded bias gradients: fewer column-sum launches
     for k in grads[0][0]:
         check(grads[0][0][k], grads[1][0][k], 1e-5, atol=1e-6, name="patch grad." + k)
+
+
+def test_small_grid_split_plan_is_stable_for_captured_graphs(monkeypatch):
+    """Host side of the two-run split of the 4x4 level (_ops.SplitK.plan): offered exactly where the 64x64-tile grid has <= 128 blocks and
+    K is long enough; the workspace is reserved once at full size, so the pointers a captured graph holds never move; the switch turns it off."""
+    from ddpm_torch import _ops
+    sk = _ops.SplitK("cpu")
+    s, ws, cnt = sk.plan(128 * 16, 256, 9 * 256, _hip.BF16)                  # CIFAR 4x4 level: 128 tiles of 64x64, 36 K-steps
+    assert s == 2 and ws and cnt
+    assert sk.plan(128 * 64, 256, 9 * 256, _hip.BF16) == (1, 0, 0)           # 8x8 level: 512 tiles
+    assert sk.plan(128 * 16, 256, 512, _hip.BF16) == (1, 0, 0)               # 1x1 shortcut: 8 K-steps
+    assert sk.plan(128 * 16, 256, 512, _hip.F32)[0] == 2                     # ... 16 of fp32
+    for M, N, K in ((2 * 16, 64, 9 * 512), (100 * 16, 192, 9 * 256), (128 * 16, 256, 9 * 512)):
+        assert sk.plan(M, N, K, _hip.BF16) == (2, ws, cnt)                   # same buffers whatever came before
+    assert sk.ws.numel() >= 128 * 2 * 16384 and int(sk.cnt.abs().sum()) == 0
+    monkeypatch.setattr(_ops, "_SPLITK64", False)
+    assert _ops.SplitK("cpu").plan(128 * 16, 256, 9 * 256, _hip.BF16) == (1, 0, 0)
