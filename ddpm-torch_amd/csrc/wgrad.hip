@@ -35,6 +35,7 @@ constexpr int DY_ROW = TN * 2, X_ROW = TC * 2;  // LDS row bytes: one pixel of t
 struct Wg3Args {
     const void* dy; long long dy_ld; unsigned dy_extent;
     const void* x; long long x_ld; unsigned x_extent;
+    int ups;                                               // 1: x is stored at H/2 x W/2 (nearest 2x up-sampling folded into the halo gather)
     float* dw; long long slab_stride; float* dbias; long long bias_stride;
     int B, H, W, C, N, Nreal;
     int PH, NB, lPP;                 // stage geometry (PW is a template parameter): NB * PH * PW == stage pixels
@@ -146,7 +147,7 @@ void wgrad3x3_kernel(Wg3Args a) {
             const unsigned xp = x_pos[i];
             const int gi = img0 + (int)(xp & 0xff), iy = py0 + (int)(xp >> 16) - 1, ix = px0 + (int)((xp >> 8) & 0xff) - 1;
             const bool ok = xp != 0xffffffffu && gi < a.B && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-            const unsigned o = ok ? (unsigned)((((long long)(gi * a.H + iy) * a.W + ix) * a.x_ld) * 2) + x_c2 : OOB;
+            const unsigned o = ok ? (unsigned)((((long long)(gi * (a.H >> a.ups) + (iy >> a.ups)) * (a.W >> a.ups) + (ix >> a.ups)) * a.x_ld) * 2) + x_c2 : OOB;
             const int rel = (wave * 64 + 512 * i) * 16;
             char* to = (rel + 1024 <= X_BYTES) ? dst + DY_BYTES + rel : smem + DUMP_OFF;       // wave-uniform
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)to, 16, o, 0, 0, 0);
@@ -430,10 +431,11 @@ extern "C" int ddpm_conv3x3_wgrad_splits(int B, int H, int W, int C, int N, int 
 //   slab_stride  > 0: slice s stores its partial at dw + s*slab_stride and dbias + s*bias_stride; every one of the
 //                     ddpm_conv3x3_wgrad_splits(...) copies is written completely (ddpm_wgrad_reduce then sums them).
 // Returns DDPM_ERR_SHAPE for geometries the patch kernel does not cover (the caller uses ddpm_conv2d_wgrad_nhwc + ddpm_colsum).
-extern "C" int ddpm_conv3x3_wgrad_nhwc(const void* dy, long long dy_ld, const void* x, long long x_ld, float* dw, long long slab_stride,
-                                       float* dbias, long long bias_stride, int B, int H, int W, int C, int N, int Nreal, int splits,
-                                       int dtype, void* stream) {
+static int wgrad3x3_launch(const void* dy, long long dy_ld, const void* x, long long x_ld, float* dw, long long slab_stride,
+                           float* dbias, long long bias_stride, int B, int H, int W, int C, int N, int Nreal, int splits,
+                           int dtype, int ups, void* stream) {
     if (!dy || !x || !dw) return DDPM_ERR_NULL;
+    if (ups && ((H | W) & 1)) return DDPM_ERR_SHAPE;
     if (dtype != DDPM_BF16) return DDPM_ERR_DTYPE;
     if (B <= 0 || Nreal <= 0 || Nreal > N) return DDPM_ERR_SHAPE;
     if (!aligned16(dy) || !aligned16(x) || dy_ld % 8 || x_ld % 8) return DDPM_ERR_ALIGN;
@@ -441,12 +443,12 @@ extern "C" int ddpm_conv3x3_wgrad_nhwc(const void* dy, long long dy_ld, const vo
     if (!p.ok) return DDPM_ERR_SHAPE;
     if (slab_stride < 0 || (slab_stride > 0 && slab_stride < (long long)Nreal * 9 * C)) return DDPM_ERR_SHAPE;
     if (slab_stride > 0 && dbias && bias_stride < Nreal) return DDPM_ERR_SHAPE;
-    const long long dyb = ((long long)B * H * W * dy_ld - (dy_ld - N)) * 2, xb = ((long long)B * H * W * x_ld - (x_ld - C)) * 2;
+    const long long dyb = ((long long)B * H * W * dy_ld - (dy_ld - N)) * 2, xb = ((long long)B * (H >> ups) * (W >> ups) * x_ld - (x_ld - C)) * 2;
     if (dyb > 0x7ffffff0ll || xb > 0x7ffffff0ll) return DDPM_ERR_SHAPE;
     Wg3Args a; memset(&a, 0, sizeof(a));
     a.dy = dy; a.dy_ld = dy_ld; a.dy_extent = (unsigned)dyb; a.x = x; a.x_ld = x_ld; a.x_extent = (unsigned)xb;
     a.dw = dw; a.slab_stride = slab_stride; a.dbias = dbias; a.bias_stride = bias_stride;
-    a.B = B; a.H = H; a.W = W; a.C = C; a.N = N; a.Nreal = Nreal;
+    a.B = B; a.H = H; a.W = W; a.C = C; a.N = N; a.Nreal = Nreal; a.ups = ups ? 1 : 0;
     a.PH = p.PH; a.NB = p.NB;
     int lpp = 0; while ((1 << lpp) < p.PH * p.PW) ++lpp;
     a.lPP = lpp;
@@ -478,4 +480,17 @@ extern "C" int ddpm_conv3x3_wgrad_nhwc(const void* dy, long long dy_ld, const vo
     else WG_LAUNCH(128, 4, 4);
 #undef WG_LAUNCH
     return check_launch();
+}
+
+extern "C" int ddpm_conv3x3_wgrad_nhwc(const void* dy, long long dy_ld, const void* x, long long x_ld, float* dw, long long slab_stride,
+                                       float* dbias, long long bias_stride, int B, int H, int W, int C, int N, int Nreal, int splits,
+                                       int dtype, void* stream) {
+    return wgrad3x3_launch(dy, dy_ld, x, x_ld, dw, slab_stride, dbias, bias_stride, B, H, W, C, N, Nreal, splits, dtype, 0, stream);
+}
+
+// The same for the conv of an Upsample block (nearest 2x, then 3x3 / s1 / p1): H, W are the OUTPUT image (dy's), x is stored at H/2 x W/2.
+extern "C" int ddpm_conv3x3_wgrad_up_nhwc(const void* dy, long long dy_ld, const void* x, long long x_ld, float* dw, long long slab_stride,
+                                          float* dbias, long long bias_stride, int B, int H, int W, int C, int N, int Nreal, int splits,
+                                          int dtype, void* stream) {
+    return wgrad3x3_launch(dy, dy_ld, x, x_ld, dw, slab_stride, dbias, bias_stride, B, H, W, C, N, Nreal, splits, dtype, 1, stream);
 }

@@ -27,6 +27,7 @@ PROTOTYPES = {
     "ddpm_wgrad_effective_splits": [I, I, I],
     "ddpm_conv3x3_wgrad_splits": [I, I, I, I, I, I],
     "ddpm_conv3x3_wgrad_nhwc": [P, L, P, L, P, L, P, L, I, I, I, I, I, I, I, I, P],
+    "ddpm_conv3x3_wgrad_up_nhwc": [P, L, P, L, P, L, P, L, I, I, I, I, I, I, I, I, P],
     "ddpm_conv1x1_wgrad_splits": [I, I, I],
     "ddpm_conv1x1_wgrad_nhwc": [P, L, P, L, P, L, P, L, I, I, I, I, I, P],
     "ddpm_wgrad_reduce": [P, I, P],

@@ -141,11 +141,13 @@ def conv3x3_wgrad_splits(B, H, W, C, N, splits=0):
     return int(_hip.lib().ddpm_conv3x3_wgrad_splits(B, H, W, C, N, splits))
 
 
-def conv3x3_wgrad(dy, x, dw_ptr, slab_stride, dbias_ptr, bias_stride, Nreal, splits):
-    """dw[n][3][3][c] (+ dbias) of a 3x3 / stride 1 / pad 1 conv by the patch-stationary kernel (bf16)."""
+def conv3x3_wgrad(dy, x, dw_ptr, slab_stride, dbias_ptr, bias_stride, Nreal, splits, upsample=False):
+    """dw[n][3][3][c] (+ dbias) of a 3x3 / stride 1 / pad 1 conv by the patch-stationary kernel (bf16).  upsample: x is the input of an
+    Upsample block, stored at half of dy's image size."""
     _timed("wgrad3x3", 2.0 * dy.rows * Nreal * 9 * x.C, lambda: _hip.call(
-        "ddpm_conv3x3_wgrad_nhwc", dy.ptr, dy.ld, x.ptr, x.ld, dw_ptr, slab_stride, dbias_ptr, bias_stride, x.B, x.H, x.W, x.C, dy.C, Nreal,
-        splits, x.dtype, _hip.stream()), f"wgrad3x3 M={Nreal} N={9 * x.C} K={dy.rows} splits={splits}", lambda: 6)
+        "ddpm_conv3x3_wgrad_up_nhwc" if upsample else "ddpm_conv3x3_wgrad_nhwc", dy.ptr, dy.ld, x.ptr, x.ld, dw_ptr, slab_stride, dbias_ptr,
+        bias_stride, dy.B, dy.H, dy.W, x.C, dy.C, Nreal, splits, x.dtype, _hip.stream()),
+        f"wgrad3x3 M={Nreal} N={9 * x.C} K={dy.rows} splits={splits}" + (" up" if upsample else ""), lambda: 6)
 
 
 def conv1x1_wgrad_splits(P, C, N):

@@ -252,6 +252,7 @@ _SIDE_STREAM = os.environ.get("DDPM_SIDE_STREAM", "1") != "0"      # weight / bi
 _WGRAD_MINSTEPS = int(os.environ.get("DDPM_WGRAD_MINSTEPS", "20"))
 _WGRAD_SLABS = os.environ.get("DDPM_WGRAD_SLABS", "0") != "0"      # deterministic slab reduction instead of atomics
 _WGRAD3 = os.environ.get("DDPM_WGRAD3", "1") != "0"                # patch-stationary kernel for the 3x3 / stride-1 weight gradients
+_WGRAD3_UP = os.environ.get("DDPM_WGRAD3_UP", "1") != "0"          # ... also for the Upsample blocks' conv (nearest-2x gather folded into the halo loads)
 _SLAB_FLUSH_ROWS = int(os.environ.get("DDPM_SLAB_FLUSH_ROWS", "6"))   # slab reductions queued on the side stream every so many rows
 _WGRAD1 = os.environ.get("DDPM_WGRAD1", "1") != "0"                # slab kernel for the 1x1 weight gradients
 _WGRAD3_ATOMIC = os.environ.get("DDPM_WGRAD3_ATOMIC", "0") != "0"  # ... with fp32 atomics instead of slab copies
@@ -542,12 +543,13 @@ class _Engine:
         (DDPM_WGRAD_SLABS=1) store slab copies as above."""
         did_bias = False
         patch = 0
-        if (_WGRAD3 and self.T == torch.bfloat16 and R == 3 and S == 3 and not kw.get("upsample") and kw.get("stride", 1) == 1
-                and kw.get("pad_t") == 1 and kw.get("pad_l") == 1 and Creal == x.C):
-            pkey = ("w3", x.B, x.H, x.W, x.C, dy.C)
+        up = bool(kw.get("upsample"))                    # Upsample block: x stored at half of dy's size, gathered in place by the kernel
+        if (_WGRAD3 and self.T == torch.bfloat16 and R == 3 and S == 3 and (not up or (_WGRAD3_UP and dy.H == 2 * x.H and dy.W == 2 * x.W))
+                and kw.get("stride", 1) == 1 and kw.get("pad_t") == 1 and kw.get("pad_l") == 1 and Creal == x.C):
+            pkey = ("w3", x.B, dy.H, dy.W, x.C, dy.C)
             patch = self._eff_splits.get(pkey)
             if patch is None:
-                patch = self._eff_splits[pkey] = ops.conv3x3_wgrad_splits(x.B, x.H, x.W, x.C, dy.C)
+                patch = self._eff_splits[pkey] = ops.conv3x3_wgrad_splits(x.B, dy.H, dy.W, x.C, dy.C)
         point = 0
         if (not patch and _WGRAD1 and self.T == torch.bfloat16 and R == 1 and S == 1 and not kw.get("upsample") and kw.get("stride", 1) == 1
                 and not kw.get("pad_t") and not kw.get("pad_l") and Creal == x.C and Nreal == dy.C):
@@ -575,7 +577,7 @@ class _Engine:
             bias_ptr = self._pptr(ctx, bias) if bias is not None else 0
             with self._leaf(ctx, dy, x):
                 if _WGRAD3_ATOMIC:
-                    ops.conv3x3_wgrad(dy, x, self._pptr(ctx, weight), 0, bias_ptr, 0, Nreal, patch)
+                    ops.conv3x3_wgrad(dy, x, self._pptr(ctx, weight), 0, bias_ptr, 0, Nreal, patch, upsample=up)
                 else:
                     n = Nreal * 9 * Creal
                     stride = (n + 3) // 4 * 4
@@ -584,7 +586,7 @@ class _Engine:
                     if slab is None or slab.numel() < patch * (stride + bstride):
                         slab = self._slabs[id(weight)] = torch.empty(patch * (stride + bstride), dtype=torch.float32, device=self.device)
                     bslab = slab.data_ptr() + 4 * patch * stride
-                    ops.conv3x3_wgrad(dy, x, slab.data_ptr(), stride, bslab if bias is not None else 0, bstride, Nreal, patch)
+                    ops.conv3x3_wgrad(dy, x, slab.data_ptr(), stride, bslab if bias is not None else 0, bstride, Nreal, patch, upsample=up)
                     ctx["slab_rows"].append((slab.data_ptr(), self._pptr(ctx, weight), n, patch, stride))
                     if bias is not None:
                         ctx["slab_rows"].append((bslab, bias_ptr, Nreal, patch, bstride))

@@ -71,6 +71,12 @@ int ddpm_conv3x3_wgrad_splits(int B, int H, int W, int C, int N, int splits);
 int ddpm_conv3x3_wgrad_nhwc(const void* dy, long long dy_ld, const void* x, long long x_ld, float* dw, long long slab_stride,
                             float* dbias, long long bias_stride, int B, int H, int W, int C, int N, int Nreal, int splits,
                             int dtype, void* stream);
+/* ... of the conv inside an Upsample block (F.interpolate(nearest, 2x) then conv: modules.py Upsample.forward through autograd): H, W are the
+ * OUTPUT image (dy's), x is the block's input stored at H/2 x W/2; the kernel gathers stored pixel (y >> 1, x >> 1).  ddpm_conv3x3_wgrad_splits
+ * is asked with the same (output) H, W. */
+int ddpm_conv3x3_wgrad_up_nhwc(const void* dy, long long dy_ld, const void* x, long long x_ld, float* dw, long long slab_stride,
+                               float* dbias, long long bias_stride, int B, int H, int W, int C, int N, int Nreal, int splits,
+                               int dtype, void* stream);
 
 /* Weight (and bias) gradient of a 1x1 / stride-1 convolution — autograd of F.conv2d (ddpm_torch/modules.py:120-123) at the attention
  * projections and skip connections (ddpm_torch/models/unet.py:27-29, :38-39) — by the slab kernel of csrc/wgrad1x1.hip (bf16):

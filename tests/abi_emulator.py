@@ -165,6 +165,19 @@ class Emulator:
                 for c in range(copies):
                     f32(dbias + 4 * c * bias_stride, Nreal)[...] = v if c == copies - 1 else 0.0
 
+    def ddpm_conv3x3_wgrad_up_nhwc(self, dy, dy_ld, x, x_ld, dw, slab_stride, dbias, bias_stride, B, H, W, C, N, Nreal, splits, dt, st):
+        """H, W: dy's image; x stored at H/2 x W/2 and up-sampled (nearest) on the fly."""
+        copies = self.real_lib.ddpm_conv3x3_wgrad_splits(B, H, W, C, N, splits) if self.real_lib is not None else max(splits, 1)
+        assert copies > 0 and H % 2 == 0 and W % 2 == 0
+        self.ddpm_conv2d_wgrad_nhwc(dy, dy_ld, x, x_ld, dw, slab_stride, B, H // 2, W // 2, C, C, H, W, N, Nreal, 3, 3, 1, 1, 1, 1, copies, dt, st)
+        if dbias:
+            v = Mat(dy, B * H * W, N, dy_ld, dt).get()[:, :Nreal].sum(0)
+            if slab_stride == 0:
+                f32(dbias, Nreal)[...] += v
+            else:
+                for c in range(copies):
+                    f32(dbias + 4 * c * bias_stride, Nreal)[...] = v if c == copies - 1 else 0.0
+
     def ddpm_conv1x1_wgrad_nhwc(self, dy, dy_ld, x, x_ld, dw, slab_stride, dbias, bias_stride, P, C, N, splits, dt, st):
         g = Mat(dy, P, N, dy_ld, dt).get().astype(np.float64)
         v = Mat(x, P, C, x_ld, dt).get().astype(np.float64)

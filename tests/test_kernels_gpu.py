@@ -669,27 +669,29 @@ WG3_CASES = [
 ]
 
 
+@pytest.mark.parametrize("up", [0, 1], ids=["same_size", "upsampled_input"])
 @pytest.mark.parametrize("case", WG3_CASES, ids=[c[0] for c in WG3_CASES])
-def test_conv3x3_wgrad_patch_kernel(case):
+def test_conv3x3_wgrad_patch_kernel(case, up):
     """Patch-stationary 3x3 weight gradient (+ folded bias gradient) against the emulator: atomics mode on top of existing
     content, slab mode over stale copies followed by the fixed-order reduction; pitched operands, ragged image groups,
-    out-channel tiles that run past N."""
+    out-channel tiles that run past N.  up = 1: the Upsample block's conv (x stored at half of dy's image size, nearest-2x gather in the kernel)."""
     _, B, H, W, C, N, Nreal, splits = case
     dt = 1
     xld, yld = C + 8, N + 16
-    x, dy = r(B * H * W, xld, seed=1, dt=dt), r(B * H * W, yld, seed=2, dt=dt)
+    fn = "ddpm_conv3x3_wgrad_up_nhwc" if up else "ddpm_conv3x3_wgrad_nhwc"
+    x, dy = r(B * (H >> up) * (W >> up), xld, seed=1, dt=dt), r(B * H * W, yld, seed=2, dt=dt)
     copies = int(_hip.lib().ddpm_conv3x3_wgrad_splits(B, H, W, C, N, splits))
     assert copies >= 1
     n = Nreal * 9 * C
     ref_w, ref_b = torch.zeros(n), torch.zeros(Nreal)
-    Emulator(_hip.lib()).call("ddpm_conv3x3_wgrad_nhwc", dy.data_ptr(), yld, x.data_ptr(), xld, ref_w.data_ptr(), 0, ref_b.data_ptr(), 0,
+    Emulator(_hip.lib()).call(fn, dy.data_ptr(), yld, x.data_ptr(), xld, ref_w.data_ptr(), 0, ref_b.data_ptr(), 0,
                               B, H, W, C, N, Nreal, splits, dt, 0)
     xd, dyd = x.cuda(), dy.cuda()
     tol = 4e-3
     # atomics on top of existing content
     w0, b0 = r(n, seed=3), r(Nreal, seed=4)
     wd, bd = w0.cuda(), b0.cuda()
-    _hip.call("ddpm_conv3x3_wgrad_nhwc", dyd.data_ptr(), yld, xd.data_ptr(), xld, wd.data_ptr(), 0, bd.data_ptr(), 0, B, H, W, C, N, Nreal, splits, dt, _hip.stream())
+    _hip.call(fn, dyd.data_ptr(), yld, xd.data_ptr(), xld, wd.data_ptr(), 0, bd.data_ptr(), 0, B, H, W, C, N, Nreal, splits, dt, _hip.stream())
     assert float((wd.cpu() - w0 - ref_w).abs().max()) <= tol * float(ref_w.abs().max()), "atomic dw"
     assert float((bd.cpu() - b0 - ref_b).abs().max()) <= tol * float(ref_b.abs().max()), "atomic dbias"
     # slab copies + fixed-order reduction, twice: bit-identical
@@ -698,7 +700,7 @@ def test_conv3x3_wgrad_patch_kernel(case):
     for rep in range(2):
         slabs = torch.full((copies * (stride + bstride),), 7.0 + rep).cuda()          # stale content must not leak
         bptr = slabs.data_ptr() + 4 * copies * stride
-        _hip.call("ddpm_conv3x3_wgrad_nhwc", dyd.data_ptr(), yld, xd.data_ptr(), xld, slabs.data_ptr(), stride, bptr, bstride,
+        _hip.call(fn, dyd.data_ptr(), yld, xd.data_ptr(), xld, slabs.data_ptr(), stride, bptr, bstride,
                   B, H, W, C, N, Nreal, splits, dt, _hip.stream())
         out_w, out_b = torch.zeros(n).cuda(), torch.zeros(Nreal).cuda()
         table = torch.tensor([[slabs.data_ptr(), out_w.data_ptr(), n, copies, stride], [bptr, out_b.data_ptr(), Nreal, copies, bstride]], dtype=torch.int64).cuda()
@@ -709,7 +711,7 @@ def test_conv3x3_wgrad_patch_kernel(case):
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])       # deterministic
     # without a bias pointer nothing else changes
     w2 = torch.zeros(n).cuda()
-    _hip.call("ddpm_conv3x3_wgrad_nhwc", dyd.data_ptr(), yld, xd.data_ptr(), xld, w2.data_ptr(), 0, 0, 0, B, H, W, C, N, Nreal, splits, dt, _hip.stream())
+    _hip.call(fn, dyd.data_ptr(), yld, xd.data_ptr(), xld, w2.data_ptr(), 0, 0, 0, B, H, W, C, N, Nreal, splits, dt, _hip.stream())
     assert float((w2.cpu() - ref_w).abs().max()) <= tol * float(ref_w.abs().max())
 
 
