@@ -21,3 +21,11 @@ def test_committed_bench_line_matches_the_contract():
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and isinstance(c["sample"], str)
     assert abs(d["ms_per_step"] * d["value"] / 1e3 - d["config"]["global_batch"]) < 0.01 * d["config"]["global_batch"]
+    # physically possible: no kernel row above the dense peak (a row at 1.8x once exposed events bracketing the wrong stream), the kernels' summed
+    # isolated time below the step, the dominant kernel's traffic present and its in-product time consistent with launches x average
+    for table in (r["per_kernel"], r["isolated"]["per_kernel"]):
+        assert all(0 < v["frac"] < 1 for v in table.values()), {k: v["frac"] for k, v in table.items() if not 0 < v["frac"] < 1}
+    assert r["isolated"]["all_mfma_kernels"]["ms"] < d["ms_per_step"]
+    dom = r["per_kernel"][r["kernel"]]
+    assert dom["launches"] == r["launches_per_step"] and abs(dom["avg_launch_us"] - r["avg_launch_us"]) < 0.05
+    assert r["traffic"] and r["traffic"]["hbm_bytes_per_launch"] > 0 and r["runner_up"]["kernel"] != r["kernel"]
