@@ -1,7 +1,8 @@
 // Probe: steady-state rate of the "LDS fragment reads + MFMA" inner loop on gfx950, one block per CU, no global traffic.
 // Per sub-step (kc) a wave reads MI A-fragments and NJ B-fragments (ds_read_b128, conflict-free swizzled tiles) and runs
 // MI*NJ v_mfma_f32_32x32x16_bf16.  MODE 0: reads then MFMAs (wait for all); MODE 1: software-pipelined (reads of kc+1
-// in flight under the MFMAs of kc); MODE 2: MFMAs only; MODE 3: reads only.
+// in flight under the MFMAs of kc); MODE 2: MFMAs only; MODE 3: reads only.  (The block size is a template argument: with a blanket
+// __launch_bounds__(1024) the 128x64-per-wave variants were held to 128 registers and spilled their accumulators — 137 TFLOP/s "MFMA only".)
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
@@ -39,8 +40,8 @@ __device__ __forceinline__ void wait_lgkm(Frags<MI, NJ>& f) {      // ties the w
     else asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(f.a[0]), "+v"(f.a[1]), "+v"(f.a[2]), "+v"(f.a[3]), "+v"(f.b[0]), "+v"(f.b[1]) : "n"(N));
 }
 
-template <int MODE, int MI, int NJ>
-__global__ __launch_bounds__(1024) void k(float* out, int iters, int wm_count) {
+template <int MODE, int MI, int NJ, int NT>
+__global__ __launch_bounds__(NT) void k(float* out, int iters, int wm_count) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int i = tid; i < 128 * 1024 / 4; i += blockDim.x) reinterpret_cast<unsigned*>(smem)[i] = 0x3c003c00u + (i & 7);
@@ -94,14 +95,15 @@ __global__ __launch_bounds__(1024) void k(float* out, int iters, int wm_count) {
     if (s == 12345.678f) out[tid] = s;
 }
 
-template <int MODE, int MI, int NJ>
-void run(const char* name, int nw, int wm_count, float* out) {
+template <int MODE, int MI, int NJ, int NW>
+void run(const char* name, int wm_count, float* out) {
+    constexpr int nw = NW;
     const int iters = 2000;
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&k<MODE, MI, NJ>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&k<MODE, MI, NJ, NW * 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
-    hipLaunchKernelGGL((k<MODE, MI, NJ>), dim3(256), dim3(nw * 64), 128 * 1024, 0, out, 10, wm_count);
+    hipLaunchKernelGGL((k<MODE, MI, NJ, NW * 64>), dim3(256), dim3(nw * 64), 128 * 1024, 0, out, 10, wm_count);
     hipEventRecord(a);
-    hipLaunchKernelGGL((k<MODE, MI, NJ>), dim3(256), dim3(nw * 64), 128 * 1024, 0, out, iters, wm_count);
+    hipLaunchKernelGGL((k<MODE, MI, NJ, NW * 64>), dim3(256), dim3(nw * 64), 128 * 1024, 0, out, iters, wm_count);
     hipEventRecord(b); hipEventSynchronize(b);
     float ms; hipEventElapsedTime(&ms, a, b);
     const double us_per_kc = ms * 1e3 / (iters * 4.0);
@@ -111,19 +113,19 @@ void run(const char* name, int nw, int wm_count, float* out) {
 }
 int main() {
     float* out; hipMalloc(&out, 1 << 16);
-    run<2, 2, 2>("mfma only", 8, 4, out);
-    run<3, 2, 2>("reads only", 8, 4, out);
-    run<0, 2, 2>("read->wait->mfma", 4, 2, out);
-    run<0, 2, 2>("read->wait->mfma", 8, 4, out);
-    run<0, 2, 2>("read->wait->mfma", 16, 4, out);
-    run<1, 2, 2>("pipelined", 4, 2, out);
-    run<1, 2, 2>("pipelined", 8, 4, out);
-    run<1, 2, 2>("pipelined", 16, 4, out);
-    run<2, 4, 2>("mfma only", 4, 2, out);
-    run<2, 4, 2>("mfma only", 8, 2, out);
-    run<0, 4, 2>("read->wait->mfma", 4, 2, out);
-    run<0, 4, 2>("read->wait->mfma", 8, 2, out);
-    run<1, 4, 2>("pipelined", 4, 2, out);
-    run<1, 4, 2>("pipelined", 8, 2, out);
+    run<2, 2, 2, 8>("mfma only", 4, out);
+    run<3, 2, 2, 8>("reads only", 4, out);
+    run<0, 2, 2, 4>("read->wait->mfma", 2, out);
+    run<0, 2, 2, 8>("read->wait->mfma", 4, out);
+    run<0, 2, 2, 16>("read->wait->mfma", 4, out);
+    run<1, 2, 2, 4>("pipelined", 2, out);
+    run<1, 2, 2, 8>("pipelined", 4, out);
+    run<1, 2, 2, 16>("pipelined", 4, out);
+    run<2, 4, 2, 4>("mfma only", 2, out);
+    run<2, 4, 2, 8>("mfma only", 2, out);
+    run<0, 4, 2, 4>("read->wait->mfma", 2, out);
+    run<0, 4, 2, 8>("read->wait->mfma", 2, out);
+    run<1, 4, 2, 4>("pipelined", 2, out);
+    run<1, 4, 2, 8>("pipelined", 2, out);
     return 0;
 }
