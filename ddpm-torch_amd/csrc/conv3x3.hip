@@ -1,5 +1,5 @@
-// 3x3 / stride 1 / pad 1 convolution, bf16 — the hot conv of the UNet, forward and data gradient (ddpm_torch/modules.py:60-101 `Conv2d`
-// inside ddpm_torch/models/unet.py:21-34 `ResidualBlock`) — as a PERSISTENT stationary-halo kernel for images of 16x16 pixels and up.
+// 3x3 / stride 1 / pad 1 convolution, bf16 — the hot conv of the UNet, forward and data gradient (ddpm_torch/modules.py:66-123 `Conv2d`
+// inside ddpm_torch/models/unet.py:63-89 `ResidualBlock`, conv1 / conv2 at :76,79) — as a PERSISTENT stationary-halo kernel for images of 16x16 pixels and up.
 //
 // Same K-loop as conv3x3_halo_kernel (gemm.hip): a block owns one 16 x 16 output patch x 128 output channels and walks K as
 // (64-channel chunk, tap); the 18 x 18 input halo of a chunk is DMA'd into LDS once and serves all nine taps, only the 128 x 64 weight

@@ -291,6 +291,24 @@ extern "C" int ddpm_mse_bwd(const float* pred, const float* target, const float*
     return check_launch();
 }
 
+// out = sum_i x[i] * w[i] by ONE block in a fixed order (bit-reproducible): the batch mean of the per-sample losses
+// (utils/train.py:151, `loss.mean()`), with w = d(mean)/d(loss_b) = 1/B — the same vector the backward kernel consumes.
+__global__ void weighted_sum_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ out, int n) {
+    __shared__ float sh[4];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) acc += x[i] * w[i];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+extern "C" int ddpm_weighted_sum_f32(const float* x, const float* w, float* out, int n, void* stream) {
+    if (!x || !w || !out) return DDPM_ERR_NULL;
+    if (n <= 0) return DDPM_ERR_SHAPE;
+    hipLaunchKernelGGL(weighted_sum_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, x, w, out, n);
+    return check_launch();
+}
+
 // One fused sampling step for model_mean_type in {eps, x_0, mean} with a fixed variance table
 // (diffusion.py:107-158): pred_x0 -> clamp -> posterior mean -> + 1[t>0]*exp(0.5*logvar)*z.
 // tab = 7 fp32 tables of length T, concatenated: recip, recip_m1, coef1, coef2, logvar, (unused), (unused)

@@ -180,7 +180,10 @@ class GaussianDiffusion:
         if self.model_mean_type == "x_0":
             return x_0
         if self.model_mean_type == "mean":
-            return self.q_posterior_mean_var(x_0=x_0, x_t=x_t, t=t)[0]
+            # posterior mean from the device-resident tables (no host -> device upload: this runs inside captured steps)
+            c1 = self._tab("posterior_mean_coef1", x_0.device).gather(0, t).reshape((-1,) + (1,) * (x_0.ndim - 1))
+            c2 = self._tab("posterior_mean_coef2", x_0.device).gather(0, t).reshape((-1,) + (1,) * (x_0.ndim - 1))
+            return c1 * x_0 + c2 * x_t
         raise NotImplementedError(self.model_mean_type)
 
     def supports_direct_step(self):
@@ -266,11 +269,17 @@ class GaussianDiffusion:
         """Cached captured step for (denoiser, shape), capturing it on first use; None when capture is not possible."""
         cache = self.__dict__.setdefault("_sample_graphs", {})
         engines = self._engines_of(denoise_fn)
+        # engine serials: model.to() / .float() / set_compute_dtype() re-create the engine (packed weights, workspaces) — a step
+        # captured against the previous one points at freed memory and must never be replayed
         key = (id(denoise_fn), shape, str(device), default_rng, getattr(denoise_fn, "training", None),
-               tuple(e.T for e in engines) if engines else None)
+               tuple((e.serial, e.T) for e in engines) if engines else None)
         ent = cache.get(key)
         if ent is not None and ent["ref"]() is not denoise_fn:
             ent = None                                            # the id was recycled by another object
+        if ent is None and engines:
+            live = {e.serial for e in engines}
+            for k in [k for k, v in cache.items() if v["ref"]() is denoise_fn and k[5] and {sr for sr, _ in k[5]} != live]:
+                cache.pop(k)                                      # entries of this denoiser's earlier engines: dead weight (and dead pointers)
         if ent is None:
             ent = self._capture_sample_step(denoise_fn, shape, device, default_rng)
             if ent is not None and engines is not None:           # arbitrary callables are captured per call: nothing tells us when their weights change
@@ -359,11 +368,15 @@ class GaussianDiffusion:
         return self._sample_loop(denoise_fn, shape, device, noise, seed)
 
     @torch.inference_mode()
-    def p_sample_progressive(self, denoise_fn, shape, device=torch.device("cpu"), noise=None, pred_freq=10, seed=None):
-        """diffusion.py:176-198: also returns pred_x0 every ``pred_freq`` steps (on the host)."""
-        B = (shape or noise.shape)[0]
-        L = self.timesteps // pred_freq
-        preds = torch.zeros((L, B) + tuple(shape[1:]), dtype=torch.float32)
+    def p_sample_progressive(self, denoise_fn, shape, device=torch.device("cpu"), noise=None, pred_freq=10, seed=None, z_stream=None):
+        """diffusion.py:176-198: the same loop, also returning pred_x0 of every ``pred_freq``-th step (on the host), filled from
+        the back: ``preds[L-1]`` is the first one kept (t = T-1 when T is a multiple of pred_freq), ``preds[0]`` the one at
+        t = pred_freq - 1.  The per-step read-back needs the eager loop (no graph replay).  ``z_stream`` (parity tests only): as in
+        ``_sample_loop``."""
+        shape = tuple(shape or noise.shape)
+        B = shape[0]
+        L = self._num_steps() // pred_freq
+        preds = torch.zeros((L, B) + shape[1:], dtype=torch.float32)
         box = [L]
 
         def keep(ti, pred):
@@ -371,5 +384,5 @@ class GaussianDiffusion:
                 box[0] -= 1
                 preds[box[0]] = pred.cpu()
 
-        x = self._sample_loop(denoise_fn, shape, device, noise, seed, on_step=keep)
+        x = self._sample_loop(denoise_fn, shape, device, noise, seed, on_step=keep, z_stream=z_stream)
         return x.cpu(), preds

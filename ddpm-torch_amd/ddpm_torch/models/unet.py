@@ -19,6 +19,7 @@ through the C-ABI in ``csrc/`` (see ``include/ddpm_hip.h``):
 There is no CPU path: CPU tensors raise (the CPU restatement used for checking lives in ``oracle/``).
 """
 import contextlib
+import itertools
 import math
 import os
 
@@ -259,8 +260,11 @@ _WGRAD3_ATOMIC = os.environ.get("DDPM_WGRAD3_ATOMIC", "0") != "0"  # ... with fp
 
 
 class _Engine:
+    _serials = itertools.count(1)
+
     def __init__(self, model):
         self.m = model
+        self.serial = next(_Engine._serials)       # identity for caches of captured graphs (an id() can be recycled, this cannot)
         self.params = list(model.parameters())
         self.names = [k for k, _ in model.named_parameters()]
         _hip.require_cuda(self.params[0])          # no CPU path: move the model to the GPU first
@@ -295,7 +299,7 @@ class _Engine:
         self.fc_w = self.fc_b = self.fc_table = None       # concatenated time-bias projection (persistent: graph replays read it)
         self.fc_ver = None
         self._ws = None
-        self._ws_key = None
+        self._ws_need, self._ws_retired = {}, []
         self.drop_calls = 0
         self.last_tape = None
         self.debug_keep_tape = False               # tests set it to look at the tape after a step; costs the activations' lifetime
@@ -422,8 +426,12 @@ class _Engine:
         self.fc_ver = self._fc_versions()
 
     def _workspace(self, B, H, W):
+        """GroupNorm scratch for this input geometry.  Grow-only: captured graphs (training step, sampler) hold its address, and a
+        forward at another batch size in between (the per-epoch sample grid) must not free what they point at — a buffer that is
+        outgrown is retired, never released."""
         key = (B, H, W)
-        if self._ws_key != key:
+        need = self._ws_need.get(key)
+        if need is None:
             need = 0
             for i in range(self.L):                      # every GroupNorm width that occurs at level i
                 hw = (H >> i) * (W >> i)
@@ -431,8 +439,10 @@ class _Engine:
                 above = self.chs[i - 1] if i else self.hid
                 for c in {self.chs[i], above, self.chs[i] + below, 2 * self.chs[i], self.chs[i] + above}:
                     need = max(need, ops.gn_workspace_floats(B, hw, c, self.dcode))
+            self._ws_need[key] = need
+        if self._ws is None or self._ws.numel() < need:
+            self._ws_retired.append(self._ws)
             self._ws = torch.empty(need, dtype=torch.float32, device=self.device)
-            self._ws_key = key
         return self._ws
 
     # ---------------------------------------------------------------- small helpers

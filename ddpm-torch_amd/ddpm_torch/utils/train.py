@@ -216,6 +216,7 @@ class _FusedUpdate:
         self.opt, self.ema = optimizer, ema
         self.table = self.key = self.sig = None
         self.total = None
+        self.generation = 0                  # bumped whenever the pointer table is rebuilt (captured steps compare it)
 
     def eligible(self):
         opt = self.opt
@@ -276,6 +277,7 @@ class _FusedUpdate:
             if self.total is None or self.total.device != dev:
                 self.total = torch.zeros(64, dtype=torch.float32, device=dev)      # striped ||g||^2 accumulators
             self.key, self.params = key, params
+            self.generation += 1
         self.sig = self._signature(grad_ptrs) if stable_grads else None
         return self.params
 
@@ -348,6 +350,8 @@ class _DirectStep:
         self.calls = 0
         self.graph = None
         self.graph_failed = False
+        self.captures = 0                    # graph captures so far (bench.py asserts none happens inside a timed region)
+        self._baked = None                   # identity of everything whose ADDRESS the captured graph holds (see _identity)
         # auto mode: wall times (Trainer.step reports them) of a few eager and a few replayed steps decide which one stays
         self.times = {}                      # auto mode: seconds per step of the "eager" / "graph" probe phases
         self.last_kind, self.choice, self._phase = None, None, None
@@ -381,7 +385,7 @@ class _DirectStep:
         out = eng.forward(x_t, self.t, self.unet.training, tape, seed_dev=self.hyper_dev.data_ptr() + 16)
         losses = torch.empty(B, dtype=torch.float32, device=out.device)
         _hip.call("ddpm_mse_fwd", out.data_ptr(), target.data_ptr(), losses.data_ptr(), B, n, s())
-        torch.sum(losses * self.gloss, dim=0, out=self.loss)                   # mean over the batch
+        _hip.call("ddpm_weighted_sum_f32", losses.data_ptr(), self.gloss.data_ptr(), self.loss.data_ptr(), B, s())   # mean over the batch
         gout = torch.empty_like(out)
         _hip.call("ddpm_mse_bwd", out.data_ptr(), target.data_ptr(), self.gloss.data_ptr(), gout.data_ptr(), B, n, s())
         eng.backward(tape, gout, gflat=self.gflat, cut=cut, want_views=False)
@@ -423,6 +427,25 @@ class _DirectStep:
     def observe(self, seconds):
         """Kept for callers of the earlier interface: the probe now times whole phases itself."""
 
+    def settled(self):
+        """True once the form of the step (eager launches or graph replay) is final and, for the replayed form, captured."""
+        if not self.x0.is_cuda:
+            return True
+        if _TRAIN_GRAPH == "auto":
+            if self.choice is None:
+                return False
+            return self.choice == "eager" or self.graph is not None or self.graph_failed
+        return not _TRAIN_GRAPH or self.graph is not None or self.graph_failed
+
+    def _identity(self):
+        """Everything a captured step addresses by a raw pointer baked into its kernel arguments and that can be RE-CREATED behind
+        its back: the fused update's pointer table (``optimizer.load_state_dict`` / ``load_checkpoint`` re-create the Adam moments
+        and with them the table), the engine (``model.to()`` / ``.float()`` drop it: packed weights, workspaces, staging buffers)
+        and the engine's derived-copy tables.  A replay after any of these changed would write through dangling pointers."""
+        eng, fused = self.unet.engine(), self.tr._fused
+        return (eng.serial, fused.generation, fused.table.data_ptr(), eng.pack_table.data_ptr(), eng.fc_table.data_ptr(),
+                self.gflat.data_ptr(), self.unet.training)
+
     def run(self, x):
         tr, eng = self.tr, self.unet.engine()
         self.x0.copy_(x, non_blocking=True)
@@ -432,6 +455,8 @@ class _DirectStep:
         params = tr._fused.prepare(grad_ptrs=self.grad_ptrs, stable_grads=True)
         assert len(params) == len(eng.params)
         self._write_hyper()
+        if self.graph is not None and self._baked != self._identity():
+            self.graph = None                                   # stale addresses: capture again (or run eagerly) instead of replaying
         can_graph = (not self.graph_failed and self.x0.is_cuda and self.calls >= 1 and tr.input_source is None
                      and not torch.cuda.is_current_stream_capturing())
         use_graph = can_graph and self._wants_graph()
@@ -441,6 +466,8 @@ class _DirectStep:
             g.register_generator(tr.generator)
             try:
                 self.graph = g.capture(self.body)
+                self.captures += 1
+                self._baked = self._identity()
             except Exception as e:                        # capture not possible here: keep training eagerly
                 warnings.warn(f"hipGraph capture of the training step failed ({type(e).__name__}: {e}); running it eagerly")
                 torch.cuda.synchronize()
@@ -478,7 +505,9 @@ class Trainer:
         self.epochs, self.start_epoch = epochs, 0
         self.trainloader, self.sampler = trainloader, sampler
         if shape is None:
-            shape = next(iter(trainloader))[0].shape[1:]
+            first = next(iter(trainloader))
+            first = first[0] if isinstance(first, (list, tuple)) else first      # (image, label) pairs or bare image batches
+            shape = first.shape[1:]
         self.shape = tuple(shape)
         self.scheduler = DummyScheduler() if scheduler is None else scheduler
         self.num_accum, self.grad_norm = num_accum, grad_norm
@@ -639,10 +668,16 @@ class Trainer:
             images = batch[0] if isinstance(batch, (list, tuple)) else batch       # unconditional: labels are dropped
             steps += 1
             self.step(images.to(self.device), global_steps=steps)
-            seen = self.current_stats
             if self.dry_run and steps % self.num_accum == 0:
                 break
-        return steps, dict(seen)
+        # (the reference refreshes a progress-bar postfix from current_stats after every step, utils/train.py:209-212; reading the
+        #  statistics drains the pending loss read-back and would park the host on the device in every step, so they are read once,
+        #  when the epoch is over — callers that want a live figure use ``peek_stats``)
+        return steps, dict(self.current_stats) if steps > first_global_step else {}
+
+    def peek_stats(self):
+        """Running statistics WITHOUT the step whose loss is still on its way from the device (no host wait)."""
+        return RunningStatistics.extract(self.stats) if self.stats.count else {}
 
     def _write_samples(self, e, image_dir):
         self.model.eval()

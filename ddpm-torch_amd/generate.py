@@ -44,7 +44,7 @@ def parse_args(argv=None):
     add("--max-workers", default=8, type=int)
     add("--num-gpus", default=1, type=int)
     add("--compute", choices=["bf16", "fp32"], default="bf16")
-    add("--seed", default=None, type=int, help="seed of the x_T draws (default: nondeterministic, like the reference)")
+    add("--seed", default=None, type=int, help="seeds x_T AND the per-step noise of every chain (default: nondeterministic, like the reference)")
     return p.parse_args(argv)
 
 
@@ -107,13 +107,17 @@ def generate(rank, args):
     os.makedirs(out_dir, exist_ok=True)
     world = max(args.num_gpus, 1)
     mine = args.total_size // world + (1 if rank < args.total_size % world else 0)
-    gen = None if args.seed is None else torch.Generator(device).manual_seed(args.seed + rank)
-    done = 0
+    done = chain = 0
     with ThreadPoolExecutor(max_workers=args.max_workers) as pool:
         while done < mine:
             n = min(args.batch_size, mine - done)
-            x_T = torch.randn((n,) + shape, device=device, generator=gen)
-            x = process.p_sample(model, shape=(n,) + shape, device=device, noise=x_T)
+            if args.seed is None:                    # the reference's behaviour (generate.py:126-128): x_T and every z from the default RNG
+                x = process.p_sample(model, shape=(n,) + shape, device=device, noise=torch.randn((n,) + shape, device=device))
+            else:
+                # reproducible runs: ONE seeded generator per chain feeds x_T and then every per-step z (diffusion.py:164-171), so the
+                # whole chain — not only its starting point — repeats; chains and ranks get distinct streams
+                x = process.p_sample(model, shape=(n,) + shape, device=device, seed=args.seed + 1000003 * rank + chain)
+            chain += 1
             list(pool.map(lambda a: write_png(a, out_dir), list(to_uint8(x))))
             done += n
             if rank == 0:

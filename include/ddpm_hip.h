@@ -71,7 +71,7 @@ int ddpm_conv3x3_wgrad_splits(int B, int H, int W, int C, int N, int splits);
 int ddpm_conv3x3_wgrad_nhwc(const void* dy, long long dy_ld, const void* x, long long x_ld, float* dw, long long slab_stride,
                             float* dbias, long long bias_stride, int B, int H, int W, int C, int N, int Nreal, int splits,
                             int dtype, void* stream);
-/* ... of the conv inside an Upsample block (F.interpolate(nearest, 2x) then conv: modules.py Upsample.forward through autograd): H, W are the
+/* ... of the conv inside an Upsample block (`nn.Upsample(scale_factor=2, mode="nearest")` then the 3x3 conv, ddpm_torch/models/unet.py:199-202, through autograd): H, W are the
  * OUTPUT image (dy's), x is the block's input stored at H/2 x W/2; the kernel gathers stored pixel (y >> 1, x >> 1).  ddpm_conv3x3_wgrad_splits
  * is asked with the same (output) H, W. */
 int ddpm_conv3x3_wgrad_up_nhwc(const void* dy, long long dy_ld, const void* x, long long x_ld, float* dw, long long slab_stride,
@@ -79,7 +79,7 @@ int ddpm_conv3x3_wgrad_up_nhwc(const void* dy, long long dy_ld, const void* x, l
                                int dtype, void* stream);
 
 /* Weight (and bias) gradient of a 1x1 / stride-1 convolution — autograd of F.conv2d (ddpm_torch/modules.py:120-123) at the attention
- * projections and skip connections (ddpm_torch/models/unet.py:27-29, :38-39) — by the slab kernel of csrc/wgrad1x1.hip (bf16):
+ * projections and skip connections (ddpm_torch/models/unet.py:36-37,41 `AttentionBlock.project_in/out/skip`, :80 `ResidualBlock.skip`) — by the slab kernel of csrc/wgrad1x1.hip (bf16):
  *     dW[n][c] = sum_p dy[p][n] * x[p][c]      db[n] = sum_p dy[p][n]      p over the P = B*H*W pixels
  * ddpm_conv1x1_wgrad_splits returns the number of slab copies the kernel writes for this geometry (0: not covered, use
  * ddpm_conv2d_wgrad_nhwc); slice s STORES its partials at dw + s*slab_stride ([N][C] fp32) and dbias + s*bias_stride (dbias may be
@@ -188,6 +188,8 @@ int ddpm_q_sample(const float* x0, const float* noise, const long long* t, const
 /* flat_mean((target - pred)^2) (diffusion.py:239, functions.py:99-101) and its gradient w.r.t. pred */
 int ddpm_mse_fwd(const float* pred, const float* target, float* loss, int B, int n, void* stream);
 int ddpm_mse_bwd(const float* pred, const float* target, const float* gloss, float* gpred, int B, int n, void* stream);
+/* out[0] = sum_i x[i]*w[i], one block, fixed order: the batch mean of the per-sample losses (utils/train.py:151 `loss.mean()`) */
+int ddpm_weighted_sum_f32(const float* x, const float* w, float* out, int n, void* stream);
 /* p_mean_var + p_sample_step (diffusion.py:107-158; ddim.py inherits it): one fused update
  *   x0 = clamp(recip[t]*x_t - recip_m1[t]*out)   (mean_type 0 = eps; 1: x0 = out; 2: out is the mean)
  *   x_prev = coef1[t]*x0 + coef2[t]*x_t + 1[t>0]*exp(0.5*logvar[t])*z ;  pred_x0 optional.

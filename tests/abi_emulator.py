@@ -327,6 +327,9 @@ class Emulator:
         d = f32(target, B * n).reshape(B, n) - f32(pred, B * n).reshape(B, n)
         f32(loss, B)[...] = (d * d).mean(1)
 
+    def ddpm_weighted_sum_f32(self, x, w, out, n, st):
+        f32(out, 1)[0] = np.float32((f32(x, n).astype(np.float64) * f32(w, n)).sum())
+
     def ddpm_mse_bwd(self, pred, target, gloss, gpred, B, n, st):
         d = f32(pred, B * n).reshape(B, n) - f32(target, B * n).reshape(B, n)
         f32(gpred, B * n).reshape(B, n)[...] = d * (2.0 / n) * f32(gloss, B)[:, None]

@@ -40,7 +40,8 @@ def randomized(module, seed):
 
 # ----------------------------------------------------------------------------- G1 op level
 def g1_ops():
-    out = {}
+    torch.manual_seed(101)                        # module constructors draw their initial weights from the global RNG: seeded, so that
+    out = {}                                      # re-running this script reproduces the committed files bit for bit
     # GroupNorm(32, eps 1e-6) (+SiLU): unet.py:18-20,85
     for B, C, hw in [(2, 128, 4), (1, 384, 16), (2, 768, 4), (1, 128, 16)]:
         gn = ref.unet.DEFAULT_NORMALIZER(C)
@@ -93,6 +94,7 @@ def _grads(module, loss):
 
 
 def g2_blocks():
+    torch.manual_seed(202)                        # (as in g1_ops)
     out = {}
     res = ref.unet.ResidualBlock(32, 64, embed_dim=128, drop_rate=0.0)
     sd = randomized(res, 11)
@@ -239,6 +241,11 @@ def g6_loops():
         zs = torch.stack([torch.empty(shape).normal_(generator=g) for _ in range(1000)])
         out["ddpm_" + vt] = dict(seed=7, shape=shape, x_0=x, x_T=x_T, zs_sum=zs.double().sum(), zs_abs_sum=zs.double().abs().sum(),
                                  z_first=zs[0].clone(), z_last=zs[-1].clone())
+        if vt == "fixed-large":
+            # p_sample_progressive (diffusion.py:176-198): same stream, pred_x0 kept every 100 steps
+            xp, preds = dif.p_sample_progressive(m, shape=shape, device=torch.device("cpu"), pred_freq=100, seed=7)
+            assert torch.equal(xp, x)
+            out["ddpm_" + vt].update(pred_freq=100, preds=preds)
     base = ref.GaussianDiffusion(betas, "eps", "fixed-small", "mse")
     for sched, size, eta in (("linear", 50, 0.0), ("quadratic", 100, 1.0)):
         sub = ref.get_selection_schedule(sched, size, 1000)

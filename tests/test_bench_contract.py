@@ -2,6 +2,8 @@
 import glob
 import json
 import os
+import subprocess
+import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -29,3 +31,26 @@ def test_committed_bench_line_matches_the_contract():
     dom = r["per_kernel"][r["kernel"]]
     assert dom["launches"] == r["launches_per_step"] and abs(dom["avg_launch_us"] - r["avg_launch_us"]) < 0.05
     assert r["traffic"] and r["traffic"]["hbm_bytes_per_launch"] > 0 and r["runner_up"]["kernel"] != r["kernel"]
+
+
+def _bench(args, env_extra, timeout=300):
+    env = dict(os.environ, BENCH_LAUNCH_PROBE="1", **env_extra)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    env.update(env_extra)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_bare_gpus_n_starts_n_ranks():
+    """`python bench.py --gpus 2` with no WORLD_SIZE launches two ranks itself (gloo stand-in for the communicator: no GPU here)."""
+    r = _bench(["--gpus", "2"], {})
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line == {"launch_probe": True, "n_gpus": 2, "ranks_in_collective": 2}
+
+
+def test_world_size_mismatch_is_an_error():
+    r = _bench(["--gpus", "4"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "--gpus 4 but WORLD_SIZE=1" in (r.stderr + r.stdout)
+    r = _bench(["--gpus", "1"], {})
+    assert r.returncode == 0 and json.loads(r.stdout.strip().splitlines()[-1])["n_gpus"] == 1

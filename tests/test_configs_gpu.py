@@ -271,3 +271,74 @@ def test_auto_mode_picks_a_step_execution_and_keeps_training(monkeypatch):
     assert ds.graph is not None and not ds.graph_failed
     assert int(opt.state[next(iter(m.parameters()))]["step"]) == 14 and tr.ema.num_updates == 13
     assert sum(losses[-4:]) < sum(losses[:4])
+
+
+def test_captured_step_is_recaptured_when_baked_addresses_move(monkeypatch):
+    """A captured step holds raw addresses (the fused update's pointer table, the engine's packed weights and workspaces).
+    `optimizer.load_state_dict` re-creates the Adam moments (new table), `model.float()` / `.to()` drops the engine: the next
+    step must notice, capture again and give what the eager step gives — never replay through the stale pointers."""
+    from tests.test_unet_gpu import TINY3
+    runs = {}
+    for graph in (True, False):
+        monkeypatch.setattr(train_mod, "_TRAIN_GRAPH", graph)
+        torch.manual_seed(11)
+        m, _ = make(TINY3, dtype=torch.float32)
+        m.train()
+        dif = ddpm_torch.GaussianDiffusion(ddpm_torch.get_beta_schedule("linear", 1e-4, 0.02, 1000), "eps", "fixed-large", "mse")
+        opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+        tr = ddpm_torch.Trainer(m, opt, dif, epochs=1, trainloader=None, use_ema=True, shape=(3, 16, 16), device=torch.device(DEV))
+        xs = [(torch.rand(4, 3, 16, 16, generator=torch.Generator().manual_seed(70 + i)) * 2 - 1).to(DEV) for i in range(9)]
+        for i in range(3):
+            tr.step(xs[i], global_steps=i + 1)
+        ds = next(iter(tr._direct.values()))
+        assert ds.captures == (1 if graph else 0)
+        # (1) the moments are re-created: every exp_avg / exp_avg_sq tensor is a new allocation
+        state = opt.state_dict()
+        old_ptr = opt.state[next(iter(m.parameters()))]["exp_avg"].data_ptr()
+        junk = [torch.empty(1 << 20, device=DEV) for _ in range(8)]            # make address reuse unlikely
+        opt.load_state_dict(state)
+        assert opt.state[next(iter(m.parameters()))]["exp_avg"].data_ptr() != old_ptr
+        del junk
+        for i in range(3, 6):
+            tr.step(xs[i], global_steps=i + 1)
+        assert ds.captures == (2 if graph else 0)
+        # (2) the engine is re-created (parameter storage unchanged, but every derived buffer is new)
+        serial = m.engine().serial
+        m._apply(lambda t: t)
+        assert m.engine().serial != serial
+        for i in range(6, 9):
+            tr.step(xs[i], global_steps=i + 1)
+        assert ds.captures == (3 if graph else 0)
+        torch.cuda.synchronize()
+        runs[graph] = ({k: v.detach().cpu().clone() for k, v in m.named_parameters()}, tr.current_stats["loss"])
+    for k, v in runs[True][0].items():
+        scale = float(runs[False][0][k].abs().max()) or 1.0
+        assert float((v - runs[False][0][k]).abs().max()) <= 2e-4 * scale + 9 * 1e-3 * 0.3, k
+    assert abs(runs[True][1] - runs[False][1]) <= 2e-4 * abs(runs[False][1])
+
+
+def test_training_graph_survives_a_sampling_pass_at_another_batch_size(monkeypatch):
+    """Trainer.train() samples a grid between epochs (another batch size -> another GroupNorm workspace requirement); the captured
+    training step still points at the workspace it was captured with, which therefore must stay alive and in place."""
+    from tests.test_unet_gpu import TINY3
+    monkeypatch.setattr(train_mod, "_TRAIN_GRAPH", True)
+    torch.manual_seed(5)
+    m, _ = make(TINY3, dtype=torch.float32)
+    dif = ddpm_torch.GaussianDiffusion(ddpm_torch.get_beta_schedule("linear", 1e-4, 0.02, 20), "eps", "fixed-large", "mse")
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    tr = ddpm_torch.Trainer(m, opt, dif, epochs=1, trainloader=None, use_ema=True, shape=(3, 16, 16), device=torch.device(DEV))
+    x = (torch.rand(2, 3, 16, 16, generator=torch.Generator().manual_seed(1)) * 2 - 1).to(DEV)
+    m.train()
+    for i in range(3):
+        tr.step(x, global_steps=i + 1)
+    ws_before = m.engine()._ws.data_ptr()
+    m.eval()
+    s = tr.sample_fn(sample_size=16, sample_seed=3)                  # B = 16 > 2: the workspace has to grow
+    assert s.shape == (16, 3, 16, 16) and torch.isfinite(s).all()
+    eng = m.engine()
+    assert eng._ws.data_ptr() != ws_before and any(w is not None and w.data_ptr() == ws_before for w in eng._ws_retired)
+    m.train()
+    for i in range(3, 6):
+        tr.step(x, global_steps=i + 1)
+    torch.cuda.synchronize()
+    assert next(iter(tr._direct.values())).captures == 1 and all(torch.isfinite(p).all() for p in m.parameters())

@@ -516,6 +516,9 @@ def test_diffusion_algebra_kernels():
     both("ddpm_mse_fwd", A(out), A(noise), A(loss, out=True, name="loss"), B, n, tol=1e-5)
     g = torch.zeros(B, n)
     both("ddpm_mse_bwd", A(out), A(noise), A(r(B, seed=5)), A(g, out=True, name="gpred"), B, n, tol=1e-6)
+    for m in (1, 5, 128, 1000):               # batch mean of the per-sample losses: one block, fixed order
+        tot = torch.zeros(1)
+        both("ddpm_weighted_sum_f32", A(r(m, seed=6).abs()), A(torch.full((m,), 1.0 / m)), A(tot, out=True, name="mean"), m, tol=2e-6)
     for mean_type in (0, 1, 2):
         for clip in (0, 1):
             xp, px0 = torch.zeros(B, n), torch.zeros(B, n)

@@ -183,6 +183,59 @@ def test_sampling_loops_vs_reference_fixture(golden):
     assert a.is_cuda and a.shape == (2, 3, 8, 8) and torch.isfinite(a).all() and torch.equal(a, b)   # inference is bit-deterministic
 
 
+BF16_LOOP_BAR = 5e-2
+
+
+def test_sampling_loops_bf16_vs_reference_fixture(golden):
+    """The throughput mode's loops against the same fixture (the reference's fp32 CPU chains on its own noise stream).  Bar: bf16
+    storage of every activation puts ~1e-2 on a single forward (the survey measured 1.3e-2 for bf16 autocast of the reference
+    itself); the chain contracts that error at every clamped step instead of compounding it, so the END of a 1000-step DDPM chain /
+    a 50-step DDIM chain has to stay inside 5e-2 of the fixture's range (measured values are printed)."""
+    g6, g3 = golden("g6_loops.pt"), golden("g3_model.pt")
+    m, _ = tiny_from_golden(g3, dtype=torch.bfloat16)
+    m.eval()
+    betas = ddpm_torch.get_beta_schedule("linear", 1e-4, 0.02, 1000)
+    for key, proc, steps in (
+            ("ddpm_fixed-large", ddpm_torch.GaussianDiffusion(betas, "eps", "fixed-large", "mse"), 1000),
+            ("ddpm_fixed-small", ddpm_torch.GaussianDiffusion(betas, "eps", "fixed-small", "mse"), 1000),
+            ("ddim_linear_50_eta0.0", ddim_mod.DDIM(betas, "eps", "fixed-small", "mse", eta=0.0,
+                                                    subsequence=ddim_mod.get_selection_schedule("linear", 50, 1000)), 50)):
+        r = g6[key]
+        x_T, zs = _noise_stream(r["seed"], tuple(r["shape"]), steps)
+        with torch.inference_mode():
+            x = proc._sample_loop(m, tuple(r["shape"]), DEV, x_T, None, z_stream=iter(zs))
+        err = float((x.cpu() - r["x_0"]).abs().max()) / float(r["x_0"].abs().max())
+        print(f"bf16 loop {key}: rel err {err:.3e}")
+        assert torch.isfinite(x).all() and err < BF16_LOOP_BAR, (key, err)
+
+
+def test_p_sample_progressive_vs_reference_fixture_and_eager_loop(golden):
+    """diffusion.py:176-198: final sample AND the kept pred_x0 tensors against the reference's own run (fixture G6, its CPU noise
+    stream injected); then the public seeded call: same final sample as p_sample with that seed, preds filled from the back."""
+    g6, g3 = golden("g6_loops.pt"), golden("g3_model.pt")
+    m, _ = tiny_from_golden(g3)
+    m.eval()
+    dif = ddpm_torch.GaussianDiffusion(ddpm_torch.get_beta_schedule("linear", 1e-4, 0.02, 1000), "eps", "fixed-large", "mse")
+    r = g6["ddpm_fixed-large"]
+    shape = tuple(r["shape"])
+    x_T, zs = _noise_stream(r["seed"], shape, 1000)
+    x, preds = dif.p_sample_progressive(m, shape, device=DEV, noise=x_T, pred_freq=r["pred_freq"], z_stream=iter(zs))
+    assert not x.is_cuda and not preds.is_cuda and preds.shape == r["preds"].shape
+    check(x, r["x_0"], FP32_BAR, name="progressive.x_0")
+    for i in range(preds.shape[0]):
+        check(preds[i], r["preds"][i], FP32_BAR, name=f"progressive.preds[{i}]")
+    # public call with a device seed: the eager progressive loop and the (graph-replayed) p_sample consume the RNG identically
+    xa, pa = dif.p_sample_progressive(m, (2, 3, 8, 8), device=DEV, pred_freq=250, seed=21)
+    xb = dif.p_sample(m, shape=(2, 3, 8, 8), device=DEV, seed=21)
+    assert torch.equal(xa, xb.cpu()) and pa.shape == (4, 2, 3, 8, 8)
+    assert float(pa.abs().max()) <= 1.0 and all(float(pa[i].abs().max()) > 0 for i in range(4))       # clipped pred_x0, every slot written
+    # DDIM inherits it (ddim.py:96-113 goes through p_sample_step): S = 50 steps, every 10th kept
+    dd = ddim_mod.DDIM(ddpm_torch.get_beta_schedule("linear", 1e-4, 0.02, 1000), "eps", "fixed-small", "mse", eta=0.0,
+                       subsequence=ddim_mod.get_selection_schedule("linear", 50, 1000))
+    xd, pd = dd.p_sample_progressive(m, (2, 3, 8, 8), device=DEV, pred_freq=10, seed=3)
+    assert torch.equal(xd, dd.p_sample(m, shape=(2, 3, 8, 8), device=DEV, seed=3).cpu()) and pd.shape == (5, 2, 3, 8, 8)
+
+
 def test_graph_replayed_sampler_equals_eager_loop(golden, monkeypatch):
     """The hipGraph-replayed loop must consume the RNG stream and produce results exactly like the eager loop."""
     m, _ = tiny_from_golden(golden("g3_model.pt"))
