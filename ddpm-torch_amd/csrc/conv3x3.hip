@@ -128,9 +128,14 @@ void conv3x3_stream_kernel(CsArgs a) {
     // v & 7 = logical chunk ^ key, key = (hx >> 1) for 16-wide patches, (hx >> 1) ^ ((hy & 1) << 2) for 8-wide ones: the 16 pixels one
     // ds_read_b128 lane group touches (two half patch rows / four quarter rows) land on 16 distinct (bank half, chunk) pairs for every tap shift.  Pixels outside the image (and the 480 vectors past the halo in part 5) get an out-of-range offset.
     auto halo_plan = [&](const TilePos& t, unsigned (&ho)[NI]) {
+        // (opaque thread id: otherwise the row / column / chunk of every part are kept in registers from the prologue on — eighteen
+        // loop invariants for a plan that is rebuilt once per tile; at the register cap they were spilled and came back with a
+        // `s_waitcnt vmcnt(0)` each, draining the DMA ring at every tile)
+        int tid_ = tid;
+        asm volatile("" : "+v"(tid_));
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-            const int v = tid + 512 * i, hp = v >> 3;
+            const int v = tid_ + 512 * i, hp = v >> 3;
             const int hy = hp / HWD, hx = hp - hy * HWD;
             const int iy = t.py0 + hy - 1, ix = t.px0 + hx - 1;
             const bool ok = hp < HP && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
@@ -165,6 +170,11 @@ void conv3x3_stream_kernel(CsArgs a) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(dst + (wave * 64 + 512 * i) * 16), 16, base + wrow[i], 0, 0, 0);
+    };
+    auto issue_w_half = [&](int tn, int cc, int tap, int slot, int i) {           // one of the two DMA instructions of issue_w
+        char* dst = wring + slot * WT_BYTES;
+        const unsigned base = (unsigned)tn * w_tile_bytes + (unsigned)((tap * a.C + cc * 64) * 2);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(dst + (wave * 64 + 512 * i) * 16), 16, base + wrow[i], 0, 0, 0);
     };
     // first stage of a tile: its bias row (wave 0) and the time-embedding row of its image (wave 1) ride along — issued BEFORE the stage's
     // loads, so they have landed when the stage has.  Lanes >= 32 are out of range and write zeros into the slot's padding.
@@ -207,6 +217,23 @@ void conv3x3_stream_kernel(CsArgs a) {
     C3_STAMP(2);
     const int sw = (lane >> 5) ^ ((lane >> 1) & 7);
     const int hi = lane >> 5;
+    // ---- fragment reads: INLINE-ASM ds_read_b128 into two register sets, software-pipelined by hand.  Left to hipcc the K sub-steps
+    // came out as "read 4 fragments, wait for them, 4 MFMAs" with nothing in flight under the MFMAs (no registers left to hoist the
+    // reads: 256-register cap, two waves per SIMD) — every sub-step paid the LDS latency, hidden only by the partner wave: 1800-2000
+    // clk per step against 1024 clk of MFMA issue.  Now set (kc + 1) is requested before the MFMAs of set kc are issued, and the LAST
+    // set of a step is multiplied at the top of the NEXT step, right after that step's first reads have been requested — its MFMAs
+    // cover the one latency a barrier-separated step cannot prefetch across.  The LDS addresses are built per read (one or two
+    // VALU operations: the VALU idles in this loop) instead of being kept in registers.
+    // weight fragment (i, kc): row (wn * 32 NIB + 32 i + lane % 32) of the tile, 16-byte chunk (2 kc) ^ sw   -> wv[i] ^ (kc << 5) (+ slot)
+    // halo fragment (j, kc) of tap (r, s): halo pixel hp0[j] + r * HWD + s, chunk ((2 kc) | hi) ^ key(j, r, s) -> (hv[j] + tap shift) | ((hi ^ key) << 4) ^ (kc << 5)
+    const unsigned lds0 = (unsigned)(size_t)smem;
+    unsigned wv[NIB], hv[NJ];
+#pragma unroll
+    for (int i = 0; i < NIB; ++i) wv[i] = lds0 + 2 * HALO_BYTES + (unsigned)((wn * (32 * NIB) + i * 32 + (lane & 31)) * 128 + (sw << 4));
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) hv[j] = lds0 + (unsigned)(hp0[j] * 128);
+    u32x4 fw[2][NIB], fx[2][NJ];                           // fragment sets: K sub-step kc uses set kc & 1
+    bool pend = false;                                     // set 1 holds the previous step's last sub-step, not multiplied yet
     int slot = 0, hb = 0;                                  // ring slot of the step being consumed; halo buffer in use
     constexpr int ST = 2 * NIB * NJ;                       // 16-byte stores per lane in a tile's epilogue
     bool st8 = false;                                      // ... of the previous tile: may still be in flight
@@ -227,11 +254,57 @@ void conv3x3_stream_kernel(CsArgs a) {
             bool pre = false;
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {              // fully unrolled: the halo-part index and the ring arithmetic are constants
-                const char* wcur = wring + slot * WT_BYTES;
+                const int r = tap / 3, s = tap - 3 * r;
+                const int shift = r * HWD + s;
+                // per-step address parts: weight slot (wave-uniform), halo buffer + tap shift (wave-uniform), and the chunk key of this
+                // lane's pixels under the tap's column (and, for 8-wide patches, row) shift
+                const unsigned woff = (unsigned)(slot * WT_BYTES);
+                const unsigned hoffs = (unsigned)(hb * HALO_BYTES + shift * 128);
+                unsigned hk[NJ], wk[NIB];
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    // (the empty asm makes the value opaque: hipcc otherwise computes these addresses for all nine taps and every sub-step
+                    // ahead of the chunk loop and keeps ~60 registers of loop invariants alive — at the 256-register cap that meant spills,
+                    // reloaded with `s_waitcnt vmcnt(0)` at the head of every chunk: the DMA ring drained every nine steps)
+                    int px = pxl[j];
+                    asm volatile("" : "+v"(px));
+                    const int key = PATCH == 16 ? ((px + s) >> 1) & 7 : (((px + s) >> 1) ^ (((pyl[j] + r) & 1) << 2)) & 7;
+                    hk[j] = hv[j] + hoffs + (unsigned)((hi ^ key) << 4);
+                }
+#pragma unroll
+                for (int i = 0; i < NIB; ++i) { wk[i] = wv[i]; asm volatile("" : "+v"(wk[i])); }
+                auto read_set = [&](int kc, u32x4 (&dw)[NIB], u32x4 (&dx)[NJ]) {
+#pragma unroll
+                    for (int i = 0; i < NIB; ++i) {
+                        const unsigned ad = (wk[i] ^ (unsigned)(kc << 5)) + woff;
+                        asm volatile("ds_read_b128 %0, %1" : "=v"(dw[i]) : "v"(ad) : "memory");
+                    }
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        const unsigned ad = hk[j] ^ (unsigned)(kc << 5);
+                        asm volatile("ds_read_b128 %0, %1" : "=v"(dx[j]) : "v"(ad) : "memory");
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                };
+                auto mfma_set = [&](const u32x4 (&dw)[NIB], const u32x4 (&dx)[NJ]) {
+#pragma unroll
+                    for (int i = 0; i < NIB; ++i)
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, dw[i]), __builtin_bit_cast(bf16x8, dx[j]), acc[i][j], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                };
+                // waits until at most `newer` LDS reads (the set requested last) are outstanding; the scheduling barrier keeps the MFMAs that
+                // consume the older set below it (no register operands on the wait: "+v" ties make hipcc copy the fragments)
+#define C3_WAIT_SET() do { if constexpr (NIB + NJ == 4) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+                // ---- sub-step 0 is requested first thing after the barrier; the previous step's last sub-step multiplies while it travels
+                read_set(0, fw[0], fx[0]);
+                if (tap > 0 || pend) mfma_set(fw[1], fx[1]);
                 // in program order: a part of the next halo (next chunk of this tile, or chunk 0 of the next tile), then the weight tile
                 // RING - 1 steps ahead (its slot was read in the previous step; every wave is past that barrier).  Loads retire in order, so
                 // once the first weight tile of the next chunk has landed its whole halo has too (all six parts are requested in taps 0-5,
-                // that weight tile in tap 6).
+                // that weight tile in tap 6).  The requests are SPREAD over the step, one behind each group of MFMAs: an LDS-DMA
+                // instruction takes 60-180 clk to issue, which four queued MFMAs (and the partner wave's) cover; three in a row did not.
                 if (tap < NI && prefetch) issue_halo_part(hoff[tap < NI ? tap : 0], tap, ncc, hnxt);
                 if (tap == 8 && last_chunk && extra) {
                     // last step of the tile with a residual / "+=" epilogue: request those rows NOW, ahead of this step's weight tile.
@@ -253,30 +326,32 @@ void conv3x3_stream_kernel(CsArgs a) {
                                 asm volatile("global_load_dwordx2 %0, %1, off offset:%2" : "=v"(rv[j][i][g]) : "v"(base), "n"((i * 32 + 8 * g) * 2) : "memory");
                     }
                 }
+                if (tap == 9 - (RING - 1) && last_chunk && prefetch) issue_rows(nxt, (k + 1) & 1);     // rows of the next tile: ahead of its first weight tile
+                __builtin_amdgcn_sched_barrier(0);
                 const int wslot = slot + RING - 1 >= RING ? slot - 1 : slot + RING - 1;
-                if (tap + RING - 1 < 9) issue_w(cur.tn, cc, tap + RING - 1, wslot);
-                else if (prefetch) {
-                    if (tap == 9 - (RING - 1) && last_chunk) issue_rows(nxt, (k + 1) & 1);     // first stage of the next tile
-                    issue_w(ntn, ncc, tap + RING - 1 - 9, wslot);
-                }
-                const int r = tap / 3, s = tap - 3 * r;
-                const int shift = r * HWD + s;
-#pragma unroll
-                for (int kc = 0; kc < 4; ++kc) {
-                    u32x4 fw[NIB], fx[NJ];
-#pragma unroll
-                    for (int i = 0; i < NIB; ++i) fw[i] = *reinterpret_cast<const u32x4*>(wcur + (wn * (32 * NIB) + i * 32 + (lane & 31)) * 128 + (((2 * kc) ^ sw) << 4));
-#pragma unroll
-                    for (int j = 0; j < NJ; ++j) {
-                        const int key = PATCH == 16 ? ((pxl[j] + s) >> 1) & 7 : (((pxl[j] + s) >> 1) ^ (((pyl[j] + r) & 1) << 2)) & 7;
-                        fx[j] = *reinterpret_cast<const u32x4*>(hcur + (hp0[j] + shift) * 128 + ((((2 * kc) | hi) ^ key) << 4));
-                    }
-#pragma unroll
-                    for (int i = 0; i < NIB; ++i)
-#pragma unroll
-                        for (int j = 0; j < NJ; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fw[i]), __builtin_bit_cast(bf16x8, fx[j]), acc[i][j], 0, 0, 0);
-                }
+                // ---- sub-steps 1..3 requested one ahead of the MFMAs; the last one stays in its registers for the next step
+                read_set(1, fw[1], fx[1]);
+                C3_WAIT_SET();
+                mfma_set(fw[0], fx[0]);
+                if (tap + RING - 1 < 9) issue_w_half(cur.tn, cc, tap + RING - 1, wslot, 0);
+                else if (prefetch) issue_w_half(ntn, ncc, tap + RING - 1 - 9, wslot, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                read_set(2, fw[0], fx[0]);
+                C3_WAIT_SET();
+                mfma_set(fw[1], fx[1]);
+                if (tap + RING - 1 < 9) issue_w_half(cur.tn, cc, tap + RING - 1, wslot, 1);
+                else if (prefetch) issue_w_half(ntn, ncc, tap + RING - 1 - 9, wslot, 1);
+                __builtin_amdgcn_sched_barrier(0);
+                read_set(3, fw[1], fx[1]);
+                C3_WAIT_SET();
+                mfma_set(fw[0], fx[0]);
+                if (tap == 8 && last_chunk) {                // the tile ends here: nothing is carried into the epilogue
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                    mfma_set(fw[1], fx[1]);
+                    pend = false;
+                } else pend = true;
+#undef C3_WAIT_SET
                 slot = slot + 1 == RING ? 0 : slot + 1;
                 if (tap == 8 && last_chunk) break;          // the tile's last step: epilogue first, then this step's wait + barrier (below)
                 // the next step's weight tile must have landed; the RING - 2 newer tiles (2 DMA instructions each) may stay in flight.  The
@@ -286,8 +361,18 @@ void conv3x3_stream_kernel(CsArgs a) {
                 if (!prefetch && 7 - tap < RING - 2) {
                     if (7 - tap >= 3) wait_vm<6>(); else if (7 - tap == 2) wait_vm<4>(); else if (7 - tap == 1) wait_vm<2>(); else wait_vm<0>();
                 }
-                else if (tap < RING - 2 && cc == 0 && st8) wait_vm<2 * (RING - 2) + ST>();   // + the previous tile's stores: they sit between the tile
-                else wait_vm<2 * (RING - 2)>();                                               //   waited for and the newer ones in the (in-order) queue
+                else {
+                    // exact count: besides the RING - 2 newer weight tiles, the halo parts requested in this step and in the previous one
+                    // are newer than the tile waited for (a count that ignores them is safe but waits for a weight tile more than needed —
+                    // one step less of latency cover in six steps out of nine); + the previous tile's stores, which sit between the tile
+                    // waited for and the newer ones in the (in-order) queue
+                    const int hp = prefetch ? (tap < NI ? 1 : 0) + ((tap >= 1 && tap - 1 < NI) ? 1 : 0) : 0;      // (folds per unrolled tap)
+                    if (tap < RING - 2 && cc == 0 && st8) {
+                        if (hp == 2) wait_vm<2 * (RING - 2) + ST + 2>(); else if (hp == 1) wait_vm<2 * (RING - 2) + ST + 1>(); else wait_vm<2 * (RING - 2) + ST>();
+                    } else {
+                        if (hp == 2) wait_vm<2 * (RING - 2) + 2>(); else if (hp == 1) wait_vm<2 * (RING - 2) + 1>(); else wait_vm<2 * (RING - 2)>();
+                    }
+                }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
             }

@@ -32,10 +32,16 @@ class SegmentedGraph:
     # ------------------------------------------------------------------ capture
     def _begin(self):
         g = torch.cuda.CUDAGraph()
-        for gen in self._generators:
-            g.register_generator_state(gen)
-        # thread_local: other host threads (the communicator's watchdog polls events) must not invalidate the capture
-        g.capture_begin(pool=self.pool, capture_error_mode="thread_local")
+        # Registering a generator with its first graph creates the generator's graph-state tensors (seed / offset words that every
+        # capture and every replay then rewrites IN PLACE), and capture_begin registers the device's default generator the same way.
+        # Created under torch.inference_mode (the sampler captures inside @inference_mode) they would be inference tensors, and the
+        # next capture or replay from ordinary code — the training step after the first epoch's sample grid — would die with
+        # "Inplace update to inference tensor outside InferenceMode".  So: always create them as ordinary tensors.
+        with torch.inference_mode(False):
+            for gen in self._generators:
+                g.register_generator_state(gen)
+            # thread_local: other host threads (the communicator's watchdog polls events) must not invalidate the capture
+            g.capture_begin(pool=self.pool, capture_error_mode="thread_local")
         self._open = g
 
     def _end(self, callback):

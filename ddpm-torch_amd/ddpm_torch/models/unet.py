@@ -250,6 +250,7 @@ _FOLD_MIN_PIXELS = 16384            # below this the small-grid kernels serve th
 _FOLD_GN = os.environ.get("DDPM_FOLD_GN", "0") != "0"               # inference: GroupNorm+SiLU folded into the 3x3 convs (off: since the persistent conv
                                                                     # kernel, LDS GroupNorm + conv is faster than the folded form: 3.72 vs 3.83 ms per step)
 _SIDE_STREAM = os.environ.get("DDPM_SIDE_STREAM", "1") != "0"      # weight / bias gradients on a second HIP stream
+_SIDE_PRIORITY = int(os.environ.get("DDPM_SIDE_PRIORITY", "0"))    # its priority (lower number = dispatched first; clamped to the device's range)
 _WGRAD_MINSTEPS = int(os.environ.get("DDPM_WGRAD_MINSTEPS", "20"))
 _WGRAD_SLABS = os.environ.get("DDPM_WGRAD_SLABS", "0") != "0"      # deterministic slab reduction instead of atomics
 _WGRAD3 = os.environ.get("DDPM_WGRAD3", "1") != "0"                # patch-stationary kernel for the 3x3 / stride-1 weight gradients
@@ -922,7 +923,9 @@ class _Engine:
                    seed_dev=st.get("seed_dev", 0), world=1)
         if _SIDE_STREAM and gflat.is_cuda:
             if self._side is None:
-                self._side = torch.cuda.Stream(device=self.device)
+                # LOW priority: the weight-gradient stream has ~3.6 ms of work per 10.6 ms step and seven milliseconds of slack; the main
+                # stream is the step's critical path, so its workgroups go first whenever both queues have some ready
+                self._side = torch.cuda.Stream(device=self.device, priority=_SIDE_PRIORITY)
             ctx["side"] = self._side
             ctx["side_handle"] = self._side.cuda_stream
             ctx["main"] = torch.cuda.current_stream()

@@ -352,6 +352,7 @@ class _DirectStep:
         self.graph_failed = False
         self.captures = 0                    # graph captures so far (bench.py asserts none happens inside a timed region)
         self._baked = None                   # identity of everything whose ADDRESS the captured graph holds (see _identity)
+        self._warm = None                    # serial of the engine that has run an EAGER step here (lazy tables / slabs / workspaces exist)
         # auto mode: wall times (Trainer.step reports them) of a few eager and a few replayed steps decide which one stays
         self.times = {}                      # auto mode: seconds per step of the "eager" / "graph" probe phases
         self.last_kind, self.choice, self._phase = None, None, None
@@ -457,7 +458,9 @@ class _DirectStep:
         self._write_hyper()
         if self.graph is not None and self._baked != self._identity():
             self.graph = None                                   # stale addresses: capture again (or run eagerly) instead of replaying
-        can_graph = (not self.graph_failed and self.x0.is_cuda and self.calls >= 1 and tr.input_source is None
+        # capture only what has run eagerly once with THIS engine: its first backward builds descriptor tables with host -> device
+        # copies (illegal under stream capture) and allocates the persistent slabs / staging buffers
+        can_graph = (not self.graph_failed and self.x0.is_cuda and self._warm == eng.serial and tr.input_source is None
                      and not torch.cuda.is_current_stream_capturing())
         use_graph = can_graph and self._wants_graph()
         self.last_kind = None
@@ -489,6 +492,7 @@ class _DirectStep:
                 self._probe_begin("eager")                  # (nor is the very first step: lazy initialisation)
             self.body()
             self.last_kind = "eager"
+            self._warm = eng.serial
             if self.calls >= 1:
                 self._probe_end("eager")
         self.calls += 1

@@ -1,0 +1,43 @@
+"""Where does a training step's wall time go?  From a rocprofv3 --kernel-trace directory: per steady-state step, the span, the time
+with >= 1 kernel running (union over both streams), the idle time, per-queue busy time and the biggest idle gaps with the kernels
+around them.   python scripts/step_timeline.py DIR [first_step last_step]"""
+import csv, glob, sys, collections
+f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
+rows = list(csv.DictReader(open(f)))
+ev = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", "0"), r.get("Stream_Id", "")) for r in rows))
+# step boundaries: the optimiser kernel ends a step
+ends = [e for s, e, k, q, st in ev if "mt_adam_ema" in k]
+lo = int(sys.argv[2]) if len(sys.argv) > 2 else len(ends) - 6
+hi = int(sys.argv[3]) if len(sys.argv) > 3 else len(ends) - 1
+t0, t1 = ends[lo], ends[hi]
+win = [(s, e, k, q, st) for s, e, k, q, st in ev if s >= t0 and e <= t1 + 200000]
+nsteps = hi - lo
+span = (t1 - t0) / nsteps / 1e6
+busy = collections.defaultdict(float)
+for s, e, k, q, st in win:
+    busy[(q, st)] += e - s
+# union
+cur_s, cur_e, union, gaps = None, None, 0, []
+last_k = None
+for s, e, k, q, st in sorted(win):
+    if cur_e is None:
+        cur_s, cur_e, last_k = s, e, k
+    elif s > cur_e:
+        union += cur_e - cur_s
+        gaps.append((s - cur_e, last_k, k))
+        cur_s, cur_e, last_k = s, e, k
+    else:
+        if e > cur_e:
+            cur_e, last_k = e, k
+union += cur_e - cur_s
+print(f"steps {lo}..{hi}: span {span:.3f} ms/step; some kernel running {union / nsteps / 1e6:.3f} ms/step; idle {span - union / nsteps / 1e6:.3f} ms/step; launches/step {len(win) / nsteps:.0f}")
+for (q, st), b in sorted(busy.items(), key=lambda kv: -kv[1]):
+    print(f"  queue {q} stream {st}: busy {b / nsteps / 1e6:.3f} ms/step")
+tot_gap = sum(g for g, _, _ in gaps)
+print(f"idle gaps: {len(gaps) / nsteps:.0f}/step, total {tot_gap / nsteps / 1e6:.3f} ms/step; > 5 us: {sum(g for g, _, _ in gaps if g > 5000) / nsteps / 1e6:.3f} ms/step")
+agg = collections.defaultdict(lambda: [0, 0])
+for g, a, b in gaps:
+    key = (a.split("(")[0][-60:], b.split("(")[0][-60:])
+    agg[key][0] += 1; agg[key][1] += g
+for (a, b), (n, g) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:18]:
+    print(f"  {g / nsteps / 1e3:7.1f} us/step  n/step={n / nsteps:5.1f}  after [{a}] before [{b}]")
