@@ -79,6 +79,18 @@ __device__ __forceinline__ int logical_tile(int id, int total, int xcd) {       
 
 struct TilePos { int img, py0, px0, tn; };
 
+#ifdef C3_TRACE
+// debug builds only (scripts/c3_trace.py): phase stamps of four consecutive steps of waves 0 and 4 (one SIMD's pair) of block 0.  The
+// stamps are s_memtime reads into scalar registers with NO wait (the step's closing `s_waitcnt lgkmcnt(0)` covers them); steps
+// C3_TRACE_FIRST .. +3 are kept and written out when the block is done — nothing is stored inside the loop
+__device__ unsigned long long* g_c3_trace = nullptr;
+#define C3_TR(id) asm volatile("s_memtime %0" : "=s"(tr_now[id]))
+#ifndef C3_TRACE_FIRST
+#define C3_TRACE_FIRST 5
+#endif
+#else
+#define C3_TR(id)
+#endif
 #ifdef C3_TIMING
 __device__ unsigned long long* g_c3_timing = nullptr;        // debug builds only (scripts/c3_timeline.py): [block][8] stamps
 #define C3_STAMP(slot) do { if (g_c3_timing && threadIdx.x == 0) g_c3_timing[blockIdx.x * 8 + (slot)] = (slot) == 0 || (slot) == 7 ? wall_clock64() : clock64(); } while (0)
@@ -144,6 +156,20 @@ void conv3x3_stream_kernel(CsArgs a) {
             const int sy = iy >> a.ups, sx = ix >> a.ups;
             ho[i] = ok ? ((unsigned)((t.img * (a.H >> a.ups) + sy) * (a.W >> a.ups) + sx) * (unsigned)a.x_ld + (unsigned)(lc * 8)) * 2u : OOB;     // < 2^31: checked by the launcher
         }
+    };
+    // one part of a tile's plan (the main loop rebuilds the plan for the NEXT tile part by part, each in the step that requests it —
+    // done in one piece at the head of a tile's last chunk, ~170 VALU instructions with integer multiplies, it held the younger wave of
+    // every SIMD back by ~700 clk while the matrix pipe idled)
+    auto halo_part_off = [&](const TilePos& t, int i) {
+        int tid_ = tid;
+        asm volatile("" : "+v"(tid_));
+        const int v = tid_ + 512 * i, hp = v >> 3;
+        const int hy = hp / HWD, hx = hp - hy * HWD;
+        const int iy = t.py0 + hy - 1, ix = t.px0 + hx - 1;
+        const bool ok = hp < HP && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+        const int lc = (v & 7) ^ (PATCH == 16 ? (hx >> 1) & 7 : ((hx >> 1) ^ ((hy & 1) << 2)) & 7);
+        const int sy = iy >> a.ups, sx = ix >> a.ups;
+        return ok ? ((unsigned)((t.img * (a.H >> a.ups) + sy) * (a.W >> a.ups) + sx) * (unsigned)a.x_ld + (unsigned)(lc * 8)) * 2u : OOB;
     };
     auto issue_halo_part = [&](unsigned ho, int i, int cc, char* dst) {
         const unsigned o = ho == OOB ? OOB : ho + (unsigned)(cc * 128);
@@ -234,6 +260,14 @@ void conv3x3_stream_kernel(CsArgs a) {
     for (int j = 0; j < NJ; ++j) hv[j] = lds0 + (unsigned)(hp0[j] * 128);
     u32x4 fw[2][NIB], fx[2][NJ];                           // fragment sets: K sub-step kc uses set kc & 1
     bool pend = false;                                     // set 1 holds the previous step's last sub-step, not multiplied yet
+#ifdef C3_TRACE
+    int trace_step = 0;
+    unsigned long long tr_now[16], tr_keep[4][16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) tr_keep[q][i] = 0;
+#endif
     int slot = 0, hb = 0;                                  // ring slot of the step being consumed; halo buffer in use
     constexpr int ST = 2 * NIB * NJ;                       // 16-byte stores per lane in a tile's epilogue
     bool st8 = false;                                      // ... of the previous tile: may still be in flight
@@ -242,7 +276,7 @@ void conv3x3_stream_kernel(CsArgs a) {
         TilePos nxt = cur;
         if (more_tiles) nxt = tile_pos(k + 1);
         for (int cc = 0; cc < nchunks; ++cc) {
-            if (cc + 1 == nchunks && more_tiles) halo_plan(nxt, hoff);           // the last chunk prefetches the NEXT tile's halo: its plan replaces this tile's
+            // (the last chunk prefetches the NEXT tile's halo: its plan replaces this tile's, part by part, in the steps that request them)
             const char* hcur = halo + hb * HALO_BYTES;
             char* hnxt = halo + (hb ^ 1) * HALO_BYTES;
             const bool same_tile = cc + 1 < nchunks;
@@ -273,39 +307,50 @@ void conv3x3_stream_kernel(CsArgs a) {
                 }
 #pragma unroll
                 for (int i = 0; i < NIB; ++i) { wk[i] = wv[i]; asm volatile("" : "+v"(wk[i])); }
-                auto read_set = [&](int kc, u32x4 (&dw)[NIB], u32x4 (&dx)[NJ]) {
-#pragma unroll
-                    for (int i = 0; i < NIB; ++i) {
+                // One K sub-step: the MFMAs of set `cw/cx` INTERLEAVED one to one with the reads of the next set `nw/nx` — each read (and its
+                // address arithmetic) issues in the shadow of the 32-clk MFMA in front of it, and the partner wave's MFMAs slot in between;
+                // issued as "all reads, then all MFMAs" a wave's own instruction stream took ~1000 clk per step for 512 clk of MFMA work
+                // (s_memtime trace, scripts/c3_trace.py) and the two waves of a SIMD left the pipe idle a quarter of the time.
+                // Read order fw0, fx0, fx1, fw1 / MFMA order (0,0) (0,1) (1,0) (1,1).  mf = false: reads only; kc < 0: MFMAs only.
+                auto sub_step = [&](bool mf, const u32x4 (&cw)[NIB], const u32x4 (&cx)[NJ], int kc, u32x4 (&nw)[NIB], u32x4 (&nx)[NJ]) {
+                    auto rd_w = [&](int i) {
+                        if (kc < 0) return;
                         const unsigned ad = (wk[i] ^ (unsigned)(kc << 5)) + woff;
-                        asm volatile("ds_read_b128 %0, %1" : "=v"(dw[i]) : "v"(ad) : "memory");
-                    }
-#pragma unroll
-                    for (int j = 0; j < NJ; ++j) {
+                        asm volatile("ds_read_b128 %0, %1" : "=v"(nw[i]) : "v"(ad) : "memory");
+                        __builtin_amdgcn_sched_barrier(0);
+                    };
+                    auto rd_x = [&](int j) {
+                        if (kc < 0) return;
                         const unsigned ad = hk[j] ^ (unsigned)(kc << 5);
-                        asm volatile("ds_read_b128 %0, %1" : "=v"(dx[j]) : "v"(ad) : "memory");
+                        asm volatile("ds_read_b128 %0, %1" : "=v"(nx[j]) : "v"(ad) : "memory");
+                        __builtin_amdgcn_sched_barrier(0);
+                    };
+                    auto mm = [&](int i, int j) {
+                        if (!mf) return;
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, cw[i]), __builtin_bit_cast(bf16x8, cx[j]), acc[i][j], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                    };
+                    if constexpr (NIB == 2 && NJ == 2) {
+                        rd_w(0); mm(0, 0); rd_x(0); mm(0, 1); rd_x(1); mm(1, 0); rd_w(1); mm(1, 1);
+                    } else {
+                        static_assert(NIB == 1 && NJ == 1, "interleave pattern");
+                        rd_w(0); mm(0, 0); rd_x(0);
                     }
-                    __builtin_amdgcn_sched_barrier(0);
                 };
-                auto mfma_set = [&](const u32x4 (&dw)[NIB], const u32x4 (&dx)[NJ]) {
-#pragma unroll
-                    for (int i = 0; i < NIB; ++i)
-#pragma unroll
-                        for (int j = 0; j < NJ; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, dw[i]), __builtin_bit_cast(bf16x8, dx[j]), acc[i][j], 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-                };
-                // waits until at most `newer` LDS reads (the set requested last) are outstanding; the scheduling barrier keeps the MFMAs that
-                // consume the older set below it (no register operands on the wait: "+v" ties make hipcc copy the fragments)
-#define C3_WAIT_SET() do { if constexpr (NIB + NJ == 4) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
-                // ---- sub-step 0 is requested first thing after the barrier; the previous step's last sub-step multiplies while it travels
-                read_set(0, fw[0], fx[0]);
-                if (tap > 0 || pend) mfma_set(fw[1], fx[1]);
-                // in program order: a part of the next halo (next chunk of this tile, or chunk 0 of the next tile), then the weight tile
-                // RING - 1 steps ahead (its slot was read in the previous step; every wave is past that barrier).  Loads retire in order, so
-                // once the first weight tile of the next chunk has landed its whole halo has too (all six parts are requested in taps 0-5,
-                // that weight tile in tap 6).  The requests are SPREAD over the step, one behind each group of MFMAs: an LDS-DMA
-                // instruction takes 60-180 clk to issue, which four queued MFMAs (and the partner wave's) cover; three in a row did not.
-                if (tap < NI && prefetch) issue_halo_part(hoff[tap < NI ? tap : 0], tap, ncc, hnxt);
+                // every read of the set about to be multiplied has returned (nothing newer is outstanding at this point); the scheduling
+                // barrier keeps its MFMAs below the wait (no register operands on the wait: "+v" ties make hipcc copy the fragments)
+#define C3_WAIT_SET() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+                // ---- sub-step 0 is requested first thing after the barrier, under the MFMAs of the previous step's last sub-step
+                C3_TR(0);
+                sub_step(tap > 0 || pend, fw[1], fx[1], 0, fw[0], fx[0]);
+                C3_TR(1);
+                // DMA requests, in program order: the weight tile RING - 1 steps ahead FIRST (its slot was read in the previous step; every
+                // wave is past that barrier), a part of the next halo (next chunk of this tile, or chunk 0 of the next tile) LAST.  Requests
+                // retire in order and the step's closing wait is for the weight tile of the next step (an L2 hit, requested three steps
+                // back): with the halo part queued behind the weight tile of its step, a part that has to come from HBM has three steps to
+                // arrive before a wait touches it instead of two.  Once the first weight tile of the next chunk has landed its whole halo
+                // has too (all six parts are requested in taps 0-5, that weight tile in tap 6).  The requests are SPREAD over the step, one
+                // behind each group of MFMAs: an LDS-DMA instruction takes 60-180 clk to issue, which the queued MFMAs cover.
                 if (tap == 8 && last_chunk && extra) {
                     // last step of the tile with a residual / "+=" epilogue: request those rows NOW, ahead of this step's weight tile.
                     // INLINE ASM: a C++ load would make hipcc drain every pending LDS-DMA first; the wait is issued by hand below.
@@ -327,28 +372,38 @@ void conv3x3_stream_kernel(CsArgs a) {
                     }
                 }
                 if (tap == 9 - (RING - 1) && last_chunk && prefetch) issue_rows(nxt, (k + 1) & 1);     // rows of the next tile: ahead of its first weight tile
-                __builtin_amdgcn_sched_barrier(0);
                 const int wslot = slot + RING - 1 >= RING ? slot - 1 : slot + RING - 1;
-                // ---- sub-steps 1..3 requested one ahead of the MFMAs; the last one stays in its registers for the next step
-                read_set(1, fw[1], fx[1]);
-                C3_WAIT_SET();
-                mfma_set(fw[0], fx[0]);
                 if (tap + RING - 1 < 9) issue_w_half(cur.tn, cc, tap + RING - 1, wslot, 0);
                 else if (prefetch) issue_w_half(ntn, ncc, tap + RING - 1 - 9, wslot, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                read_set(2, fw[0], fx[0]);
+                // ---- sub-steps 1..3 requested under the MFMAs of the sub-step before; the last one stays in its registers for the next step
+                C3_TR(2);
                 C3_WAIT_SET();
-                mfma_set(fw[1], fx[1]);
+                C3_TR(3);
+                sub_step(true, fw[0], fx[0], 1, fw[1], fx[1]);
+                C3_TR(4);
                 if (tap + RING - 1 < 9) issue_w_half(cur.tn, cc, tap + RING - 1, wslot, 1);
                 else if (prefetch) issue_w_half(ntn, ncc, tap + RING - 1 - 9, wslot, 1);
                 __builtin_amdgcn_sched_barrier(0);
-                read_set(3, fw[1], fx[1]);
+                C3_TR(5);
                 C3_WAIT_SET();
-                mfma_set(fw[0], fx[0]);
+                C3_TR(6);
+                sub_step(true, fw[1], fx[1], 2, fw[0], fx[0]);
+                C3_TR(7);
+                if (tap < NI && prefetch) {
+                    if (last_chunk) hoff[tap < NI ? tap : 0] = halo_part_off(nxt, tap);
+                    issue_halo_part(hoff[tap < NI ? tap : 0], tap, ncc, hnxt);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                C3_TR(8);
+                C3_WAIT_SET();
+                C3_TR(9);
+                sub_step(true, fw[0], fx[0], 3, fw[1], fx[1]);
+                C3_TR(10);
                 if (tap == 8 && last_chunk) {                // the tile ends here: nothing is carried into the epilogue
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     __builtin_amdgcn_sched_barrier(0);
-                    mfma_set(fw[1], fx[1]);
+                    sub_step(true, fw[1], fx[1], -1, fw[0], fx[0]);
                     pend = false;
                 } else pend = true;
 #undef C3_WAIT_SET
@@ -366,15 +421,35 @@ void conv3x3_stream_kernel(CsArgs a) {
                     // are newer than the tile waited for (a count that ignores them is safe but waits for a weight tile more than needed —
                     // one step less of latency cover in six steps out of nine); + the previous tile's stores, which sit between the tile
                     // waited for and the newer ones in the (in-order) queue
-                    const int hp = prefetch ? (tap < NI ? 1 : 0) + ((tap >= 1 && tap - 1 < NI) ? 1 : 0) : 0;      // (folds per unrolled tap)
+                    // (halo parts newer than the weight tile waited for: those of this step and of the RING - 2 steps before it, as far
+                    //  as they lie in this chunk — the previous chunk's last steps request none)
+                    int hp = 0;
+                    if (prefetch) {
+#pragma unroll
+                        for (int b = 0; b <= RING - 2; ++b) hp += (tap - b >= 0 && tap - b < NI) ? 1 : 0;                 // (folds per unrolled tap)
+                    }
+                    static_assert(RING - 2 <= 4, "hp cases");
                     if (tap < RING - 2 && cc == 0 && st8) {
-                        if (hp == 2) wait_vm<2 * (RING - 2) + ST + 2>(); else if (hp == 1) wait_vm<2 * (RING - 2) + ST + 1>(); else wait_vm<2 * (RING - 2) + ST>();
+                        if (hp >= 3) wait_vm<2 * (RING - 2) + ST + 3>(); else if (hp == 2) wait_vm<2 * (RING - 2) + ST + 2>(); else if (hp == 1) wait_vm<2 * (RING - 2) + ST + 1>(); else wait_vm<2 * (RING - 2) + ST>();
                     } else {
-                        if (hp == 2) wait_vm<2 * (RING - 2) + 2>(); else if (hp == 1) wait_vm<2 * (RING - 2) + 1>(); else wait_vm<2 * (RING - 2)>();
+                        if (hp >= 3) wait_vm<2 * (RING - 2) + 3>(); else if (hp == 2) wait_vm<2 * (RING - 2) + 2>(); else if (hp == 1) wait_vm<2 * (RING - 2) + 1>(); else wait_vm<2 * (RING - 2)>();
                     }
                 }
+                C3_TR(11);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                C3_TR(12);
                 __builtin_amdgcn_s_barrier();
+                C3_TR(13);
+#ifdef C3_TRACE
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (trace_step == C3_TRACE_FIRST + q) {
+#pragma unroll
+                        for (int i = 0; i < 14; ++i) tr_keep[q][i] = tr_now[i];
+                    }
+                ++trace_step;
+#endif
             }
             if (last_chunk) {
                 if (k == 0) C3_STAMP(3); else if (k == 1) C3_STAMP(5);
@@ -470,10 +545,21 @@ void conv3x3_stream_kernel(CsArgs a) {
         cur = nxt;
     }
     C3_STAMP(7);
+#ifdef C3_TRACE
+    if (g_c3_trace && blockIdx.x == 0 && (wave & 3) == 0 && lane == 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) g_c3_trace[((wave >> 2) * 64 + q) * 16 + i] = tr_keep[q][i];
+    }
+#endif
 }
 
 }  // namespace
 
+#ifdef C3_TRACE
+extern "C" int ddpm_debug_set_c3_trace(void* p) { return hipMemcpyToSymbol(HIP_SYMBOL(g_c3_trace), &p, sizeof(p)) == hipSuccess ? 0 : -1; }
+#endif
 #ifdef C3_TIMING
 extern "C" int ddpm_debug_set_c3_timing(void* p) { return hipMemcpyToSymbol(HIP_SYMBOL(g_c3_timing), &p, sizeof(p)) == hipSuccess ? 0 : -1; }
 #endif
