@@ -269,7 +269,7 @@ void conv3x3_stream_kernel(CsArgs a) {
         for (int i = 0; i < 16; ++i) tr_keep[q][i] = 0;
 #endif
     int slot = 0, hb = 0;                                  // ring slot of the step being consumed; halo buffer in use
-    constexpr int ST = 2 * NIB * NJ;                       // 16-byte stores per lane in a tile's epilogue
+    constexpr int ST = NIB * (32 * NJ / 16);               // 16-byte stores per lane in a tile's epilogue
     bool st8 = false;                                      // ... of the previous tile: may still be in flight
     for (int k = 0; k < my_tiles; ++k) {
         const bool more_tiles = k + 1 < my_tiles;
@@ -402,6 +402,9 @@ void conv3x3_stream_kernel(CsArgs a) {
                 C3_TR(10);
                 if (tap == 8 && last_chunk) {                // the tile ends here: nothing is carried into the epilogue
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    // every wave has read its last fragments of this halo buffer once it is past this barrier: the epilogue stages the
+                    // output tile through the buffer (nothing is requested into it before the next tile's first step)
+                    __builtin_amdgcn_s_barrier();
                     __builtin_amdgcn_sched_barrier(0);
                     sub_step(true, fw[1], fx[1], -1, fw[0], fx[0]);
                     pend = false;
@@ -474,12 +477,25 @@ void conv3x3_stream_kernel(CsArgs a) {
                     }
                 }
                 const int n0 = cur.tn * 128 + wn * (32 * NIB);
-                bf16_t* orow[NJ];
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) {
-                    const int p = wm * (32 * NJ) + j * 32 + (lane & 31);
-                    orow[j] = a.out + ((long long)(cur.img * a.H + cur.py0 + (p >> LP)) * a.W + cur.px0 + (p & (PATCH - 1))) * a.out_ld;
-                }
+                // ---- stores.  In the accumulator layout a lane owns ONE pixel (16-byte pieces of its row): stored from there, every lane of a
+                // store instruction is its own 16-byte write request to a different row — 4096 requests per tile and CU, 2.6 us per tile
+                // (measured by compiling the stores out), a sixth of a two-tile block.  So each 32-channel block of the wave's tile
+                // (32 NJ pixels x 64 bytes) takes a turn through LDS — the halo buffer this tile has finished with; wave-private slices, no
+                // barrier — and leaves with FOUR consecutive lanes on the 64 contiguous bytes of a pixel: a quarter of the requests, all of
+                // them 64-byte runs that pair up to full lines in L2.  (16-byte slot s of pixel row P sits at s ^ ((P >> 2) & 3): the eight
+                // lanes of a ds_write_b128 group and the sixteen of a ds_read_b128 group each touch every bank once.)
+                constexpr int STG_PX = 32 * NJ, NRR = STG_PX / 16;
+                const unsigned stg = lds0 + (unsigned)(hb * HALO_BYTES + wave * (STG_PX * 64));
+                static_assert(8 * STG_PX * 64 <= HALO_BYTES, "staging slices fit the halo buffer");
+                // output address of read-back vector rr: pixel rr * 16 + lane / 4 of the wave's pixel block, channels n0 + 8 (lane % 4) ...
+                // (built per store from one 64-bit base: four row pointers kept across the loop cost eight registers the kernel does not have)
+                bf16_t* const obase = a.out + ((long long)(cur.img * a.H + cur.py0) * a.W + cur.px0) * a.out_ld + n0 + 8 * (lane & 3);
+                auto orow = [&](int rr) {
+                    int q = lane >> 2;
+                    asm volatile("" : "+v"(q));
+                    const int p = wm * STG_PX + rr * 16 + q;
+                    return obase + (long long)(((p >> LP) * a.W + (p & (PATCH - 1))) * (int)a.out_ld);
+                };
 #pragma unroll
                 for (int i = 0; i < NIB; ++i) {
                     f32x4v bsum[4], brow[4];
@@ -514,16 +530,34 @@ void conv3x3_stream_kernel(CsArgs a) {
                             pk[g].x = pack_bf2(v[0], v[1]); pk[g].y = pack_bf2(v[2], v[3]);
                         }
                         // lanes l and l + 32 hold channels +0..3 / +4..7 of every 8-channel group of pixel l: the lower lane takes both halves of
-                        // the even groups, the upper lane both halves of the odd groups -> every lane stores 16 contiguous bytes, a pair 32
+                        // the even groups, the upper lane both halves of the odd groups -> every lane holds 16 contiguous bytes: slot 2 q2 + hi
+                        // of pixel row j * 32 + l % 32
 #pragma unroll
                         for (int q2 = 0; q2 < 2; ++q2) {
                             const u32x2 sx = __builtin_amdgcn_permlane32_swap(pk[2 * q2].x, pk[2 * q2 + 1].x, false, false);
                             const u32x2 sy = __builtin_amdgcn_permlane32_swap(pk[2 * q2].y, pk[2 * q2 + 1].y, false, false);
-                            const int n = n0 + i * 32 + 16 * q2 + 8 * (lane >> 5);
-                            if (n < a.N) {
-                                u32x4 o; o.x = sx.x; o.y = sy.x; o.z = sx.y; o.w = sy.y;
-                                *reinterpret_cast<u32x4*>(orow[j] + n) = o;
-                            }
+                            u32x4 o; o.x = sx.x; o.y = sy.x; o.z = sx.y; o.w = sy.y;
+                            const int P = j * 32 + (lane & 31), sl = (2 * q2 + hi) ^ ((P >> 2) & 3);
+                            const unsigned ad = stg + (unsigned)(P * 64 + (sl << 4));
+                            asm volatile("ds_write_b128 %0, %1" :: "v"(ad), "v"(o) : "memory");
+                        }
+                    }
+                    u32x4 back[NRR];
+#pragma unroll
+                    for (int rr = 0; rr < NRR; ++rr) {
+                        const int Q = rr * 16 + (lane >> 2), sl = (lane & 3) ^ ((Q >> 2) & 3);
+                        const unsigned ad = stg + (unsigned)(Q * 64 + (sl << 4));
+                        asm volatile("ds_read_b128 %0, %1" : "=v"(back[rr]) : "v"(ad) : "memory");     // (a wave's LDS operations execute in order)
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // ... and the slice may be overwritten by the next block
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (n0 < a.N) {
+#pragma unroll
+                        for (int rr = 0; rr < NRR; ++rr) {
+#ifdef C3_NO_STORE
+                            if (back[rr].x == 0x12345678u)
+#endif
+                            *reinterpret_cast<u32x4*>(orow(rr) + i * 32) = back[rr];
                         }
                     }
                 }
