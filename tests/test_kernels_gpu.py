@@ -200,7 +200,8 @@ def test_conv1x1_wgrad_slab_kernel(P, C, N):
     assert _hip.lib().ddpm_conv1x1_wgrad_splits(8192, C, N) == 0 and _hip.lib().ddpm_conv1x1_wgrad_splits(P, C + 4, N) == 0
 
 
-PW_CASES = [(32, 32, 128, 256), (64, 32, 128, 256), (35, 31, 64, 192), (128, 16, 256, 768), (130, 16, 320, 384), (70, 31, 192, 104), (128, 16, 768, 256)]
+PW_CASES = [(32, 32, 128, 256), (64, 32, 128, 256), (35, 31, 64, 192), (128, 16, 256, 768), (130, 16, 320, 384), (70, 31, 192, 104), (128, 16, 768, 256),
+            (128, 16, 256, 256), (33, 32, 256, 128), (128, 16, 512, 256), (128, 16, 256, 512), (37, 31, 384, 128), (36, 31, 448, 96)]
 
 
 @pytest.mark.parametrize("B,H,C,N", PW_CASES)
