@@ -96,18 +96,18 @@ extern "C" int ddpm_pack_weight(const float* w, void* wf, void* wd, int N, int C
 // in 64-byte runs.  (The first version gathered with a 36-byte stride between lanes: 520 us for the 35.7 M parameters of the
 // CIFAR UNet, once per training step; this one moves the same 290 MB in a fifth of that.)
 constexpr int PK_T = 32;
-template <typename T>
-__global__ __launch_bounds__(256)
-void pack_weight_multi_kernel(const long long* __restrict__ descs) {
-    const long long* d = descs + 8 * (long long)blockIdx.y;
-    const float* w = reinterpret_cast<const float*>(d[0]);
-    T* wf = reinterpret_cast<T*>(d[1]);
-    T* wd = reinterpret_cast<T*>(d[2]);
-    const int N = (int)d[3], C = (int)d[4], R = (int)d[5] & 0xff, Cp = (int)d[6], Np = (int)d[7];
-    const bool up_dgrad = ((int)d[5] & 0x100) != 0;
-    const int RS = R * R;
-    __shared__ float tile[PK_T * (PK_T * 9 + 1)];
-    const int pitch = PK_T * RS + 1;                                   // odd pitch: the n-fastest reads below are conflict-free
+// two adjacent elements of a derived layout leave as ONE store (bf16: 4 bytes per lane instead of 2; the padded extents Cp / Np are
+// multiples of 8, so pairs never straddle a row end)
+template <typename T> __device__ __forceinline__ void pk_store2(T* p, float a, float b);
+template <> __device__ __forceinline__ void pk_store2<bf16_t>(bf16_t* p, float a, float b) { *reinterpret_cast<unsigned*>(p) = pack_bf2(a, b); }
+template <> __device__ __forceinline__ void pk_store2<float>(float* p, float a, float b) { *reinterpret_cast<float2*>(p) = make_float2(a, b); }
+
+// RS is a template argument: every index split below is a division by a constant (the first version divided by the runtime R*S in
+// 64-bit arithmetic for every element — the kernel was bound by integer VALU work, 170 us for 286 MB)
+template <typename T, int RS>
+__device__ __forceinline__ void pack_tensor(const float* __restrict__ w, T* __restrict__ wf, T* __restrict__ wd, int N, int C, int Cp, int Np, bool up_dgrad,
+                                            float* tile) {
+    constexpr int pitch = PK_T * RS + 1;                               // odd pitch: the n-fastest reads below are conflict-free
     const int tiles_c = (Cp + PK_T - 1) / PK_T, tiles_n = (Np + PK_T - 1) / PK_T;
     const int tid = threadIdx.x;
     for (int t = blockIdx.x; t < tiles_c * tiles_n; t += gridDim.x) {
@@ -121,38 +121,62 @@ void pack_weight_multi_kernel(const long long* __restrict__ descs) {
         }
         __syncthreads();
         if (wf) {                                                      // wf[n][tap][c], c fastest
-            for (int i = tid; i < PK_T * RS * PK_T; i += 256) {
-                const int cl = i % PK_T, r1 = i / PK_T, tap = r1 % RS, nl = r1 / RS;
+            for (int i = tid; i < PK_T * RS * (PK_T / 2); i += 256) {
+                const int cl = (i % (PK_T / 2)) * 2, r1 = i / (PK_T / 2), tap = r1 % RS, nl = r1 / RS;
                 if (n0 + nl < N && c0 + cl < Cp)
-                    Elem<T>::st(wf + ((long long)(n0 + nl) * RS + tap) * Cp + c0 + cl, tile[nl * pitch + cl * RS + tap]);
+                    pk_store2<T>(wf + ((long long)(n0 + nl) * RS + tap) * Cp + c0 + cl, tile[nl * pitch + cl * RS + tap], tile[nl * pitch + (cl + 1) * RS + tap]);
             }
         }
-        if (wd && up_dgrad) {
-            // Gradient of (nearest-2x upsample -> 3x3 / pad 1 conv) w.r.t. its LOW-resolution input, as ONE strided conv over dy:
-            //   dx[i][j] = sum_{a,b in {0,1}} sum_{r,s} dy[2i+a+r-1][2j+b+s-1] * D[r][s]        (D = flipped 3x3 dgrad kernel)
-            //            = sum_{P,Q in 0..3} dy[2i+P-1][2j+Q-1] * E[P][Q],   E[P][Q] = sum_{a+r=P} sum_{b+s=Q} D[r][s]
-            // i.e. a 4x4 / stride 2 / pad 1 convolution: 16 taps on a quarter of the pixels instead of 9 taps at full resolution
-            // plus a 2x2 reduction pass.  E is formed in fp32 from the master weights and rounded once.  Layout [C][4][4][Np].
-            for (int i = tid; i < PK_T * 16 * PK_T; i += 256) {
-                const int nl = i % PK_T, r1 = i / PK_T, tap = r1 % 16, cl = r1 / 16;
-                if (c0 + cl >= C || n0 + nl >= Np) continue;
-                const int P = tap >> 2, Q = tap & 3;
-                float acc = 0.f;
-                for (int a = 0; a < 2; ++a)
-                    for (int b2 = 0; b2 < 2; ++b2) {
-                        const int r = P - a, s2 = Q - b2;
-                        if (r >= 0 && r < 3 && s2 >= 0 && s2 < 3) acc += tile[nl * pitch + cl * 9 + (8 - (r * 3 + s2))];
-                    }
-                Elem<T>::st(wd + ((long long)(c0 + cl) * 16 + tap) * Np + n0 + nl, acc);
+        if constexpr (RS == 9) {
+            if (wd && up_dgrad) {
+                // Gradient of (nearest-2x upsample -> 3x3 / pad 1 conv) w.r.t. its LOW-resolution input, as ONE strided conv over dy:
+                //   dx[i][j] = sum_{a,b in {0,1}} sum_{r,s} dy[2i+a+r-1][2j+b+s-1] * D[r][s]        (D = flipped 3x3 dgrad kernel)
+                //            = sum_{P,Q in 0..3} dy[2i+P-1][2j+Q-1] * E[P][Q],   E[P][Q] = sum_{a+r=P} sum_{b+s=Q} D[r][s]
+                // i.e. a 4x4 / stride 2 / pad 1 convolution: 16 taps on a quarter of the pixels instead of 9 taps at full resolution
+                // plus a 2x2 reduction pass.  E is formed in fp32 from the master weights and rounded once.  Layout [C][4][4][Np].
+                for (int i = tid; i < PK_T * 16 * (PK_T / 2); i += 256) {
+                    const int nl = (i % (PK_T / 2)) * 2, r1 = i / (PK_T / 2), tap = r1 % 16, cl = r1 / 16;
+                    if (c0 + cl >= C || n0 + nl >= Np) continue;
+                    const int P = tap >> 2, Q = tap & 3;
+                    float acc0 = 0.f, acc1 = 0.f;
+#pragma unroll
+                    for (int a = 0; a < 2; ++a)
+#pragma unroll
+                        for (int b2 = 0; b2 < 2; ++b2) {
+                            const int r = P - a, s2 = Q - b2;
+                            if (r >= 0 && r < 3 && s2 >= 0 && s2 < 3) {
+                                acc0 += tile[nl * pitch + cl * 9 + (8 - (r * 3 + s2))];
+                                acc1 += tile[(nl + 1) * pitch + cl * 9 + (8 - (r * 3 + s2))];
+                            }
+                        }
+                    pk_store2<T>(wd + ((long long)(c0 + cl) * 16 + tap) * Np + n0 + nl, acc0, acc1);
+                }
+                continue;
             }
-        } else if (wd) {                                               // wd[c][tap][n] with flipped taps, n fastest
-            for (int i = tid; i < PK_T * RS * PK_T; i += 256) {
-                const int nl = i % PK_T, r1 = i / PK_T, tap = r1 % RS, cl = r1 / RS;
+        }
+        if (wd) {                                                      // wd[c][tap][n] with flipped taps, n fastest
+            for (int i = tid; i < PK_T * RS * (PK_T / 2); i += 256) {
+                const int nl = (i % (PK_T / 2)) * 2, r1 = i / (PK_T / 2), tap = r1 % RS, cl = r1 / RS;
                 if (c0 + cl < C && n0 + nl < Np)
-                    Elem<T>::st(wd + ((long long)(c0 + cl) * RS + tap) * Np + n0 + nl, tile[nl * pitch + cl * RS + (RS - 1 - tap)]);
+                    pk_store2<T>(wd + ((long long)(c0 + cl) * RS + tap) * Np + n0 + nl, tile[nl * pitch + cl * RS + (RS - 1 - tap)],
+                                 tile[(nl + 1) * pitch + cl * RS + (RS - 1 - tap)]);
             }
         }
     }
+}
+template <typename T>
+__global__ __launch_bounds__(256)
+void pack_weight_multi_kernel(const long long* __restrict__ descs) {
+    const long long* d = descs + 8 * (long long)blockIdx.y;
+    const float* w = reinterpret_cast<const float*>(d[0]);
+    T* wf = reinterpret_cast<T*>(d[1]);
+    T* wd = reinterpret_cast<T*>(d[2]);
+    const int N = (int)d[3], C = (int)d[4], R = (int)d[5] & 0xff, Cp = (int)d[6], Np = (int)d[7];
+    const bool up_dgrad = ((int)d[5] & 0x100) != 0;
+    __shared__ float tile[PK_T * (PK_T * 9 + 1)];
+    if (R == 3) pack_tensor<T, 9>(w, wf, wd, N, C, Cp, Np, up_dgrad, tile);
+    else if (R == 1) pack_tensor<T, 1>(w, wf, wd, N, C, Cp, Np, false, tile);
+    else if (R == 2) pack_tensor<T, 4>(w, wf, wd, N, C, Cp, Np, false, tile);
 }
 extern "C" int ddpm_pack_weight_multi(const long long* descs, int n_tensors, int dtype, void* stream) {
     if (!descs) return DDPM_ERR_NULL;
@@ -165,23 +189,50 @@ extern "C" int ddpm_pack_weight_multi(const long long* descs, int n_tensors, int
 
 // packed conv weight gradients [N][R*S][C] -> parameter layout [N][C][R*S], all layers in one launch.
 // descs[i] = {src offset (floats) in gpack, dst offset in gflat, N, C, R*S}; grid = (blocks, n_tensors).
-__global__ void wgrad_unpack_kernel(const float* __restrict__ gpack, float* __restrict__ gflat, const long long* __restrict__ descs, float scale) {
+// sumsq (optional): bank of 64 fp32 accumulators that receives the sum of squares of everything written — the global gradient norm of
+// nn.utils.clip_grad_norm_ (ddpm_torch/utils/train.py:159) falls out of this pass instead of costing another read of all gradients.
+__global__ __launch_bounds__(256) void wgrad_unpack_kernel(const float* __restrict__ gpack, float* __restrict__ gflat, const long long* __restrict__ descs, float scale,
+                                                            float* __restrict__ sumsq) {
+    __shared__ float sh[4];
     const long long* d = descs + 5 * (long long)blockIdx.y;
-    const long long src = d[0], dst = d[1];
-    const int C = (int)d[3], RS = (int)d[4];
-    const long long total = d[2] * C * RS;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int tap = (int)(i % RS);
-        const long long nc = i / RS;
-        const int c = (int)(nc % C);
-        const long long n = nc / C;
-        gflat[dst + i] = gpack[src + (n * RS + tap) * C + c] * scale;
+    const float* src = gpack + d[0];
+    float* dst = gflat + d[1];
+    const unsigned C = (unsigned)d[3], RS = (unsigned)d[4];
+    const unsigned total = (unsigned)(d[2] * C * RS);                       // < 2^31 per tensor (checked by the host: the flat buffer is indexed with ints elsewhere too)
+    float acc = 0.f;
+    if (RS == 1) {                                                          // plain copies (everything but the conv weights)
+        for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+            const float v = src[i] * scale;
+            dst[i] = v; acc += v * v;
+        }
+    } else {
+        for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+            const unsigned nc = i / RS, tap = i - nc * RS;                  // (32-bit divisions by a block-uniform divisor)
+            const unsigned n = nc / C, c = nc - n * C;
+            const float v = src[((unsigned long long)n * RS + tap) * C + c] * scale;
+            dst[i] = v; acc += v * v;
+        }
+    }
+    if (sumsq) {
+        acc = wave_sum(acc);
+        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const float t = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+            if (t != 0.f) atomicAdd(sumsq + ((blockIdx.y * gridDim.x + blockIdx.x) & 63), t);
+        }
     }
 }
 extern "C" int ddpm_wgrad_unpack(const float* gpack, float* gflat, const long long* descs, int n_tensors, float scale, void* stream) {
     if (!gpack || !gflat || !descs) return DDPM_ERR_NULL;
     if (n_tensors <= 0) return DDPM_OK;
-    hipLaunchKernelGGL(wgrad_unpack_kernel, dim3(64, n_tensors), dim3(256), 0, (hipStream_t)stream, gpack, gflat, descs, scale);
+    hipLaunchKernelGGL(wgrad_unpack_kernel, dim3(64, n_tensors), dim3(256), 0, (hipStream_t)stream, gpack, gflat, descs, scale, (float*)nullptr);
+    return check_launch();
+}
+extern "C" int ddpm_wgrad_unpack_sumsq(const float* gpack, float* gflat, const long long* descs, int n_tensors, float scale, float* total_sq, void* stream) {
+    if (!gpack || !gflat || !descs || !total_sq) return DDPM_ERR_NULL;
+    if (n_tensors <= 0) return DDPM_OK;
+    hipLaunchKernelGGL(wgrad_unpack_kernel, dim3(64, n_tensors), dim3(256), 0, (hipStream_t)stream, gpack, gflat, descs, scale, total_sq);
     return check_launch();
 }
 

@@ -32,6 +32,7 @@ PROTOTYPES = {
     "ddpm_conv1x1_wgrad_nhwc": [P, L, P, L, P, L, P, L, I, I, I, I, I, P],
     "ddpm_wgrad_reduce": [P, I, P],
     "ddpm_wgrad_unpack": [P, P, P, I, F, P],
+    "ddpm_wgrad_unpack_sumsq": [P, P, P, I, F, P, P],
     "ddpm_gemm": [P, L, L, I, P, L, L, I, P, L, L, P, P, L, L, I, I, I, I, F, I, I, I, I, P],
     "ddpm_groupnorm_silu_fwd": [P, L, P, L, P, P, P, P, I, I, I, I, F, I, F, U, P, I, P],
     "ddpm_groupnorm_silu_bwd": [P, L, P, L, P, L, P, P, P, P, P, P, I, I, I, I, I, F, U, P, I, P, L, P, L, I, P],

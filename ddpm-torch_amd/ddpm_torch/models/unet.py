@@ -920,7 +920,7 @@ class _Engine:
             self._gpack = torch.empty(self.ptotal, dtype=torch.float32, device=self.device)
         gpack = self._gpack.zero_()           # persistent (stable addresses for the slab-reduce tables): packed conv weight grads [N][RS][C] + tail
         ctx = dict(gflat=gflat, gpack=gpack, ws=ws, B=B, dtb=dtb, pending=None, works=self._works, slab_rows=[], side=None, keep=[], cut=cut,
-                   seed_dev=st.get("seed_dev", 0), world=1)
+                   seed_dev=st.get("seed_dev", 0), world=1, sumsq=0)
         if _SIDE_STREAM and gflat.is_cuda:
             if self._side is None:
                 # LOW priority: the weight-gradient stream has ~3.6 ms of work per 10.6 ms step and seven milliseconds of slack; the main
@@ -957,10 +957,13 @@ class _Engine:
                 works.clear()
             self._comm(ctx, finish)
         wdesc = self._wgrad_table()
-        _hip.call("ddpm_wgrad_unpack", gpack.data_ptr(), gflat.data_ptr(), wdesc.data_ptr(), wdesc.shape[0], 1.0 / ctx["world"], _hip.stream())
+        if ctx["sumsq"]:           # the caller's squared-norm accumulators: the clip norm comes out of this pass (no second read of all gradients)
+            _hip.call("ddpm_wgrad_unpack_sumsq", gpack.data_ptr(), gflat.data_ptr(), wdesc.data_ptr(), wdesc.shape[0], 1.0 / ctx["world"], ctx["sumsq"], _hip.stream())
+        else:
+            _hip.call("ddpm_wgrad_unpack", gpack.data_ptr(), gflat.data_ptr(), wdesc.data_ptr(), wdesc.shape[0], 1.0 / ctx["world"], _hip.stream())
         return gflat
 
-    def backward(self, tape, gout, gflat=None, cut=None, want_views=True):
+    def backward(self, tape, gout, gflat=None, cut=None, want_views=True, sumsq=0):
         """Replays the tape in reverse.  ``gflat``: caller-owned flat gradient buffer (stable address for captured steps).
         ``cut(fn)``: when the step is being captured as a sequence of hipGraphs, the communicator calls are not captured —
         ``cut`` ends the current graph segment, registers ``fn`` to run eagerly between the segments at replay time, and
@@ -972,6 +975,7 @@ class _Engine:
         gout = gout.contiguous().float()
         H, W = gout.shape[2], gout.shape[3]
         ctx = self._open_backward(st, gflat, cut)
+        ctx["sumsq"] = sumsq             # device address of a zeroed bank of 64 fp32 accumulators for ||grad||^2 (0: not wanted)
         # ---- head
         _, cur, act, stats, _ = head
         norm, conv = m.out_conv[0], m.out_conv[2]

@@ -287,14 +287,15 @@ class _FusedUpdate:
         st = self.opt.state.get(params[0], {})
         return int(st["step"]) if "step" in st else 0
 
-    def launch(self, max_norm, scalars=None, hyper_dev=0):
+    def launch(self, max_norm, scalars=None, hyper_dev=0, have_sumsq=False):
         """The two launches.  ``scalars`` = (lr, bias_corr1, bias_corr2, ema_w) by value, or ``hyper_dev`` = address of the
-        same four floats in device memory (captured steps)."""
+        same four floats in device memory (captured steps).  ``have_sumsq``: ``self.total`` already holds the squared gradient
+        norm (the engine's backward accumulated it while writing the flat gradient): only the update is launched."""
         g = self.opt.param_groups[0]
         b1, b2 = g["betas"]
         n, s = len(self.params), _hip.stream()
         clip = bool(max_norm) and max_norm > 0
-        if clip:
+        if clip and not have_sumsq:
             self.total.zero_()
             _hip.call("ddpm_mt_grad_sumsq", self.table.data_ptr(), n, self.total.data_ptr(), s)
         lr, bc1, bc2, ema_w = scalars if scalars is not None else (0.0, 1.0, 1.0, 0.0)
@@ -389,8 +390,12 @@ class _DirectStep:
         _hip.call("ddpm_weighted_sum_f32", losses.data_ptr(), self.gloss.data_ptr(), self.loss.data_ptr(), B, s())   # mean over the batch
         gout = torch.empty_like(out)
         _hip.call("ddpm_mse_bwd", out.data_ptr(), target.data_ptr(), self.gloss.data_ptr(), gout.data_ptr(), B, n, s())
-        eng.backward(tape, gout, gflat=self.gflat, cut=cut, want_views=False)
-        tr._fused.launch(tr.grad_norm, hyper_dev=self.hyper_dev.data_ptr())
+        clip = bool(tr.grad_norm) and tr.grad_norm > 0
+        if clip:
+            tr._fused.total.zero_()
+        # (the backward's last launch, which rewrites the staging buffer into the flat gradient, also accumulates its squared norm)
+        eng.backward(tape, gout, gflat=self.gflat, cut=cut, want_views=False, sumsq=tr._fused.total.data_ptr() if clip else 0)
+        tr._fused.launch(tr.grad_norm, hyper_dev=self.hyper_dev.data_ptr(), have_sumsq=clip)
         eng.refresh_unconditionally()                                          # the next forward reads the re-derived copies
 
     PROBE = 4

@@ -91,6 +91,10 @@ int ddpm_conv1x1_wgrad_nhwc(const void* dy, long long dy_ld, const void* x, long
 int ddpm_wgrad_reduce(const long long* table, int n_tensors, void* stream);
 
 int ddpm_wgrad_unpack(const float* gpack, float* gflat, const long long* descs, int n_tensors, float scale, void* stream);
+/* ... the same pass, also accumulating the sum of squares of everything it writes into total_sq (the bank of 64 fp32 accumulators that
+ * ddpm_mt_grad_sumsq fills and ddpm_mt_adam_ema reads; zero on entry): the global gradient norm of nn.utils.clip_grad_norm_
+ * (ddpm_torch/utils/train.py:159) without another read of all gradients */
+int ddpm_wgrad_unpack_sumsq(const float* gpack, float* gflat, const long long* descs, int n_tensors, float scale, float* total_sq, void* stream);
 
 /* F.linear (modules.py:58-59; unet.py:77,123,125) and torch.einsum in AttentionBlock.qkv (unet.py:46,50):
  *   C[b][m][n] = alpha * sum_k A[b][m][k] * B[b][n][k] + bias[n] + residual[b][m][n]   (+ C when accumulate)

@@ -41,3 +41,13 @@ for g, a, b in gaps:
     agg[key][0] += 1; agg[key][1] += g
 for (a, b), (n, g) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:18]:
     print(f"  {g / nsteps / 1e3:7.1f} us/step  n/step={n / nsteps:5.1f}  after [{a}] before [{b}]")
+
+# per-queue kernel breakdown (what sits on the critical stream?)
+perq = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0]))
+for s_, e_, k, q, st in win:
+    name = k.split("(")[0].replace("void ", "").replace("(anonymous namespace)::", "")[:70]
+    perq[(q, st)][name][0] += 1; perq[(q, st)][name][1] += e_ - s_
+for key, d in perq.items():
+    print(f"--- queue {key[0]} stream {key[1]}: {sum(v[0] for v in d.values()) / nsteps:.0f} launches/step")
+    for name, (n, t) in sorted(d.items(), key=lambda kv: -kv[1][1])[:40]:
+        print(f"  {t / nsteps / 1e3:8.1f} us/step  n/step={n / nsteps:5.1f}  avg {t / n / 1e3:6.1f} us  {name}")

@@ -200,6 +200,14 @@ class Emulator:
             v = f32(gpack + 4 * int(src), int(N * C * RS)).reshape(N, RS, C).transpose(0, 2, 1)
             f32(gflat + 4 * int(dst), int(N * C * RS)).reshape(N, C, RS)[...] = v * np.float32(scale)
 
+    def ddpm_wgrad_unpack_sumsq(self, gpack, gflat, descs, n, scale, total, st):
+        self.ddpm_wgrad_unpack(gpack, gflat, descs, n, scale, st)
+        tot = 0.0
+        for src, dst, N, C, RS in i64(descs, 5 * n).reshape(n, 5):
+            g = f32(gflat + 4 * int(dst), int(N * C * RS)).astype(np.float64)
+            tot += float((g * g).sum())
+        f32(total, 64)[0] += np.float32(tot)
+
     def _operand(self, p, ld, bs, trans, rows, K, batch, dt):
         es = 2 if dt == BF16 else 4
         mats = []

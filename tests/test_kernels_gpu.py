@@ -727,3 +727,59 @@ def test_conv3x3_wgrad_patch_kernel_rejects_unsupported_geometry():
     t = torch.zeros(64, device="cuda")
     assert lib.ddpm_conv3x3_wgrad_nhwc(t.data_ptr(), 64, t.data_ptr(), 64, t.data_ptr(), 0, 0, 0, 2, 12, 12, 64, 64, 64, 0, 1, _hip.stream()) == 1
     assert lib.ddpm_conv3x3_wgrad_nhwc(t.data_ptr(), 64, t.data_ptr(), 64, t.data_ptr(), 0, 0, 0, 2, 16, 16, 64, 64, 64, 0, 0, _hip.stream()) == 2     # fp32
+
+
+def test_wgrad_unpack_and_fused_norm():
+    """ddpm_wgrad_unpack / ddpm_wgrad_unpack_sumsq: packed [N][R*S][C] -> [N][C][R*S] (x scale) for several tensors in one launch, plain
+    segment copies (R*S = 1), and — fused form — the squared norm of everything written, against float64."""
+    g = torch.Generator().manual_seed(5)
+    shapes = [(64, 48, 9), (7, 24, 9), (1, 1000, 1), (33, 5, 1), (16, 16, 16)]
+    src_off, dst_off, rows = 0, 0, []
+    for N, C, RS in shapes:
+        rows.append([src_off, dst_off, N, C, RS])
+        src_off += (N * C * RS + 3) // 4 * 4 + 4
+        dst_off += (N * C * RS + 3) // 4 * 4
+    gpack = torch.randn(src_off, generator=g)
+    descs = torch.tensor(rows, dtype=torch.int64)
+    for fused in (0, 1):
+        gflat = torch.full((dst_off,), 3.0)
+        total = torch.zeros(64)
+        if fused:
+            both("ddpm_wgrad_unpack_sumsq", A(gpack), A(gflat, out=True, name="gflat"), A(descs), len(rows), 0.5, A(total), tol=0.0)
+            dp, df, dd, dtot = gpack.cuda(), torch.zeros(dst_off).cuda(), descs.cuda(), torch.zeros(64).cuda()
+            _hip.call("ddpm_wgrad_unpack_sumsq", dp.data_ptr(), df.data_ptr(), dd.data_ptr(), len(rows), 0.5, dtot.data_ptr(), _hip.stream())
+            ref = sum(float((0.5 * gpack[s:s + N * C * RS].double()).pow(2).sum()) for s, _, N, C, RS in rows)
+            assert abs(float(dtot.double().sum()) - ref) <= 1e-5 * ref
+        else:
+            both("ddpm_wgrad_unpack", A(gpack), A(gflat, out=True, name="gflat"), A(descs), len(rows), 0.5, tol=0.0)
+
+
+@pytest.mark.parametrize("dt", [0, 1])
+def test_pack_weight_multi(dt):
+    """All derived weight layouts in one launch: forward pack [N][tap][Cp], dgrad pack [C][flipped tap][Np], the 4x4 / stride-2 effective
+    dgrad kernel of the Upsample convs, channel padding, ragged 32-tiles — bit-exact against the numpy restatement (the 4x4 kernel, a sum
+    of up to four fp32 taps, to fp32 / bf16 rounding)."""
+    vec = 4 if dt == 0 else 8
+    pad = lambda n: -(-n // vec) * vec
+    cases = [(64, 64, 3, 0), (40, 24, 3, 0), (3, 128, 3, 0), (128, 3, 3, 0), (96, 72, 1, 0), (64, 64, 3, 0x100), (40, 72, 3, 0x100)]
+    ws, wfs, wds, rows, keep = [], [], [], [], []
+    for i, (N, C, R, flag) in enumerate(cases):
+        w = r(N, C, R, R, seed=10 + i)
+        Cp, Np = pad(C), pad(N)
+        wf = torch.zeros(N * R * R * Cp, dtype=DT[dt])
+        wd = torch.zeros(C * (16 if flag else R * R) * Np, dtype=DT[dt])
+        ws.append(w); wfs.append(wf); wds.append(wd)
+    host = [(w.data_ptr(), wf.data_ptr(), wd.data_ptr()) for w, wf, wd in zip(ws, wfs, wds)]
+    dev = [(w.cuda(), wf.cuda(), wd.cuda()) for w, wf, wd in zip(ws, wfs, wds)]
+    mk = lambda ptrs: torch.tensor([[p[0], p[1], p[2], N, C, R | flag, pad(C), pad(N)] for p, (N, C, R, flag) in zip(ptrs, cases)], dtype=torch.int64)
+    htab = mk(host)                                                   # (kept alive: the emulator reads it through its address)
+    Emulator().call("ddpm_pack_weight_multi", htab.data_ptr(), len(cases), dt, 0)
+    dtab = mk([(a.data_ptr(), b.data_ptr(), c.data_ptr()) for a, b, c in dev]).cuda()
+    _hip.call("ddpm_pack_weight_multi", dtab.data_ptr(), len(cases), dt, _hip.stream())
+    torch.cuda.synchronize()
+    for (N, C, R, flag), wf, wd, (_, dwf, dwd) in zip(cases, wfs, wds, dev):
+        assert torch.equal(dwf.cpu(), wf), (N, C, R, flag, "wf")
+        if flag:
+            assert float((dwd.cpu().float() - wd.float()).abs().max()) <= (1e-6 if dt == 0 else 2e-2) * float(wd.float().abs().max()), (N, C, "wd 4x4")
+        else:
+            assert torch.equal(dwd.cpu(), wd), (N, C, R, flag, "wd")
