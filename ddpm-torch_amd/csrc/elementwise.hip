@@ -3,6 +3,7 @@
 // Every kernel is a grid-stride or one-row-per-wave stream with coalesced accesses; no device allocation,
 // no synchronisation — all entry points enqueue on the caller's stream and return.
 #include "common.h"
+#include <stdlib.h>
 
 static inline int grid_for(long long n, int block = 256, int cap = 256 * 16) {
     long long g = (n + block - 1) / block;
@@ -181,8 +182,9 @@ void pack_weight_multi_kernel(const long long* __restrict__ descs) {
 extern "C" int ddpm_pack_weight_multi(const long long* descs, int n_tensors, int dtype, void* stream) {
     if (!descs) return DDPM_ERR_NULL;
     if (n_tensors <= 0) return DDPM_OK;                 // (kernel sizes: R <= 3 — the LDS tile holds 32 x 32 x 9 floats; the caller only has 1x1 and 3x3)
-    if (dtype == DDPM_BF16) hipLaunchKernelGGL(pack_weight_multi_kernel<bf16_t>, dim3(64, n_tensors), dim3(256), 0, (hipStream_t)stream, descs);
-    else if (dtype == DDPM_F32) hipLaunchKernelGGL(pack_weight_multi_kernel<float>, dim3(64, n_tensors), dim3(256), 0, (hipStream_t)stream, descs);
+    static const int pk_blocks = getenv("DDPM_PACK_BLOCKS") ? atoi(getenv("DDPM_PACK_BLOCKS")) : 256;    // (blocks per tensor: 64 left the 128-tile tensors two serial load -> store rounds per block)
+    if (dtype == DDPM_BF16) hipLaunchKernelGGL(pack_weight_multi_kernel<bf16_t>, dim3(pk_blocks, n_tensors), dim3(256), 0, (hipStream_t)stream, descs);
+    else if (dtype == DDPM_F32) hipLaunchKernelGGL(pack_weight_multi_kernel<float>, dim3(pk_blocks, n_tensors), dim3(256), 0, (hipStream_t)stream, descs);
     else return DDPM_ERR_DTYPE;
     return check_launch();
 }
