@@ -302,15 +302,17 @@ def main():
         achieved = dom[1] / dom[2] / 1e12
         ru_name, ru = max(((k, v) for k, v in agg.items() if k != dom_name), key=lambda kv: kv[1][2])
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")
-        if os.path.exists(tpath):
+        import glob
+        tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")))
+        tpath = tfiles[-1] if tfiles else ""                       # the latest committed counter passes (scripts/gpu_profile.sh)
+        if tpath:
             recs = json.load(open(tpath)).get("kernels", [])
             exact = [r for r in recs if dom_name.split(" ")[0] in r["kernel"]]          # same template instance when the name carries it
             for rec in (exact or recs):
                 if traffic is None and rec["match"] in dom_name:
                     traffic = {"hbm_bytes_per_launch": rec["fetch_bytes_per_launch"] + rec["write_bytes_per_launch"],
                                "fetch_bytes_per_launch": rec["fetch_bytes_per_launch"], "write_bytes_per_launch": rec["write_bytes_per_launch"],
-                               "source": rec.get("source", "profiles/r02_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; FETCH_SIZE x2 per the gfx950 guide)")}
+                               "source": rec.get("source", "profiles/" + os.path.basename(tpath) + " (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, not collected in this run; FETCH_SIZE x2 per the gfx950 guide)")}
         roofline = {"bound": "mfma", "kernel": dom_name, "achieved": round(achieved, 1), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(achieved / peak, 4), "traffic": traffic,
                     "launches_per_step": dom[0], "avg_launch_us": round(dom[2] / dom[0] * 1e6, 2),
@@ -405,6 +407,15 @@ def main():
                 "model_tflops": round(2 * 10 / h_el * 3 * FWD_GFLOP["celebahq"] / 1e3, 1),
                 "frac_of_peak": round(2 * 10 / h_el * 3 * FWD_GFLOP["celebahq"] / 1e3 / peak, 4), "dtype": args.dtype,
                 "final_loss": round(th.current_stats["loss"], 4)}
+            # (4) 256 x 256 sampling (north star: "sampling throughput on 32x32 and 256x256 batches"): the same CelebA-HQ net, eval mode, B = 8,
+            # ancestral steps through the captured graph; a 20-step chain is timed (identical per-step work) and scaled to 1000 steps
+            nh.eval()
+            d20 = ddpm_torch.GaussianDiffusion(ddpm_torch.get_beta_schedule("linear", 1e-4, 0.02, 20), "eps", "fixed-small", "mse")
+            q_el = chain(d20, mh, (8, 3, 256, 256), 131071, 20) / 20
+            extras["celebahq256_sampling_b8"] = {
+                "batch": 8, "ms_per_step": round(q_el * 1e3, 2), "samples_per_s_1000_steps": round(8 / (q_el * 1000), 4),
+                "model_tflops": round(8 * FWD_GFLOP["celebahq"] / q_el / 1e3, 1), "frac_of_peak": round(8 * FWD_GFLOP["celebahq"] / q_el / 1e3 / peak, 4),
+                "dtype": args.dtype, "note": "20-step chain timed, scaled to 1000 steps"}
             del mh, nh, th
             out["other_configs"] = extras
     if rank == 0 and not args.no_cpu_baseline and world == 1:

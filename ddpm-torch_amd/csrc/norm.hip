@@ -105,21 +105,9 @@ __global__ void gn_apply_kernel(const T* __restrict__ x, T* __restrict__ y, GnSh
     __shared__ float sh_mean[64], sh_rstd[64];
     const int b = blockIdx.y, slab = blockIdx.x;
     const int t = threadIdx.y * blockDim.x + threadIdx.x, nt = blockDim.x * blockDim.y;
-    if (t < s.G) {
-        double sum = 0.0, sq = 0.0;
-        for (int i = 0; i < s.S; ++i) {
-            const float* o = partial + (((long long)b * s.S + i) * s.G + t) * 2;
-            sum += o[0]; sq += o[1];
-        }
-        const double n = (double)s.HW * s.cpg;
-        const double dmean = sum / n;                       // moments of (x - pivot): see gn_pivot
-        double var = sq / n - dmean * dmean;
-        if (var < 0.0) var = 0.0;
-        const double mean = (double)gn_pivot(x, s.x_ld, s.HW, b, t, s.cpg) + dmean;
-        const float rstd = (float)(1.0 / sqrt(var + (double)a.eps));
-        sh_mean[t] = (float)mean; sh_rstd[t] = rstd;
-        if (a.stats && slab == 0) { a.stats[((long long)b * s.G + t) * 2] = (float)mean; a.stats[((long long)b * s.G + t) * 2 + 1] = rstd; }
-    }
+    // `partial` = the FINISHED statistics [B][G][2] (mean, rstd) written by gn_stats_finalize_kernel (every block used to re-sum
+    // the S per-slab partials of its sample here, serially, before touching a pixel: at 256 x 256 with S = 256 that was most of the kernel)
+    if (t < s.G) { sh_mean[t] = partial[((long long)b * s.G + t) * 2]; sh_rstd[t] = partial[((long long)b * s.G + t) * 2 + 1]; }
     __syncthreads();
     for (int c = t; c < s.C; c += nt) {
         const int g = c / s.cpg;
@@ -136,6 +124,7 @@ __global__ void gn_apply_kernel(const T* __restrict__ x, T* __restrict__ y, GnSh
     T* yb = y + ((long long)b * s.HW) * s.y_ld + cx * VEC;
     const float keep_scale = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
     const unsigned long long seed = gn_seed(a);
+#pragma unroll 4
     for (int p = p0 + py; p < p1; p += PY) {
         float f[VEC];
         Elem<T>::unpack(ldg16(xb + (long long)p * s.x_ld), f);
@@ -150,6 +139,68 @@ __global__ void gn_apply_kernel(const T* __restrict__ x, T* __restrict__ y, GnSh
             f[j] = z;
         }
         stg16(yb + (long long)p * s.y_ld, Elem<T>::pack(f));
+    }
+}
+
+// Statistics of the streaming path, finished ONCE per sample: (mean, rstd) of every group from the S per-slab partial moments, summed in
+// a fixed order (thread (g, k) takes slabs k, k + K, ...; the K partial sums are added in order): deterministic like the partials.
+// final[b][g] = (mean, rstd); `stats` (optional) receives a copy for the backward.
+template <typename T>
+__global__ __launch_bounds__(64) void gn_stats_finalize_kernel(const T* __restrict__ x, GnShape s, const float* __restrict__ partial /*[B][S][G][2]*/,
+                                                                float eps, float* __restrict__ fin /*[B][G][2]*/, float* __restrict__ stats) {
+    // one wave per (sample, group): lane l takes slabs l, l + 64, ...; lane 0 adds the 64 lane sums in order
+    __shared__ double sh[2][64];
+    const int g = blockIdx.x, b = blockIdx.y, l = threadIdx.x;
+    double sum = 0.0, sq = 0.0;
+#pragma unroll 4
+    for (int i = l; i < s.S; i += 64) {
+        const float* o = partial + (((long long)b * s.S + i) * s.G + g) * 2;
+        sum += o[0]; sq += o[1];
+    }
+    sh[0][l] = sum; sh[1][l] = sq;
+    __syncthreads();
+    if (l == 0) {
+        sum = 0.0; sq = 0.0;
+        for (int i = 0; i < 64; ++i) { sum += sh[0][i]; sq += sh[1][i]; }
+        const double n = (double)s.HW * s.cpg;
+        const double dmean = sum / n;                       // moments of (x - pivot): see gn_pivot
+        double var = sq / n - dmean * dmean;
+        if (var < 0.0) var = 0.0;
+        const float mean = (float)((double)gn_pivot(x, s.x_ld, s.HW, b, g, s.cpg) + dmean);
+        const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+        fin[((long long)b * s.G + g) * 2] = mean; fin[((long long)b * s.G + g) * 2 + 1] = rstd;
+        if (stats) { stats[((long long)b * s.G + g) * 2] = mean; stats[((long long)b * s.G + g) * 2 + 1] = rstd; }
+    }
+}
+
+// Backward twin: per-(sample, channel) sums A1 = sum dz*xhat, A2 = sum dz over the S slabs, in a fixed order; also the dgamma / dbeta
+// contribution of the sample (atomics, one per (b, c)).  grid = (ceil(C / 16), B), 256 threads = 16 channels (128 contiguous bytes per
+// slab) x 16 slab lanes, eight loads in flight per thread.
+__global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(GnShape s, const float* __restrict__ partial /*[B][S][C][2]*/, float* __restrict__ fin /*[B][C][2]*/,
+                                                               float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    __shared__ float sh[2][256];
+    const int b = blockIdx.y, t = threadIdx.x, cl = t & 15, k = t >> 4, c = blockIdx.x * 16 + cl;
+    float a1 = 0.f, a2 = 0.f;
+    if (c < s.C) {
+        const float2* col = reinterpret_cast<const float2*>(partial) + (long long)b * s.S * s.C + c;
+        int i = k;
+        for (; i + 7 * 16 < s.S; i += 8 * 16) {
+            float2 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = col[(long long)(i + 16 * u) * s.C];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { a1 += v[u].x; a2 += v[u].y; }
+        }
+        for (; i < s.S; i += 16) { const float2 v = col[(long long)i * s.C]; a1 += v.x; a2 += v.y; }
+    }
+    sh[0][t] = a1; sh[1][t] = a2;
+    __syncthreads();
+    if (t < 16 && c < s.C) {
+        a1 = 0.f; a2 = 0.f;
+        for (int i = 0; i < 16; ++i) { a1 += sh[0][i * 16 + t]; a2 += sh[1][i * 16 + t]; }
+        fin[((long long)b * s.C + c) * 2] = a1; fin[((long long)b * s.C + c) * 2 + 1] = a2;
+        if (dgamma) atomicAdd(dgamma + c, a1);
+        if (dbeta) atomicAdd(dbeta + c, a2);
     }
 }
 
@@ -955,20 +1006,11 @@ __global__ void gn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict
     const int cx = threadIdx.x, py = threadIdx.y, PY = blockDim.y;
     const int t = threadIdx.y * blockDim.x + threadIdx.x, nt = blockDim.x * blockDim.y;
     const int p0 = slab * s.pix_per_slab, p1 = min(s.HW, p0 + s.pix_per_slab);
-    // group coefficients of this sample from the per-slab channel sums (every block of the sample recomputes them: a few
-    // KB from L2 instead of a third launch); the slab-0 block also owns the dgamma / dbeta contribution of the sample
+    // group coefficients of this sample from its FINISHED channel sums [B][C][2] (gn_bwd_finalize_kernel; every block used to re-sum
+    // the S per-slab partials here first — serial, S up to 256 — and block 0 issued the dgamma / dbeta atomics)
     for (int c = t; c < s.C; c += nt) {
-        float a1 = 0.f, a2 = 0.f;
-        for (int i = 0; i < s.S; ++i) {
-            const float* o = partial + (((long long)b * s.S + i) * s.C + c) * 2;
-            a1 += o[0]; a2 += o[1];
-        }
         const float gmc = a.gamma[c];
-        sh1[c] = a1 * gmc; sh2[c] = a2 * gmc;
-        if (slab == 0) {
-            if (dgamma) atomicAdd(dgamma + c, a1);
-            if (dbeta) atomicAdd(dbeta + c, a2);
-        }
+        sh1[c] = partial[((long long)b * s.C + c) * 2] * gmc; sh2[c] = partial[((long long)b * s.C + c) * 2 + 1] * gmc;
     }
     __syncthreads();
     if (t < s.G) {
@@ -992,6 +1034,7 @@ __global__ void gn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict
     const T* xb = x + ((long long)b * s.HW) * s.x_ld + cx * VEC;
     const T* db = dy + ((long long)b * s.HW) * dy_ld + cx * VEC;
     T* ob = dx + ((long long)b * s.HW) * dx_ld + cx * VEC;
+#pragma unroll 2
     for (int p = p0 + py; p < p1; p += PY) {
         float f[VEC], d[VEC], o[VEC], ad[VEC];
         Elem<T>::unpack(ldg16(xb + (long long)p * s.x_ld), f);
@@ -1071,12 +1114,14 @@ static int gn_geometry(int B, int HW, int C, int G, long long x_ld, long long y_
     int py = GN_THREADS / cv; if (py < 1) py = 1;
     if (py > HW) py = HW;
     block = dim3(cv, py);
-    // enough slabs to give every CU several blocks, but at least ~4 pixel-iterations of work each
-    int S = (1024 + B - 1) / B;
+    // enough slabs to give every CU a dozen blocks (256 threads each: ~8 resident per CU and a queue behind them), but at least ~4
+    // pixel-iterations of work each.  (Was: 1024 blocks in all, <= 256 slabs — two blocks per CU on the 256 x 256 tensors at B = 2,
+    // every thread with one load in flight: 67 us for 67 MB.)
+    int S = (3072 + B - 1) / B;
     int maxS = (HW + 4 * py - 1) / (4 * py);
     if (S > maxS) S = maxS;
     if (S < 1) S = 1;
-    if (S > 256) S = 256;
+    if (S > 512) S = 512;                 // (the per-sample sums over S are finished by small, latency-bound kernels: ~28 us at S = 1024)
     int pps = (HW + S - 1) / S;
     S = (HW + pps - 1) / pps;
     s.B = B; s.HW = HW; s.C = C; s.G = G; s.cpg = C / G; s.x_ld = x_ld; s.y_ld = y_ld; s.S = S; s.pix_per_slab = pps;
@@ -1095,7 +1140,7 @@ static GnApply make_apply(const float* gamma, const float* beta, float eps, int 
 extern "C" long long ddpm_gn_workspace_floats(int B, int HW, int C, int G, int dtype) {
     GnShape s; dim3 block, grid;
     if (gn_geometry(B, HW, C, G, C, C, dtype == DDPM_BF16 ? 2 : 4, s, block, grid)) return -1;
-    return (long long)B * s.S * C * 2 + (long long)B * G * 2;
+    return (long long)B * s.S * C * 2 + (long long)B * C * 2 + (long long)B * G * 2;     // per-slab partials | finished channel sums | finished statistics
 }
 
 extern "C" int ddpm_groupnorm_silu_fwd(const void* x, long long x_ld, void* y, long long y_ld, const float* gamma, const float* beta,
@@ -1135,12 +1180,15 @@ extern "C" int ddpm_groupnorm_silu_fwd(const void* x, long long x_ld, void* y, l
 #undef GN_FWD
         return check_launch();
     }
+    float* fin = workspace + (long long)B * s.S * C * 2 + (long long)B * C * 2;        // [B][G][2]
     if (dtype == DDPM_BF16) {
         hipLaunchKernelGGL(gn_stats_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)x, s, workspace);
-        hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)x, (bf16_t*)y, s, workspace, a);
+        hipLaunchKernelGGL(gn_stats_finalize_kernel<bf16_t>, dim3(G, B), dim3(64), 0, st, (const bf16_t*)x, s, workspace, eps, fin, stats);
+        hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)x, (bf16_t*)y, s, fin, a);
     } else {
         hipLaunchKernelGGL(gn_stats_kernel<float>, grid, block, 0, st, (const float*)x, s, workspace);
-        hipLaunchKernelGGL(gn_apply_kernel<float>, grid, block, 0, st, (const float*)x, (float*)y, s, workspace, a);
+        hipLaunchKernelGGL(gn_stats_finalize_kernel<float>, dim3(G, B), dim3(64), 0, st, (const float*)x, s, workspace, eps, fin, stats);
+        hipLaunchKernelGGL(gn_apply_kernel<float>, grid, block, 0, st, (const float*)x, (float*)y, s, fin, a);
     }
     return check_launch();
 }
@@ -1196,14 +1244,16 @@ extern "C" int ddpm_groupnorm_silu_bwd(const void* x, long long x_ld, const void
         return check_launch();                                  // (the kernel wrote the per-sample column sums itself)
     }
     float* partial = workspace;                                   // [B][S][C][2]
+    float* fin2 = workspace + (long long)B * s.S * C * 2;         // [B][C][2]
     if (dtype == DDPM_BF16)
         hipLaunchKernelGGL(gn_bwd_reduce_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)x, (const bf16_t*)dy, s, dy_ld, stats, a, partial);
     else
         hipLaunchKernelGGL(gn_bwd_reduce_kernel<float>, grid, block, 0, st, (const float*)x, (const float*)dy, s, dy_ld, stats, a, partial);
+    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3((C + 15) / 16, B), dim3(256), 0, st, s, partial, fin2, dgamma, dbeta);
     if (dtype == DDPM_BF16)
-        hipLaunchKernelGGL(gn_bwd_apply_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx, s, dy_ld, dx_ld, stats, partial, dgamma, dbeta, a, accumulate, (const bf16_t*)add, add_ld);
+        hipLaunchKernelGGL(gn_bwd_apply_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx, s, dy_ld, dx_ld, stats, fin2, dgamma, dbeta, a, accumulate, (const bf16_t*)add, add_ld);
     else
-        hipLaunchKernelGGL(gn_bwd_apply_kernel<float>, grid, block, 0, st, (const float*)x, (const float*)dy, (float*)dx, s, dy_ld, dx_ld, stats, partial, dgamma, dbeta, a, accumulate, (const float*)add, add_ld);
+        hipLaunchKernelGGL(gn_bwd_apply_kernel<float>, grid, block, 0, st, (const float*)x, (const float*)dy, (float*)dx, s, dy_ld, dx_ld, stats, fin2, dgamma, dbeta, a, accumulate, (const float*)add, add_ld);
     const int rc3 = check_launch();
     return rc3 ? rc3 : colsum_after.run();
 }
