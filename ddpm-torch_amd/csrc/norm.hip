@@ -143,25 +143,28 @@ __global__ void gn_apply_kernel(const T* __restrict__ x, T* __restrict__ y, GnSh
 }
 
 // Statistics of the streaming path, finished ONCE per sample: (mean, rstd) of every group from the S per-slab partial moments, summed in
-// a fixed order (thread (g, k) takes slabs k, k + K, ...; the K partial sums are added in order): deterministic like the partials.
+// a fixed order (lane l takes slabs l, l + 64, ...; the 64 lane sums meet in a fixed butterfly): deterministic like the partials.
 // final[b][g] = (mean, rstd); `stats` (optional) receives a copy for the backward.
+// Neither finishing kernel uses LDS: in the backward pass the weight-gradient blocks of the side stream hold all 160 KiB of most CUs,
+// and a block that needs even 2 KiB waits for one of them to retire (measured on the CelebA-HQ step: 3 us alone, 27 us average, up
+// to 84 us beside wgrad3x3) — registers and wave slots are still free there.
+__device__ __forceinline__ double gn_wave_sum(double v) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
 template <typename T>
 __global__ __launch_bounds__(64) void gn_stats_finalize_kernel(const T* __restrict__ x, GnShape s, const float* __restrict__ partial /*[B][S][G][2]*/,
                                                                 float eps, float* __restrict__ fin /*[B][G][2]*/, float* __restrict__ stats) {
-    // one wave per (sample, group): lane l takes slabs l, l + 64, ...; lane 0 adds the 64 lane sums in order
-    __shared__ double sh[2][64];
     const int g = blockIdx.x, b = blockIdx.y, l = threadIdx.x;
     double sum = 0.0, sq = 0.0;
 #pragma unroll 4
     for (int i = l; i < s.S; i += 64) {
-        const float* o = partial + (((long long)b * s.S + i) * s.G + g) * 2;
-        sum += o[0]; sq += o[1];
+        const float2 o = *reinterpret_cast<const float2*>(partial + (((long long)b * s.S + i) * s.G + g) * 2);
+        sum += o.x; sq += o.y;
     }
-    sh[0][l] = sum; sh[1][l] = sq;
-    __syncthreads();
+    sum = gn_wave_sum(sum); sq = gn_wave_sum(sq);
     if (l == 0) {
-        sum = 0.0; sq = 0.0;
-        for (int i = 0; i < 64; ++i) { sum += sh[0][i]; sq += sh[1][i]; }
         const double n = (double)s.HW * s.cpg;
         const double dmean = sum / n;                       // moments of (x - pivot): see gn_pivot
         double var = sq / n - dmean * dmean;
@@ -174,30 +177,31 @@ __global__ __launch_bounds__(64) void gn_stats_finalize_kernel(const T* __restri
 }
 
 // Backward twin: per-(sample, channel) sums A1 = sum dz*xhat, A2 = sum dz over the S slabs, in a fixed order; also the dgamma / dbeta
-// contribution of the sample (atomics, one per (b, c)).  grid = (ceil(C / 16), B), 256 threads = 16 channels (128 contiguous bytes per
-// slab) x 16 slab lanes, eight loads in flight per thread.
-__global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(GnShape s, const float* __restrict__ partial /*[B][S][C][2]*/, float* __restrict__ fin /*[B][C][2]*/,
-                                                               float* __restrict__ dgamma, float* __restrict__ dbeta) {
-    __shared__ float sh[2][256];
-    const int b = blockIdx.y, t = threadIdx.x, cl = t & 15, k = t >> 4, c = blockIdx.x * 16 + cl;
+// contribution of the sample (atomics, one per (b, c)).  grid = (ceil(C / CL), B), ONE wave = CL channels (8 CL contiguous bytes per
+// slab) x 64 / CL slab lanes, eight loads in flight per thread; the slab lanes meet in a butterfly over the upper lane bits.
+// CL = 16 while a lane gets <= 16 slabs (fewest, widest blocks: B = 128 means S = 24 and C / 4 x 128 single-wave blocks otherwise),
+// 4 for the long reductions of the big-image / small-batch tensors (S = 512).
+template <int CL>
+__global__ __launch_bounds__(64) void gn_bwd_finalize_kernel(GnShape s, const float* __restrict__ partial /*[B][S][C][2]*/, float* __restrict__ fin /*[B][C][2]*/,
+                                                              float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    constexpr int KL = 64 / CL;
+    const int b = blockIdx.y, t = threadIdx.x, cl = t % CL, k = t / CL, c = blockIdx.x * CL + cl;
     float a1 = 0.f, a2 = 0.f;
     if (c < s.C) {
         const float2* col = reinterpret_cast<const float2*>(partial) + (long long)b * s.S * s.C + c;
         int i = k;
-        for (; i + 7 * 16 < s.S; i += 8 * 16) {
+        for (; i + 7 * KL < s.S; i += 8 * KL) {
             float2 v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = col[(long long)(i + 16 * u) * s.C];
+            for (int u = 0; u < 8; ++u) v[u] = col[(long long)(i + KL * u) * s.C];
 #pragma unroll
             for (int u = 0; u < 8; ++u) { a1 += v[u].x; a2 += v[u].y; }
         }
-        for (; i < s.S; i += 16) { const float2 v = col[(long long)i * s.C]; a1 += v.x; a2 += v.y; }
+        for (; i < s.S; i += KL) { const float2 v = col[(long long)i * s.C]; a1 += v.x; a2 += v.y; }
     }
-    sh[0][t] = a1; sh[1][t] = a2;
-    __syncthreads();
-    if (t < 16 && c < s.C) {
-        a1 = 0.f; a2 = 0.f;
-        for (int i = 0; i < 16; ++i) { a1 += sh[0][i * 16 + t]; a2 += sh[1][i * 16 + t]; }
+#pragma unroll
+    for (int off = CL; off < 64; off <<= 1) { a1 += __shfl_xor(a1, off, 64); a2 += __shfl_xor(a2, off, 64); }
+    if (t < CL && c < s.C) {
         fin[((long long)b * s.C + c) * 2] = a1; fin[((long long)b * s.C + c) * 2 + 1] = a2;
         if (dgamma) atomicAdd(dgamma + c, a1);
         if (dbeta) atomicAdd(dbeta + c, a2);
@@ -533,15 +537,15 @@ __device__ __forceinline__ void gn_lane_reduce(float (&v)[CNT], int sv, int lane
     }
 }
 
-// NARR partial vectors at once (same barriers): sh_row holds NARR x [8 waves][seg_ch], sh_ch NARR x [seg_ch]
-template <int VEC, int NARR>
+// NARR partial vectors at once (same barriers): sh_row holds NARR x [NW waves][seg_ch], sh_ch NARR x [seg_ch]
+template <int VEC, int NARR, int NW = 8>
 __device__ __forceinline__ void gn_block_sum_w(float (&v)[NARR * VEC], const GnFused& f, int j, int tid, float* sh_row, float* sh_ch) {
     const int lane = tid & 63, wave = tid >> 6;
     __syncthreads();                                  // previous users of the scratch are done
     if ((f.seg_vecs & (f.seg_vecs - 1)) == 0) {
         gn_lane_reduce<NARR * VEC, 32>(v, f.seg_vecs, lane, 0, [&](int gi, float val) {
             const int m = gi / VEC, e = gi - m * VEC;        // VEC is a compile-time power of two
-            sh_row[(m * 8 + wave) * f.seg_ch + j * VEC + e] = val;      // lanes holding copies of a total store the same value
+            sh_row[(m * NW + wave) * f.seg_ch + j * VEC + e] = val;      // lanes holding copies of a total store the same value
         });
     } else {
         // lanes l, l + seg_vecs, l + 2 seg_vecs, ... hold the same vector column (3 / 6 / 12 vectors per pixel of the 384-channel
@@ -555,34 +559,34 @@ __device__ __forceinline__ void gn_block_sum_w(float (&v)[NARR * VEC], const GnF
         }
         if (lane < f.seg_vecs) {
 #pragma unroll
-            for (int gi = 0; gi < NARR * VEC; ++gi) sh_row[((gi / VEC) * 8 + wave) * f.seg_ch + j * VEC + (gi % VEC)] = v[gi];
+            for (int gi = 0; gi < NARR * VEC; ++gi) sh_row[((gi / VEC) * NW + wave) * f.seg_ch + j * VEC + (gi % VEC)] = v[gi];
         }
     }
     __syncthreads();
-    for (int c = tid; c < NARR * f.seg_ch; c += 512) {
+    for (int c = tid; c < NARR * f.seg_ch; c += NW * 64) {
         const int m = c / f.seg_ch, cc = c - m * f.seg_ch;
         float acc = 0.f;
 #pragma unroll
-        for (int w = 0; w < 8; ++w) acc += sh_row[(m * 8 + w) * f.seg_ch + cc];
+        for (int w = 0; w < NW; ++w) acc += sh_row[(m * NW + w) * f.seg_ch + cc];
         sh_ch[c] = acc;
     }
     __syncthreads();
 }
-template <int VEC>
+template <int VEC, int NW = 8>
 __device__ __forceinline__ void gn_block_channel_sum_w(const float (&part)[VEC], const GnFused& f, bool active, int j, int prow, int tid,
                                                        float* sh_row, float* sh_ch) {
     float v[VEC];
 #pragma unroll
     for (int e = 0; e < VEC; ++e) v[e] = active ? part[e] : 0.f;
-    gn_block_sum_w<VEC, 1>(v, f, j, tid, sh_row, sh_ch);
+    gn_block_sum_w<VEC, 1, NW>(v, f, j, tid, sh_row, sh_ch);
 }
-template <int VEC>
+template <int VEC, int NW = 8>
 __device__ __forceinline__ void gn_block_channel_sum2_w(const float (&pa)[VEC], const float (&pb)[VEC], const GnFused& f, bool active, int j, int tid,
                                                         float* sh_row, float* sh_ch) {
     float v[2 * VEC];
 #pragma unroll
     for (int e = 0; e < VEC; ++e) { v[e] = active ? pa[e] : 0.f; v[VEC + e] = active ? pb[e] : 0.f; }
-    gn_block_sum_w<VEC, 2>(v, f, j, tid, sh_row, sh_ch);
+    gn_block_sum_w<VEC, 2, NW>(v, f, j, tid, sh_row, sh_ch);
 }
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t gn_slice_rsrc(const void* base, long long bytes) {
@@ -613,12 +617,18 @@ __device__ __forceinline__ void gn_block_slice(const GnFused& f, int& b, int& ch
     } else { b = blockIdx.y; chunk = blockIdx.x; }
 }
 
+// ---- the eight-vectors-per-thread backward (the 32 x 32 tensors), kept in its first form: dz in 32 registers, per-channel constants
+// in registers, predicated rows.  The restructured kernel below needs ~130 registers at NV = 8 (50-62 spilled, each reload a
+// vmcnt(0)); the variant that parks dy / dz in LDS instead (1024 threads, one block per CU) exposes its reduction phases — nothing
+// else is resident to run meanwhile — and measured 40.6 / 76.2 / 195.8 us against this kernel's 37.3 / 69.6 / 145.9 us on the
+// 32 x 32 x {128, 256, 384} tensors at B = 128 (scripts/gn_bench.py).  Both passes are VALU-bound here (exp, rcp, the dropout
+// hash: ~930 clk per 8-channel vector and wave), which is why hiding the load phase under pass 1 changed nothing.
 //   backward pass 1: A1[c] = sum dz*xhat, A2[c] = sum dz -> dgamma / dbeta atomics, group coefficients c1, c2
 //            pass 2: dx = rstd * (dz*gamma - xhat*c1 - c2) (+= when accumulate), optionally the per-(sample, channel) sums of dx
 //                    (the time-bias gradient of the block, ddpm_torch/models/unet.py:86: no separate column-sum launch).
 template <typename T, int NV>
 __global__ __launch_bounds__(512, 4)
-void gn_lds_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx, GnShape s, GnFused f, long long dy_ld,
+void gn_lds_bwd8_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx, GnShape s, GnFused f, long long dy_ld,
                        long long dx_ld, const float* __restrict__ stats, float* __restrict__ dgamma, float* __restrict__ dbeta, GnApply a,
                        int accumulate, float* __restrict__ dx_colsum, long long colsum_ld, const T* __restrict__ addp, long long add_ld) {
     constexpr int VEC = Elem<T>::VEC, ES = (int)sizeof(T);
@@ -753,18 +763,69 @@ void gn_lds_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __r
     GN_STAMP(6); GN_STAMP(7);
 }
 
-// forward twin: x slice in LDS; pivot-shifted moments accumulated while the slice lands (one pass), then
-// y = drop(silu(x * a_c + b_c)) streamed out.
-template <typename T, int NV>
-__global__ __launch_bounds__(512, 4)
-void gn_lds_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, GnShape s, GnFused f, GnApply a) {
+// ---- LDS accesses of the staged kernels while their DMA is in flight go through inline asm.  hipcc cannot tell which LDS bytes an
+// outstanding `buffer_load ... lds` will write, so it puts `s_waitcnt vmcnt(0)` in front of EVERY ds_read / ds_write it generates
+// itself after the DMA was issued (disassembly of the first version: the counted waits below were each followed by a vmcnt(0), and
+// the 16 spilled bytes of the backward kernel were reloaded with another one) — the whole slice had to land before the first
+// vector was touched, and the VALU-heavy first pass (exp, rcp and the dropout hash: ~25 instructions per element) ran after the load
+// phase instead of under it.  The asm forms carry no such dependency; a wave only reads LDS bytes it fetched itself, after its own
+// counted wait.
+__device__ __forceinline__ u32x4 gn_lds_rd16(unsigned addr) {
+    u32x4 v;
+    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+    return v;
+}
+__device__ __forceinline__ void gn_lds_wr4(unsigned addr, float v) { asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory"); }
+// the VEC per-channel constants of a thread's vector column from a [seg_ch] float array in LDS
+template <int VEC>
+__device__ __forceinline__ void gn_lds_rd_consts(unsigned addr, float (&o)[VEC]) {
+#pragma unroll
+    for (int q = 0; q < VEC; q += 4) {
+        const u32x4 v = gn_lds_rd16(addr + q * 4);
+        o[q] = __uint_as_float(v.x); o[q + 1] = __uint_as_float(v.y); o[q + 2] = __uint_as_float(v.z); o[q + 3] = __uint_as_float(v.w);
+    }
+}
+// Global accesses of these kernels are buffer instructions with 32-bit offsets into the block's slice: a lane without a pixel gets an
+// out-of-range offset (reads return 0, writes are dropped) instead of a branch.  Branch-free matters beyond the saved address
+// arithmetic: hipcc's counted waits assume the FEWEST younger VMEM operations over all paths, so loads skipped under `if` turn every
+// later wait into vmcnt(0).
+constexpr unsigned GN_OOB = 0x7ffffff0u;
+__device__ __forceinline__ u32x4 gn_buf_ld16(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+}
+__device__ __forceinline__ void gn_buf_st16(__amdgpu_buffer_rsrc_t r, unsigned off, const u32x4& v) {
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, off, 0, 0);
+}
+// barrier that publishes asm LDS writes without draining the DMA (__syncthreads() would wait for vmcnt(0))
+__device__ __forceinline__ void gn_lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+}
+
+//   backward pass 1: A1[c] = sum dz*xhat, A2[c] = sum dz -> dgamma / dbeta atomics, group coefficients c1, c2
+//            pass 2: dx = rstd * (dz*gamma - xhat*c1 - c2) (+= when accumulate), optionally the per-(sample, channel) sums of dx
+//                    (the time-bias gradient of the block, ddpm_torch/models/unet.py:86: no separate column-sum launch).
+// Per-channel constants live in LDS ([8][seg_ch], built by the first seg_ch threads from ONE load each of gamma, beta and the
+// group's statistics while the slice is in flight) and a thread fetches the eight of its vector column when a pass needs them:
+//   pass 1  z = x*ca + cb (ca = rstd*gamma, cb = beta - mean*ca), sums of dz*(x - mean) [scaled by rstd once per channel] and dz;
+//   pass 2  dx = dz*ca + xhat*k2 + k3 (xhat = x*rs + ms, k2 = -rstd*c1, k3 = -rstd*c2) folded to dz*ca + x*q2 + q3 — two fmas per element.
+// (NV <= 4; eight vectors per thread run gn_lds_bwd8_kernel above.)  NT = 512 for the 16 - 64 KiB slices, 256 for the small ones
+// (<= 8 KiB: the 8 x 8 and 4 x 4 tensors).
+template <typename T, int NV, int NT>
+__global__ __launch_bounds__(NT, NT == 512 ? 4 : 2)
+void gn_lds_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx, GnShape s, GnFused f, long long dy_ld,
+                       long long dx_ld, const float* __restrict__ stats, float* __restrict__ dgamma, float* __restrict__ dbeta, GnApply a,
+                       int accumulate, float* __restrict__ dx_colsum, long long colsum_ld, const T* __restrict__ addp, long long add_ld) {
     constexpr int VEC = Elem<T>::VEC, ES = (int)sizeof(T);
     extern __shared__ __attribute__((aligned(16))) char lsm[];
-    char* xs = lsm;
-    float* sh_row = reinterpret_cast<float*>(lsm + NV * 512 * 16);
-    float* sh_ch = sh_row + 16 * f.seg_ch;
-    float* sh_mean = sh_ch + 2 * f.seg_ch;
-    float* sh_rstd = sh_mean + 32;
+    constexpr int NW = NT / 64;
+    char* xs = lsm;                                               // [NV][NT] vectors of x
+    float* sh_row = reinterpret_cast<float*>(lsm + NV * NT * 16);
+    float* sh_ch = sh_row + 2 * NW * f.seg_ch;
+    float* sh_c1 = sh_ch + 2 * f.seg_ch;
+    float* sh_c2 = sh_c1 + 32;
+    float* sh_k = sh_c2 + 32;                                    // [8][seg_ch]: rs, ms, mean, ca, cb, gamma, q2, q3
+    enum { K_RS, K_MS, K_MEAN, K_CA, K_CB, K_GAM, K_K2, K_K3 };
     GN_STAMP(0); GN_STAMP(1);
     int b, chunk;
     gn_block_slice(f, b, chunk);
@@ -772,38 +833,223 @@ void gn_lds_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, GnShape s, Gn
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool active = tid < f.nta;
     const int j = tid % f.seg_vecs, prow = tid / f.seg_vecs;
+    const unsigned lds0 = (unsigned)(size_t)lsm, k0 = (unsigned)(size_t)sh_k;
+    const unsigned kcol = k0 + (unsigned)(j * VEC * 4), kstride = (unsigned)(f.seg_ch * 4);
     const __amdgpu_buffer_rsrc_t rx = gn_slice_rsrc(x + ((long long)b * s.HW) * s.x_ld + c0, ((long long)(s.HW - 1) * s.x_ld + f.seg_ch) * ES);
-    float gmv[VEC], btv[VEC], piv[VEC];
-    const float piv_g = tid < f.GPB ? gn_pivot(x, s.x_ld, s.HW, b, chunk * f.GPB + tid, s.cpg) : 0.f;     // used by the threads that finalise a group
-    gn_ld_channels<VEC>(a.gamma + c0 + j * VEC, active, gmv);
-    gn_ld_channels<VEC>(a.beta + c0 + j * VEC, active, btv);
-    {
-        float cur = 0.f;
-        gn_per_group<VEC>(c0 + j * VEC, s.cpg, active, [&](int e, bool load, int g) {
-            if (load) cur = gn_pivot(x, s.x_ld, s.HW, b, g, s.cpg);
-            piv[e] = cur;
-        });
-    }
+    // per-channel inputs first: ordinary loads issued BEFORE the DMA complete before it (in-order return), so a counted wait covers them
+    // (all threads load, channel index clamped: no branch around VMEM)
+    const int kc = c0 + min(tid, f.seg_ch - 1);
+    const float in_g = a.gamma[kc], in_b = a.beta[kc];
+    const gn_f32x2 in_st = *reinterpret_cast<const gn_f32x2*>(stats + ((long long)b * s.G + gn_gidx(kc, s.cpg)) * 2);
+    const __amdgpu_buffer_rsrc_t rdy = gn_slice_rsrc(dy + ((long long)b * s.HW) * dy_ld + c0, ((long long)(s.HW - 1) * dy_ld + f.seg_ch) * ES);
+    const __amdgpu_buffer_rsrc_t rdx = gn_slice_rsrc(dx + ((long long)b * s.HW) * dx_ld + c0, ((long long)(s.HW - 1) * dx_ld + f.seg_ch) * ES);
+    const __amdgpu_buffer_rsrc_t rad = gn_slice_rsrc(addp ? addp + ((long long)b * s.HW) * add_ld + c0 : x, addp ? ((long long)(s.HW - 1) * add_ld + f.seg_ch) * ES : 0);
+    const unsigned h0 = dropout_h0(gn_seed(a));            // (its load, if any, also goes out before the DMA)
+    // slice offsets of pixel row prow + i * R: base + i * step (the slices are < 2^31 bytes: checked by the host)
+    const unsigned x_o = (unsigned)((prow * s.x_ld + j * VEC) * ES), x_st = (unsigned)(f.rows_per_iter * s.x_ld * ES);
+    const unsigned dy_o = (unsigned)((prow * dy_ld + j * VEC) * ES), dy_st = (unsigned)(f.rows_per_iter * dy_ld * ES);
+    const unsigned dx_o = (unsigned)((prow * dx_ld + j * VEC) * ES), dx_st = (unsigned)(f.rows_per_iter * dx_ld * ES);
+    const unsigned ad_o = (unsigned)((prow * add_ld + j * VEC) * ES), ad_st = (unsigned)(f.rows_per_iter * add_ld * ES);
+    auto row_ok = [&](int i) { return active && prow + i * f.rows_per_iter < s.HW; };
+    u32x4 vd[NV];
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
+    for (int i = 0; i < NV; ++i) {                     // issue order x_0, dy_0, x_1, dy_1, ...: pair i is complete at vmcnt(2 (NV-1-i))
+        const bool ok = row_ok(i);
+        unsigned ox = ok ? x_o + i * x_st : GN_OOB, od = ok ? dy_o + i * dy_st : GN_OOB;
+        asm volatile("" : "+v"(ox), "+v"(od));          // one DMA + one load per row on every path (hipcc otherwise splits the select into two predicated DMA instructions)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(xs + (i * NT + wave * 64) * 16), 16, ox, 0, 0, 0);
+        vd[i] = gn_buf_ld16(rdy, od);
+    }
+    if (tid < f.seg_ch) {
+        const float rs = in_st.y, mean = in_st.x, ca = rs * in_g;
+        const unsigned ad = k0 + (unsigned)(tid * 4);
+        gn_lds_wr4(ad + K_RS * kstride, rs); gn_lds_wr4(ad + K_MS * kstride, -mean * rs); gn_lds_wr4(ad + K_MEAN * kstride, mean);
+        gn_lds_wr4(ad + K_CA * kstride, ca); gn_lds_wr4(ad + K_CB * kstride, in_b - mean * ca); gn_lds_wr4(ad + K_GAM * kstride, in_g);
+    }
+    gn_lds_barrier();
+    float ca[VEC], cb[VEC], mean[VEC];
+    gn_lds_rd_consts<VEC>(kcol + K_CA * kstride, ca);
+    gn_lds_rd_consts<VEC>(kcol + K_CB * kstride, cb);
+    gn_lds_rd_consts<VEC>(kcol + K_MEAN * kstride, mean);
+    const float keep_scale = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
+    const unsigned idx0 = (unsigned)(((unsigned)b * (unsigned)s.HW) * (unsigned)s.C + (unsigned)(c0 + j * VEC));   // < 2^32: checked by the host
+    float a1[VEC], a2[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) a1[e] = a2[e] = 0.f;
+    const unsigned myx_ad = lds0 + (unsigned)(tid * 16);
+    static_for_gn<NV>([&](auto ic) {
+        constexpr int i = decltype(ic)::v;
+        gn_wait_vm<2 * (NV - 1 - i)>(0);
         const int p = prow + i * f.rows_per_iter;
-        const unsigned ox = (active && p < s.HW) ? (unsigned)(((long long)p * s.x_ld + j * VEC) * ES) : 0x7ffffff0u;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(xs + (i * 512 + wave * 64) * 16), 16, ox, 0, 0, 0);
+        {                                              // rows without a pixel hold zeros in both operands: dz = 0, nothing is added
+            float fx[VEC], fd[VEC];
+            Elem<T>::unpack(gn_lds_rd16(myx_ad + i * (NT * 16)), fx); Elem<T>::unpack(vd[i], fd);
+            // dz = dy * dropout mask * silu'(z): one hash word per pair of channels
+            const unsigned q0 = (idx0 + (unsigned)p * (unsigned)s.C) >> 1;
+#pragma unroll
+            for (int h = 0; h < VEC; h += 4) {
+                if (a.drop_p > 0.f) {
+#pragma unroll
+                    for (int e = h; e < h + 4; e += 2) {
+                        const unsigned w = dropout_word32(h0, q0 + (e >> 1));
+                        fd[e] = (w & 0xffffu) >= a.thresh16 ? fd[e] * keep_scale : 0.f;
+                        fd[e + 1] = (w >> 16) >= a.thresh16 ? fd[e + 1] * keep_scale : 0.f;
+                    }
+                }
+                if (a.silu) {
+#pragma unroll
+                    for (int e = h; e < h + 4; ++e) fd[e] *= silu_grad_fast_(fx[e] * ca[e] + cb[e]);
+                }
+#pragma unroll
+                for (int e = h; e < h + 4; ++e) { a1[e] += fd[e] * (fx[e] - mean[e]); a2[e] += fd[e]; }
+            }
+            // pass 2 reuses dz (stored at the tensor dtype, as an autograd graph would) instead of redoing the mask and silu'
+            vd[i] = Elem<T>::pack(fd);
+        }
+        __builtin_amdgcn_sched_barrier(0);             // one vector at a time: without the branches of the predicated version hipcc hoists the hash words of all eight vectors (70 spilled registers)
+    });
+    GN_STAMP(2);
+    // `add` (the residual gradient that joins dx) is requested now and consumed in pass 2: its latency hides behind the reduction
+    u32x4 adn = gn_buf_ld16(rad, addp && row_ok(0) ? ad_o : GN_OOB);
+    const float inv_n = 1.0f / ((float)s.HW * s.cpg);
+    gn_block_channel_sum2_w<VEC, NW>(a1, a2, f, active, j, tid, sh_row, sh_ch);        // sh_ch = [sum dz (x - mean) | sum dz]
+    for (int c = tid; c < 2 * f.seg_ch; c += NT) {
+        const bool second = c >= f.seg_ch;
+        const int cc = second ? c - f.seg_ch : c;
+        const float v = second ? sh_ch[c] : sh_ch[c] * sh_k[K_RS * f.seg_ch + cc];      // A1 = rstd * sum dz (x - mean)
+        float* dst = second ? dbeta : dgamma;
+        if (dst) atomicAdd(dst + c0 + cc, v);
+        sh_ch[c] = v * sh_k[K_GAM * f.seg_ch + cc];
+    }
+    __syncthreads();
+    if (tid < 2 * f.GPB) {
+        const int second = tid >= f.GPB, g = tid - second * f.GPB;
+        float acc = 0.f;
+        for (int c = g * s.cpg; c < (g + 1) * s.cpg; ++c) acc += sh_ch[second * f.seg_ch + c];
+        (second ? sh_c2 : sh_c1)[g] = acc * inv_n;
+    }
+    __syncthreads();
+    if (tid < f.seg_ch) {
+        // dx = dz*ca + xhat*k2 + k3 with xhat = x*rs + ms, k2 = -rstd*c1, k3 = -rstd*c2  ->  dx = dz*ca + x*q2 + q3 (two fmas per element)
+        const int g = gn_gidx(tid, s.cpg);
+        const float rs = sh_k[K_RS * f.seg_ch + tid], k2 = -rs * sh_c1[g], k3 = -rs * sh_c2[g];
+        sh_k[K_K2 * f.seg_ch + tid] = rs * k2;
+        sh_k[K_K3 * f.seg_ch + tid] = sh_k[K_MS * f.seg_ch + tid] * k2 + k3;
+    }
+    __syncthreads();
+    GN_STAMP(3);
+    float q2[VEC], q3[VEC], cs[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+        const int c = j * VEC + e;
+        q2[e] = sh_k[K_K2 * f.seg_ch + c]; q3[e] = sh_k[K_K3 * f.seg_ch + c]; cs[e] = 0.f;
     }
     const u32x4* myx = reinterpret_cast<const u32x4*>(xs) + tid;
+    // (opaque copies: hipcc otherwise computes the eight store / load offsets of this pass before pass 1 and parks them in scratch)
+    unsigned dx_o2 = dx_o, ad_o2 = ad_o;
+    int prow2 = prow;
+    asm volatile("" : "+v"(dx_o2), "+v"(ad_o2), "+v"(prow2));
+    auto row_ok2 = [&](int i) { return active && prow2 + i * f.rows_per_iter < s.HW; };
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const bool ok = row_ok2(i);
+        const u32x4 adc = adn;
+        if (i + 1 < NV) adn = gn_buf_ld16(rad, addp && row_ok2(i + 1) ? ad_o2 + (i + 1) * ad_st : GN_OOB);
+        {
+            float fx[VEC], fd[VEC], o[VEC];
+            Elem<T>::unpack(myx[i * NT], fx); Elem<T>::unpack(vd[i], fd);
+            float ad[VEC];
+            if (accumulate) Elem<T>::unpack(gn_buf_ld16(rdx, ok ? dx_o2 + i * dx_st : GN_OOB), o);
+            if (addp) Elem<T>::unpack(adc, ad);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                float r = fd[e] * ca[e] + q3[e];                                   // fd holds dz here
+                r = fx[e] * q2[e] + r;
+                if (addp) r += ad[e];
+                o[e] = accumulate ? o[e] + r : r;
+            }
+            u32x4 packed = Elem<T>::pack(o);
+            if (dx_colsum) {                                   // sums of the values as STORED (what a column sum over dx would read)
+                if (!ok) packed = zero16();
+                float q[VEC];
+                Elem<T>::unpack(packed, q);
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) cs[e] += q[e];
+            }
+            gn_buf_st16(rdx, ok ? dx_o2 + i * dx_st : GN_OOB, packed);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    GN_STAMP(4);
+    if (dx_colsum) {
+        gn_block_channel_sum_w<VEC, NW>(cs, f, active, j, prow, tid, sh_row, sh_ch);
+        for (int c = tid; c < f.seg_ch; c += NT) dx_colsum[(long long)b * colsum_ld + c0 + c] = sh_ch[c];     // one owner per (b, c): plain store
+    }
+    GN_STAMP(5);
+#ifdef GN_TIMING
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    GN_STAMP(6); GN_STAMP(7);
+}
+
+// forward twin: x slice in LDS; pivot-shifted moments accumulated while the slice lands (one pass), then
+// y = drop(silu(x * a_c + b_c)) streamed out.
+template <typename T, int NV, int NT>
+__global__ __launch_bounds__(NT, NT == 512 ? 4 : 2)
+void gn_lds_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, GnShape s, GnFused f, GnApply a) {
+    constexpr int VEC = Elem<T>::VEC, ES = (int)sizeof(T), NW = NT / 64;
+    extern __shared__ __attribute__((aligned(16))) char lsm[];
+    char* xs = lsm;
+    float* sh_row = reinterpret_cast<float*>(lsm + NV * NT * 16);
+    float* sh_ch = sh_row + 2 * NW * f.seg_ch;
+    float* sh_mean = sh_ch + 2 * f.seg_ch;
+    float* sh_rstd = sh_mean + 32;
+    float* sh_k = sh_rstd + 32;                                  // [8][seg_ch]: gamma, beta, pivot of the channel's group
+    enum { K_GAM, K_BET, K_PIV };
+    GN_STAMP(0); GN_STAMP(1);
+    int b, chunk;
+    gn_block_slice(f, b, chunk);
+    const int c0 = chunk * f.seg_ch, tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool active = tid < f.nta;
+    const int j = tid % f.seg_vecs, prow = tid / f.seg_vecs;
+    const unsigned lds0 = (unsigned)(size_t)lsm, k0 = (unsigned)(size_t)sh_k;
+    const unsigned kcol = k0 + (unsigned)(j * VEC * 4), kstride = (unsigned)(f.seg_ch * 4);
+    const __amdgpu_buffer_rsrc_t rx = gn_slice_rsrc(x + ((long long)b * s.HW) * s.x_ld + c0, ((long long)(s.HW - 1) * s.x_ld + f.seg_ch) * ES);
+    // per-channel inputs: all threads load (channel index clamped: no branch around VMEM), the first seg_ch publish; the pivot stays
+    // raw until after the DMA is out — its conversion would otherwise wait for the load right here
+    const int kc = c0 + min(tid, f.seg_ch - 1);
+    const float in_g = a.gamma[kc], in_b = a.beta[kc];
+    T in_praw = x[(long long)b * s.HW * s.x_ld + gn_gidx(kc, s.cpg) * s.cpg];
+    const unsigned x_o = (unsigned)((prow * s.x_ld + j * VEC) * ES), x_st = (unsigned)(f.rows_per_iter * s.x_ld * ES);
+    auto row_ok = [&](int i) { return active && prow + i * f.rows_per_iter < s.HW; };
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        unsigned ox = row_ok(i) ? x_o + i * x_st : GN_OOB;
+        asm volatile("" : "+v"(ox));                     // exactly one DMA per row on every path (hipcc otherwise splits the select into two predicated instructions)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(xs + (i * NT + wave * 64) * 16), 16, ox, 0, 0, 0);
+    }
+    if (tid < f.seg_ch) {
+        const unsigned ad = k0 + (unsigned)(tid * 4);
+        gn_lds_wr4(ad + K_GAM * kstride, in_g); gn_lds_wr4(ad + K_BET * kstride, in_b); gn_lds_wr4(ad + K_PIV * kstride, Elem<T>::ld(&in_praw));
+    }
+    gn_lds_barrier();
+    float piv[VEC];
+    gn_lds_rd_consts<VEC>(kcol + K_PIV * kstride, piv);
     const float n = (float)s.HW * (float)s.cpg;
     // single pass over the slice while it lands: moments of (x - pivot), pivot = the group's first element (gn_pivot) — accurate
     // when |mean| >> std, and the statistics cost nothing beyond the load phase
     float s1[VEC], s2[VEC];
 #pragma unroll
     for (int e = 0; e < VEC; ++e) s1[e] = s2[e] = 0.f;
+    const unsigned myx_ad = lds0 + (unsigned)(tid * 16);
     static_for_gn<NV>([&](auto ic) {
         constexpr int i = decltype(ic)::v;
         gn_wait_vm<NV - 1 - i>(0);
         const int p = prow + i * f.rows_per_iter;
         if (active && p < s.HW) {
             float fv[VEC];
-            Elem<T>::unpack(myx[i * 512], fv);
+            Elem<T>::unpack(gn_lds_rd16(myx_ad + i * (NT * 16)), fv);
 #pragma unroll
             for (int e = 0; e < VEC; ++e) { const float d = fv[e] - piv[e]; s1[e] += d; s2[e] += d * d; }
         }
@@ -813,14 +1059,14 @@ void gn_lds_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, GnShape s, Gn
     __syncthreads();          // timing builds: separate 'waiting for the slowest wave' from the reduction proper
 #endif
     GN_STAMP(3);
-    gn_block_channel_sum2_w<VEC>(s1, s2, f, active, j, tid, sh_row, sh_ch);
+    gn_block_channel_sum2_w<VEC, NW>(s1, s2, f, active, j, tid, sh_row, sh_ch);
     if (tid < f.GPB) {
         float acc = 0.f, sq = 0.f;
         for (int c = tid * s.cpg; c < (tid + 1) * s.cpg; ++c) { acc += sh_ch[c]; sq += sh_ch[f.seg_ch + c]; }
         // fp32 is enough here: the moments are of (x - pivot) with the pivot inside the data, so E[d^2] - E[d]^2 does not cancel
         const float inv_n = 1.0f / n, dmean = acc * inv_n;
         const float var = fmaxf(sq * inv_n - dmean * dmean, 0.f);
-        const float mean_g = piv_g + dmean;
+        const float mean_g = sh_k[K_PIV * f.seg_ch + tid * s.cpg] + dmean;
         float rstd = __builtin_amdgcn_rsqf(var + a.eps);
         rstd = rstd * (1.5f - 0.5f * (var + a.eps) * rstd * rstd);          // one Newton step on the hardware estimate
         sh_mean[tid] = mean_g; sh_rstd[tid] = rstd;
@@ -830,27 +1076,26 @@ void gn_lds_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, GnShape s, Gn
         }
     }
     __syncthreads();
-    float mean[VEC];
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) mean[e] = sh_mean[active ? gn_gidx(j * VEC + e, s.cpg) : 0];
     GN_STAMP(4);
     if (!active) return;
     float ca[VEC], cb[VEC];
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
-        ca[e] = sh_rstd[gn_gidx(j * VEC + e, s.cpg)] * gmv[e];
-        cb[e] = btv[e] - mean[e] * ca[e];
+        const int g = gn_gidx(j * VEC + e, s.cpg);
+        ca[e] = sh_rstd[g] * sh_k[K_GAM * f.seg_ch + j * VEC + e];
+        cb[e] = sh_k[K_BET * f.seg_ch + j * VEC + e] - sh_mean[g] * ca[e];
     }
     const float keep_scale = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
     const unsigned h0 = dropout_h0(gn_seed(a));
     const unsigned idx0 = (unsigned)(((unsigned)b * (unsigned)s.HW) * (unsigned)s.C + (unsigned)(c0 + j * VEC));
-    T* yb = y + ((long long)b * s.HW) * s.y_ld + c0 + j * VEC;
+    const u32x4* myx = reinterpret_cast<const u32x4*>(xs) + tid;
+    const __amdgpu_buffer_rsrc_t ry = gn_slice_rsrc(y + ((long long)b * s.HW) * s.y_ld + c0, ((long long)(s.HW - 1) * s.y_ld + f.seg_ch) * ES);
+    const unsigned y_o = (unsigned)((prow * s.y_ld + j * VEC) * ES), y_st = (unsigned)(f.rows_per_iter * s.y_ld * ES);
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int p = prow + i * f.rows_per_iter;
-        if (p >= s.HW) break;
         float fv[VEC];
-        Elem<T>::unpack(myx[i * 512], fv);
+        Elem<T>::unpack(myx[i * NT], fv);
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
             float z = fv[e] * ca[e] + cb[e];
@@ -866,7 +1111,7 @@ void gn_lds_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, GnShape s, Gn
                 fv[e + 1] = (w >> 16) >= a.thresh16 ? fv[e + 1] * keep_scale : 0.f;
             }
         }
-        stg16(yb + (long long)p * s.y_ld, Elem<T>::pack(fv));
+        gn_buf_st16(ry, row_ok(i) ? y_o + i * y_st : GN_OOB, Elem<T>::pack(fv));
     }
     GN_STAMP(5);
 #ifdef GN_TIMING
@@ -884,6 +1129,10 @@ static const long long gn_fused_max_bytes = getenv("DDPM_GN_FUSED_MAX_KB") ? ato
 
 // LDS-staged kernels: largest group chunk whose x slice fits 64 KiB with <= 8 vectors per thread; prefers >= 512 blocks
 // (two per CU) as long as a pixel segment stays >= 128 bytes
+// slice | sh_row (2 arrays x waves x seg_ch) | sh_ch | group scalars | [8][seg_ch] constants
+static size_t gn_lds_bytes(int nvt, int nt, int seg_ch) {
+    return (size_t)nvt * nt * 16 + ((size_t)2 * (nt / 64) * seg_ch + 2 * seg_ch + 64 + 8 * seg_ch) * sizeof(float);
+}
 static bool gn_lds_plan(const GnShape& s, int esize, GnFused& f, size_t& lds_bytes) {
     const int vec = 16 / esize;
     int best = 0;
@@ -902,13 +1151,11 @@ static bool gn_lds_plan(const GnShape& s, int esize, GnFused& f, size_t& lds_byt
     f.nta = (512 / f.seg_vecs) * f.seg_vecs; f.rows_per_iter = f.nta / f.seg_vecs;
     f.nv = (s.HW + f.rows_per_iter - 1) / f.rows_per_iter;
     if (f.nv > 8) return false;
-    // measured (scripts/gn_bench.py, B = 128): the staged kernels win from 4 vectors per thread on (32^2 x 128: backward 51 vs 70 us,
-    // 16^2 x 256: 25 vs 44 us).  Vector columns that do not divide a wave (384 channels: 3 / 12 vectors per pixel) are fine: the
-    // wave reduction is a strided tree (gn_block_channel_sum_w)
-    if (f.nv < 4 || f.seg_vecs > 32) return false;
+    // Vector columns that do not divide a wave (384 channels: 3 / 12 vectors per pixel) are fine: the wave reduction is a strided
+    // tree (gn_block_channel_sum_w).  One vector per thread = a slice of <= 8 KiB: those run the 256-thread form (callers).
+    if (f.nv < 2 || f.seg_vecs > 32) return false;
     const int nvt = f.nv <= 1 ? 1 : f.nv <= 2 ? 2 : f.nv <= 4 ? 4 : 8;
-    const size_t scratch = (size_t)8 * f.seg_ch;
-    lds_bytes = (size_t)nvt * 512 * 16 + (2 * scratch + 3 * f.seg_ch + 64) * sizeof(float);
+    lds_bytes = gn_lds_bytes(nvt, 512, f.seg_ch);
     static const bool no_remap = getenv("DDPM_GN_NO_XCD_REMAP") != nullptr;
     f.xcd_remap = no_remap ? 0 : 1;
     return lds_bytes <= 160 * 1024 && (long long)s.B * s.HW * s.C < (1ll << 32);
@@ -1160,11 +1407,15 @@ extern "C" int ddpm_groupnorm_silu_fwd(const void* x, long long x_ld, void* y, l
     static const bool no_lds = getenv("DDPM_GN_NO_LDS_FWD") != nullptr;
     GnFused fl; size_t lds_l = 0;
     const bool reg_ok = !no_fused && gn_fused_plan(s, es, f, lds);
-    if (!no_lds && !(reg_ok && f.nv <= 2) && gn_lds_plan(s, es, fl, lds_l)) {        // x staged in LDS: single launch, 1 read + 1 write of HBM
+    // small slices (<= 2 vectors per thread of a 256-thread block): the staged kernel in its 256-thread form
+    static const bool small_reg = getenv("DDPM_GN_SMALL_REG") != nullptr;
+    const bool small = reg_ok && f.nv <= 2 && f.nt == 256 && f.seg_vecs <= 32 && !small_reg && !no_lds;
+    if (small) { fl = f; fl.xcd_remap = 0; lds_l = gn_lds_bytes(f.nv <= 1 ? 1 : 2, 256, f.seg_ch); }
+    if (small || (!no_lds && !(reg_ok && f.nv <= 2) && gn_lds_plan(s, es, fl, lds_l))) {        // x staged in LDS: single launch, 1 read + 1 write of HBM
         const dim3 fgrid(G / fl.GPB, B);
-#define GN_LF(T, NV) do { static bool attr = false; if (!attr) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_lds_fwd_kernel<T, NV>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return DDPM_ERR_LAUNCH; attr = true; } \
-        hipLaunchKernelGGL((gn_lds_fwd_kernel<T, NV>), fgrid, dim3(512), lds_l, st, (const T*)x, (T*)y, s, fl, a); } while (0)
-#define GN_LF_NV(T) do { if (fl.nv <= 1) GN_LF(T, 1); else if (fl.nv <= 2) GN_LF(T, 2); else if (fl.nv <= 4) GN_LF(T, 4); else GN_LF(T, 8); } while (0)
+#define GN_LF(T, NV, NT) do { static bool attr = false; if (!attr) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_lds_fwd_kernel<T, NV, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return DDPM_ERR_LAUNCH; attr = true; } \
+        hipLaunchKernelGGL((gn_lds_fwd_kernel<T, NV, NT>), fgrid, dim3(NT), lds_l, st, (const T*)x, (T*)y, s, fl, a); } while (0)
+#define GN_LF_NV(T) do { if (small) { if (fl.nv <= 1) GN_LF(T, 1, 256); else GN_LF(T, 2, 256); } else if (fl.nv <= 2) GN_LF(T, 2, 512); else if (fl.nv <= 4) GN_LF(T, 4, 512); else GN_LF(T, 8, 512); } while (0)
         if (dtype == DDPM_BF16) GN_LF_NV(bf16_t); else GN_LF_NV(float);
 #undef GN_LF_NV
 #undef GN_LF
@@ -1218,12 +1469,16 @@ extern "C" int ddpm_groupnorm_silu_bwd(const void* x, long long x_ld, const void
     // 1) slices too big for two register vectors per thread: (x, dy) staged in LDS, one launch, one HBM read of each input
     GnFused fl; size_t lds_l = 0;
     const bool small = !no_fused && gn_fused_plan(s, es, f, lds) && f.nv <= 2;
-    if (!small && !no_lds && gn_lds_plan(s, es, fl, lds_l)) {
+    static const bool small_reg = getenv("DDPM_GN_SMALL_REG") != nullptr;
+    const bool small_lds = small && f.nt == 256 && f.seg_vecs <= 32 && !small_reg && !no_lds;
+    if (small_lds) { fl = f; fl.xcd_remap = 0; lds_l = gn_lds_bytes(f.nv <= 1 ? 1 : 2, 256, f.seg_ch); }
+    if (small_lds || (!small && !no_lds && gn_lds_plan(s, es, fl, lds_l))) {
         const dim3 fgrid(G / fl.GPB, B);
-#define GN_LDS(T, NV) do { static bool attr = false; if (!attr) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_lds_bwd_kernel<T, NV>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return DDPM_ERR_LAUNCH; attr = true; } \
-        hipLaunchKernelGGL((gn_lds_bwd_kernel<T, NV>), fgrid, dim3(512), lds_l, st, (const T*)x, (const T*)dy, (T*)dx, s, fl, dy_ld, dx_ld, stats, dgamma, dbeta, a, accumulate, dx_colsum, colsum_ld, (const T*)add, add_ld); } while (0)
-#define GN_LDS_NV(T) do { if (fl.nv <= 1) GN_LDS(T, 1); else if (fl.nv <= 2) GN_LDS(T, 2); else if (fl.nv <= 4) GN_LDS(T, 4); else GN_LDS(T, 8); } while (0)
-        if (dtype == DDPM_BF16) GN_LDS_NV(bf16_t); else GN_LDS_NV(float);
+#define GN_LDS(K, NT, ...) do { static bool attr = false; if (!attr) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(&K<__VA_ARGS__>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return DDPM_ERR_LAUNCH; attr = true; } \
+        hipLaunchKernelGGL((K<__VA_ARGS__>), fgrid, dim3(NT), lds_l, st, (const T_*)x, (const T_*)dy, (T_*)dx, s, fl, dy_ld, dx_ld, stats, dgamma, dbeta, a, accumulate, dx_colsum, colsum_ld, (const T_*)add, add_ld); } while (0)
+#define GN_LDS_NV() do { if (small_lds) { if (fl.nv <= 1) GN_LDS(gn_lds_bwd_kernel, 256, T_, 1, 256); else GN_LDS(gn_lds_bwd_kernel, 256, T_, 2, 256); } \
+                         else if (fl.nv <= 2) GN_LDS(gn_lds_bwd_kernel, 512, T_, 2, 512); else if (fl.nv <= 4) GN_LDS(gn_lds_bwd_kernel, 512, T_, 4, 512); else GN_LDS(gn_lds_bwd8_kernel, 512, T_, 8); } while (0)
+        if (dtype == DDPM_BF16) { typedef bf16_t T_; GN_LDS_NV(); } else { typedef float T_; GN_LDS_NV(); }
 #undef GN_LDS_NV
 #undef GN_LDS
         return check_launch();
@@ -1249,7 +1504,9 @@ extern "C" int ddpm_groupnorm_silu_bwd(const void* x, long long x_ld, const void
         hipLaunchKernelGGL(gn_bwd_reduce_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)x, (const bf16_t*)dy, s, dy_ld, stats, a, partial);
     else
         hipLaunchKernelGGL(gn_bwd_reduce_kernel<float>, grid, block, 0, st, (const float*)x, (const float*)dy, s, dy_ld, stats, a, partial);
-    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3((C + 15) / 16, B), dim3(256), 0, st, s, partial, fin2, dgamma, dbeta);
+    if (s.S <= 64) hipLaunchKernelGGL(gn_bwd_finalize_kernel<16>, dim3((C + 15) / 16, B), dim3(64), 0, st, s, partial, fin2, dgamma, dbeta);
+    else if (s.S <= 192) hipLaunchKernelGGL(gn_bwd_finalize_kernel<8>, dim3((C + 7) / 8, B), dim3(64), 0, st, s, partial, fin2, dgamma, dbeta);
+    else hipLaunchKernelGGL(gn_bwd_finalize_kernel<4>, dim3((C + 3) / 4, B), dim3(64), 0, st, s, partial, fin2, dgamma, dbeta);
     if (dtype == DDPM_BF16)
         hipLaunchKernelGGL(gn_bwd_apply_kernel<bf16_t>, grid, block, 0, st, (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx, s, dy_ld, dx_ld, stats, fin2, dgamma, dbeta, a, accumulate, (const bf16_t*)add, add_ld);
     else
