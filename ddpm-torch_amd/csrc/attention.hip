@@ -174,10 +174,20 @@ __device__ __forceinline__ void product_nt(P1<NJ>& t, const Opnd& X, int r0, con
     bool jok[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) jok[j] = (wc + 4 * j) * 32 < Lpad;
+#ifdef ATTN_TIMING
+    unsigned long long tq[5] = {0, 0, 0, 0, 0};
+#define P1_T(k) do { if (ch == 1) tq[k] = clock64(); } while (0)
+#else
+#define P1_T(k)
+#endif
     for (int ch = 0; ch < nchunks; ++ch) {
+        P1_T(0);
         wait_vm_rt(ch + 1 < nchunks ? per : 0);                   // chunk ch has landed (this wave's part); chunk ch + 1 may stay in flight
+        P1_T(1);
         __builtin_amdgcn_s_barrier();                             // ... everyone's part, and every wave is done with chunk ch - 1
+        P1_T(2);
         if (ch + 2 < nchunks) issue(ch + 2);                      // into the slot of chunk ch - 1
+        P1_T(3);
         const unsigned cur = lds0 + (unsigned)((ch % P1_RING) * slot_bytes);
         // fragment reads one K-step ahead of the MFMAs (two register sets): the wave's LDS latency hides behind its own four MFMAs
         // instead of only behind the partner wave's
@@ -203,7 +213,13 @@ __device__ __forceinline__ void product_nt(P1<NJ>& t, const Opnd& X, int r0, con
                     if (jok[j]) t.acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag(fa[kc & cs][i]), as_frag(fb[kc & cs][j]), t.acc[i][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
+        P1_T(4);
     }
+#ifdef ATTN_TIMING
+    if (g_attn_timing && threadIdx.x == 0 && tq[4])
+        g_attn_timing[(blockIdx.y * gridDim.x + blockIdx.x) * 8 + 7] = ((tq[1] - tq[0]) & 0xffff) | (((tq[2] - tq[1]) & 0xffff) << 16) | (((tq[3] - tq[2]) & 0xffff) << 32) | (((tq[4] - tq[3]) & 0xffff) << 48);
+#endif
+#undef P1_T
     __syncthreads();                                              // every wave is past its reads: the caller may reuse the LDS
 }
 

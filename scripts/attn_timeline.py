@@ -20,5 +20,9 @@ for B, L, C in ((128, 256, 256), (128, 256, 128), (128, 64, 256)):
     w0 = t[:, 0].min()
     names = ["P1 (Q K^T)", "softmax", "write tile", "P2 (P V)", "store issue", "store drain"]
     ph = [((t[:, i + 1] - t[:, i]) / 100.0).median().item() for i in range(6)]
+    q7 = tb.view(-1, 8).cpu()[:, 7]; q7 = q7[q7 != 0]
+    if len(q7):
+        q = [((q7 >> sft) & 0xffff).double().median().item() for sft in (0, 16, 32, 48)]
+        print(f"   P1 chunk 1, wave 0 (clk): vmcnt wait {q[0]:.0f} | barrier {q[1]:.0f} | DMA issue {q[2]:.0f} | reads + MFMA {q[3]:.0f}")
     print(f"B={B} L={L} C={C}: blocks={len(t)} span {((t[:, 6].max() - w0) / 100.0):.1f} us; start spread {((t[:, 0].max() - w0) / 100):.1f} us | " +
           " | ".join(f"{n} {v:.2f}" for n, v in zip(names, ph)), flush=True)
