@@ -538,10 +538,15 @@ __device__ __forceinline__ void gn_lane_reduce(float (&v)[CNT], int sv, int lane
 }
 
 // NARR partial vectors at once (same barriers): sh_row holds NARR x [NW waves][seg_ch], sh_ch NARR x [seg_ch]
+// sum over the cpg consecutive lanes of a channel group (cpg a power of two <= 64, groups aligned to it)
+__device__ __forceinline__ float gn_group_lanes_sum(float v, int cpg) {
+    for (int off = 1; off < cpg; off <<= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+// first stage alone: per-wave totals into sh_row (no barrier after it)
 template <int VEC, int NARR, int NW = 8>
-__device__ __forceinline__ void gn_block_sum_w(float (&v)[NARR * VEC], const GnFused& f, int j, int tid, float* sh_row, float* sh_ch) {
+__device__ __forceinline__ void gn_wave_partials(float (&v)[NARR * VEC], const GnFused& f, int j, int tid, float* sh_row) {
     const int lane = tid & 63, wave = tid >> 6;
-    __syncthreads();                                  // previous users of the scratch are done
     if ((f.seg_vecs & (f.seg_vecs - 1)) == 0) {
         gn_lane_reduce<NARR * VEC, 32>(v, f.seg_vecs, lane, 0, [&](int gi, float val) {
             const int m = gi / VEC, e = gi - m * VEC;        // VEC is a compile-time power of two
@@ -562,6 +567,11 @@ __device__ __forceinline__ void gn_block_sum_w(float (&v)[NARR * VEC], const GnF
             for (int gi = 0; gi < NARR * VEC; ++gi) sh_row[((gi / VEC) * NW + wave) * f.seg_ch + j * VEC + (gi % VEC)] = v[gi];
         }
     }
+}
+template <int VEC, int NARR, int NW = 8>
+__device__ __forceinline__ void gn_block_sum_w(float (&v)[NARR * VEC], const GnFused& f, int j, int tid, float* sh_row, float* sh_ch) {
+    __syncthreads();                                  // previous users of the scratch are done
+    gn_wave_partials<VEC, NARR, NW>(v, f, j, tid, sh_row);
     __syncthreads();
     for (int c = tid; c < NARR * f.seg_ch; c += NW * 64) {
         const int m = c / f.seg_ch, cc = c - m * f.seg_ch;
@@ -912,31 +922,57 @@ void gn_lds_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __r
     // `add` (the residual gradient that joins dx) is requested now and consumed in pass 2: its latency hides behind the reduction
     u32x4 adn = gn_buf_ld16(rad, addp && row_ok(0) ? ad_o : GN_OOB);
     const float inv_n = 1.0f / ((float)s.HW * s.cpg);
+    const bool fast = (s.cpg & (s.cpg - 1)) == 0 && s.cpg <= 64;
+    if (fast) {
+        // two barriers, as in the forward: thread c < seg_ch adds the waves' totals of its channel, emits the parameter gradients, the
+        // cpg lanes of a group add up their gamma-weighted sums by shuffles and every lane derives its channel's pass-2 constants
+        float v2[2 * VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) { v2[e] = a1[e]; v2[VEC + e] = a2[e]; }       // (rows without a pixel contributed zeros)
+        gn_wave_partials<VEC, 2, NW>(v2, f, j, tid, sh_row);
+        __syncthreads();
+        if (tid < f.seg_ch) {
+            float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) { t1 += sh_row[w * f.seg_ch + tid]; t2 += sh_row[(NW + w) * f.seg_ch + tid]; }
+            const float rs = sh_k[K_RS * f.seg_ch + tid], gam = sh_k[K_GAM * f.seg_ch + tid];
+            t1 *= rs;                                                   // A1 = rstd * sum dz (x - mean)
+            if (dgamma) atomicAdd(dgamma + c0 + tid, t1);
+            if (dbeta) atomicAdd(dbeta + c0 + tid, t2);
+            const float c1 = gn_group_lanes_sum(t1 * gam, s.cpg) * inv_n, c2 = gn_group_lanes_sum(t2 * gam, s.cpg) * inv_n;
+            // dx = dz*ca + xhat*k2 + k3 with xhat = x*rs + ms, k2 = -rstd*c1, k3 = -rstd*c2  ->  dx = dz*ca + x*q2 + q3 (two fmas per element)
+            const float k2 = -rs * c1, k3 = -rs * c2;
+            sh_k[K_K2 * f.seg_ch + tid] = rs * k2;
+            sh_k[K_K3 * f.seg_ch + tid] = sh_k[K_MS * f.seg_ch + tid] * k2 + k3;
+        }
+        __syncthreads();
+    } else {
     gn_block_channel_sum2_w<VEC, NW>(a1, a2, f, active, j, tid, sh_row, sh_ch);        // sh_ch = [sum dz (x - mean) | sum dz]
-    for (int c = tid; c < 2 * f.seg_ch; c += NT) {
-        const bool second = c >= f.seg_ch;
-        const int cc = second ? c - f.seg_ch : c;
-        const float v = second ? sh_ch[c] : sh_ch[c] * sh_k[K_RS * f.seg_ch + cc];      // A1 = rstd * sum dz (x - mean)
-        float* dst = second ? dbeta : dgamma;
-        if (dst) atomicAdd(dst + c0 + cc, v);
-        sh_ch[c] = v * sh_k[K_GAM * f.seg_ch + cc];
+        for (int c = tid; c < 2 * f.seg_ch; c += NT) {
+            const bool second = c >= f.seg_ch;
+            const int cc = second ? c - f.seg_ch : c;
+            const float v = second ? sh_ch[c] : sh_ch[c] * sh_k[K_RS * f.seg_ch + cc];      // A1 = rstd * sum dz (x - mean)
+            float* dst = second ? dbeta : dgamma;
+            if (dst) atomicAdd(dst + c0 + cc, v);
+            sh_ch[c] = v * sh_k[K_GAM * f.seg_ch + cc];
+        }
+        __syncthreads();
+        if (tid < 2 * f.GPB) {
+            const int second = tid >= f.GPB, g = tid - second * f.GPB;
+            float acc = 0.f;
+            for (int c = g * s.cpg; c < (g + 1) * s.cpg; ++c) acc += sh_ch[second * f.seg_ch + c];
+            (second ? sh_c2 : sh_c1)[g] = acc * inv_n;
+        }
+        __syncthreads();
+        if (tid < f.seg_ch) {
+            // dx = dz*ca + xhat*k2 + k3 with xhat = x*rs + ms, k2 = -rstd*c1, k3 = -rstd*c2  ->  dx = dz*ca + x*q2 + q3 (two fmas per element)
+            const int g = gn_gidx(tid, s.cpg);
+            const float rs = sh_k[K_RS * f.seg_ch + tid], k2 = -rs * sh_c1[g], k3 = -rs * sh_c2[g];
+            sh_k[K_K2 * f.seg_ch + tid] = rs * k2;
+            sh_k[K_K3 * f.seg_ch + tid] = sh_k[K_MS * f.seg_ch + tid] * k2 + k3;
+        }
+        __syncthreads();
     }
-    __syncthreads();
-    if (tid < 2 * f.GPB) {
-        const int second = tid >= f.GPB, g = tid - second * f.GPB;
-        float acc = 0.f;
-        for (int c = g * s.cpg; c < (g + 1) * s.cpg; ++c) acc += sh_ch[second * f.seg_ch + c];
-        (second ? sh_c2 : sh_c1)[g] = acc * inv_n;
-    }
-    __syncthreads();
-    if (tid < f.seg_ch) {
-        // dx = dz*ca + xhat*k2 + k3 with xhat = x*rs + ms, k2 = -rstd*c1, k3 = -rstd*c2  ->  dx = dz*ca + x*q2 + q3 (two fmas per element)
-        const int g = gn_gidx(tid, s.cpg);
-        const float rs = sh_k[K_RS * f.seg_ch + tid], k2 = -rs * sh_c1[g], k3 = -rs * sh_c2[g];
-        sh_k[K_K2 * f.seg_ch + tid] = rs * k2;
-        sh_k[K_K3 * f.seg_ch + tid] = sh_k[K_MS * f.seg_ch + tid] * k2 + k3;
-    }
-    __syncthreads();
     GN_STAMP(3);
     float q2[VEC], q3[VEC], cs[VEC];
 #pragma unroll
@@ -982,8 +1018,15 @@ void gn_lds_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __r
     }
     GN_STAMP(4);
     if (dx_colsum) {
-        gn_block_channel_sum_w<VEC, NW>(cs, f, active, j, prow, tid, sh_row, sh_ch);
-        for (int c = tid; c < f.seg_ch; c += NT) dx_colsum[(long long)b * colsum_ld + c0 + c] = sh_ch[c];     // one owner per (b, c): plain store
+        __syncthreads();                                       // (the scratch's earlier readers are done)
+        gn_wave_partials<VEC, 1, NW>(cs, f, j, tid, sh_row);
+        __syncthreads();
+        for (int c = tid; c < f.seg_ch; c += NT) {
+            float acc = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) acc += sh_row[w * f.seg_ch + c];
+            dx_colsum[(long long)b * colsum_ld + c0 + c] = acc;      // one owner per (b, c): plain store
+        }
     }
     GN_STAMP(5);
 #ifdef GN_TIMING
@@ -1005,7 +1048,7 @@ void gn_lds_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, GnShape s, Gn
     float* sh_mean = sh_ch + 2 * f.seg_ch;
     float* sh_rstd = sh_mean + 32;
     float* sh_k = sh_rstd + 32;                                  // [8][seg_ch]: gamma, beta, pivot of the channel's group
-    enum { K_GAM, K_BET, K_PIV };
+    enum { K_GAM, K_BET, K_PIV, K_CA, K_CB };
     GN_STAMP(0); GN_STAMP(1);
     int b, chunk;
     gn_block_slice(f, b, chunk);
@@ -1059,6 +1102,43 @@ void gn_lds_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, GnShape s, Gn
     __syncthreads();          // timing builds: separate 'waiting for the slowest wave' from the reduction proper
 #endif
     GN_STAMP(3);
+    float ca[VEC], cb[VEC];
+    const bool fast = (s.cpg & (s.cpg - 1)) == 0 && s.cpg <= 64;
+    if (fast) {
+        // Finish in TWO barriers: per-wave totals -> (barrier) -> thread c < seg_ch adds the waves' totals of its channel, the cpg lanes of
+        // a group add up by shuffles, every lane of the group derives (mean, rstd) and publishes its channel's scale / shift -> (barrier)
+        // -> everyone reads its eight.  (Was: channel sums, group statistics and coefficients in separate steps of 32-512 active threads
+        // with a barrier after each: 2.0 of the 16 x 16 forward's 7.2 us per block.)
+        float v2[2 * VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) { v2[e] = active ? s1[e] : 0.f; v2[VEC + e] = active ? s2[e] : 0.f; }
+        gn_wave_partials<VEC, 2, NW>(v2, f, j, tid, sh_row);
+        __syncthreads();
+        if (tid < f.seg_ch) {
+            float acc = 0.f, sq = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) { acc += sh_row[w * f.seg_ch + tid]; sq += sh_row[(NW + w) * f.seg_ch + tid]; }
+            acc = gn_group_lanes_sum(acc, s.cpg); sq = gn_group_lanes_sum(sq, s.cpg);
+            // fp32 is enough here: the moments are of (x - pivot) with the pivot inside the data, so E[d^2] - E[d]^2 does not cancel
+            const float inv_n = 1.0f / n, dmean = acc * inv_n;
+            const float var = fmaxf(sq * inv_n - dmean * dmean, 0.f);
+            const float mean_g = sh_k[K_PIV * f.seg_ch + tid] + dmean;
+            float rstd = __builtin_amdgcn_rsqf(var + a.eps);
+            rstd = rstd * (1.5f - 0.5f * (var + a.eps) * rstd * rstd);          // one Newton step on the hardware estimate
+            const float cag = rstd * sh_k[K_GAM * f.seg_ch + tid];
+            sh_k[K_CA * f.seg_ch + tid] = cag;
+            sh_k[K_CB * f.seg_ch + tid] = sh_k[K_BET * f.seg_ch + tid] - mean_g * cag;
+            if (a.stats && (tid & (s.cpg - 1)) == 0) {
+                const long long gi = (long long)b * s.G + chunk * f.GPB + gn_gidx(tid, s.cpg);
+                a.stats[gi * 2] = mean_g; a.stats[gi * 2 + 1] = rstd;
+            }
+        }
+        __syncthreads();
+        GN_STAMP(4);
+        if (!active) return;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) { ca[e] = sh_k[K_CA * f.seg_ch + j * VEC + e]; cb[e] = sh_k[K_CB * f.seg_ch + j * VEC + e]; }
+    } else {
     gn_block_channel_sum2_w<VEC, NW>(s1, s2, f, active, j, tid, sh_row, sh_ch);
     if (tid < f.GPB) {
         float acc = 0.f, sq = 0.f;
@@ -1078,12 +1158,12 @@ void gn_lds_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, GnShape s, Gn
     __syncthreads();
     GN_STAMP(4);
     if (!active) return;
-    float ca[VEC], cb[VEC];
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
         const int g = gn_gidx(j * VEC + e, s.cpg);
         ca[e] = sh_rstd[g] * sh_k[K_GAM * f.seg_ch + j * VEC + e];
         cb[e] = sh_k[K_BET * f.seg_ch + j * VEC + e] - sh_mean[g] * ca[e];
+    }
     }
     const float keep_scale = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
     const unsigned h0 = dropout_h0(gn_seed(a));
