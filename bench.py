@@ -41,7 +41,8 @@ PEAK = {"bf16": 2500.0, "fp32": 157.3}                    # dense MFMA TFLOP/s, 
 B_PER_GPU = 128
 VARIANT = {1: "gemm_kernel<4 waves,128x128>", 2: "gemm_kernel<8 waves,128x128>", 3: "gemm_kernel<deep ring,128x128>",
            4: "gemm64_kernel<64x64>", 5: "conv3x3_halo_kernel<256px x 128>", 6: "wgrad3x3_kernel<64x32 x 9 taps>", 7: "pw_conv_kernel<persistent 1x1>", 8: "conv3x3_stream_kernel<16> (persistent, 256px x 128)",
-           9: "wgrad1x1_kernel<128c x 128n slabs>", 10: "conv3x3_stream_kernel<8> (persistent, 64px x 128)"}
+           9: "wgrad1x1_kernel<128c x 128n slabs>", 10: "conv3x3_stream_kernel<8> (persistent, 64px x 128)",
+           11: "conv3x3_few_out_kernel (out_conv)", 12: "conv3x3_few_in_kernel (in_conv)"}
 
 
 def host_cpu():

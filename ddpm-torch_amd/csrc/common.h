@@ -141,6 +141,11 @@ static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0;
 // pointwise.hip: launcher of the persistent 1x1-conv kernel (-1: geometry not covered)
 int ddpm_pointwise_launch(const void* x, long long x_ld, const void* w, void* y, long long y_ld, const float* bias, const void* residual,
                           long long res_ld, int accumulate, int M, int N, int K, int dry, void* stream);
+// edgeconv.hip: launchers of the few-output-channel / few-input-channel 3x3 kernels (-1: geometry not covered)
+int ddpm_edgeconv_few_out_launch(const void* x, long long x_ld, const void* w, void* y, const float* bias, int B, int H, int W, int C, int N,
+                                 int dry, void* stream);
+int ddpm_edgeconv_few_in_launch(const void* x, long long x_ld, const void* w, void* y, long long y_ld, const float* bias, int B, int H, int W,
+                                int C, int N, int dry, void* stream);
 // conv3x3.hip: launcher of the persistent stationary-halo 3x3 kernel (-1: geometry not covered)
 int ddpm_conv3x3_stream_launch(const void* x, long long x_ld, const void* w, void* y, long long y_ld, const float* bias, const float* rowbias,
                                long long rowbias_ld, const void* residual, long long res_ld, int accumulate, int B, int H, int W, int C, int N,

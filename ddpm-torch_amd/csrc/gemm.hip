@@ -1357,7 +1357,7 @@ template __global__ void attn_fwd_kernel<8>(MatDesc, MatDesc, MatDesc, bf16_t*, 
 // ---------------------------------------------------------------------------------------------- host side
 
 // Kernel ids reported by the ddpm_*_variant queries (bench.py attributes its per-launch timings with them):
-// 1 gemm_kernel 4-wave, 2 gemm_kernel 8-wave, 3 gemm_kernel deep ring, 4 gemm64_kernel, 5 conv3x3_halo_kernel, 7 pw_conv_kernel (pointwise.hip), 8 conv3x3_stream_kernel (conv3x3.hip).
+// 1 gemm_kernel 4-wave, 2 gemm_kernel 8-wave, 3 gemm_kernel deep ring, 4 gemm64_kernel, 5 conv3x3_halo_kernel, 7 pw_conv_kernel (pointwise.hip), 8 / 10 conv3x3_stream_kernel (conv3x3.hip, 16 x 16 / 8 x 8 patches), 11 / 12 conv3x3_few_out / few_in (edgeconv.hip).
 // The queries run the SAME dispatch code with `dry` set (nothing is launched): the library keeps no mutable state.
 static const int g_xcd_swizzle = getenv("DDPM_NO_XCD_SWIZZLE") ? 0 : 1;
 static thread_local int g_variant_query = 0, g_variant_result = 0;      // scoped to ONE ddpm_*_variant call (set and cleared inside it)
@@ -1608,6 +1608,14 @@ extern "C" int ddpm_conv2d_nhwc(const void* x, long long x_ld, const void* w, vo
     g.ep.residual = residual; g.ep.res_ld = res_ld; g.ep.accumulate = accumulate;
     g.ep.HW = Ho * Wo; g.ep.dHW = make_fastdiv((unsigned)(Ho * Wo));
     g.splits = splits; g.ep.splitk_ws = splitk_ws; g.ep.splitk_cnt = splitk_cnt;
+    // the UNet's edge convs (3 -> hid, hid -> 3) on full-size images: their own kernels (edgeconv.hip)
+    if (dtype == DDPM_BF16 && R == 3 && S == 3 && stride == 1 && pad_t == 1 && pad_l == 1 && !upsample && !dilate && Ho == H && Wo == W &&
+        !rowbias && !residual && !accumulate && g.M >= 16384) {
+        int rc = -1, id = 0;
+        if (out_mode == 3 && N <= 16) { rc = ddpm_edgeconv_few_out_launch(x, x_ld, w, y, bias, B, H, W, C, N, g.dry, stream); id = 11; }
+        else if (out_mode == 0 && C == 8) { rc = ddpm_edgeconv_few_in_launch(x, x_ld, w, y, y_ld, bias, B, H, W, C, N, g.dry, stream); id = 12; }
+        if (rc >= 0) { if (g.dry) { g_variant_result = id; return DDPM_OK; } return rc; }
+    }
     // hot case: 3x3 / stride 1 / pad 1 on bf16 -> persistent stationary-halo kernel (conv3x3.hip: 16 x 16 patches, or 8 x 8 for the 8 x 8 level)
     // (`splits` is an offer, not a demand: this kernel needs no split; the nearest-2x up-sampled input of the Upsample blocks is gathered in place)
     if (dtype == DDPM_BF16 && R == 3 && S == 3 && stride == 1 && pad_t == 1 && pad_l == 1 && !dilate && out_mode == 0 &&

@@ -244,6 +244,7 @@ class _ConvW:
 _WGRAD_TARGET_BLOCKS = int(os.environ.get("DDPM_WGRAD_BLOCKS", "512"))
 _FUSED_ATTENTION = os.environ.get("DDPM_FUSED_ATTENTION", "1") != "0"
 _FLASH_ATTENTION = os.environ.get("DDPM_FLASH_ATTENTION", "1") != "0"     # 0: the five-product path with L x L tensors (A/B only)
+_FLASH_INFERENCE = os.environ.get("DDPM_FLASH_INFERENCE", "1") != "0"     # inference attention through the training forward kernel (no lse stored)
 _UP_DGRAD_FUSED = os.environ.get("DDPM_UP_DGRAD_FUSED", "1") != "0"    # upsample convs: dgrad as one 4x4 stride-2 conv
 _FOLD_MAX_CHANNELS = 128
 _FOLD_MIN_PIXELS = 16384            # below this the small-grid kernels serve the layer better than the 256-pixel-tile conv
@@ -885,8 +886,10 @@ class _Engine:
         prob = lse = None
         scale = 1.0 / math.sqrt(C)
         flash = _FLASH_ATTENTION and self.T == torch.bfloat16 and Lk <= 256 and Lk % 16 == 0 and C <= 512 and C % 32 == 0
-        if not save and _FUSED_ATTENTION and self.T == torch.bfloat16 and Lk % 128 == 0 and C in (128, 256):
-            # inference: one kernel, the L x L logits / probabilities stay in LDS and registers (unet.py:41-52)
+        if not save and _FUSED_ATTENTION and not (flash and _FLASH_INFERENCE) and self.T == torch.bfloat16 and Lk % 128 == 0 and C in (128, 256):
+            # inference: one kernel, the L x L logits / probabilities stay in LDS and registers (unet.py:41-52); since the training
+            # forward got its DMA rings and the one-butterfly softmax it is the faster one (27 vs 32 us at B=128, L=256, C=256) and serves
+            # inference too; DDPM_FLASH_INFERENCE=0 brings this kernel back
             _hip.call("ddpm_attention_fwd", qkv.ptr, qkv.ld, o.ptr, o.ld, B, Lk, C, scale, self.dcode, _hip.stream())
         elif flash:
             # training (and the geometries the kernel above does not serve): same, plus the row log-sum-exp the backward

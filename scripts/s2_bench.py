@@ -35,7 +35,12 @@ for name, Cin, Cout in (("in_conv", 8, 128), ("out_conv", 128, 8)):
     x, y = V(B, 32, 32, Cin), V(B, 32, 32, Cout)
     w = (torch.randn(Cout, 9 * Cin, device=DEV) / math.sqrt(9 * Cin)).to(dt)
     bias = torch.zeros(Cout, device=DEV)
-    fwd = lambda: ops.conv2d(x, w.data_ptr(), y.ptr, y.ld, Cout, 3, 3, 32, 32, pad_t=1, pad_l=1, bias=bias.data_ptr(), splitk=SK)
+    if name == "out_conv":        # as the engine calls it: 3 real output channels, NCHW fp32 result
+        w = (torch.randn(3, 9 * Cin, device=DEV) / math.sqrt(9 * Cin)).to(dt)
+        o32 = torch.empty(B, 3, 32, 32, device=DEV)
+        fwd = lambda: ops.conv2d(x, w.data_ptr(), o32.data_ptr(), 0, 3, 3, 3, 32, 32, pad_t=1, pad_l=1, bias=bias.data_ptr(), out_mode=3, splitk=SK)
+    else:
+        fwd = lambda: ops.conv2d(x, w.data_ptr(), y.ptr, y.ld, Cout, 3, 3, 32, 32, pad_t=1, pad_l=1, bias=bias.data_ptr(), splitk=SK)
     print(f"{name}: fwd {timeit(fwd):6.1f} us", flush=True)
     if name == "out_conv":
         wd = (torch.randn(Cin, 9 * Cout, device=DEV)).to(dt)

@@ -280,6 +280,31 @@ def test_conv_out3_channels_nchw(dt):
          B, H, H, C, H, H, N, 3, 3, 1, 1, 1, 0, 0, 0, 3, 1, None, None, dt, tol=TOL[0] if dt == 0 else 4e-3)
 
 
+@pytest.mark.parametrize("B,H,W,C,N", [(16, 32, 32, 128, 3), (5, 64, 64, 64, 3), (17, 32, 32, 128, 8), (64, 16, 16, 256, 3)])
+def test_conv_edge_few_output_channels(B, H, W, C, N):
+    """out_conv on full-size images (>= 16384 pixels, bf16): the few-output-channel kernel — NCHW fp32 result, pitched input, bias or none."""
+    ld = C + 16
+    x, w = r(B * H * W, ld, seed=1, dt=1), r(N, 9 * C, seed=2, dt=1, scale=0.03)
+    for bias in (A(r(N, seed=3)), None):
+        y = torch.zeros(B, N, H, W)
+        both("ddpm_conv2d_nhwc", A(x), ld, A(w), A(y, out=True, name="y"), 0, bias, None, 0, None, 0,
+             B, H, W, C, H, W, N, 3, 3, 1, 1, 1, 0, 0, 0, 3, 1, None, None, 1, tol=4e-3)
+    assert _hip.lib().ddpm_conv2d_variant(ld, 0, B, H, W, C, H, W, N, 3, 3, 1, 1, 1, 0, 0, 3, 1, 1) == 11
+
+
+@pytest.mark.parametrize("B,H,W,N", [(16, 32, 32, 128), (5, 64, 64, 64), (17, 32, 32, 96), (64, 16, 16, 128)])
+def test_conv_edge_few_input_channels(B, H, W, N):
+    """in_conv on full-size images (3 image channels stored as 8, bf16): the few-input-channel kernel — pitched NHWC output, bias or none."""
+    C, ld, yld = 8, 8, N + 32
+    x = r(B * H * W, ld, seed=1, dt=1)
+    w = r(N, 9 * C, seed=2, dt=1, scale=0.2)
+    for bias in (A(r(N, seed=3)), None):
+        y = r(B * H * W, yld, seed=6, dt=1)
+        both("ddpm_conv2d_nhwc", A(x), ld, A(w), A(y, out=True, name="y"), yld, bias, None, 0, None, 0,
+             B, H, W, C, H, W, N, 3, 3, 1, 1, 1, 0, 0, 0, 0, 1, None, None, 1, tol=TOL[1])
+    assert _hip.lib().ddpm_conv2d_variant(ld, yld, B, H, W, C, H, W, N, 3, 3, 1, 1, 1, 0, 0, 0, 1, 1) == 12
+
+
 WGRAD_CASES = [
     # B, H, W, C, Creal, N, Nreal, R, stride, pt, pl, ups, Ho, Wo, splits
     ("3x3", 2, 8, 8, 32, 32, 64, 64, 3, 1, 1, 1, 0, 8, 8, 1),
