@@ -899,8 +899,14 @@ void gemm64_kernel(MatDesc A, MatDesc B, Epilogue ep, int M, int N, int K, int t
         const long long tile_id = (long long)batch * gridDim.x + lid;
         float* slabs = ep.splitk_ws + tile_id * nsplit * (T64 * T64);
         float* mine = slabs + (long long)by * (T64 * T64);
-        for (int v = tid; v < T64 * T64; v += NT)
-            __hip_atomic_store(mine + v, cs[(v >> 6) * LD64 + (v & 63)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // 16-byte agent-scope accesses (global_* ... sc1), two per thread and slab: thread q owns elements 4 q .. 4 q + 3 of the tile
+        f32x4 own[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int q = tid + NT * h;
+            own[h] = *reinterpret_cast<const f32x4*>(cs + (q >> 4) * LD64 + (q & 15) * 4);
+            asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(mine + q * 4), "v"(own[h]) : "memory");
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         float* flag = cs + T64;                      // row 0, first padding column
@@ -911,13 +917,27 @@ void gemm64_kernel(MatDesc A, MatDesc B, Epilogue ep, int M, int N, int K, int t
         }
         __syncthreads();
         if (*flag == 0.f) return;
-        for (int v = tid; v < T64 * T64; v += NT) {
-            float* c = cs + (v >> 6) * LD64 + (v & 63);
-            const float own = *c;
-            float a = (by == 0) ? own : __hip_atomic_load(slabs + v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            for (int sp = 1; sp < nsplit; ++sp)
-                a += (sp == by) ? own : __hip_atomic_load(slabs + (long long)sp * (T64 * T64) + v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            *c = a;
+        // all the other runs' vectors are requested before the first is used (up to 7 x 2 loads in flight), then added in run order
+        constexpr int MAXR = 8;
+        f32x4 other[MAXR][2];
+#pragma unroll
+        for (int sp = 0; sp < MAXR; ++sp) {
+            if (sp < nsplit && sp != by) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+                    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(other[sp][h]) : "v"(slabs + (long long)sp * (T64 * T64) + (tid + NT * h) * 4) : "memory");
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            f32x4 a4 = (f32x4)(0.f);
+#pragma unroll
+            for (int sp = 0; sp < MAXR; ++sp)
+                if (sp < nsplit) a4 += (sp == by) ? own[h] : other[sp][h];
+            const int q = tid + NT * h;
+            *reinterpret_cast<f32x4*>(cs + (q >> 4) * LD64 + (q & 15) * 4) = a4;
         }
         __syncthreads();
     }
@@ -1465,7 +1485,14 @@ static int launch_t(GemmArgs& g, hipStream_t st) {
         // two K runs per tile when the caller offers the workspace (splits == 2), the tiles alone leave half the CUs idle and every
         // run still gets >= 4 groups: the loop is bound by what ONE CU can move into its LDS (scripts/g64_timeline.py)
         const int groups64 = ((g.K + BK - 1) / BK + G64 - 1) / G64;
-        const int sp64 = (splits == 2 && (long long)((g.M + T64 - 1) / T64) * t64n * g.batch <= 128 && groups64 >= 8) ? 2 : 1;
+        // (round 3) up to eight runs where the tiles are fewer still — the 16 x 16 / 8 x 8 levels at the CelebA-HQ per-GPU batch of 2 have
+        // 16-64 tiles and K = 2304 / 4608: as long as tiles x runs <= 256 and a run keeps >= 4 groups
+        int sp64 = 1;
+        if (splits == 2) {
+            const long long tiles64 = (long long)((g.M + T64 - 1) / T64) * t64n * g.batch;
+            static const int max_runs = getenv("DDPM_SPLITK64_RUNS") ? atoi(getenv("DDPM_SPLITK64_RUNS")) : 8;
+            while (sp64 * 2 <= max_runs && tiles64 * sp64 * 2 <= 256 && groups64 / (sp64 * 2) >= 4) sp64 *= 2;
+        }
         const dim3 grid64(((g.M + T64 - 1) / T64) * t64n, sp64, g.batch);
 #define LAUNCH64(NG)                                                                                                     \
     do {                                                                                                                 \

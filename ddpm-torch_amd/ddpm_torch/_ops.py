@@ -100,7 +100,7 @@ class SplitK:
         self.ws = None
         self.cnt = None
 
-    # every two-run plan fits: <= 128 tiles x 2 runs x one 128x128 fp32 tile.  Reserved in one piece at first use so that the
+    # every plan of the small-grid kernel fits (2 / 4 / 8 runs, tiles x runs <= 256 slabs of 64 x 64): <= 128 tiles x 2 runs x one 128x128 fp32 tile.  Reserved in one piece at first use so that the
     # pointers a captured graph holds stay valid; a buffer that does get outgrown (DDPM_SPLITK=1 only) is retired, never freed.
     FLOATS64 = 128 * 2 * 16384
 

@@ -30,8 +30,9 @@ extern "C" {
  * flipped/transposed pack and pad = R-1-pad.  out_mode: 0 NHWC dtype (pitch y_ld) | 1 NHWC fp32 | 3 NCHW fp32.
  * splits > 1 splits K over blocks and reduces in-launch (for layers with few output tiles): splitk_ws holds
  * max(ceil(M/128)*ceil(N/128)*16384, ceil(M/64)*ceil(N/64)*4096)*splits floats and splitk_cnt one zero-initialised counter
- * per 64x64 output tile (left zero) — the library picks the tile size; with splits == 2 and at most 128 tiles of 64x64 it is the
- * small-grid kernel with two K runs per tile. */
+ * per 64x64 output tile (left zero) — the library picks the tile size.  splits == 2 is an OFFER to the small-grid kernel (at most
+ * 128 tiles of 64x64): it takes 2, 4 or 8 K runs per tile with tiles x runs <= 256, so for splits == 2 splitk_ws must hold at
+ * least 256*4096 floats (4 MiB) as well. */
 int ddpm_conv2d_nhwc(const void* x, long long x_ld, const void* w, void* y, long long y_ld,
                      const float* bias, const float* rowbias, long long rowbias_ld,
                      const void* residual, long long res_ld,

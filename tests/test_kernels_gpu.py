@@ -138,9 +138,11 @@ def test_conv3x3_upsampled_input_persistent_path(B, Hs, C, N):
 
 
 @pytest.mark.parametrize("dt", [0, 1])
-@pytest.mark.parametrize("B,H,C,N,R", [(128, 4, 256, 256, 3), (128, 4, 512, 256, 3), (100, 4, 256, 192, 3), (16, 8, 1024, 64, 1), (128, 4, 64, 256, 3)])
+@pytest.mark.parametrize("B,H,C,N,R", [(128, 4, 256, 256, 3), (128, 4, 512, 256, 3), (100, 4, 256, 192, 3), (16, 8, 1024, 64, 1), (128, 4, 64, 256, 3),
+                                       (2, 8, 512, 512, 3), (2, 16, 512, 512, 3), (2, 4, 512, 256, 3)])
 def test_conv_small_grid_split_k(B, H, C, N, R, dt):
-    """Layers whose 64x64-tile grid has <= 128 blocks take two K runs per tile when the caller offers the workspace (splits = 2):
+    """Layers whose 64x64-tile grid has <= 128 blocks take two to eight K runs per tile (tiles x runs <= 256, >= 4 groups per run: the last
+    three cases, the CelebA-HQ small levels at B = 2, get 8 / 4 / 8) when the caller offers the workspace (splits = 2):
     slabs + arrival counters, summed in run order by the last arriver.  Results match the emulator, the counters are back at zero,
     two launches agree bit for bit; the last case (9 K-steps of bf16: too short to split, 18 of fp32: split) covers the launcher's >= 8-groups rule both ways."""
     M = B * H * H
@@ -151,7 +153,7 @@ def test_conv_small_grid_split_k(B, H, C, N, R, dt):
     res, y = r(M, yld, seed=5, dt=dt), r(M, yld, seed=6, dt=dt)
     tiles = -(-M // 64) * -(-N // 64)
     assert tiles <= 128
-    ws = torch.zeros(max(tiles * 2 * 4096, -(-M // 128) * -(-N // 128) * 2 * 16384))
+    ws = torch.zeros(max(256 * 4096, tiles * 2 * 4096, -(-M // 128) * -(-N // 128) * 2 * 16384))
     cnt = torch.zeros(1024, dtype=torch.int32)
     pad = R // 2
     for acc in (0, 1):
@@ -262,7 +264,7 @@ def test_conv_fwd_inlaunch_splitk(dt, splits):
     x, w = r(M, C, seed=1, dt=dt), r(N, 9 * C, seed=2, dt=dt, scale=0.02)
     bias, rowb, res = r(N, seed=3), r(B, N, seed=4), r(M, N, seed=5, dt=dt)
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
-    ws, cnt = torch.zeros(tiles * splits * 16384), torch.zeros(tiles * 4, dtype=torch.int32)     # one counter per 64x64 tile
+    ws, cnt = torch.zeros(max(tiles * splits * 16384, 256 * 4096)), torch.zeros(tiles * 4, dtype=torch.int32)     # one counter per 64x64 tile
     for rep in range(2):
         y = r(M, N, seed=6, dt=dt)
         wsd, cntd = ws.cuda(), cnt.cuda()
