@@ -145,9 +145,9 @@ __global__ void gn_apply_kernel(const T* __restrict__ x, T* __restrict__ y, GnSh
 // Statistics of the streaming path, finished ONCE per sample: (mean, rstd) of every group from the S per-slab partial moments, summed in
 // a fixed order (lane l takes slabs l, l + 64, ...; the 64 lane sums meet in a fixed butterfly): deterministic like the partials.
 // final[b][g] = (mean, rstd); `stats` (optional) receives a copy for the backward.
-// Neither finishing kernel uses LDS: in the backward pass the weight-gradient blocks of the side stream hold all 160 KiB of most CUs,
-// and a block that needs even 2 KiB waits for one of them to retire (measured on the CelebA-HQ step: 3 us alone, 27 us average, up
-// to 84 us beside wgrad3x3) — registers and wave slots are still free there.
+// Neither finishing kernel uses LDS (shuffles do): they are 64-thread blocks that fit wherever a wave slot is free.  (They were
+// suspected of queueing for LDS behind the side stream's weight-gradient blocks — 3 us alone, 27 us average on the CelebA-HQ step;
+// the real cause was that those blocks take a CU's whole register file: see the block budget in wgrad.hip.)
 __device__ __forceinline__ double gn_wave_sum(double v) {
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) v += __shfl_xor(v, off, 64);

@@ -404,9 +404,14 @@ static Plan make_plan(int B, int H, int W, int C, int N, int want_splits) {
     const int tiles = p.tiles_n * p.tiles_c;
     int splits = want_splits;
     if (splits <= 0) {
-        // one block per CU (the stage ring fills the LDS): slices so that tiles x slices ~ 256, rounded to whole waves of blocks;
-        // keep >= 4 stages per slice so that the block's prologue / final reduction amortise
-        splits = 256 / tiles;                                  // never more blocks than CUs: a second, nearly empty wave of blocks doubles the time
+        // One block per CU (the stage ring fills the LDS, 512 threads x up to 256 registers fill the register file): a launch that
+        // takes all 256 CUs leaves NOTHING for the main stream — its next kernels, however small, wait for a whole block of this one
+        // (31-93 us; seen as a bimodal 3 / 30+ us duration of the GroupNorm finishing kernels on the CelebA-HQ step).  Half the chip
+        // is the measured optimum: tiles x slices ~ 128 (same-box A/B of the step: 256 -> 10.31, 160 -> 9.95, 128 -> 10.08 / 9.81,
+        // 96 -> 10.3, 64 -> 11.0 ms; CelebA-HQ B = 2: 12.36 -> 11.97 ms), which also halves the slab copies ddpm_wgrad_reduce sums.
+        // Keep >= 4 stages per slice so that the block's prologue / final reduction amortise.
+        static const int cu_budget = getenv("DDPM_WGRAD3_CUS") ? atoi(getenv("DDPM_WGRAD3_CUS")) : 128;
+        splits = cu_budget / tiles;
         const int cap = p.stages >= 4 ? p.stages / 4 : 1;
         if (splits > cap) splits = cap;
         if (splits < 1) splits = 1;
