@@ -45,6 +45,10 @@ VARIANT = {1: "gemm_kernel<4 waves,128x128>", 2: "gemm_kernel<8 waves,128x128>",
            11: "conv3x3_few_out_kernel (out_conv)", 12: "conv3x3_few_in_kernel (in_conv)"}
 
 
+# share of the 256 CUs a wgrad3x3 launch takes (csrc/wgrad.hip: block budget, DDPM_WGRAD3_CUS)
+WGRAD3_CU_SHARE = min(int(os.environ.get("DDPM_WGRAD3_CUS", "128")), 256) / 256.0
+
+
 def host_cpu():
     model, phys = "unknown", set()
     try:
@@ -298,10 +302,13 @@ def main():
         # stable from run to run, and the order rocprofv3's kernel-trace of the product step gives); its `achieved` below is the
         # in-product figure.  The event-bracketed durations of the side stream's weight-gradient kernels include queueing behind
         # main-stream workgroups, which is why the runner-up is listed with them.
-        dom_name = max(agg_iso.items(), key=lambda kv: kv[1][2])[0]
+        # (GPU time = launch duration x the share of the chip the launch occupies: the 3x3 weight-gradient kernel is launched on HALF the CUs
+        #  by design — csrc/wgrad.hip — so that the main stream keeps the other half; its duration doubles, its CU time does not)
+        share = {k: (WGRAD3_CU_SHARE if k.startswith("wgrad3x3_kernel") else 1.0) for k in agg_iso}
+        dom_name = max(agg_iso.items(), key=lambda kv: kv[1][2] * share[kv[0]])[0]
         dom = agg[dom_name]
         achieved = dom[1] / dom[2] / 1e12
-        ru_name, ru = max(((k, v) for k, v in agg.items() if k != dom_name), key=lambda kv: kv[1][2])
+        ru_name, ru = max(((k, v) for k, v in agg.items() if k != dom_name), key=lambda kv: kv[1][2] * share.get(kv[0], 1.0))
         traffic = None
         import glob
         tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")))
@@ -318,9 +325,12 @@ def main():
                     "frac": round(achieved / peak, 4), "traffic": traffic,
                     "launches_per_step": dom[0], "avg_launch_us": round(dom[2] / dom[0] * 1e6, 2),
                     "note": "durations as they occur in the product step (two HIP streams share the GPU); `isolated` = same step, one stream; "
-                            "dominant = most GPU time in the isolated pass",
+                            "dominant = most GPU time (duration x share of the CUs a launch occupies) in the isolated pass",
                     "runner_up": {"kernel": ru_name, "achieved": round(ru[1] / ru[2] / 1e12, 1), "frac": round(ru[1] / ru[2] / 1e12 / peak, 4),
-                                  "launches_per_step": ru[0], "avg_launch_us": round(ru[2] / ru[0] * 1e6, 2)},
+                                  "launches_per_step": ru[0], "avg_launch_us": round(ru[2] / ru[0] * 1e6, 2),
+                                  **({"cu_share": share[ru_name], "frac_of_occupied_cus": round(ru[1] / ru[2] / 1e12 / (peak * share[ru_name]), 4),
+                                      "note": "launched on half the CUs by design (the main stream keeps the other half): frac_of_occupied_cus prices it against the CUs it holds"}
+                                     if share.get(ru_name, 1.0) != 1.0 else {})},
                     "all_mfma_kernels": total(agg, peak), "per_kernel": table(agg, peak),
                     "isolated": {"all_mfma_kernels": total(agg_iso, peak), "per_kernel": table(agg_iso, peak)}}
         out = {"metric": "training imgs/s/GPU + 1000-step DDPM samples/s, CIFAR-10 UNet @1/2/4/8 MI355X",
