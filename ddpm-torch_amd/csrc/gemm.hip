@@ -1479,8 +1479,9 @@ static int launch_t(GemmArgs& g, hipStream_t st) {
     dim3 grid(tiles_m * tiles_n, splits, g.batch);
     // small grids of k-contiguous products: 64x64 tiles put 4x as many CUs to work (see gemm64_kernel)
     static const bool no_t64 = getenv("DDPM_GEMM_NO_T64") != nullptr;
+    static const int t64_max_tiles = getenv("DDPM_GEMM_T64_TILES") ? atoi(getenv("DDPM_GEMM_T64_TILES")) : 64;
     if (!no_t64 && !g.A.trans && !g.B.trans && (splits == 1 || (splits == 2 && g.ep.splitk_ws && g.ep.splitk_cnt)) &&
-        (g.ep.mode == 0 || g.ep.mode == 1) && (long long)tiles_m * tiles_n * g.batch <= 128) {
+        (g.ep.mode == 0 || g.ep.mode == 1) && (long long)tiles_m * tiles_n * g.batch <= t64_max_tiles) {
         const int t64n = (g.N + T64 - 1) / T64;
         // two K runs per tile when the caller offers the workspace (splits == 2), the tiles alone leave half the CUs idle and every
         // run still gets >= 4 groups: the loop is bound by what ONE CU can move into its LDS (scripts/g64_timeline.py)
