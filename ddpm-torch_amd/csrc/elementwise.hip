@@ -450,6 +450,25 @@ __global__ void add_i64_kernel(long long* __restrict__ t, int B, long long delta
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < B) t[i] += delta;
 }
+// out[r][:] = table[idx[r]][:] (fp32 rows of row_len floats, a multiple of 4): the sampler's per-step time biases out of the table
+// precomputed for every timestep (all samples of a sampling step share one t; the table replaces the embedding MLP's six launches).
+// An index outside [0, table_rows) poisons the row with NaN, as ddpm_p_sample_step does for t.
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ table, const long long* __restrict__ idx, float* __restrict__ out,
+                                                          int row_len, int table_rows) {
+    const long long t = idx[blockIdx.x];
+    const bool ok = t >= 0 && t < table_rows;
+    const f32x4* src = reinterpret_cast<const f32x4*>(table + (ok ? t : 0) * row_len);
+    f32x4* dst = reinterpret_cast<f32x4*>(out + (long long)blockIdx.x * row_len);
+    const f32x4 poison = (f32x4)(__builtin_nanf(""));
+    for (int i = threadIdx.x; i < row_len / 4; i += 256) dst[i] = ok ? src[i] : poison;
+}
+extern "C" int ddpm_gather_rows_f32(const float* table, const long long* idx, float* out, int rows, int row_len, int table_rows, void* stream) {
+    if (!table || !idx || !out) return DDPM_ERR_NULL;
+    if (rows <= 0 || row_len <= 0 || row_len % 4 || table_rows <= 0) return DDPM_ERR_SHAPE;
+    if (!aligned16(table) || !aligned16(out)) return DDPM_ERR_ALIGN;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, table, idx, out, row_len, table_rows);
+    return check_launch();
+}
 extern "C" int ddpm_gather_i64(const long long* idx, const long long* map, long long* out, int B, void* stream) {
     if (!idx || !map || !out) return DDPM_ERR_NULL;
     hipLaunchKernelGGL(gather_i64_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, idx, map, out, B);

@@ -56,6 +56,7 @@ PROTOTYPES = {
     "ddpm_p_sample_step": [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, P],
     "ddpm_gather_i64": [P, P, P, I, P],
     "ddpm_add_i64": [P, I, L, P],
+    "ddpm_gather_rows_f32": [P, P, P, I, I, I, P],
     "ddpm_silu_fwd": [P, P, L, P],
     "ddpm_silu_bwd": [P, P, P, L, I, P],
     "ddpm_colsum": [P, L, P, L, P, I, I, I, I, P],

@@ -14,6 +14,7 @@ per-sample coefficients by ``t`` on the device:
 Arithmetic is fp32 with the reference's operation order (no fused multiply-add contraction) so identical
 (x_t, t, noise) give matching results.  No CPU path: CPU tensors raise.
 """
+import contextlib
 import os
 
 import torch
@@ -222,6 +223,10 @@ class GaussianDiffusion:
         return t
 
     def _sample_loop(self, denoise_fn, shape, device, noise, seed, on_step=None, z_stream=None):
+        with self._time_tables(denoise_fn):
+            return self._sample_loop_impl(denoise_fn, shape, device, noise, seed, on_step, z_stream)
+
+    def _sample_loop_impl(self, denoise_fn, shape, device, noise, seed, on_step=None, z_stream=None):
         """The T-step (or S-step) loop.  ``z_stream`` (parity tests only) is an iterator of per-step noise tensors
         that replaces the generator draws, so an identical (x_T, z_1..z_T) stream can be injected.
 
@@ -256,6 +261,20 @@ class GaussianDiffusion:
         return x_t
 
     # ---- captured sampling step
+    @contextlib.contextmanager
+    def _time_tables(self, denoise_fn):
+        """While a sampling loop (or the capture of its step) runs, the UNets under ``denoise_fn`` take their per-block time biases from
+        the [T][sum Cout] table of all timesteps instead of running the embedding MLP every step (models/unet.py: time_table)."""
+        engines = self._engines_of(denoise_fn) if os.environ.get("DDPM_TIME_TABLE", "1") != "0" else None
+        for e in engines or ():
+            e.enable_time_table(self.timesteps)
+            e.tt_on = True
+        try:
+            yield
+        finally:
+            for e in engines or ():
+                e.tt_on = False
+
     @staticmethod
     def _engines_of(denoise_fn):
         """Engines of every UNet of this package reachable from ``denoise_fn`` (their derived weight copies must be
@@ -317,7 +336,7 @@ class GaussianDiffusion:
         device = torch.device(device)
         if device.type != "cuda" or os.environ.get("DDPM_TORCH_AMD_GRAPH", "1") == "0" or self._num_steps() < 4:
             return False
-        with torch.inference_mode():
+        with torch.inference_mode(), self._time_tables(denoise_fn):
             return self._graph_entry(denoise_fn, tuple(shape), device, default_rng=not seeded) is not None
 
     def _capture_sample_step(self, denoise_fn, shape, device, default_rng):

@@ -300,6 +300,8 @@ class _Engine:
         self.freqs = torch.exp(-torch.arange(half, dtype=torch.float32) * rate).to(self.device)   # functions.py:19-20
         self.fc_w = self.fc_b = self.fc_table = None       # concatenated time-bias projection (persistent: graph replays read it)
         self.fc_ver = None
+        self.tt = None                                    # [T][sum Cout] time biases of every timestep (sampling only; see time_table)
+        self.tt_T, self.tt_key, self.tt_idx, self.tt_on = 0, None, None, False
         self._ws = None
         self._ws_need, self._ws_retired = {}, []
         self.drop_calls = 0
@@ -408,6 +410,50 @@ class _Engine:
     def _launch_fc(self):
         _hip.call("ddpm_mt_gather_f32", self.fc_table.data_ptr(), self.fc_table.shape[0], _hip.stream())
 
+    # ---- time biases of ALL timesteps (sampling).  Every ResidualBlock's fc(act(t_emb)) depends on t alone (unet.py:86 behind UNet.embed
+    # :122-126,207), and all samples of a sampling step share one t: the sampler asks for the [T][sum Cout] table once per weight version
+    # and each step gathers its rows — one launch instead of the embedding MLP's six (sinusoid, 3 fp32 GEMMs, 2 SiLUs: ~60 us of a
+    # 3-ms step).  Only forwards issued by a sampler (tt_on, set around its loop / capture) read it: t is known to lie inside the schedule
+    # there; training and plain eval calls run the MLP.
+    def enable_time_table(self, T):
+        """Called by the samplers (GaussianDiffusion / DDIM) with the length of the schedule the model is evaluated on."""
+        if T > self.tt_T:
+            self.tt_T, self.tt_key = int(T), None
+            if self.tt is not None:
+                self._ws_retired.append(self.tt)          # a captured step may still point at it
+            with torch.inference_mode(False):             # (the samplers run under inference_mode: a tensor born there could not be refilled outside it)
+                self.tt = self._f32(self.tt_T, self.tb_total)
+                self.tt_idx = torch.arange(self.tt_T, dtype=torch.int64, device=self.device)
+
+    def _embed_versions(self):
+        m = self.m
+        return tuple((p._version, p.data_ptr()) for p in (m.embed[0].weight, m.embed[0].bias, m.embed[2].weight, m.embed[2].bias))
+
+    def _time_biases(self, t, B):
+        """[B][sum Cout] time biases (+ conv1 biases) of timesteps ``t``, and what the backward of the path needs."""
+        m, E = self.m, self.E
+        temb = self._f32(B, self.hid)
+        _hip.call("ddpm_timestep_embedding", t.data_ptr(), self.freqs.data_ptr(), temb.data_ptr(), B, self.hid, _hip.stream())
+        e1 = self._linear(temb, m.embed[0].weight, m.embed[0].bias, B, E, self.hid)
+        s1 = self._f32(B, E)
+        _hip.call("ddpm_silu_fwd", e1.data_ptr(), s1.data_ptr(), B * E, _hip.stream())
+        t_emb = self._linear(s1, m.embed[2].weight, m.embed[2].bias, B, E, E)
+        s_t = self._f32(B, E)                                  # SiLU(t_emb): shared by every block (unet.py:86)
+        _hip.call("ddpm_silu_fwd", t_emb.data_ptr(), s_t.data_ptr(), B * E, _hip.stream())
+        fc_w, fc_b = self._fc_all()
+        tb = self._linear(s_t, fc_w, fc_b, B, self.tb_total, E)   # [B, sum Cout]: every block's time bias (+conv1 bias)
+        return tb, (temb, e1, s1, t_emb, s_t, fc_w)
+
+    def time_table(self):
+        """The table, rebuilt (in place: captured steps hold its address) when a parameter of the path changed."""
+        self._fc_all()
+        key = (self.fc_ver, self._embed_versions())
+        if key != self.tt_key:
+            tb, _ = self._time_biases(self.tt_idx, self.tt_T)
+            self.tt.copy_(tb)
+            self.tt_key = key
+        return self.tt
+
     # ---- derived-copy management for replayed hipGraphs (the kernels of a captured step read the packed copies through
     # fixed addresses; nothing inside a graph can look at version counters)
     def ensure_fresh(self, need_dgrad=False):
@@ -415,6 +461,8 @@ class _Engine:
         master parameters — what forward() does on entry; callers replaying a captured graph do it before the replay."""
         self._refresh_packs(need_dgrad)
         self._fc_all()
+        if self.tt_T:
+            self.time_table()
 
     def refresh_unconditionally(self):
         """Launch the derivation kernels regardless of version counters (the tail of a captured training step: the
@@ -701,20 +749,14 @@ class _Engine:
             st["seed"] = 0
 
         # ---- time embedding path (fp32; functions.py:10-26, unet.py:122-126,207)
-        E = self.E
-        temb = self._f32(B, self.hid)
-        _hip.call("ddpm_timestep_embedding", t.data_ptr(), self.freqs.data_ptr(), temb.data_ptr(), B, self.hid, _hip.stream())
-        e1 = self._linear(temb, m.embed[0].weight, m.embed[0].bias, B, E, self.hid)
-        s1 = self._f32(B, E)
-        _hip.call("ddpm_silu_fwd", e1.data_ptr(), s1.data_ptr(), B * E, _hip.stream())
-        t_emb = self._linear(s1, m.embed[2].weight, m.embed[2].bias, B, E, E)
-        s_t = self._f32(B, E)                                  # SiLU(t_emb): shared by every block (unet.py:86)
-        _hip.call("ddpm_silu_fwd", t_emb.data_ptr(), s_t.data_ptr(), B * E, _hip.stream())
-        fc_w, fc_b = self._fc_all()
-        tb = self._linear(s_t, fc_w, fc_b, B, self.tb_total, E)   # [B, sum Cout]: every block's time bias (+conv1 bias)
+        if not save and self.tt_on:                              # inside a sampler: the rows of the precomputed table (see time_table)
+            tb = self._f32(B, self.tb_total)
+            _hip.call("ddpm_gather_rows_f32", self.time_table().data_ptr(), t.data_ptr(), tb.data_ptr(), B, self.tb_total, self.tt_T, _hip.stream())
+        else:
+            tb, saved = self._time_biases(t, B)
+            if save:
+                st["temb_saved"] = saved
         st["tb"] = tb
-        if save:
-            st["temb_saved"] = (temb, e1, s1, t_emb, s_t, fc_w)
 
         # ---- decoder concat buffers: encoder outputs are written straight into their slice
         n, L = self.n, self.L

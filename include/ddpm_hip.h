@@ -205,6 +205,10 @@ int ddpm_p_sample_step(const float* x_t, const float* model_out, const float* z,
 /* subsequence.gather(0, t) (ddim.py:101) and t += delta (t.fill_ in diffusion.py:172, device-side for graph replay) */
 int ddpm_gather_i64(const long long* idx, const long long* map, long long* out, int B, void* stream);
 int ddpm_add_i64(long long* t, int B, long long delta, void* stream);
+/* out[r][:] = table[idx[r]][:], fp32 rows of row_len (% 4 == 0) floats; idx outside [0, table_rows) -> the row is NaN.  Sampling only: every
+ * ResidualBlock's time bias fc(act(t_emb)) (unet.py:86, with UNet.embed :122-126,207 in front of it) depends on t alone, so the sampler
+ * precomputes the [T][sum Cout] table once per weight version and each step gathers its rows instead of running the embedding MLP. */
+int ddpm_gather_rows_f32(const float* table, const long long* idx, float* out, int rows, int row_len, int table_rows, void* stream);
 
 /* nn.SiLU on the time-embedding path (unet.py:86,124) */
 int ddpm_silu_fwd(const float* x, float* y, long long n, void* stream);

@@ -395,6 +395,13 @@ class Emulator:
         ii = i64(idx, B)
         i64(out, B)[...] = i64(mp, int(ii.max()) + 1)[ii]
 
+    def ddpm_gather_rows_f32(self, table, idx, out, rows, row_len, table_rows, st):
+        ii = i64(idx, rows)
+        tab = f32(table, table_rows * row_len).reshape(table_rows, row_len)
+        o = f32(out, rows * row_len).reshape(rows, row_len)
+        ok = (ii >= 0) & (ii < table_rows)
+        o[...] = np.where(ok[:, None], tab[np.clip(ii, 0, table_rows - 1)], np.nan)
+
     def ddpm_add_i64(self, t, B, delta, st):
         i64(t, B)[...] += delta
 

@@ -307,6 +307,19 @@ def test_conv_edge_few_input_channels(B, H, W, N):
     assert _hip.lib().ddpm_conv2d_variant(ld, yld, B, H, W, C, H, W, N, 3, 3, 1, 1, 1, 0, 0, 0, 1, 1) == 12
 
 
+def test_gather_rows_time_table():
+    """Rows of the sampler's [T][sum Cout] time-bias table by timestep; an index outside the table poisons its row."""
+    T, L, B = 37, 4992, 9
+    table = r(T, L, seed=1)
+    idx = torch.tensor([0, 36, 5, 5, 17, 1, 36, 0, 20], dtype=torch.int64)
+    both("ddpm_gather_rows_f32", A(table), A(idx), A(torch.zeros(B, L), out=True, name="rows"), B, L, T, tol=0.0)
+    td, od = table.cuda(), torch.zeros(3, L, device="cuda")
+    bad = torch.tensor([3, T, -1], dtype=torch.int64, device="cuda")
+    _hip.call("ddpm_gather_rows_f32", td.data_ptr(), bad.data_ptr(), od.data_ptr(), 3, L, T, _hip.stream())
+    torch.cuda.synchronize()
+    assert torch.equal(od[0].cpu(), table[3]) and bool(torch.isnan(od[1:]).all())
+
+
 WGRAD_CASES = [
     # B, H, W, C, Creal, N, Nreal, R, stride, pt, pl, ups, Ho, Wo, splits
     ("3x3", 2, 8, 8, 32, 32, 64, 64, 3, 1, 1, 1, 0, 8, 8, 1),
