@@ -1,15 +1,18 @@
 // Fused GroupNorm(32, eps) [+ SiLU] [+ dropout] forward / backward over NHWC activations (gfx950).
 // Reference semantics: nn.GroupNorm(32, C, eps=1e-6) -> SiLU -> Dropout (ddpm_torch/models/unet.py:18-20,85-87).
 //
-// HBM-bound: algorithmic traffic is one read of x + one write of y per element.  Two launches:
-//   gn_stats : grid (S, B) — each block reduces a slab of pixels of one sample to per-group partial
-//              (sum, sum of squares) with 16-byte coalesced loads and a wavefront/LDS reduction;
-//   gn_apply : grid (S, B) — combines the S partials (fp64), builds per-channel scale/shift in LDS and
-//              streams y = silu(x*a_c + b_c) [* keep/(1-p)]; the second read of x is an L2/MALL hit at
-//              the CIFAR sizes (<= 64 MB per tensor vs 256 MB Infinity Cache).
-// Backward mirrors it: gn_bwd_reduce (per-slab per-channel sums of dz and dz*xhat), gn_bwd_apply (per-sample group
-// coefficients from those sums + dgamma/dbeta atomics by the slab-0 blocks, then dx).  SiLU and the dropout mask are
-// recomputed.
+// Algorithmic traffic: one read of x + one write of y per element (backward: x, dy read, dx written).  Three families of kernels:
+//   staged (gn_lds_fwd / gn_lds_bwd / gn_lds_bwd8): ONE launch, a block owns (sample, chunk of groups) = all pixels x <= 64 KiB of
+//       channels; the x slice is DMA'd into LDS, statistics are taken while it lands, the result is produced from LDS.  512 threads
+//       for the 16-64 KiB slices, 256 for the <= 8 KiB ones (the 8x8 / 4x4 levels).  Every tensor of the CIFAR / CelebA-64 nets at
+//       B = 128 goes through here; they are VALU-bound (exp, rcp, the dropout hash), not memory-bound — see DESIGN.md;
+//   streaming (gn_stats + gn_stats_finalize + gn_apply; gn_bwd_reduce + gn_bwd_finalize + gn_bwd_apply): slices that do not fit
+//       (the 256 x 256 ... 64 x 64 tensors of CelebA-HQ at B = 2, the 32 x 32 x 384 concat tensors): per-slab partial moments /
+//       channel sums, finished once per sample in a fixed order, then one streaming pass; the second read of x is an L2 / Infinity
+//       Cache hit at these sizes;
+//   register-resident (gn_reg_fwd / gn_reg_bwd): the first single-launch form, kept as the fallback for geometries the staged plan
+//       declines.
+// SiLU and the dropout mask are recomputed in the backward (one hash word per two channels).
 #include "common.h"
 #include <stdlib.h>
 
