@@ -7,7 +7,7 @@
 //       for the 16-64 KiB slices, 256 for the <= 8 KiB ones (the 8x8 / 4x4 levels).  Every tensor of the CIFAR / CelebA-64 nets at
 //       B = 128 goes through here; they are VALU-bound (exp, rcp, the dropout hash), not memory-bound — see DESIGN.md;
 //   streaming (gn_stats + gn_stats_finalize + gn_apply; gn_bwd_reduce + gn_bwd_finalize + gn_bwd_apply): slices that do not fit
-//       (the 256 x 256 ... 64 x 64 tensors of CelebA-HQ at B = 2, the 32 x 32 x 384 concat tensors): per-slab partial moments /
+//       (the 256 x 256 ... 64 x 64 tensors of CelebA-HQ at B = 2): per-slab partial moments /
 //       channel sums, finished once per sample in a fixed order, then one streaming pass; the second read of x is an L2 / Infinity
 //       Cache hit at these sizes;
 //   register-resident (gn_reg_fwd / gn_reg_bwd): the first single-launch form, kept as the fallback for geometries the staged plan
