@@ -290,14 +290,15 @@ class GaussianDiffusion:
         engines = self._engines_of(denoise_fn)
         # engine serials: model.to() / .float() / set_compute_dtype() re-create the engine (packed weights, workspaces) — a step
         # captured against the previous one points at freed memory and must never be replayed
+        # ... and so is the time-bias table the step gathers from: a sampler with a longer schedule re-allocates it
         key = (id(denoise_fn), shape, str(device), default_rng, getattr(denoise_fn, "training", None),
-               tuple((e.serial, e.T) for e in engines) if engines else None)
+               tuple((e.serial, e.T, e.tt.data_ptr() if e.tt_on and e.tt is not None else 0) for e in engines) if engines else None)
         ent = cache.get(key)
         if ent is not None and ent["ref"]() is not denoise_fn:
             ent = None                                            # the id was recycled by another object
         if ent is None and engines:
             live = {e.serial for e in engines}
-            for k in [k for k, v in cache.items() if v["ref"]() is denoise_fn and k[5] and {sr for sr, _ in k[5]} != live]:
+            for k in [k for k, v in cache.items() if v["ref"]() is denoise_fn and k[5] and {q[0] for q in k[5]} != live]:
                 cache.pop(k)                                      # entries of this denoiser's earlier engines: dead weight (and dead pointers)
         if ent is None:
             ent = self._capture_sample_step(denoise_fn, shape, device, default_rng)

@@ -234,6 +234,47 @@ def test_sampler_graph_is_cached_and_follows_weight_changes(golden, monkeypatch)
     assert torch.equal(c_graph, c_eager)
 
 
+def test_sampler_time_table_follows_weights_and_schedule_length(golden, monkeypatch):
+    """The samplers take the per-block time biases from a [T][sum Cout] table of all timesteps (one gather per step instead of the
+    embedding MLP): same samples as with the MLP run every step (DDPM_TIME_TABLE=0) up to the fp32 summation order of the two GEMM
+    shapes; a sampler with a LONGER schedule re-allocates the table, after which the first sampler must not replay a step captured
+    against the old one — checked across an in-place weight change in between."""
+    m, _ = tiny_from_golden(golden("g3_model.pt"))
+    m.eval()
+    mk = lambda T: ddpm_torch.GaussianDiffusion(ddpm_torch.get_beta_schedule("linear", 1e-4, 0.02, T), "eps", "fixed-large", "mse")
+    d20, d40 = mk(20), mk(40)
+    shape = (2, 3, 8, 8)
+
+    def both_ways(dif, seed):
+        monkeypatch.setenv("DDPM_TIME_TABLE", "1")
+        a = dif.p_sample(m, shape=shape, device=DEV, seed=seed)
+        monkeypatch.setenv("DDPM_TIME_TABLE", "0")
+        b = dif.p_sample(m, shape=shape, device=DEV, seed=seed)
+        monkeypatch.setenv("DDPM_TIME_TABLE", "1")
+        assert torch.isfinite(a).all() and float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()), float((a - b).abs().max())
+        return a
+
+    a20 = both_ways(d20, 3)
+    eng = m.engine()
+    assert eng.tt_T == 20 and not eng.tt_on                      # the flag is only up inside a sampler
+    both_ways(d40, 4)
+    assert eng.tt_T == 40
+    with torch.no_grad():
+        for p in m.parameters():
+            p.mul_(1.02)
+    b20 = both_ways(d20, 3)                                      # new weights, table moved: a stale captured step would reproduce a20
+    assert not torch.equal(a20, b20)
+    # a t outside the table (a schedule longer than any sampler announced) cannot be read silently: rows come back as NaN
+    t_bad = torch.full((2,), 45, dtype=torch.int64, device=DEV)
+    eng.tt_on = True
+    try:
+        with torch.no_grad():
+            y = m(torch.zeros(shape, device=DEV), t_bad)
+    finally:
+        eng.tt_on = False
+    assert bool(torch.isnan(y).any())
+
+
 def test_ddim50_celeba_quadratic_eta1_vs_eager(monkeypatch):
     """BASELINE config 4 network at 64x64 (B = 2): DDIM (quadratic, eta = 1: noise is consumed) graph == eager, finite."""
     from tests.test_unet_gpu import CELEBA
