@@ -42,7 +42,8 @@ B_PER_GPU = 128
 VARIANT = {1: "gemm_kernel<4 waves,128x128>", 2: "gemm_kernel<8 waves,128x128>", 3: "gemm_kernel<deep ring,128x128>",
            4: "gemm64_kernel<64x64>", 5: "conv3x3_halo_kernel<256px x 128>", 6: "wgrad3x3_kernel<64x32 x 9 taps>", 7: "pw_conv_kernel<persistent 1x1>", 8: "conv3x3_stream_kernel<16> (persistent, 256px x 128)",
            9: "wgrad1x1_kernel<128c x 128n slabs>", 10: "conv3x3_stream_kernel<8> (persistent, 64px x 128)",
-           11: "conv3x3_few_out_kernel (out_conv)", 12: "conv3x3_few_in_kernel (in_conv)"}
+           11: "conv3x3_few_out_kernel (out_conv)", 12: "conv3x3_few_in_kernel (in_conv)",
+           13: "conv3x3_pc_kernel (persistent, 256px x 128, loader + consumer waves)"}
 
 
 # share of the 256 CUs a wgrad3x3 launch takes (csrc/wgrad.hip: block budget, DDPM_WGRAD3_CUS)

@@ -36,6 +36,7 @@ struct CsArgs {
     int B, H, W, C, N, K;                                 // H, W: OUTPUT (= virtual input) image; ups = 1: x is stored at half that size (nearest 2x)
     int ups;
     int tiles_y, tiles_x, tiles_n, total_tiles, xcd;
+    int flags;                                            // conv3x3_pc_kernel: bit 0 = consumers at s_setprio 1
     FastDiv d_tiles_n, d_tpi, d_tiles_x;
 };
 
@@ -589,6 +590,404 @@ void conv3x3_stream_kernel(CsArgs a) {
 #endif
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// Round 4: the same tile, LDS image and K sequence with the waves SPECIALISED (16 x 16 patches only).
+//
+// What the counters said about the kernel above (profiles/r04_conv3x3_lds_counters.txt): no bank conflicts, LDS array busy < 50 %, but a
+// wave is parked in a wait or at the barrier 35 % of its life and every wave carries three LDS-DMA instructions per K-step (60-180 clk of
+// issue each, in order with its MFMAs) plus one fragment read per MFMA.  Here waves 0-3 — one per SIMD — only multiply: each owns
+// 64 channels x 128 pixels (2 x 4 accumulator blocks: SIX fragment reads feed EIGHT MFMAs, 0.75 KiB of LDS traffic per MFMA instead of
+// 1), its stream is ds_read_b128 / v_mfma / one barrier per step and it never touches the vector-memory queue inside the loop.  Waves
+// 4-7 — the second wave of every SIMD — are LOADERS: they own the whole DMA schedule (weight ring, next halo, bias rows), count their own
+// vmcnt queue (a wave's counter sees only its own requests, so the consumers' stores no longer sit in the ring's in-order queue) and
+// meet the consumers at the step barrier.  Barrier k of a step says two things at once: the loaders have seen the NEXT step's weight
+// tile land, and the consumers have finished reading THIS step's slot (their lgkmcnt(0) precedes it) — which the loaders refill first
+// thing in the next step.
+#ifdef C3_TIMING
+// debug builds only (scripts/pc_timeline.py): consumer wave 0's phase stamps [block][8] as for the kernel above, then [block][64] clocks at the end of its first 64 K-steps
+#define PC_STAMP(slot) do { if (g_c3_timing && threadIdx.x == 0) g_c3_timing[blockIdx.x * 8 + (slot)] = (slot) == 0 || (slot) == 7 ? wall_clock64() : clock64(); } while (0)
+#define PC_STEP() do { if (g_c3_timing && threadIdx.x == 0 && gstep < 64) g_c3_timing[2048 + blockIdx.x * 64 + gstep] = clock64(); ++gstep; } while (0)
+#else
+#define PC_STAMP(slot)
+#define PC_STEP()
+#endif
+__global__ __launch_bounds__(512, 2)
+void conv3x3_pc_kernel(CsArgs a) {
+    typedef Geo<16> G_;
+    constexpr int HWD = G_::HWD, HP = G_::HP, RING = G_::RING;
+    constexpr int HALO_BYTES = G_::HALO_BYTES, DUMP_AT = Lds<16>::DUMP_AT, ROWS_AT = Lds<16>::ROWS_AT;
+    constexpr int NP = 11;                                  // halo parts of 256 vectors: 10 x 256 + 32
+    static_assert(RING == 4, "the vmcnt tables below are written for a ring of four");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* halo = smem;
+    char* wring = smem + 2 * HALO_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int G = gridDim.x;
+    const int my_tiles = a.total_tiles > (int)blockIdx.x ? (a.total_tiles - 1 - (int)blockIdx.x) / G + 1 : 0;
+    if (my_tiles == 0) return;
+    auto tile_pos = [&](int k) {
+        const int lid = logical_tile(blockIdx.x + k * G, a.total_tiles, a.xcd);
+        const int tmi = (int)fdiv((unsigned)lid, a.d_tiles_n);
+        const int tpi = a.tiles_y * a.tiles_x;
+        const int img = (int)fdiv((unsigned)tmi, a.d_tpi), pt = tmi - img * tpi;
+        const int ty = (int)fdiv((unsigned)pt, a.d_tiles_x);
+        TilePos t; t.img = img; t.py0 = ty * 16; t.px0 = (pt - ty * a.tiles_x) * 16; t.tn = lid - tmi * a.tiles_n;
+        return t;
+    };
+    const int nchunks = a.C >> 6;
+
+    if (wave >= 4) {
+        // =============================================================== loaders
+        const int lw = wave - 4, lid = lw * 64 + lane;
+        auto rsrc_of = [&](const void* p, unsigned extent) {
+            const unsigned long long ad = (unsigned long long)p;
+            const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)ad), hi = __builtin_amdgcn_readfirstlane((unsigned)(ad >> 32));
+            return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0,
+                                                     __builtin_amdgcn_readfirstlane((int)extent), 0x00020000);
+        };
+        const __amdgpu_buffer_rsrc_t rx = rsrc_of(a.x, a.x_extent), rw = rsrc_of(a.w, a.w_extent);
+        const __amdgpu_buffer_rsrc_t rbias = rsrc_of(a.bias ? (const void*)a.bias : (const void*)a.w, a.bias ? (unsigned)(a.N * 4) : 0u);
+        const __amdgpu_buffer_rsrc_t rrow = rsrc_of(a.rowbias ? (const void*)a.rowbias : (const void*)a.w, a.rowbias ? a.rowbias_extent : 0u);
+        // halo part p of a tile: vector v = lid + 256 p -> halo pixel v >> 3, physical 16-byte chunk v & 7 = logical ^ key(hx) (the image the
+        // consumers' reads expect is the one described at halo_plan above)
+        auto halo_part_off = [&](const TilePos& t, int p) {
+            int lid_ = lid;
+            asm volatile("" : "+v"(lid_));
+            const int v = lid_ + 256 * p, hp = v >> 3;
+            const int hy = hp / HWD, hx = hp - hy * HWD;
+            const int iy = t.py0 + hy - 1, ix = t.px0 + hx - 1;
+            const bool ok = hp < HP && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+            const int lc = (v & 7) ^ ((hx >> 1) & 7);
+            const int sy = iy >> a.ups, sx = ix >> a.ups;
+            return ok ? ((unsigned)((t.img * (a.H >> a.ups) + sy) * (a.W >> a.ups) + sx) * (unsigned)a.x_ld + (unsigned)(lc * 8)) * 2u : OOB;
+        };
+        auto issue_halo_part = [&](const TilePos& t, int p, int cc, char* dst) {
+            const unsigned ho = halo_part_off(t, p);
+            const unsigned o = ho == OOB ? OOB : ho + (unsigned)(cc * 128);
+            // part 10 holds the last 32 vectors: loader 0 writes them (+ 32 zero vectors of padding), the others' lanes are all out of range
+            char* d = p < 10 ? dst + (lw * 64 + 256 * p) * 16 : (lw == 0 ? dst + 2560 * 16 : smem + DUMP_AT);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)d, 16, o, 0, 0, 0);
+        };
+        // weight tile: vector v = lid + 256 i -> row v >> 3, physical chunk v & 7 = logical ^ ((row >> 1) & 7)
+        unsigned wrow[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int v = lid + 256 * i, row = v >> 3, lc = (v & 7) ^ ((row >> 1) & 7);
+            wrow[i] = (unsigned)(((long long)row * a.K + lc * 8) * 2);
+        }
+        const unsigned w_tile_bytes = (unsigned)((long long)128 * a.K * 2);
+        auto issue_w = [&](int tn, int cc, int tap, int slot) {
+            char* dst = wring + slot * WT_BYTES;
+            const unsigned base = (unsigned)tn * w_tile_bytes + (unsigned)((tap * a.C + cc * 64) * 2);      // rows beyond N: past the extent -> zeros
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(dst + (lw * 64 + 256 * i) * 16), 16, base + wrow[i], 0, 0, 0);
+        };
+        // the tile's bias row (loader 0) and its image's time-embedding row (loader 1); EVERY loader issues exactly one request here (the
+        // others an out-of-range one into the dump area) so that the vmcnt tables below are the same for all four
+        auto issue_rows = [&](const TilePos& t, int parity) {
+            char* slot = smem + ROWS_AT + parity * 2048;
+            if (lw == 0)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rbias, (__attribute__((address_space(3))) void*)slot, 16,
+                                                         (lane < 32 && a.bias) ? (unsigned)((t.tn * 128 + lane * 4) * 4) : OOB, 0, 0, 0);
+            else if (lw == 1)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rrow, (__attribute__((address_space(3))) void*)(slot + 1024), 16,
+                                                         (lane < 32 && a.rowbias) ? (unsigned)(((long long)t.img * a.rowbias_ld + t.tn * 128 + lane * 4) * 4) : OOB, 0, 0, 0);
+            else
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(smem + DUMP_AT), 16, OOB, 0, 0, 0);
+        };
+        TilePos cur = tile_pos(0);
+#pragma unroll
+        for (int p = 0; p < NP; ++p) issue_halo_part(cur, p, 0, halo);
+        issue_rows(cur, 0);
+#pragma unroll
+        for (int t = 0; t < RING - 1; ++t) issue_w(cur.tn, 0, t, t);
+        wait_vm<8>();                                       // the halo, the rows and weight tile 0 are in; tiles 1 and 2 may be on their way
+        __builtin_amdgcn_s_barrier();
+        int slot = 0, hb = 0;
+        for (int k = 0; k < my_tiles; ++k) {
+            const bool more_tiles = k + 1 < my_tiles;
+            TilePos nxt = cur;
+            if (more_tiles) nxt = tile_pos(k + 1);
+            for (int cc = 0; cc < nchunks; ++cc) {
+                char* hnxt = halo + (hb ^ 1) * HALO_BYTES;
+                const bool same_tile = cc + 1 < nchunks;
+                const bool prefetch = same_tile || more_tiles;
+                const bool last_chunk = !same_tile;
+                const int ncc = same_tile ? cc + 1 : 0;
+                const int ntn = same_tile ? cur.tn : nxt.tn;
+                const bool rows_here = last_chunk && prefetch;
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    // requests of this step, in queue order: parts of the next halo (taps 0-5: 2 2 2 2 2 1), the next tile's rows (tap 6 of a
+                    // tile's last chunk), then the weight tile three steps ahead — into the slot the consumers left at the last barrier
+#ifndef PC_ABL_NO_HALO
+                    if (prefetch && tap < 6) {
+                        if (tap < 5) { issue_halo_part(same_tile ? cur : nxt, 2 * tap, ncc, hnxt); issue_halo_part(same_tile ? cur : nxt, 2 * tap + 1, ncc, hnxt); }
+                        else issue_halo_part(same_tile ? cur : nxt, 10, ncc, hnxt);
+                    }
+#endif
+                    if (tap == 6 && rows_here) issue_rows(nxt, (k + 1) & 1);
+                    const int wslot = slot + RING - 1 >= RING ? slot - 1 : slot + RING - 1;
+#ifndef PC_ABL_NO_W
+                    if (tap + RING - 1 < 9) issue_w(cur.tn, cc, tap + RING - 1, wslot);
+                    else if (prefetch) issue_w(ntn, ncc, tap + RING - 1 - 9, wslot);
+#endif
+                    slot = slot + 1 == RING ? 0 : slot + 1;
+                    if (tap == 8 && last_chunk) __builtin_amdgcn_s_barrier();      // the consumers' "halo buffer is free for the epilogue" barrier
+                    // The next step's weight tile (requested two steps back, LAST in its step) has to be in; everything requested in the
+                    // previous step and in this one is newer and may stay in flight.  When the next step opens a chunk, that chunk's halo
+                    // (requested in taps 0-5) and — for a new tile — its rows (tap 6, ahead of the weights) are older than the tile waited for.
+                    if (prefetch) {
+                        if (tap == 0) wait_vm<10>();
+                        else if (tap < 5) wait_vm<12>();
+                        else if (tap == 5) wait_vm<11>();
+                        else if (tap == 6) { if (rows_here) wait_vm<10>(); else wait_vm<9>(); }
+                        else if (tap == 7) { if (rows_here) wait_vm<9>(); else wait_vm<8>(); }
+                        else wait_vm<8>();
+                    } else {
+                        if (tap < 6) wait_vm<8>(); else if (tap == 6) wait_vm<4>(); else wait_vm<0>();
+                    }
+                    __builtin_amdgcn_s_barrier();
+                }
+                hb ^= 1;
+            }
+            cur = nxt;
+        }
+        return;
+    }
+
+    // =================================================================== consumers
+    constexpr int NIB = 2, NJ = 4;
+    const int wn = wave >> 1, wm = wave & 1;              // 64 channels x 128 pixels (patch rows 8 wm .. 8 wm + 7)
+    if (a.flags & 1) __builtin_amdgcn_s_setprio(1);
+    const bool extra = a.res || a.accumulate;
+    int hp0[NJ], pxl[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int p = wm * 128 + j * 32 + (lane & 31);
+        hp0[j] = (p >> 4) * HWD + (p & 15);
+        pxl[j] = p & 15;
+    }
+    f32x16 acc[NIB][NJ];
+#pragma unroll
+    for (int i = 0; i < NIB; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x16)(0.f);
+    const int sw = (lane >> 5) ^ ((lane >> 1) & 7);
+    const int hi = lane >> 5;
+    const unsigned lds0 = (unsigned)(size_t)smem;
+    unsigned wv[NIB], hv[NJ];
+#pragma unroll
+    for (int i = 0; i < NIB; ++i) wv[i] = lds0 + 2 * HALO_BYTES + (unsigned)((wn * 64 + i * 32 + (lane & 31)) * 128 + (sw << 4));
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) hv[j] = lds0 + (unsigned)(hp0[j] * 128);
+    u32x4 fw[2][NIB], fx[2][NJ];                           // fragment sets: K sub-step kc uses set kc & 1
+    bool pend = false;
+    TilePos cur = tile_pos(0);
+#ifdef C3_TIMING
+    int gstep = 0;
+#endif
+    PC_STAMP(0); PC_STAMP(1);
+    __builtin_amdgcn_s_barrier();                           // the loaders' prologue: halo 0, rows 0 and weight tile 0 are in LDS
+    PC_STAMP(2);
+    int slot = 0, hb = 0;
+    for (int k = 0; k < my_tiles; ++k) {
+        for (int cc = 0; cc < nchunks; ++cc) {
+            const bool last_chunk = cc + 1 == nchunks;
+            u32x2 rv[NJ][4];                                 // residual OR previous output of ONE 32-channel block (the launcher admits one of them)
+            // residual / "+=" rows of 32-channel block i: one address per pixel, the 4-channel runs at constant offsets.  INLINE ASM and
+            // UNCONDITIONAL (see the kernel above); waves whose 64 channels lie beyond N read the start of their row instead
+            auto request_extra = [&](int i) {
+                const int n0 = cur.tn * 128 + wn * 64 + 4 * (lane >> 5);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const int p = wm * 128 + j * 32 + (lane & 31);
+                    const bf16_t* base = (a.res ? a.res : a.out) + ((long long)(cur.img * a.H + cur.py0 + (p >> 4)) * a.W + cur.px0 + (p & 15)) * (a.res ? a.res_ld : a.out_ld)
+                                         + (n0 < a.N ? n0 : 0) + i * 32;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        asm volatile("global_load_dwordx2 %0, %1, off offset:%2" : "=v"(rv[j][g]) : "v"(base), "n"(8 * g * 2) : "memory");
+                }
+            };
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int r = tap / 3, s = tap - 3 * r;
+                const int shift = r * HWD + s;
+                const unsigned woff = (unsigned)(slot * WT_BYTES);
+                const unsigned hoffs = (unsigned)(hb * HALO_BYTES + shift * 128);
+                unsigned hk[NJ], wk[NIB];
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    int px = pxl[j];
+                    asm volatile("" : "+v"(px));
+                    const int key = ((px + s) >> 1) & 7;
+                    hk[j] = hv[j] + hoffs + (unsigned)((hi ^ key) << 4);
+                }
+#pragma unroll
+                for (int i = 0; i < NIB; ++i) { wk[i] = wv[i] + woff; asm volatile("" : "+v"(wk[i])); }
+                // One K sub-step: the eight MFMAs of set `cw/cx`, the six reads of the next set `nw/nx` two per gap behind the first three —
+                // every read has five MFMAs (160 clk) of cover before the wait that closes the sub-step.  mf = false: reads only; kc < 0: MFMAs only.
+                auto sub_step = [&](bool mf, const u32x4 (&cw)[NIB], const u32x4 (&cx)[NJ], int kc, u32x4 (&nw)[NIB], u32x4 (&nx)[NJ]) {
+                    auto rd_w = [&](int i) {
+                        if (kc < 0) return;
+#ifdef PC_ABL_NO_READS
+                        return;
+#endif
+                        const unsigned ad = wk[i] ^ (unsigned)(kc << 5);
+                        asm volatile("ds_read_b128 %0, %1" : "=v"(nw[i]) : "v"(ad) : "memory");
+                        __builtin_amdgcn_sched_barrier(0);
+                    };
+                    auto rd_x = [&](int j) {
+                        if (kc < 0) return;
+#ifdef PC_ABL_NO_READS
+                        return;
+#endif
+                        const unsigned ad = hk[j] ^ (unsigned)(kc << 5);
+                        asm volatile("ds_read_b128 %0, %1" : "=v"(nx[j]) : "v"(ad) : "memory");
+                        __builtin_amdgcn_sched_barrier(0);
+                    };
+                    auto mm = [&](int i, int j) {
+                        if (!mf) return;
+#ifdef PC_ABL_NO_MFMA
+                        return;
+#endif
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, cw[i]), __builtin_bit_cast(bf16x8, cx[j]), acc[i][j], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                    };
+                    mm(0, 0); rd_w(0); rd_x(0);
+                    mm(1, 0); rd_w(1); rd_x(1);
+                    mm(0, 1); rd_x(2); rd_x(3);
+                    mm(1, 1); mm(0, 2); mm(1, 2); mm(0, 3); mm(1, 3);
+                };
+#define PC_WAIT_SET() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+                if (tap == 8 && last_chunk && extra) { request_extra(0); __builtin_amdgcn_sched_barrier(0); }
+                sub_step(tap > 0 || pend, fw[1], fx[1], 0, fw[0], fx[0]);
+                PC_WAIT_SET();
+                sub_step(true, fw[0], fx[0], 1, fw[1], fx[1]);
+                PC_WAIT_SET();
+                sub_step(true, fw[1], fx[1], 2, fw[0], fx[0]);
+                PC_WAIT_SET();
+                sub_step(true, fw[0], fx[0], 3, fw[1], fx[1]);
+                slot = slot + 1 == RING ? 0 : slot + 1;
+                if (tap == 8 && last_chunk) {                // the tile ends here: nothing is carried into the epilogue
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if (k == 0) PC_STAMP(3); else if (k == 1) PC_STAMP(5);
+                    __builtin_amdgcn_s_barrier();             // every consumer has read its last fragments of this halo buffer
+                    __builtin_amdgcn_sched_barrier(0);
+                    sub_step(true, fw[1], fx[1], -1, fw[0], fx[0]);
+                    pend = false;
+                    break;
+                }
+                pend = true;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                PC_STEP();
+#undef PC_WAIT_SET
+            }
+            if (last_chunk) {
+                // ---- tile done: out = acc + bias + time bias (+ residual | + out), staged through the finished halo buffer in wave-private
+                // slices of 64 pixels x 64 bytes so that four consecutive lanes store the 64 contiguous bytes of a pixel (as above)
+                const char* rows = smem + ROWS_AT + (k & 1) * 2048;
+                const int n0 = cur.tn * 128 + wn * 64;
+                const bool live = n0 < a.N;
+                const unsigned stg = lds0 + (unsigned)(hb * HALO_BYTES + wave * (64 * 64));
+                bf16_t* const obase = a.out + ((long long)(cur.img * a.H + cur.py0) * a.W + cur.px0) * a.out_ld + n0 + 8 * (lane & 3);
+                auto orow = [&](int q16) {                   // pixel q16 * 16 + lane / 4 of the wave's 128
+                    int q = lane >> 2;
+                    asm volatile("" : "+v"(q));
+                    const int p = wm * 128 + q16 * 16 + q;
+                    return obase + (long long)(((p >> 4) * a.W + (p & 15)) * (int)a.out_ld);
+                };
+#pragma unroll
+                for (int i = 0; i < NIB; ++i) {
+                    f32x4v bsum[4], brow[4];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const unsigned ad = (unsigned)(size_t)(rows + (wn * 64 + i * 32 + 8 * g + 4 * (lane >> 5)) * 4);
+                        asm volatile("ds_read_b128 %0, %1" : "=v"(bsum[g]) : "v"(ad) : "memory");
+                        asm volatile("ds_read_b128 %0, %1 offset:1024" : "=v"(brow[g]) : "v"(ad) : "memory");
+                    }
+                    if (extra) {
+                        // block 0's rows were requested in the tile's last step, block 1's behind block 0's last use (four stores of block 0
+                        // — none when the wave's channels lie beyond N — are newer than those)
+                        if (i == 0 || !live) wait_vm<0>(); else wait_vm<4>();
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        if (!a.bias) bsum[g] = (f32x4v)(0.f);
+                        if (!a.rowbias) brow[g] = (f32x4v)(0.f);
+                        bsum[g] += brow[g];
+                    }
+                    if (extra && !live) {
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                            for (int g = 0; g < 4; ++g) rv[j][g] = (u32x2)(0u);
+                    }
+#pragma unroll
+                    for (int jh = 0; jh < 2; ++jh) {
+#pragma unroll
+                        for (int jj = 0; jj < 2; ++jj) {
+                            const int j = 2 * jh + jj;
+                            uint2 pk[4];
+#pragma unroll
+                            for (int g = 0; g < 4; ++g) {
+                                float v[4] = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                                v[0] += bsum[g].x; v[1] += bsum[g].y; v[2] += bsum[g].z; v[3] += bsum[g].w;
+                                if (extra) {
+                                    const u32x2 r2 = rv[j][g];
+                                    v[0] += __uint_as_float(r2.x << 16); v[1] += __uint_as_float(r2.x & 0xffff0000u);
+                                    v[2] += __uint_as_float(r2.y << 16); v[3] += __uint_as_float(r2.y & 0xffff0000u);
+                                }
+                                pk[g].x = pack_bf2(v[0], v[1]); pk[g].y = pack_bf2(v[2], v[3]);
+                            }
+#pragma unroll
+                            for (int q2 = 0; q2 < 2; ++q2) {
+                                const u32x2 sx = __builtin_amdgcn_permlane32_swap(pk[2 * q2].x, pk[2 * q2 + 1].x, false, false);
+                                const u32x2 sy = __builtin_amdgcn_permlane32_swap(pk[2 * q2].y, pk[2 * q2 + 1].y, false, false);
+                                u32x4 o; o.x = sx.x; o.y = sy.x; o.z = sx.y; o.w = sy.y;
+                                const int P = jj * 32 + (lane & 31), sl = (2 * q2 + hi) ^ ((P >> 2) & 3);
+                                const unsigned ad = stg + (unsigned)(P * 64 + (sl << 4));
+                                asm volatile("ds_write_b128 %0, %1" :: "v"(ad), "v"(o) : "memory");
+                            }
+                        }
+                        if (extra && i == 0 && jh == 1) { __builtin_amdgcn_sched_barrier(0); request_extra(1); __builtin_amdgcn_sched_barrier(0); }
+                        u32x4 back[4];
+#pragma unroll
+                        for (int rr = 0; rr < 4; ++rr) {
+                            const int Q = rr * 16 + (lane >> 2), sl = (lane & 3) ^ ((Q >> 2) & 3);
+                            const unsigned ad = stg + (unsigned)(Q * 64 + (sl << 4));
+                            asm volatile("ds_read_b128 %0, %1" : "=v"(back[rr]) : "v"(ad) : "memory");     // (a wave's LDS operations execute in order)
+                        }
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (live) {
+#pragma unroll
+                            for (int rr = 0; rr < 4; ++rr) *reinterpret_cast<u32x4*>(orow(jh * 4 + rr) + i * 32) = back[rr];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < NIB; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x16)(0.f);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();                 // the barrier of the tile's last step
+                PC_STEP();
+                if (k == 0) PC_STAMP(4); else if (k == 1) PC_STAMP(6);
+            }
+            hb ^= 1;
+        }
+        if (k + 1 < my_tiles) cur = tile_pos(k + 1);
+    }
+    PC_STAMP(7);
+}
+
 }  // namespace
 
 #ifdef C3_TRACE
@@ -613,7 +1012,10 @@ int ddpm_conv3x3_stream_launch(const void* x, long long x_ld, const void* w, voi
     const long long xbytes = ((long long)B * (H >> upsample) * (W >> upsample) * x_ld - (x_ld - C)) * 2, wbytes = (long long)N * 9 * C * 2;
     const long long rbbytes = rowbias ? ((long long)(B - 1) * rowbias_ld + N) * 4 : 0;
     if (xbytes > 0x7ffffff0ll || wbytes > 0x7ffffff0ll || rbbytes > 0x7ffffff0ll) return -1;
-    if (dry) return patch;
+    // 16 x 16 patches: the wave-specialised kernel (loaders + consumers) unless DDPM_CONV_NO_PC is set; DDPM_C3_PC_FLAGS: bit 0 = consumers at priority 1
+    static const bool use_pc = getenv("DDPM_CONV_NO_PC") == nullptr;
+    static const int pc_flags = getenv("DDPM_C3_PC_FLAGS") ? atoi(getenv("DDPM_C3_PC_FLAGS")) : 0;
+    if (dry) return patch == 16 && use_pc ? 17 : patch;
     CsArgs a; memset(&a, 0, sizeof(a));
     a.x = (const bf16_t*)x; a.x_ld = x_ld; a.x_extent = (unsigned)xbytes;
     a.w = (const bf16_t*)w; a.w_extent = (unsigned)wbytes;
@@ -637,7 +1039,16 @@ int ddpm_conv3x3_stream_launch(const void* x, long long x_ld, const void* w, voi
         }                                                                                                                              \
         hipLaunchKernelGGL(conv3x3_stream_kernel<PATCHV>, dim3(grid), dim3(512), Lds<PATCHV>::BYTES, (hipStream_t)stream, a);           \
     } while (0)
-    if (patch == 16) C3_LAUNCH(16); else C3_LAUNCH(8);
+    if (patch == 16 && use_pc) {
+        a.flags = pc_flags;
+        static bool pc_attr_set = false;
+        if (!pc_attr_set) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_pc_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, Lds<16>::BYTES) != hipSuccess) return DDPM_ERR_LAUNCH;
+            pc_attr_set = true;
+        }
+        hipLaunchKernelGGL(conv3x3_pc_kernel, dim3(grid), dim3(512), Lds<16>::BYTES, (hipStream_t)stream, a);
+    }
+    else if (patch == 16) C3_LAUNCH(16); else C3_LAUNCH(8);
 #undef C3_LAUNCH
     return check_launch();
 }

@@ -1377,7 +1377,7 @@ template __global__ void attn_fwd_kernel<8>(MatDesc, MatDesc, MatDesc, bf16_t*, 
 // ---------------------------------------------------------------------------------------------- host side
 
 // Kernel ids reported by the ddpm_*_variant queries (bench.py attributes its per-launch timings with them):
-// 1 gemm_kernel 4-wave, 2 gemm_kernel 8-wave, 3 gemm_kernel deep ring, 4 gemm64_kernel, 5 conv3x3_halo_kernel, 7 pw_conv_kernel (pointwise.hip), 8 / 10 conv3x3_stream_kernel (conv3x3.hip, 16 x 16 / 8 x 8 patches), 11 / 12 conv3x3_few_out / few_in (edgeconv.hip).
+// 1 gemm_kernel 4-wave, 2 gemm_kernel 8-wave, 3 gemm_kernel deep ring, 4 gemm64_kernel, 5 conv3x3_halo_kernel, 7 pw_conv_kernel (pointwise.hip), 8 / 10 conv3x3_stream_kernel (conv3x3.hip, 16 x 16 / 8 x 8 patches), 13 conv3x3_pc_kernel (conv3x3.hip, loader / consumer waves), 11 / 12 conv3x3_few_out / few_in (edgeconv.hip).
 // The queries run the SAME dispatch code with `dry` set (nothing is launched): the library keeps no mutable state.
 static const int g_xcd_swizzle = getenv("DDPM_NO_XCD_SWIZZLE") ? 0 : 1;
 static thread_local int g_variant_query = 0, g_variant_result = 0;      // scoped to ONE ddpm_*_variant call (set and cleared inside it)
@@ -1650,7 +1650,7 @@ extern "C" int ddpm_conv2d_nhwc(const void* x, long long x_ld, const void* w, vo
         Ho == (H << (upsample ? 1 : 0)) && Wo == (W << (upsample ? 1 : 0))) {
         const int rc = ddpm_conv3x3_stream_launch(x, x_ld, w, y, y_ld, bias, rowbias, rowbias_ld, residual, res_ld, accumulate, B, Ho, Wo, C, N,
                                                   upsample ? 1 : 0, g_xcd_swizzle, g.dry, stream);
-        if (rc >= 0) { if (g.dry) { g_variant_result = rc == 8 ? 10 : 8; return DDPM_OK; } return rc; }
+        if (rc >= 0) { if (g.dry) { g_variant_result = rc == 8 ? 10 : (rc == 17 ? 13 : 8); return DDPM_OK; } return rc; }
     }
     // ... or the one-tile-per-block form (what conv3x3.hip does not cover)
     static const bool no_halo = getenv("DDPM_CONV_NO_HALO") != nullptr;

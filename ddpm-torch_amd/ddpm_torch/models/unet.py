@@ -461,8 +461,8 @@ class _Engine:
         master parameters — what forward() does on entry; callers replaying a captured graph do it before the replay."""
         self._refresh_packs(need_dgrad)
         self._fc_all()
-        if self.tt_T:
-            self.time_table()
+        if self.tt_on:                                   # only a sampler reads the [T][sum Cout] table: a training step after the per-epoch
+            self.time_table()                            # sample grid must not rebuild it (1000-row embedding MLP) before every replay
 
     def refresh_unconditionally(self):
         """Launch the derivation kernels regardless of version counters (the tail of a captured training step: the
