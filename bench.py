@@ -261,9 +261,20 @@ def main():
     # overlap switched off (every kernel alone on the GPU), which is what says how good each kernel is by itself.
     peak = PEAK[args.dtype]
 
+    # The eager step is host-bound (~7 ms of launch work for ~9 ms of GPU work): with the GPU keeping up with the host, a kernel's start event
+    # is stamped when the queue is EMPTY and its launch arrives microseconds later — the bracket then measures the host.  So the whole
+    # step is enqueued behind a gate (a spin kernel of ~20 ms on the main stream, which the side stream's first wait depends on too) and
+    # runs back to back once the gate opens, exactly as the launches of the pipelined product steps do.
+    torch.cuda.synchronize()
+    t_g = time.perf_counter(); torch.cuda._sleep(20_000_000); torch.cuda.synchronize()
+    gate_cycles = int(20_000_000 * 20e-3 / max(time.perf_counter() - t_g, 1e-4))
+
     def profile_step(trainer, x, step_no):
         graph_was, train_mod._TRAIN_GRAPH = train_mod._TRAIN_GRAPH, False       # per-launch events need the eager form of the step
         _ops.PROFILE = []
+        torch.cuda.synchronize()
+        if os.environ.get("BENCH_NO_GATE") is None:
+            torch.cuda._sleep(gate_cycles)
         trainer.step(x, global_steps=step_no)
         torch.cuda.synchronize()
         prof, _ops.PROFILE = _ops.PROFILE, None
@@ -297,8 +308,10 @@ def main():
     if rank == 0:
         if os.environ.get("BENCH_SHAPES"):
             with open(os.environ["BENCH_SHAPES"], "w") as f:
-                for k, v in sorted(shapes_iso.items(), key=lambda kv: -kv[1][2]):
-                    f.write(f"{v[2] * 1e3:8.3f} ms  n={v[0]:3d}  {v[1] / v[2] / 1e12:7.1f} TF  {k}\n")
+                for title, tab in (("in the product step (two streams)", shapes), ("isolated (one stream)", shapes_iso)):
+                    f.write(f"# {title}\n")
+                    for k, v in sorted(tab.items(), key=lambda kv: -kv[1][2]):
+                        f.write(f"{v[2] * 1e3:8.3f} ms  n={v[0]:3d}  {v[2] / v[0] * 1e6:7.1f} us  {v[1] / v[2] / 1e12:7.1f} TF  {k}\n")
         # dominant kernel = the one with the most GPU time per step when every kernel has the chip to itself (the isolated pass:
         # stable from run to run, and the order rocprofv3's kernel-trace of the product step gives); its `achieved` below is the
         # in-product figure.  The event-bracketed durations of the side stream's weight-gradient kernels include queueing behind

@@ -592,22 +592,64 @@ void conv3x3_stream_kernel(CsArgs a) {
 
 
 // ------------------------------------------------------------------------------------------------------------------------------------
-// Round 4: the same tile, LDS image and K sequence with the waves SPECIALISED (16 x 16 patches only).
+// Round 4: the same tile, LDS image and K sequence with the waves SPECIALISED and NO per-step barrier (16 x 16 patches only).
 //
-// What the counters said about the kernel above (profiles/r04_conv3x3_lds_counters.txt): no bank conflicts, LDS array busy < 50 %, but a
-// wave is parked in a wait or at the barrier 35 % of its life and every wave carries three LDS-DMA instructions per K-step (60-180 clk of
-// issue each, in order with its MFMAs) plus one fragment read per MFMA.  Here waves 0-3 — one per SIMD — only multiply: each owns
-// 64 channels x 128 pixels (2 x 4 accumulator blocks: SIX fragment reads feed EIGHT MFMAs, 0.75 KiB of LDS traffic per MFMA instead of
-// 1), its stream is ds_read_b128 / v_mfma / one barrier per step and it never touches the vector-memory queue inside the loop.  Waves
-// 4-7 — the second wave of every SIMD — are LOADERS: they own the whole DMA schedule (weight ring, next halo, bias rows), count their own
-// vmcnt queue (a wave's counter sees only its own requests, so the consumers' stores no longer sit in the ring's in-order queue) and
-// meet the consumers at the step barrier.  Barrier k of a step says two things at once: the loaders have seen the NEXT step's weight
-// tile land, and the consumers have finished reading THIS step's slot (their lgkmcnt(0) precedes it) — which the loaders refill first
-// thing in the next step.
+// What the counters and the timelines said about the kernel above (profiles/r04_conv3x3_*): no bank conflicts, the LDS array busy < 50 %,
+// yet a wave is parked in a wait or at the barrier 35 % of its life; every wave carries three LDS-DMA instructions per K-step (60-180 clk
+// of issue each, in order with its MFMAs) and one fragment read per MFMA; and a first split into loader and consumer waves that kept the
+// barrier ran its 1024 clk of MFMAs per step in 1600 clk with ALL memory traffic compiled out — the pipe drains into every barrier and
+// refills behind it.  So here:
+//   * waves 0-3 — one per SIMD — only multiply: each owns 64 channels x 128 pixels (2 x 4 accumulator blocks: SIX fragment reads feed
+//     EIGHT MFMAs, 0.75 KiB of LDS traffic per MFMA instead of 1).  Their instruction stream is ds_read_b128 / v_mfma in one software
+//     pipeline that runs across K-steps, chunks and (but for the epilogue) tiles: the fragments of sub-step q + 1 are requested under
+//     the MFMAs of sub-step q, the addresses of the next step are built in the gaps of the current step's last sub-step;
+//   * waves 4-7 — the second wave of every SIMD — are LOADERS: they own the whole DMA schedule (weight ring, next halo, bias rows) and
+//     count their own vmcnt queue (a wave's counter sees only its own requests: the consumers' stores no longer sit in the ring's
+//     in-order queue);
+//   * the two sides meet through three COUNTERS IN LDS instead of s_barrier.  `ready`: a loader adds 1 when its share of the next step's
+//     weight tile (and everything older: halo, rows) has landed — a consumer starts step s when ready >= 4 (s + 1); it reads the
+//     counter with the last fragments of step s - 1, so the check costs no latency.  `freed`: a consumer adds 1 when its last read of a
+//     step's slot has been issued (LDS executes a wave's operations in order) — a loader refills the slot of step g - 1 when
+//     freed >= 4 g.  `edone`: the consumers' own rendezvous before a tile's epilogue (which stages through the halo buffer the slowest
+//     of them may still be reading).  An increment is one ds_add_u32 with every lane on its own copy of the counter (no exec masking,
+//     no bank conflict); only copy 0 is ever read.  Nobody waits for a wave that is not late: the consumers drift apart by up to the
+//     depth of the ring and the pipe never drains;
+//   * bias + time bias are the accumulators' INITIAL value (the rows ride into LDS with the tile's first stage, as above), so the
+//     epilogue is convert, swap, stage, store.
+constexpr int PC_CNT_AT = Lds<16>::BYTES;                  // three counters x 64 copies
+constexpr int PC_BYTES = PC_CNT_AT + 1024;
+static_assert(PC_BYTES <= 160 * 1024, "LDS");
+constexpr int PC_READY = 0, PC_FREED = 256, PC_EDONE = 512;
+
+__device__ __forceinline__ void pc_wait_ge(unsigned addr, unsigned target) {
+#ifdef PC_ABL_NO_SYNC
+    return;
+#endif
+    // bounded: a protocol error must end the launch with an error the host sees (trap), never hang the GPU
+    for (unsigned spins = 0;; ++spins) {
+        unsigned v;
+        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(addr) : "memory");
+        if ((int)((unsigned)__builtin_amdgcn_readfirstlane((int)v) - target) >= 0) break;
+        if (spins > (1u << 22)) __builtin_trap();
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+__device__ __forceinline__ void pc_signal(unsigned lane_addr) {
+#ifdef PC_ABL_NO_SYNC
+    return;
+#endif
+    const unsigned one = 1u;
+    asm volatile("ds_add_u32 %0, %1" :: "v"(lane_addr), "v"(one) : "memory");
+}
+
 #ifdef C3_TIMING
 // debug builds only (scripts/pc_timeline.py): consumer wave 0's phase stamps [block][8] as for the kernel above, then [block][64] clocks at the end of its first 64 K-steps
 #define PC_STAMP(slot) do { if (g_c3_timing && threadIdx.x == 0) g_c3_timing[blockIdx.x * 8 + (slot)] = (slot) == 0 || (slot) == 7 ? wall_clock64() : clock64(); } while (0)
-#define PC_STEP() do { if (g_c3_timing && threadIdx.x == 0 && gstep < 64) g_c3_timing[2048 + blockIdx.x * 64 + gstep] = clock64(); ++gstep; } while (0)
+#ifdef PC_ABL_NO_STEPSTAMP
+#define PC_STEP()
+#else
+#define PC_STEP() do { if (g_c3_timing && threadIdx.x == 0 && tstep < 64) g_c3_timing[2048 + blockIdx.x * 64 + tstep] = clock64(); ++tstep; } while (0)
+#endif
 #else
 #define PC_STAMP(slot)
 #define PC_STEP()
@@ -627,6 +669,8 @@ void conv3x3_pc_kernel(CsArgs a) {
     const int G = gridDim.x;
     const int my_tiles = a.total_tiles > (int)blockIdx.x ? (a.total_tiles - 1 - (int)blockIdx.x) / G + 1 : 0;
     if (my_tiles == 0) return;
+    if (tid < 256) reinterpret_cast<unsigned*>(smem + PC_CNT_AT)[tid] = 0u;
+    __syncthreads();                                        // the only barrier of the kernel
     auto tile_pos = [&](int k) {
         const int lid = logical_tile(blockIdx.x + k * G, a.total_tiles, a.xcd);
         const int tmi = (int)fdiv((unsigned)lid, a.d_tiles_n);
@@ -637,6 +681,8 @@ void conv3x3_pc_kernel(CsArgs a) {
         return t;
     };
     const int nchunks = a.C >> 6;
+    const unsigned lds0 = (unsigned)(size_t)smem;
+    const unsigned cnt0 = lds0 + PC_CNT_AT, my_cnt = cnt0 + (unsigned)(lane * 4);
 
     if (wave >= 4) {
         // =============================================================== loaders
@@ -685,8 +731,9 @@ void conv3x3_pc_kernel(CsArgs a) {
             for (int i = 0; i < 4; ++i)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(dst + (lw * 64 + 256 * i) * 16), 16, base + wrow[i], 0, 0, 0);
         };
-        // the tile's bias row (loader 0) and its image's time-embedding row (loader 1); EVERY loader issues exactly one request here (the
-        // others an out-of-range one into the dump area) so that the vmcnt tables below are the same for all four
+        // the tile's bias row (loader 0) and its image's time-embedding row (loader 1) — zeros when the launch has none: the consumers start
+        // their accumulators from these rows unconditionally.  EVERY loader issues exactly one request here (the others an out-of-range
+        // one into the dump area) so that the vmcnt tables below are the same for all four
         auto issue_rows = [&](const TilePos& t, int parity) {
             char* slot = smem + ROWS_AT + parity * 2048;
             if (lw == 0)
@@ -705,8 +752,12 @@ void conv3x3_pc_kernel(CsArgs a) {
 #pragma unroll
         for (int t = 0; t < RING - 1; ++t) issue_w(cur.tn, 0, t, t);
         wait_vm<8>();                                       // the halo, the rows and weight tile 0 are in; tiles 1 and 2 may be on their way
-        __builtin_amdgcn_s_barrier();
+        pc_signal(my_cnt + PC_READY);
+#ifdef PC_ABL_NO_LOADERS
+        return;
+#endif
         int slot = 0, hb = 0;
+        unsigned g4 = 0;                                    // 4 x (flat step index)
         for (int k = 0; k < my_tiles; ++k) {
             const bool more_tiles = k + 1 < my_tiles;
             TilePos nxt = cur;
@@ -721,8 +772,11 @@ void conv3x3_pc_kernel(CsArgs a) {
                 const bool rows_here = last_chunk && prefetch;
 #pragma unroll
                 for (int tap = 0; tap < 9; ++tap) {
+                    // every consumer is past step g - 1: its weight slot, the halo buffer of the chunk before this one and (when step g - 1
+                    // closed a tile) the staging area of that tile's epilogue are free
+                    pc_wait_ge(cnt0 + PC_FREED, g4);
                     // requests of this step, in queue order: parts of the next halo (taps 0-5: 2 2 2 2 2 1), the next tile's rows (tap 6 of a
-                    // tile's last chunk), then the weight tile three steps ahead — into the slot the consumers left at the last barrier
+                    // tile's last chunk), then the weight tile three steps ahead
 #ifndef PC_ABL_NO_HALO
                     if (prefetch && tap < 6) {
                         if (tap < 5) { issue_halo_part(same_tile ? cur : nxt, 2 * tap, ncc, hnxt); issue_halo_part(same_tile ? cur : nxt, 2 * tap + 1, ncc, hnxt); }
@@ -736,7 +790,6 @@ void conv3x3_pc_kernel(CsArgs a) {
                     else if (prefetch) issue_w(ntn, ncc, tap + RING - 1 - 9, wslot);
 #endif
                     slot = slot + 1 == RING ? 0 : slot + 1;
-                    if (tap == 8 && last_chunk) __builtin_amdgcn_s_barrier();      // the consumers' "halo buffer is free for the epilogue" barrier
                     // The next step's weight tile (requested two steps back, LAST in its step) has to be in; everything requested in the
                     // previous step and in this one is newer and may stay in flight.  When the next step opens a chunk, that chunk's halo
                     // (requested in taps 0-5) and — for a new tile — its rows (tap 6, ahead of the weights) are older than the tile waited for.
@@ -750,7 +803,8 @@ void conv3x3_pc_kernel(CsArgs a) {
                     } else {
                         if (tap < 6) wait_vm<8>(); else if (tap == 6) wait_vm<4>(); else wait_vm<0>();
                     }
-                    __builtin_amdgcn_s_barrier();
+                    pc_signal(my_cnt + PC_READY);
+                    g4 += 4;
                 }
                 hb ^= 1;
             }
@@ -764,80 +818,108 @@ void conv3x3_pc_kernel(CsArgs a) {
     const int wn = wave >> 1, wm = wave & 1;              // 64 channels x 128 pixels (patch rows 8 wm .. 8 wm + 7)
     if (a.flags & 1) __builtin_amdgcn_s_setprio(1);
     const bool extra = a.res || a.accumulate;
-    int hp0[NJ], pxl[NJ];
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        const int p = wm * 128 + j * 32 + (lane & 31);
-        hp0[j] = (p >> 4) * HWD + (p & 15);
-        pxl[j] = p & 15;
-    }
+    // Fragment addresses.  Pixel block j of the wave = patch rows 8 wm + 2 j, 2 j + 1: lane l reads pixel (2 j + (l % 32) / 16, l % 16), so the
+    // four blocks sit at a CONSTANT 2 x 18 x 128 bytes from each other, their chunk key ((px + s) >> 1) is the same, and ONE address
+    // register + ds_read's immediate offset serves all four; likewise the two 32-row weight blocks (4096 bytes apart).  The sub-step
+    // term (kc << 5, bits 5-6) is XORed into that one register: the offsets are multiples of 512 and do not touch those bits.
     f32x16 acc[NIB][NJ];
-#pragma unroll
-    for (int i = 0; i < NIB; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x16)(0.f);
     const int sw = (lane >> 5) ^ ((lane >> 1) & 7);
     const int hi = lane >> 5;
-    const unsigned lds0 = (unsigned)(size_t)smem;
-    unsigned wv[NIB], hv[NJ];
+    constexpr int XJ = 2 * HWD * 128, WI = 32 * 128;      // byte distance of pixel blocks / weight blocks
+    const unsigned wv0 = lds0 + 2 * HALO_BYTES + (unsigned)((wn * 64 + (lane & 31)) * 128 + (sw << 4));
+    unsigned kx[3];                                        // halo address of tap (0, s) in buffer 0, s = 0 .. 2 (without the tap's row / buffer offset)
+    {
+        const int p = wm * 128 + (lane & 31), px = p & 15;
+        const unsigned hv0 = lds0 + (unsigned)(((p >> 4) * HWD + px) * 128);
 #pragma unroll
-    for (int i = 0; i < NIB; ++i) wv[i] = lds0 + 2 * HALO_BYTES + (unsigned)((wn * 64 + i * 32 + (lane & 31)) * 128 + (sw << 4));
+        for (int s_ = 0; s_ < 3; ++s_) kx[s_] = hv0 + (unsigned)(s_ * 128) + (unsigned)((hi ^ (((px + s_) >> 1) & 7)) << 4);
+    }
+    // accumulators start from bias + time bias of the tile's channels (lane: channels 8 g + 4 hi + 0..3 of each 32-channel block, any pixel)
+    auto init_acc = [&](int parity) {
+        const char* rows = smem + ROWS_AT + parity * 2048;
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) hv[j] = lds0 + (unsigned)(hp0[j] * 128);
+        for (int i = 0; i < NIB; ++i) {
+            f32x4v bsum[4], brow[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const unsigned ad = (unsigned)(size_t)(rows + (wn * 64 + i * 32 + 8 * g + 4 * (lane >> 5)) * 4);
+                asm volatile("ds_read_b128 %0, %1" : "=v"(bsum[g]) : "v"(ad) : "memory");
+                asm volatile("ds_read_b128 %0, %1 offset:1024" : "=v"(brow[g]) : "v"(ad) : "memory");
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4v sum = bsum[g] + brow[g];
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) { acc[i][j][4 * g] = sum.x; acc[i][j][4 * g + 1] = sum.y; acc[i][j][4 * g + 2] = sum.z; acc[i][j][4 * g + 3] = sum.w; }
+            }
+        }
+    };
+    // LDS addresses of a step's fragments (without the sub-step term): halo pixel of tap (r, s) in buffer hb_, weight rows in slot slot_
+    auto halo_addr = [&](int tap_, int hb_) {
+        const int r = tap_ / 3, s_ = tap_ - 3 * r;
+        unsigned v = kx[s_] + (unsigned)(hb_ * HALO_BYTES + r * HWD * 128);
+        asm volatile("" : "+v"(v));
+        return v;
+    };
+    auto w_addr = [&](int slot_) { unsigned v = wv0 + (unsigned)(slot_ * WT_BYTES); asm volatile("" : "+v"(v)); return v; };
     u32x4 fw[2][NIB], fx[2][NJ];                           // fragment sets: K sub-step kc uses set kc & 1
-    bool pend = false;
+    unsigned hk, wk, hkn = 0, wkn = 0;                     // this step's / the next step's addresses
+    unsigned rcp = 0;                                      // `ready` as read in the previous step's third sub-step (written by the asm read itself: no copies)
     TilePos cur = tile_pos(0);
 #ifdef C3_TIMING
-    int gstep = 0;
+    int tstep = 0;
 #endif
     PC_STAMP(0); PC_STAMP(1);
-    __builtin_amdgcn_s_barrier();                           // the loaders' prologue: halo 0, rows 0 and weight tile 0 are in LDS
+    unsigned need = 4;                                      // `ready` value that opens the step about to start
+    pc_wait_ge(cnt0 + PC_READY, need);                     // the loaders' prologue: halo 0, rows 0 and weight tile 0 are in LDS
     PC_STAMP(2);
+    init_acc(0);
     int slot = 0, hb = 0;
+    hk = halo_addr(0, 0);
+    wk = w_addr(0);
+    bool pend = false;
     for (int k = 0; k < my_tiles; ++k) {
         for (int cc = 0; cc < nchunks; ++cc) {
             const bool last_chunk = cc + 1 == nchunks;
-            u32x2 rv[NJ][4];                                 // residual OR previous output of ONE 32-channel block (the launcher admits one of them)
-            // residual / "+=" rows of 32-channel block i: one address per pixel, the 4-channel runs at constant offsets.  INLINE ASM and
-            // UNCONDITIONAL (see the kernel above); waves whose 64 channels lie beyond N read the start of their row instead
-            auto request_extra = [&](int i) {
+            u32x2 rv[2][4];                                  // residual OR previous output (the launcher admits one of them) of ONE epilogue round
+            // residual / "+=" rows of round (i, jh) = 32 channels x pixel blocks 2 jh, 2 jh + 1: one address per pixel, the 4-channel runs at
+            // constant offsets.  INLINE ASM and UNCONDITIONAL (see the kernel above); waves whose 64 channels lie beyond N read the start of
+            // their row instead
+            auto request_extra = [&](int i, int jh) {
                 const int n0 = cur.tn * 128 + wn * 64 + 4 * (lane >> 5);
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) {
-                    const int p = wm * 128 + j * 32 + (lane & 31);
+                for (int jj = 0; jj < 2; ++jj) {
+                    const int p = wm * 128 + (2 * jh + jj) * 32 + (lane & 31);
                     const bf16_t* base = (a.res ? a.res : a.out) + ((long long)(cur.img * a.H + cur.py0 + (p >> 4)) * a.W + cur.px0 + (p & 15)) * (a.res ? a.res_ld : a.out_ld)
                                          + (n0 < a.N ? n0 : 0) + i * 32;
 #pragma unroll
                     for (int g = 0; g < 4; ++g)
-                        asm volatile("global_load_dwordx2 %0, %1, off offset:%2" : "=v"(rv[j][g]) : "v"(base), "n"(8 * g * 2) : "memory");
+                        asm volatile("global_load_dwordx2 %0, %1, off offset:%2" : "=v"(rv[jj][g]) : "v"(base), "n"(8 * g * 2) : "memory");
                 }
             };
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
-                const int r = tap / 3, s = tap - 3 * r;
-                const int shift = r * HWD + s;
-                const unsigned woff = (unsigned)(slot * WT_BYTES);
-                const unsigned hoffs = (unsigned)(hb * HALO_BYTES + shift * 128);
-                unsigned hk[NJ], wk[NIB];
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) {
-                    int px = pxl[j];
-                    asm volatile("" : "+v"(px));
-                    const int key = ((px + s) >> 1) & 7;
-                    hk[j] = hv[j] + hoffs + (unsigned)((hi ^ key) << 4);
-                }
-#pragma unroll
-                for (int i = 0; i < NIB; ++i) { wk[i] = wv[i] + woff; asm volatile("" : "+v"(wk[i])); }
-                // One K sub-step: the eight MFMAs of set `cw/cx`, the six reads of the next set `nw/nx` two per gap behind the first three —
-                // every read has five MFMAs (160 clk) of cover before the wait that closes the sub-step.  mf = false: reads only; kc < 0: MFMAs only.
-                auto sub_step = [&](bool mf, const u32x4 (&cw)[NIB], const u32x4 (&cx)[NJ], int kc, u32x4 (&nw)[NIB], u32x4 (&nx)[NJ]) {
+                const bool tile_end = tap == 8 && last_chunk;
+                const int nslot = slot + 1 == RING ? 0 : slot + 1;
+                // One K sub-step = the eight MFMAs of fragment set `cw/cx` + the six reads of the next set `nw/nx`, two per gap behind the first
+                // three MFMAs.  NO full wait anywhere: LDS returns a wave's reads in order, so each MFMA waits (counted lgkmcnt) for exactly
+                // the fragments it is the first to use — a batch of six 1-KiB reads takes ~250 clk to come back, more than the 256 clk of a
+                // sub-step's MFMAs leave when all six must be in before the first multiply (measured: 390 clk per sub-step that way).
+                // Queue on entry: the six reads of cw/cx (issue order w0 x0 w1 x1 x2 x3), then `pre` newer operations (the counter read /
+                // signal of the previous sub-step).  post: 1 = read the `ready` counter behind the new reads, 2 = signal `sig` there.
+                // mf = false: reads only (first sub-step of a tile); kc < 0: MFMAs only (last sub-step of a tile).
+                auto sub_step = [&](bool mf, const u32x4 (&cw)[NIB], const u32x4 (&cx)[NJ], int kc, u32x4 (&nw)[NIB], u32x4 (&nx)[NJ], int pre, int post, unsigned sig, bool nextaddr) {
+                    unsigned aw = 0, ax = 0;
+                    if (kc >= 0) { aw = wk ^ (unsigned)(kc << 5); ax = hk ^ (unsigned)(kc << 5); }
+                    const int rd = kc >= 0 ? 1 : 0;            // new reads are issued in this sub-step
                     auto rd_w = [&](int i) {
                         if (kc < 0) return;
 #ifdef PC_ABL_NO_READS
                         return;
 #endif
-                        const unsigned ad = wk[i] ^ (unsigned)(kc << 5);
-                        asm volatile("ds_read_b128 %0, %1" : "=v"(nw[i]) : "v"(ad) : "memory");
+                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(nw[i]) : "v"(aw), "n"(i * WI) : "memory");
                         __builtin_amdgcn_sched_barrier(0);
                     };
                     auto rd_x = [&](int j) {
@@ -845,8 +927,7 @@ void conv3x3_pc_kernel(CsArgs a) {
 #ifdef PC_ABL_NO_READS
                         return;
 #endif
-                        const unsigned ad = hk[j] ^ (unsigned)(kc << 5);
-                        asm volatile("ds_read_b128 %0, %1" : "=v"(nx[j]) : "v"(ad) : "memory");
+                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(nx[j]) : "v"(ax), "n"(j * XJ) : "memory");
                         __builtin_amdgcn_sched_barrier(0);
                     };
                     auto mm = [&](int i, int j) {
@@ -857,40 +938,85 @@ void conv3x3_pc_kernel(CsArgs a) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, cw[i]), __builtin_bit_cast(bf16x8, cx[j]), acc[i][j], 0, 0, 0);
                         __builtin_amdgcn_sched_barrier(0);
                     };
+                    // wait until at most `n` LDS operations of this wave are outstanding (n is a constant after inlining)
+                    auto wl = [&](int n) {
+                        if (!mf) return;
+                        switch (n) {
+                            case 0: asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); break;
+                            case 1: asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory"); break;
+                            case 2: asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory"); break;
+                            case 3: asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory"); break;
+                            case 4: asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory"); break;
+                            case 5: asm volatile("s_waitcnt lgkmcnt(5)" ::: "memory"); break;
+                            case 6: asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory"); break;
+                            case 7: asm volatile("s_waitcnt lgkmcnt(7)" ::: "memory"); break;
+                            case 8: asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory"); break;
+                            default: asm volatile("s_waitcnt lgkmcnt(9)" ::: "memory"); break;
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    };
+                    const int po = post ? 1 : 0;
+                    wl(4 + pre);                             // w0, x0 are in (w1 x1 x2 x3 and the `pre` operations may be on their way)
                     mm(0, 0); rd_w(0); rd_x(0);
+                    wl(3 + pre + 2 * rd);                    // w1
                     mm(1, 0); rd_w(1); rd_x(1);
+                    wl(2 + pre + 4 * rd);                    // x1
                     mm(0, 1); rd_x(2); rd_x(3);
-                    mm(1, 1); mm(0, 2); mm(1, 2); mm(0, 3); mm(1, 3);
+                    if (post == 1) {
+#ifndef PC_ABL_NO_SYNC
+                        asm volatile("ds_read_b32 %0, %1" : "=v"(rcp) : "v"(cnt0 + PC_READY) : "memory");
+#endif
+                        __builtin_amdgcn_sched_barrier(0);
+                    } else if (post == 2) {
+                        pc_signal(sig);                      // (behind this step's last reads in the wave's LDS queue)
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    mm(1, 1);
+                    if (nextaddr) {
+                        hkn = tap < 8 ? halo_addr(tap + 1, hb) : halo_addr(0, hb ^ 1);
+                        wkn = w_addr(nslot);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    wl(1 + pre + 6 * rd + po);               // x2
+                    mm(0, 2); mm(1, 2);
+                    wl(pre + 6 * rd + po);                   // x3
+                    mm(0, 3); mm(1, 3);
                 };
-#define PC_WAIT_SET() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
-                if (tap == 8 && last_chunk && extra) { request_extra(0); __builtin_amdgcn_sched_barrier(0); }
-                sub_step(tap > 0 || pend, fw[1], fx[1], 0, fw[0], fx[0]);
-                PC_WAIT_SET();
-                sub_step(true, fw[0], fx[0], 1, fw[1], fx[1]);
-                PC_WAIT_SET();
-                sub_step(true, fw[1], fx[1], 2, fw[0], fx[0]);
-                PC_WAIT_SET();
-                sub_step(true, fw[0], fx[0], 3, fw[1], fx[1]);
-                slot = slot + 1 == RING ? 0 : slot + 1;
-                if (tap == 8 && last_chunk) {                // the tile ends here: nothing is carried into the epilogue
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    if (k == 0) PC_STAMP(3); else if (k == 1) PC_STAMP(5);
-                    __builtin_amdgcn_s_barrier();             // every consumer has read its last fragments of this halo buffer
+                if (tile_end && extra) { request_extra(0, 0); __builtin_amdgcn_sched_barrier(0); }
+                // sub-step 1: the previous step's last fragments (behind them in the queue: that step's signal) | reads kc = 0.  The `ready`
+                // counter read in the previous step's third sub-step is older than those fragments: valid once the first wait is through,
+                // and checked BEFORE this step's first read is issued
+#ifndef PC_ABL_NO_SYNC
+                if (tap > 0 || pend) {
+                    asm volatile("s_waitcnt lgkmcnt(5)" ::: "memory");
                     __builtin_amdgcn_sched_barrier(0);
-                    sub_step(true, fw[1], fx[1], -1, fw[0], fx[0]);
+                    if ((int)((unsigned)__builtin_amdgcn_readfirstlane((int)rcp) - need) < 0) pc_wait_ge(cnt0 + PC_READY, need);
+                }
+#endif
+                sub_step(tap > 0 || pend, fw[1], fx[1], 0, fw[0], fx[0], 1, 0, 0u, false);
+                sub_step(true, fw[0], fx[0], 1, fw[1], fx[1], 0, 0, 0u, false);
+                sub_step(true, fw[1], fx[1], 2, fw[0], fx[0], 0, 1, 0u, false);
+                // (a tile's last step hands its slot back AFTER the epilogue, with the staging area; here it signals the consumers' rendezvous)
+                sub_step(true, fw[0], fx[0], 3, fw[1], fx[1], 1, 2, tile_end ? my_cnt + PC_EDONE : my_cnt + PC_FREED, !tile_end);
+                slot = nslot;
+                need += 4;
+                if (tile_end) {
+                    sub_step(true, fw[1], fx[1], -1, fw[0], fx[0], 1, 0, 0u, false);
                     pend = false;
+                    if (k == 0) PC_STAMP(3); else if (k == 1) PC_STAMP(5);
+                    pc_wait_ge(cnt0 + PC_EDONE, 4u * (unsigned)(k + 1));
                     break;
                 }
                 pend = true;
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
+                hk = hkn; wk = wkn;
+                // the fragment sets live in registers across the chunk loop's back edge: everything requested is in before it is taken (the
+                // compiler may place copies there, and it does not know about the reads in flight)
+                if (tap == 8) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
                 PC_STEP();
-#undef PC_WAIT_SET
             }
             if (last_chunk) {
-                // ---- tile done: out = acc + bias + time bias (+ residual | + out), staged through the finished halo buffer in wave-private
-                // slices of 64 pixels x 64 bytes so that four consecutive lanes store the 64 contiguous bytes of a pixel (as above)
-                const char* rows = smem + ROWS_AT + (k & 1) * 2048;
+                // ---- tile done: out = acc (+ residual | + out), staged through the finished halo buffer in wave-private slices of
+                // 64 pixels x 64 bytes so that four consecutive lanes store the 64 contiguous bytes of a pixel (as above)
                 const int n0 = cur.tn * 128 + wn * 64;
                 const bool live = n0 < a.N;
                 const unsigned stg = lds0 + (unsigned)(hb * HALO_BYTES + wave * (64 * 64));
@@ -903,34 +1029,20 @@ void conv3x3_pc_kernel(CsArgs a) {
                 };
 #pragma unroll
                 for (int i = 0; i < NIB; ++i) {
-                    f32x4v bsum[4], brow[4];
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const unsigned ad = (unsigned)(size_t)(rows + (wn * 64 + i * 32 + 8 * g + 4 * (lane >> 5)) * 4);
-                        asm volatile("ds_read_b128 %0, %1" : "=v"(bsum[g]) : "v"(ad) : "memory");
-                        asm volatile("ds_read_b128 %0, %1 offset:1024" : "=v"(brow[g]) : "v"(ad) : "memory");
-                    }
-                    if (extra) {
-                        // block 0's rows were requested in the tile's last step, block 1's behind block 0's last use (four stores of block 0
-                        // — none when the wave's channels lie beyond N — are newer than those)
-                        if (i == 0 || !live) wait_vm<0>(); else wait_vm<4>();
-                    }
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        if (!a.bias) bsum[g] = (f32x4v)(0.f);
-                        if (!a.rowbias) brow[g] = (f32x4v)(0.f);
-                        bsum[g] += brow[g];
-                    }
-                    if (extra && !live) {
-#pragma unroll
-                        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-                            for (int g = 0; g < 4; ++g) rv[j][g] = (u32x2)(0u);
-                    }
 #pragma unroll
                     for (int jh = 0; jh < 2; ++jh) {
+                        if (extra) {
+                            // round 0's rows were requested in the tile's last step, every later round's behind the previous round's last use
+                            // (that round's four stores — none when the wave's channels lie beyond N — are newer than those)
+                            if ((i == 0 && jh == 0) || !live) wait_vm<0>(); else wait_vm<4>();
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (!live) {
+#pragma unroll
+                                for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                                    for (int g = 0; g < 4; ++g) rv[jj][g] = (u32x2)(0u);
+                            }
+                        }
 #pragma unroll
                         for (int jj = 0; jj < 2; ++jj) {
                             const int j = 2 * jh + jj;
@@ -938,9 +1050,8 @@ void conv3x3_pc_kernel(CsArgs a) {
 #pragma unroll
                             for (int g = 0; g < 4; ++g) {
                                 float v[4] = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-                                v[0] += bsum[g].x; v[1] += bsum[g].y; v[2] += bsum[g].z; v[3] += bsum[g].w;
                                 if (extra) {
-                                    const u32x2 r2 = rv[j][g];
+                                    const u32x2 r2 = rv[jj][g];
                                     v[0] += __uint_as_float(r2.x << 16); v[1] += __uint_as_float(r2.x & 0xffff0000u);
                                     v[2] += __uint_as_float(r2.y << 16); v[3] += __uint_as_float(r2.y & 0xffff0000u);
                                 }
@@ -956,7 +1067,11 @@ void conv3x3_pc_kernel(CsArgs a) {
                                 asm volatile("ds_write_b128 %0, %1" :: "v"(ad), "v"(o) : "memory");
                             }
                         }
-                        if (extra && i == 0 && jh == 1) { __builtin_amdgcn_sched_barrier(0); request_extra(1); __builtin_amdgcn_sched_barrier(0); }
+                        if (extra && !(i == NIB - 1 && jh == 1)) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (jh == 0) request_extra(i, 1); else request_extra(i + 1, 0);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
                         u32x4 back[4];
 #pragma unroll
                         for (int rr = 0; rr < 4; ++rr) {
@@ -972,18 +1087,20 @@ void conv3x3_pc_kernel(CsArgs a) {
                         }
                     }
                 }
-#pragma unroll
-                for (int i = 0; i < NIB; ++i)
-#pragma unroll
-                    for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x16)(0.f);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();                 // the barrier of the tile's last step
+                // the staging reads are done (waited for above): slot, halo buffer and staging area go back to the loaders
+                pc_signal(my_cnt + PC_FREED);
+                if (k + 1 < my_tiles) {
+                    cur = tile_pos(k + 1);
+                    pc_wait_ge(cnt0 + PC_READY, need);         // the next tile's first weight tile, its halo and its rows are in
+                    init_acc((k + 1) & 1);
+                    hk = halo_addr(0, hb ^ 1);
+                    wk = w_addr(slot);
+                }
                 PC_STEP();
                 if (k == 0) PC_STAMP(4); else if (k == 1) PC_STAMP(6);
             }
             hb ^= 1;
         }
-        if (k + 1 < my_tiles) cur = tile_pos(k + 1);
     }
     PC_STAMP(7);
 }
@@ -1013,7 +1130,11 @@ int ddpm_conv3x3_stream_launch(const void* x, long long x_ld, const void* w, voi
     const long long rbbytes = rowbias ? ((long long)(B - 1) * rowbias_ld + N) * 4 : 0;
     if (xbytes > 0x7ffffff0ll || wbytes > 0x7ffffff0ll || rbbytes > 0x7ffffff0ll) return -1;
     // 16 x 16 patches: the wave-specialised kernel (loaders + consumers) unless DDPM_CONV_NO_PC is set; DDPM_C3_PC_FLAGS: bit 0 = consumers at priority 1
+#ifdef PC_DEFAULT_OFF
+    static const bool use_pc = false;                       // (scripts/build_variant.sh prev: the round-3 kernel for same-process A/Bs)
+#else
     static const bool use_pc = getenv("DDPM_CONV_NO_PC") == nullptr;
+#endif
     static const int pc_flags = getenv("DDPM_C3_PC_FLAGS") ? atoi(getenv("DDPM_C3_PC_FLAGS")) : 0;
     if (dry) return patch == 16 && use_pc ? 17 : patch;
     CsArgs a; memset(&a, 0, sizeof(a));
@@ -1043,10 +1164,10 @@ int ddpm_conv3x3_stream_launch(const void* x, long long x_ld, const void* w, voi
         a.flags = pc_flags;
         static bool pc_attr_set = false;
         if (!pc_attr_set) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_pc_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, Lds<16>::BYTES) != hipSuccess) return DDPM_ERR_LAUNCH;
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_pc_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, PC_BYTES) != hipSuccess) return DDPM_ERR_LAUNCH;
             pc_attr_set = true;
         }
-        hipLaunchKernelGGL(conv3x3_pc_kernel, dim3(grid), dim3(512), Lds<16>::BYTES, (hipStream_t)stream, a);
+        hipLaunchKernelGGL(conv3x3_pc_kernel, dim3(grid), dim3(512), PC_BYTES, (hipStream_t)stream, a);
     }
     else if (patch == 16) C3_LAUNCH(16); else C3_LAUNCH(8);
 #undef C3_LAUNCH
