@@ -46,6 +46,10 @@ VARIANT = {1: "gemm_kernel<4 waves,128x128>", 2: "gemm_kernel<8 waves,128x128>",
            13: "conv3x3_pc_kernel (persistent, 256px x 128, loader + consumer waves)"}
 
 
+HBM_KIND = {"hbm_gn_fwd": "GroupNorm(32)+SiLU(+dropout) forward (gn_lds_fwd / gn_apply family, norm.hip)",
+            "hbm_gn_bwd": "GroupNorm(32)+SiLU(+dropout) backward (gn_lds_bwd / gn_bwd_apply family, norm.hip)"}
+HBM_ACHIEVABLE = 6300.0                                   # GB/s: measured float4-copy rate, MI355X_MICROARCH.md (8000 spec)
+
 # share of the 256 CUs a wgrad3x3 launch takes (csrc/wgrad.hip: block budget, DDPM_WGRAD3_CUS)
 WGRAD3_CU_SHARE = min(int(os.environ.get("DDPM_WGRAD3_CUS", "128")), 256) / 256.0
 
@@ -214,7 +218,17 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     ranks_seen = 1
-    if distributed:
+    # BENCH_DDP=native on ONE GPU: a world-size-1 RCCL communicator, so that the exchange path (chunked all-reduces issued from inside the
+    # backward, loss reduce, barrier) runs and config.dp can be read before a node is available
+    self_ddp = world == 1 and os.environ.get("BENCH_DDP") == "native"
+    if self_ddp:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port1 = sk.getsockname()[1]
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port1}", world_size=1, rank=0)
+        distributed = True
+    elif distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", init_method="env://", world_size=world, rank=rank)     # "nccl" is RCCL on ROCm
         probe = torch.ones(1, device=dev)
@@ -272,22 +286,33 @@ def main():
     def profile_step(trainer, x, step_no):
         graph_was, train_mod._TRAIN_GRAPH = train_mod._TRAIN_GRAPH, False       # per-launch events need the eager form of the step
         _ops.PROFILE = []
+        eng = model.engine()
+        eng.dp_trace = [] if eng.pg is not None else None
         torch.cuda.synchronize()
         if os.environ.get("BENCH_NO_GATE") is None:
             torch.cuda._sleep(gate_cycles)
         trainer.step(x, global_steps=step_no)
         torch.cuda.synchronize()
         prof, _ops.PROFILE = _ops.PROFILE, None
+        dp_trace, eng.dp_trace = eng.dp_trace, None
+        if dp_trace:
+            profile_step.dp = dp_trace
         train_mod._TRAIN_GRAPH = graph_was
-        agg, shapes = {}, {}
+        agg, shapes, hbm = {}, {}, {}
         for kind, flops, a, b, shape, variant in prof:
             dt_s = a.elapsed_time(b) * 1e-3
+            if kind.startswith("hbm_"):                       # GroupNorm launches: `flops` holds algorithmic BYTES
+                e = hbm.setdefault(HBM_KIND[kind], [0, 0.0, 0.0])
+                e[0] += 1; e[1] += flops; e[2] += dt_s
+                e2 = hbm.setdefault(HBM_KIND[kind] + " | " + shape, [0, 0.0, 0.0])
+                e2[0] += 1; e2[1] += flops; e2[2] += dt_s
+                continue
             name = VARIANT.get(variant, "other") + (" wgrad (both operands k-strided)" if kind == "gemm_tt" else "")
             e = agg.setdefault(name, [0, 0.0, 0.0])
             e[0] += 1; e[1] += flops; e[2] += dt_s
             e2 = shapes.setdefault(f"{name} | {kind} {shape}", [0, 0.0, 0.0])
             e2[0] += 1; e2[1] += flops; e2[2] += dt_s
-        return agg, shapes
+        return agg, shapes, hbm
 
     def table(agg, pk):
         return {k: {"launches": v[0], "gflop": round(v[1] / 1e9, 1), "ms": round(v[2] * 1e3, 3), "tflops": round(v[1] / v[2] / 1e12, 1),
@@ -298,12 +323,30 @@ def main():
         f, t = sum(v[1] for v in agg.values()), sum(v[2] for v in agg.values())
         return {"tflops": round(f / t / 1e12, 1), "ms": round(t * 1e3, 3), "frac": round(f / t / 1e12 / pk, 4)}
 
-    agg, shapes = profile_step(tr, x0, args.warmup + args.steps + 1)
+    agg, shapes, hbm = profile_step(tr, x0, args.warmup + args.steps + 1)
     side_was = unet_mod._SIDE_STREAM
     unet_mod._SIDE_STREAM = False
-    agg_iso, shapes_iso = profile_step(tr, x0, args.warmup + args.steps + 2)
+    agg_iso, shapes_iso, hbm_iso = profile_step(tr, x0, args.warmup + args.steps + 2)
     unet_mod._SIDE_STREAM = side_was
     # (every rank ran the two extra steps above: with N > 1 they contain the gradient all-reduce and the loss reduce)
+    # What the matrix pipe SUSTAINS on this box: an MFMA-only loop on register-resident random bf16 operands, ~0.3 s (the chip clocks to
+    # its power budget; 2.5 PFLOP/s is reached on zero operands only — profiles/r04_probe_mfma_power.txt).  Context for `frac`, not a target.
+    practical = None
+    if args.dtype == "bf16" and rank == 0:
+        from ddpm_torch import _hip as hip_
+        sink = torch.zeros(256, device=dev)
+        it_p = 200000
+        st_p = torch.cuda.current_stream().cuda_stream
+        for _ in range(3):
+            hip_.call("ddpm_mfma_probe", sink.data_ptr(), it_p, 0, st_p)
+        ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ea.record()
+        for _ in range(6):
+            hip_.call("ddpm_mfma_probe", sink.data_ptr(), it_p, 0, st_p)
+        eb.record(); torch.cuda.synchronize()
+        practical = {"tflops": round(6 * it_p * 16 * 32768.0 * 1024 / (ea.elapsed_time(eb) * 1e-3) / 1e12, 1),
+                     "what": "ddpm_mfma_probe: MFMA-only loop (v_mfma_f32_32x32x16_bf16, 8 accumulators per wave, one wave per SIMD, all 256 CUs) on random bf16 "
+                             "operands held in registers, sustained ~0.3 s after warm-up on this box; zero operands reach the nominal peak"}
     out = None
     if rank == 0:
         if os.environ.get("BENCH_SHAPES"):
@@ -335,8 +378,38 @@ def main():
                     traffic = {"hbm_bytes_per_launch": rec["fetch_bytes_per_launch"] + rec["write_bytes_per_launch"],
                                "fetch_bytes_per_launch": rec["fetch_bytes_per_launch"], "write_bytes_per_launch": rec["write_bytes_per_launch"],
                                "source": rec.get("source", "profiles/" + os.path.basename(tpath) + " (committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, not collected in this run; FETCH_SIZE x2 per the gfx950 guide)")}
+        by_dur = max(agg.items(), key=lambda kv: kv[1][2])[0]
+        by_cu = max(agg.items(), key=lambda kv: kv[1][2] * share.get(kv[0], 1.0))[0]
+
+        def hbm_table(tab):
+            out_t = {}
+            for k, v in sorted(tab.items(), key=lambda kv: -kv[1][2]):
+                if " | " in k and len(out_t) >= 12:
+                    continue
+                gbs = v[1] / v[2] / 1e9
+                rec = {"launches": v[0], "algorithmic_mb": round(v[1] / 1e6, 1), "ms": round(v[2] * 1e3, 3), "gb_per_s": round(gbs, 1),
+                       "frac_of_achievable_6300": round(gbs / HBM_ACHIEVABLE, 4), "frac_of_spec_8000": round(gbs / 8000.0, 4)}
+                out_t[k] = rec
+            return out_t
+        hbm_counter = None
+        if tpath:
+            recs = json.load(open(tpath)).get("kernels", [])
+            # (HBM bytes per launch from the committed FETCH_SIZE x 2 / WRITE_SIZE passes, per kernel instantiation; compare with
+            #  algorithmic_mb / launches of the shapes that instantiation serves)
+            hbm_counter = {r["kernel"].replace("void ", "")[:44]: {"fetch_mb": round(r["fetch_bytes_per_launch"] / 1e6, 1), "write_mb": round(r["write_bytes_per_launch"] / 1e6, 1)}
+                           for r in recs if r.get("match", "").startswith("gn_")}
+            hbm_counter["source"] = "profiles/" + os.path.basename(tpath)
         roofline = {"bound": "mfma", "kernel": dom_name, "achieved": round(achieved, 1), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(achieved / peak, 4), "traffic": traffic,
+                    "dominant_by_duration": {"kernel": by_dur, "ms_in_step": round(agg[by_dur][2] * 1e3, 3),
+                                             "frac": round(agg[by_dur][1] / agg[by_dur][2] / 1e12 / peak, 4)},
+                    "dominant_by_cu_time": {"kernel": by_cu, "ms_in_step_x_cu_share": round(agg[by_cu][2] * share.get(by_cu, 1.0) * 1e3, 3),
+                                            "frac": round(agg[by_cu][1] / agg[by_cu][2] / 1e12 / peak, 4)},
+                    "practical_peak": practical,
+                    "frac_of_practical_peak": round(achieved / practical["tflops"], 4) if practical else None,
+                    "hbm_kernels": {"bound": "hbm", "peak_gb_per_s": 8000.0, "achievable_gb_per_s": HBM_ACHIEVABLE,
+                                    "note": "algorithmic bytes (SURVEY 8d: forward x + y; backward x + dy + dx [+ the residual gradient it adds]) / event-bracketed duration",
+                                    "in_step": hbm_table(hbm), "isolated": hbm_table(hbm_iso), "counters": hbm_counter},
                     "launches_per_step": dom[0], "avg_launch_us": round(dom[2] / dom[0] * 1e6, 2),
                     "note": "durations as they occur in the product step (two HIP streams share the GPU); `isolated` = same step, one stream; "
                             "dominant = most GPU time (duration x share of the CUs a launch occupies) in the isolated pass",
@@ -347,12 +420,26 @@ def main():
                                      if share.get(ru_name, 1.0) != 1.0 else {})},
                     "all_mfma_kernels": total(agg, peak), "per_kernel": table(agg, peak),
                     "isolated": {"all_mfma_kernels": total(agg_iso, peak), "per_kernel": table(agg_iso, peak)}}
+        dp = None
+        tr_dp = getattr(profile_step, "dp", None)
+        if tr_dp:
+            done = [e for w, _, e in tr_dp if w == "backward_compute_done"][-1]
+            fin = [e for w, _, e in tr_dp if w == "exchange_done"][-1]
+            ars = [(nb, e) for w, nb, e in tr_dp if w == "all_reduce"]
+            ars = ars[-(len(model.engine().chunks) + 1):]                 # the last profiled backward (the isolated pass)
+            dp = {"collective": "RCCL all-reduce (sum) of the packed fp32 gradient staging buffer, in chunks issued from inside the backward; 1/world applied in the unpack kernel",
+                  "world": world, "chunks": len(ars), "bytes_per_chunk": [nb for nb, _ in ars], "total_mb": round(sum(nb for nb, _ in ars) / 1e6, 1),
+                  "issued_ms_before_end_of_backward": [round(e.elapsed_time(done), 3) for _, e in ars],
+                  "exposed_wait_ms": round(done.elapsed_time(fin), 3),
+                  "chunk_target": os.environ.get("DDPM_DP_CHUNK_MB", "conv-weight region / 6 (~24 MB)") ,
+                  "note": "timestamps on the compute stream of the profiled eager step (side stream off); the last chunk is the small-tensor tail. "
+                          "On one GPU the communicator has a single rank: the times show WHEN the exchanges are issued, not what xGMI does with them"}
         out = {"metric": "training imgs/s/GPU + 1000-step DDPM samples/s, CIFAR-10 UNet @1/2/4/8 MI355X",
                "value": round(imgs_per_s, 2), "unit": "imgs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": args.dtype, "data": "synthetic",
                "config": {"workload": "configs/cifar10.json UNet (35.7M params), full Trainer.step, B=128 per GPU, 32x32, T=1000, dropout 0.1, Adam+clip+EMA",
-                          "global_batch": B_PER_GPU * world, "rccl_ranks": ranks_seen,
+                          "global_batch": B_PER_GPU * world, "rccl_ranks": ranks_seen, "dp": dp,
                           "parallelism": f"dp{world}" + ("" if world == 1 else (" (native chunked RCCL all-reduce inside backward)" if native else " (torch DDP)")),
                           "step_execution": step_mode, "imgs_per_s_per_gpu": round(imgs_per_s / world, 2),
                           "train_model_tflops_per_gpu": round(imgs_per_s / world * 3 * FWD_GFLOP["cifar"] / 1e3, 1),

@@ -65,6 +65,7 @@ PROTOTYPES = {
     "ddpm_softmax_fwd": [P, P, L, I, I, P],
     "ddpm_softmax_bwd": [P, P, P, L, I, I, P],
     "ddpm_dropout_mask": [P, L, F, U, P],
+    "ddpm_mfma_probe": [P, I, I, P],
     "ddpm_mt_grad_sumsq": [P, I, P, P],
     "ddpm_mt_adam_ema": [P, I, P, F, F, F, F, F, F, F, F, P, P],
     "ddpm_mt_gather_f32": [P, I, P],

@@ -14,7 +14,8 @@ GN_GROUPS = 32
 GN_EPS = 1e-6
 
 # Optional per-launch timing (bench.py's roofline leg): when a list, every MFMA launch appends
-# (kernel id, algorithmic flops, start event, end event) recorded on the launch stream.
+# (kind, algorithmic flops, start event, end event, shape, kernel id) recorded on the launch stream; kinds starting with "hbm_" are the
+# HBM-bound GroupNorm launches, whose second field is algorithmic BYTES.
 PROFILE = None
 
 
@@ -184,8 +185,12 @@ def gn_workspace_floats(B, HW, C, dtype):
 def gn_fwd(x, y, gamma, beta, stats, ws, silu, drop_p=0.0, seed=0, seed_dev=0):
     """seed_dev: address of a device uint64 added to `seed` inside the kernel (0 = none) — the per-step part of the dropout
     seed when the step is a replayed hipGraph."""
-    _hip.call("ddpm_groupnorm_silu_fwd", x.ptr, x.ld, y.ptr, y.ld, _hip.ptr(gamma), _hip.ptr(beta), _hip.ptr(stats), _hip.ptr(ws),
-         x.B, x.H * x.W, x.C, GN_GROUPS, GN_EPS, int(silu), float(drop_p), seed, seed_dev, x.dtype, _hip.stream())
+    es = 2 if x.dtype == _hip.BF16 else 4
+    # (bench.py's HBM roofline leg: algorithmic bytes = read x once + write y once, SURVEY.md section 8d)
+    _timed("hbm_gn_fwd", 2.0 * x.B * x.H * x.W * x.C * es, lambda: _hip.call(
+        "ddpm_groupnorm_silu_fwd", x.ptr, x.ld, y.ptr, y.ld, _hip.ptr(gamma), _hip.ptr(beta), _hip.ptr(stats), _hip.ptr(ws),
+        x.B, x.H * x.W, x.C, GN_GROUPS, GN_EPS, int(silu), float(drop_p), seed, seed_dev, x.dtype, _hip.stream()),
+        f"GroupNorm fwd B={x.B} HW={x.H * x.W} C={x.C}" + (" +dropout" if drop_p > 0 else ""))
 
 
 def gn_stats(x, stats):
@@ -204,9 +209,13 @@ def conv3x3_gn(x, stats, gamma, beta, w_ptr, y_ptr, y_ld, N, silu=True, bias=0, 
 def gn_bwd(x, dy, dx, gamma, beta, stats, dgamma_ptr, dbeta_ptr, ws, silu, drop_p=0.0, seed=0, accumulate=0, seed_dev=0, colsum_ptr=0, colsum_ld=0, add=None):
     """colsum_ptr: zero-initialised [B][colsum_ld] fp32 buffer that receives the per-sample channel sums of dx (0 = not wanted).
     add: View of a second gradient contribution summed into dx in the same pass (the identity branch of a residual connection)."""
-    _hip.call("ddpm_groupnorm_silu_bwd", x.ptr, x.ld, dy.ptr, dy.ld, dx.ptr, dx.ld, _hip.ptr(gamma), _hip.ptr(beta), _hip.ptr(stats), dgamma_ptr, dbeta_ptr,
-         _hip.ptr(ws), x.B, x.H * x.W, x.C, GN_GROUPS, int(silu), float(drop_p), seed, seed_dev, accumulate, colsum_ptr, colsum_ld,
-         add.ptr if add is not None else 0, add.ld if add is not None else 0, x.dtype, _hip.stream())
+    es = 2 if x.dtype == _hip.BF16 else 4
+    # algorithmic bytes: read x and dy, write dx (+ read the identity-residual gradient it adds, + read dx when it accumulates)
+    _timed("hbm_gn_bwd", (3.0 + (add is not None) + (1 if accumulate else 0)) * x.B * x.H * x.W * x.C * es, lambda: _hip.call(
+        "ddpm_groupnorm_silu_bwd", x.ptr, x.ld, dy.ptr, dy.ld, dx.ptr, dx.ld, _hip.ptr(gamma), _hip.ptr(beta), _hip.ptr(stats), dgamma_ptr, dbeta_ptr,
+        _hip.ptr(ws), x.B, x.H * x.W, x.C, GN_GROUPS, int(silu), float(drop_p), seed, seed_dev, accumulate, colsum_ptr, colsum_ld,
+        add.ptr if add is not None else 0, add.ld if add is not None else 0, x.dtype, _hip.stream()),
+        f"GroupNorm bwd B={x.B} HW={x.H * x.W} C={x.C}" + (" +dropout" if drop_p > 0 else "") + (" +add" if add is not None else ""))
 
 
 def colsum(dy, per_sample_ptr, ps_ld, total_ptr):

@@ -239,9 +239,9 @@ class GaussianDiffusion:
         _hip.require_cuda(torch.empty(0, device=device))        # no CPU fallback: sampling runs on the GPU only
         B = (shape or noise.shape)[0]
         steps = self._num_steps()
-        if (on_step is None and z_stream is None and steps >= 4 and device.type == "cuda"
+        if (on_step is None and steps >= 4 and device.type == "cuda"
                 and os.environ.get("DDPM_TORCH_AMD_GRAPH", "1") != "0" and not torch.cuda.is_current_stream_capturing()):
-            done = self._graph_loop(denoise_fn, tuple(shape or noise.shape), device, noise, seed, steps)
+            done = self._graph_loop(denoise_fn, tuple(shape or noise.shape), device, noise, seed, steps, z_stream)
             if done is not None:
                 return done
         rng = torch.Generator(device).manual_seed(seed) if seed is not None else None       # diffusion.py:164-166
@@ -284,14 +284,15 @@ class GaussianDiffusion:
             return None
         return [m.engine() for m in denoise_fn.modules() if isinstance(m, UNet)]
 
-    def _graph_entry(self, denoise_fn, shape, device, default_rng):
-        """Cached captured step for (denoiser, shape), capturing it on first use; None when capture is not possible."""
+    def _graph_entry(self, denoise_fn, shape, device, default_rng, external_z=False):
+        """Cached captured step for (denoiser, shape), capturing it on first use; None when capture is not possible.
+        ``external_z`` (parity tests): the step does not draw its noise, the caller fills the captured ``z`` buffer before every replay."""
         cache = self.__dict__.setdefault("_sample_graphs", {})
         engines = self._engines_of(denoise_fn)
         # engine serials: model.to() / .float() / set_compute_dtype() re-create the engine (packed weights, workspaces) — a step
         # captured against the previous one points at freed memory and must never be replayed
         # ... and so is the time-bias table the step gathers from: a sampler with a longer schedule re-allocates it
-        key = (id(denoise_fn), shape, str(device), default_rng, getattr(denoise_fn, "training", None),
+        key = (id(denoise_fn), shape, str(device), (default_rng, external_z), getattr(denoise_fn, "training", None),
                tuple((e.serial, e.T, e.tt.data_ptr() if e.tt_on and e.tt is not None else 0) for e in engines) if engines else None)
         ent = cache.get(key)
         if ent is not None and ent["ref"]() is not denoise_fn:
@@ -301,7 +302,7 @@ class GaussianDiffusion:
             for k in [k for k, v in cache.items() if v["ref"]() is denoise_fn and k[5] and {q[0] for q in k[5]} != live]:
                 cache.pop(k)                                      # entries of this denoiser's earlier engines: dead weight (and dead pointers)
         if ent is None:
-            ent = self._capture_sample_step(denoise_fn, shape, device, default_rng)
+            ent = self._capture_sample_step(denoise_fn, shape, device, default_rng, external_z)
             if ent is not None and engines is not None:           # arbitrary callables are captured per call: nothing tells us when their weights change
                 import weakref
                 ent["ref"] = weakref.ref(denoise_fn)
@@ -310,10 +311,11 @@ class GaussianDiffusion:
                 cache[key] = ent
         return ent
 
-    def _graph_loop(self, denoise_fn, shape, device, noise, seed, steps):
+    def _graph_loop(self, denoise_fn, shape, device, noise, seed, steps, z_stream=None):
         """Replay the captured sampling step ``steps`` times; returns None if capture is not possible (the caller then
-        runs the eager loop; no RNG state has been consumed)."""
-        ent = self._graph_entry(denoise_fn, shape, device, default_rng=seed is None)
+        runs the eager loop; no RNG state has been consumed).  ``z_stream`` (parity tests only): per-step noise tensors that are copied
+        into the captured step's noise buffer instead of being drawn inside it."""
+        ent = self._graph_entry(denoise_fn, shape, device, default_rng=seed is None, external_z=z_stream is not None)
         if ent is None:
             return None
         x_t, t, rng, graph = ent["x_t"], ent["t"], ent["rng"], ent["graph"]
@@ -327,6 +329,8 @@ class GaussianDiffusion:
             x_t.copy_(noise)
         t.fill_(steps - 1)
         for _ in range(steps):
+            if z_stream is not None:
+                ent["z"].copy_(next(z_stream))
             graph.replay()
         return x_t.clone()
 
@@ -340,7 +344,7 @@ class GaussianDiffusion:
         with torch.inference_mode(), self._time_tables(denoise_fn):
             return self._graph_entry(denoise_fn, tuple(shape), device, default_rng=not seeded) is not None
 
-    def _capture_sample_step(self, denoise_fn, shape, device, default_rng):
+    def _capture_sample_step(self, denoise_fn, shape, device, default_rng, external_z=False):
         dev = device
         x_t = torch.zeros(shape, dtype=torch.float32, device=dev)
         z = torch.empty_like(x_t)
@@ -353,7 +357,8 @@ class GaussianDiffusion:
 
         def body(cut=None):
             out = denoise_fn(x_t, self._model_t(t)).contiguous().float()
-            z.normal_(generator=rng)
+            if not external_z:
+                z.normal_(generator=rng)
             _hip.call("ddpm_p_sample_step", x_t.data_ptr(), out.data_ptr(), z.data_ptr(), t.data_ptr(), *[tb.data_ptr() for tb in tabs],
                       x_t.data_ptr(), 0, B, n, mean_code, 1, T, _hip.stream())         # in place: each element is read once, then written
             _hip.call("ddpm_add_i64", t.data_ptr(), B, -1, _hip.stream())

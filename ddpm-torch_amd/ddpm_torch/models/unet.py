@@ -309,6 +309,7 @@ class _Engine:
         self.debug_keep_tape = False               # tests set it to look at the tape after a step; costs the activations' lifetime
         self.splitk = ops.SplitK(self.device)
         self.pg = None                              # process group of the native data-parallel path (set_process_group)
+        self.dp_trace = None                        # list -> (what, bytes, event) records of one backward's exchange (bench.py's config.dp)
         self.pack_table = self.pack_ptrs = self.pack_key = None
         self.pack_has_dgrad = False
         _hip.lib()
@@ -547,7 +548,11 @@ class _Engine:
             # become final one after another as the backward walks the network in reverse; the small tail goes last.
             convs = list(self.convs.values())
             conv_end = self.poff[id(convs[-1].mod.weight)] + (convs[-1].mod.weight.numel() + 3) // 4 * 4
+            # ~6 chunks of ~24 MB for the CIFAR / CelebA nets (143 MB of gradients); DDPM_DP_CHUNK_MB overrides the chunk size — xGMI rings
+            # are per-link bound, so the right size is a property of the node and is to be swept there (bench.py prints config.dp)
             target = max(conv_end // 6, 1 << 20)
+            if os.environ.get("DDPM_DP_CHUNK_MB"):
+                target = max(int(float(os.environ["DDPM_DP_CHUNK_MB"]) * (1 << 18)), 1 << 16)
             self.chunks, start, members = [], 0, []
             for i, cw in enumerate(convs):
                 members.append(id(cw.mod.weight))
@@ -704,7 +709,17 @@ class _Engine:
 
     def _all_reduce(self, t):
         import torch.distributed as dist
+        if self.dp_trace is not None:                      # bench.py: when (on the compute stream's timeline) each exchange is issued
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            self.dp_trace.append(("all_reduce", t.numel() * 4, ev))
         return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+
+    def _dp_mark(self, what):
+        if self.dp_trace is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            self.dp_trace.append((what, 0, ev))
 
     def _pptr(self, ctx, p):
         return ctx["gpack"].data_ptr() + 4 * self.poff[p if isinstance(p, (str, tuple)) else id(p)]
@@ -996,10 +1011,12 @@ class _Engine:
             works, tail = ctx["works"], gpack[self.tail[0]:self.tail[1]]
 
             def finish():
+                self._dp_mark("backward_compute_done")
                 works.append(self._all_reduce(tail))
                 for w in works:
                     w.wait()                               # the compute stream waits for the communicator; no host sync
                 works.clear()
+                self._dp_mark("exchange_done")
             self._comm(ctx, finish)
         wdesc = self._wgrad_table()
         if ctx["sumsq"]:           # the caller's squared-norm accumulators: the clip norm comes out of this pass (no second read of all gradients)

@@ -249,6 +249,12 @@ int ddpm_mt_adam_ema(const long long* table, int n_tensors, const float* total_s
  * concatenated time-bias projection (all ResidualBlock.fc weights; fc.bias + conv1.bias, ddpm_torch/models/unet.py:77,85-86). */
 int ddpm_mt_gather_f32(const long long* table, int n_tensors, void* stream);
 
+/* measurement hook (bench.py's roofline leg; no upstream counterpart): one launch of an MFMA-only loop on every CU — 256 blocks x 4 waves,
+ * 16 * iters v_mfma_f32_32x32x16_bf16 per wave on register-resident random bf16 operands (zero_operands = 1: zeros) =
+ * iters * 16 * 32768 * 1024 FLOP.  Timed over a few hundred ms it gives the rate the matrix pipe SUSTAINS at the chip's power
+ * budget (~1.7 PFLOP/s on random operands, ~2.5 on zeros).  sink: >= 256 floats, never written in practice. */
+int ddpm_mfma_probe(float* sink, int iters, int zero_operands, void* stream);
+
 /* test hook: the keep-mask (1/0) the GroupNorm kernels regenerate for element indices 0..n-1 */
 int ddpm_dropout_mask(float* mask, long long n, float p, unsigned long long seed, void* stream);
 

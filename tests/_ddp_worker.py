@@ -11,6 +11,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "ddpm-torch_amd")]
 
 TINY = dict(in_channels=3, hid_channels=32, out_channels=3, ch_multipliers=[1, 2], num_res_blocks=1, apply_attn=[False, True], drop_rate=0.0)
+CIFAR = dict(in_channels=3, hid_channels=128, out_channels=3, ch_multipliers=[1, 2, 2, 2], num_res_blocks=2, apply_attn=[False, True, False, False], drop_rate=0.0)
+# DDP_WORKER_CFG=cifar: the configs/cifar10.json geometry at B = 4 per rank (tests/test_multi_gpu.py) — the chunk plan, the packed gradient
+# staging buffer and the hot kernels of BASELINE config 3 instead of the 8 x 8 toy
+BIG = os.environ.get("DDP_WORKER_CFG") == "cifar"
+CFG, SHAPE = (CIFAR, (4, 3, 32, 32)) if BIG else (TINY, (2, 3, 8, 8))
 
 
 def install_emulator():
@@ -37,12 +42,12 @@ def run(rank, world, port, mode, out_dir, kind="cpu"):
     import ddpm_torch
     from oracle import unet_ref as U
     torch.manual_seed(100 + rank)                        # different initial weights per rank: the broadcast must fix that
-    model = ddpm_torch.UNet(**TINY)
+    model = ddpm_torch.UNet(**CFG)
     if rank == 0:
         torch.manual_seed(7)
-        model.load_state_dict(U.randomize_state_dict(ddpm_torch.UNet(**TINY).state_dict(), 17))
+        model.load_state_dict(U.randomize_state_dict(ddpm_torch.UNet(**CFG).state_dict(), 17))
     g = torch.Generator().manual_seed(1000 + rank)       # each rank sees its own shard
-    x, gy, t = torch.randn(2, 3, 8, 8, generator=g), torch.randn(2, 3, 8, 8, generator=g), torch.randint(0, 1000, (2,), generator=g)
+    x, gy, t = torch.randn(*SHAPE, generator=g), torch.randn(*SHAPE, generator=g), torch.randint(0, 1000, (SHAPE[0],), generator=g)
     model.to(dev)
     native = mode.startswith("native")
     if native:
@@ -63,7 +68,7 @@ def run(rank, world, port, mode, out_dir, kind="cpu"):
         train_mod._TRAIN_GRAPH = mode != "native_eager"             # force the captured / the eager form (the default picks by measurement)
         dif = ddpm_torch.GaussianDiffusion(ddpm_torch.get_beta_schedule("linear", 1e-4, 0.02, 1000), "eps", "fixed-large", "mse")
         opt = torch.optim.Adam(model.parameters(), lr=1e-3)
-        tr = ddpm_torch.Trainer(model, opt, dif, epochs=1, trainloader=None, sampler=object(), use_ema=True, shape=(3, 8, 8),
+        tr = ddpm_torch.Trainer(model, opt, dif, epochs=1, trainloader=None, sampler=object(), use_ema=True, shape=SHAPE[1:],
                                 device=dev, distributed=True, rank=rank)
         model.zero_grad(set_to_none=True)
         losses = []
@@ -71,7 +76,7 @@ def run(rank, world, port, mode, out_dir, kind="cpu"):
             tr.stats.reset()
             tr.step(x.clamp(-1, 1).to(dev), global_steps=i + 1)
             losses.append(tr.current_stats["loss"])
-        ds = tr._direct.get(((2, 3, 8, 8), True))
+        ds = tr._direct.get((SHAPE, True))
         torch.save(dict(sd=cpu(model.state_dict()), shadow=cpu(tr.ema.shadow), losses=losses,
                         segments=None if ds is None or ds.graph is None else ds.graph.launches,
                         direct=ds is not None), os.path.join(out_dir, f"after_step_{mode}_{rank}.pt"))

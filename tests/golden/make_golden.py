@@ -336,8 +336,52 @@ def g8_toy():
     save("g8_toy.pt", out)
 
 
+
+# ----------------------------------------------------------------------------- G10 the north-star sentence on CONFIG 2 ITSELF
+def _shipped_model(name, init_seed, rand_seed):
+    cfg = json.load(open(os.path.join(LR.REFERENCE_ROOT, "configs", name + ".json")))
+    mc = dict(cfg["model"]); mc.pop("block_size", None)
+    mc["out_channels"] = mc["in_channels"]
+    torch.manual_seed(init_seed)
+    m = ref.UNet(**mc)
+    randomized(m, rand_seed)                      # the zero-initialised layers (conv2, project_out, out_conv) get weights: every path carries signal
+    return m.eval(), mc
+
+
+def g10_config2():
+    """UNet forward and the sampling loops of the SHIPPED configurations (configs/cifar10.json at 32 x 32 — BASELINE config 2 — and
+    configs/celeba.json at 64 x 64 for DDIM-50), where the product's hot kernels run (the G6 net is an 8 x 8 toy).  The 35.7 M weights
+    do not travel: the fixture keeps the seeds (seeded init is bit-identical in the product, tests/test_unet_gpu.py::test_g3_keys_and_init,
+    then oracle.unet_ref.randomize_state_dict), the inputs and the reference's outputs.  ~3 minutes per 1000-step chain on one core."""
+    out = {}
+    betas = ref.get_beta_schedule("linear", 1e-4, 0.02, 1000)
+    m, mc = _shipped_model("cifar10", 1234, 61)
+    out["cifar"] = dict(cfg=mc, init_seed=1234, rand_seed=61)
+    x, t = rnd(2, 3, 32, 32, seed=62), torch.tensor([3, 977])
+    with torch.no_grad():
+        out["cifar"]["fwd"] = dict(x_seed=62, t=t, y=m(x, t))
+    shape = (1, 3, 32, 32)
+    dif = ref.GaussianDiffusion(betas, "eps", "fixed-large", "mse")
+    xp, preds = dif.p_sample_progressive(m, shape=shape, device=torch.device("cpu"), pred_freq=250, seed=7)      # diffusion.py:176-198
+    g = torch.Generator("cpu").manual_seed(7)
+    x_T = torch.empty(shape).normal_(generator=g)
+    zs = torch.stack([torch.empty(shape).normal_(generator=g) for _ in range(1000)])
+    out["cifar"]["ddpm_fixed-large"] = dict(seed=7, shape=shape, x_0=xp, pred_freq=250, preds=preds, x_T_sum=x_T.double().sum(),
+                                             zs_sum=zs.double().sum(), zs_abs_sum=zs.double().abs().sum())
+    # p_sample (diffusion.py:160-174) consumes the same stream and must end on the same sample: 40 steps of it are enough to pin that
+    short = ref.GaussianDiffusion(ref.get_beta_schedule("linear", 1e-4, 0.02, 40), "eps", "fixed-large", "mse")
+    out["cifar"]["ddpm40_fixed-large"] = dict(seed=9, shape=(2, 3, 32, 32), timesteps=40,
+                                               x_0=short.p_sample(m, shape=(2, 3, 32, 32), device=torch.device("cpu"), seed=9))
+    m2, mc2 = _shipped_model("celeba", 4321, 63)
+    base = ref.GaussianDiffusion(betas, "eps", "fixed-small", "mse")
+    ddim = ref.DDIM.from_ddpm(base, eta=0.0, subsequence=ref.get_selection_schedule("linear", 50, 1000))        # ddim.py:96-113
+    out["celeba"] = dict(cfg=mc2, init_seed=4321, rand_seed=63,
+                         ddim_linear_50=dict(seed=11, shape=(1, 3, 64, 64), x_0=ddim.p_sample(m2, shape=(1, 3, 64, 64), device=torch.device("cpu"), seed=11)))
+    save("g10_config2.pt", out)
+
+
 if __name__ == "__main__":
     import sys
-    ALL = dict(g1=g1_ops, g2=g2_blocks, g3=g3_model, g4=g4_tables, g5=g5_steps, g6=g6_loops, g7=g7_train, g8=g8_toy, g9=g9_train_lr)
+    ALL = dict(g1=g1_ops, g2=g2_blocks, g3=g3_model, g4=g4_tables, g5=g5_steps, g6=g6_loops, g7=g7_train, g8=g8_toy, g9=g9_train_lr, g10=g10_config2)
     for name in (sys.argv[1:] or list(ALL)):          # `make_golden.py g9` regenerates one fixture, no argument = all
         ALL[name]()

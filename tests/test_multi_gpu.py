@@ -21,11 +21,11 @@ def _world():
     return min(torch.cuda.device_count(), 8)
 
 
-def _launch(mode, out_dir, world):
+def _launch(mode, out_dir, world, **extra_env):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **extra_env)
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_ddp_worker.py"), str(r), str(world), str(port), mode, str(out_dir), "cuda"],
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env) for r in range(world)]
     outs = []
@@ -84,3 +84,24 @@ def test_captured_data_parallel_step_equals_eager(tmp_path):
         scale = float(e[0]["sd"][k].abs().max()) or 1.0
         assert float((g[0]["sd"][k] - e[0]["sd"][k]).abs().max()) <= 2e-3 * scale + 2e-4, k
     assert g[0]["losses"] == pytest.approx(e[0]["losses"], rel=1e-3)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs at least two GPUs")
+def test_cifar_geometry_native_exchange_equals_torch_ddp(tmp_path):
+    """BASELINE config 3's geometry (configs/cifar10.json at 32 x 32, B = 4 per rank; upstream train.py:110, utils/train.py:166-169):
+    the native chunked all-reduce (6 chunks + tail of the packed staging buffer, issued inside the backward) gives every rank the
+    gradients torch's DistributedDataParallel gives, the ranks agree bit for bit, and the distributed Trainer.steps on top keep the
+    replicas in lock-step."""
+    world = _world()
+    (tmp_path / "n").mkdir(); (tmp_path / "d").mkdir()
+    nat = _launch("native", tmp_path / "n", world, DDP_WORKER_CFG="cifar", DDPM_TORCH_AMD_COMPUTE="fp32")
+    ddp = _launch("ddp", tmp_path / "d", world, DDP_WORKER_CFG="cifar", DDPM_TORCH_AMD_COMPUTE="fp32")
+    for k, g0 in nat[0]["grads"].items():
+        for r in nat[1:]:
+            assert torch.equal(g0, r["grads"][k]), f"{k}: ranks disagree after the all-reduce"
+        scale = max(float(ddp[0]["grads"][k].abs().max()), 1e-6)
+        assert float((g0 - ddp[0]["grads"][k]).abs().max()) <= 1e-4 * scale + 1e-7, k
+    after = [torch.load(os.path.join(tmp_path / "n", f"after_step_native_{r}.pt"), weights_only=True) for r in range(world)]
+    for r in range(1, world):
+        for k in after[0]["sd"]:
+            assert float((after[0]["sd"][k] - after[r]["sd"][k]).abs().max()) < 1e-7, f"{k}: replicas diverged"

@@ -229,6 +229,22 @@ def test_g6_loops(golden):
             check(x, r["x_0"], 2e-4, name="ddim_" + sched)
 
 
+def test_g10_config2_forward_and_short_chain(golden):
+    """The oracle on BASELINE config 2 itself (configs/cifar10.json at 32 x 32): forward at B = 2 and the 40-step ancestral chain at
+    B = 2 against the reference's outputs (the 1000-step chain of the fixture is left to the GPU side: minutes on one core here)."""
+    g = golden("g10_config2.pt")["cifar"]
+    torch.manual_seed(g["init_seed"])
+    sd = U.randomize_state_dict(U.init_state_dict(g["cfg"]), g["rand_seed"])
+    fn = lambda x, t: U.unet_forward(sd, g["cfg"], x, t)
+    with torch.no_grad():
+        f = g["fwd"]
+        check(fn(rnd(2, 3, 32, 32, seed=f["x_seed"]), f["t"]), f["y"], 2e-5, name="g10.fwd")
+        r = g["ddpm40_fixed-large"]
+        x_T, zs = _noise_stream(r["seed"], tuple(r["shape"]), r["timesteps"])
+        x = D.sample_loop(D.ddpm_tables(D.beta_schedule("linear", 1e-4, 0.02, r["timesteps"]), "fixed-large"), fn, x_T, zs)
+        check(x, r["x_0"], 2e-4, name="g10.ddpm40")
+
+
 def test_g7_train_steps(golden):
     g = golden("g7_train.pt")
     torch.manual_seed(g["init_seed"])
