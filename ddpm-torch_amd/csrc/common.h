@@ -80,7 +80,11 @@ __device__ __forceinline__ float wave_max(float v) {
 __device__ __forceinline__ float sigmoidf_(float z) { return 1.0f / (1.0f + __expf(-z)); }
 __device__ __forceinline__ float siluf_(float z) { return z * sigmoidf_(z); }
 // hardware reciprocal (v_rcp_f32, 1 ulp) instead of the IEEE division: for values that are rounded to bf16 right after
+#ifdef GN_ABL_NO_TRANS       // timing-only ablation (scripts/gpu_gn_abl.sh): what do the transcendentals cost?  WRONG numerics by construction
+__device__ __forceinline__ float silu_fast_(float z) { return z * fminf(fmaxf(0.5f + 0.25f * z, 0.f), 1.f); }
+#else
 __device__ __forceinline__ float silu_fast_(float z) { return z * __builtin_amdgcn_rcpf(1.0f + __expf(-z)); }
+#endif
 // d/dz [z*sigmoid(z)] = s*(1 + z*(1-s))
 __device__ __forceinline__ float silu_gradf_(float z) { float s = sigmoidf_(z); return s * (1.0f + z * (1.0f - s)); }
 
@@ -124,14 +128,22 @@ __device__ __forceinline__ bool dropout_keep(unsigned long long seed, unsigned l
 __device__ __forceinline__ unsigned dropout_h0(unsigned long long seed) {
     return mix32((unsigned)seed) ^ ((unsigned)(seed >> 32) * 0x9E3779B9u);
 }
+#ifdef GN_ABL_NO_HASH         // timing-only ablation: what does the mask hash cost?
+__device__ __forceinline__ unsigned dropout_word32(unsigned h0, unsigned pair) { return (pair ^ h0) * 0x10001u; }
+#else
 __device__ __forceinline__ unsigned dropout_word32(unsigned h0, unsigned pair) { return mix32(pair ^ h0); }
+#endif
 static inline unsigned dropout_thresh16(float p) {
     const double th = (double)p * 65536.0;
     return th <= 0 ? 0u : (th >= 65536.0 ? 65536u : (unsigned)(th + 0.5));
 }
 // d/dz [z*sigmoid(z)] with the hardware reciprocal (1 ulp) instead of the IEEE division
 __device__ __forceinline__ float silu_grad_fast_(float z) {
+#ifdef GN_ABL_NO_TRANS
+    const float s = fminf(fmaxf(0.5f + 0.25f * z, 0.f), 1.f);
+#else
     const float s = __builtin_amdgcn_rcpf(1.0f + __expf(-z));
+#endif
     return s * (1.0f + z * (1.0f - s));
 }
 

@@ -607,25 +607,47 @@ void conv3x3_stream_kernel(CsArgs a) {
 //     count their own vmcnt queue (a wave's counter sees only its own requests: the consumers' stores no longer sit in the ring's
 //     in-order queue);
 //   * the two sides meet through three COUNTERS IN LDS instead of s_barrier.  `ready`: a loader adds 1 when its share of the next step's
-//     weight tile (and everything older: halo, rows) has landed — a consumer starts step s when ready >= 4 (s + 1); it reads the
-//     counter with the last fragments of step s - 1, so the check costs no latency.  `freed`: a consumer adds 1 when its last read of a
-//     step's slot has been issued (LDS executes a wave's operations in order) — a loader refills the slot of step g - 1 when
-//     freed >= 4 g.  `edone`: the consumers' own rendezvous before a tile's epilogue (which stages through the halo buffer the slowest
-//     of them may still be reading).  An increment is one ds_add_u32 with every lane on its own copy of the counter (no exec masking,
-//     no bank conflict); only copy 0 is ever read.  Nobody waits for a wave that is not late: the consumers drift apart by up to the
-//     depth of the ring and the pipe never drains;
+//     weight tile (and everything older: halo, rows) has landed — a consumer starts step s when every loader's ready >= s + 1; it reads
+//     the counters with the fragments of step s - 1, so the check costs no latency.  `freed`: a consumer adds 1 when its last read of a
+//     step's slot has been issued (LDS executes a wave's operations in order) — a loader refills the slot of step g - 1 when every
+//     consumer's freed >= g.  `edone`: the consumers' own rendezvous before a tile's epilogue (which stages through the halo buffer the slowest
+//     of them may still be reading).  `ready` and `freed` are FOUR counters each, one per signalling wave (a sum would let a wave that
+//     runs ahead stand in for one that is behind), read together by one ds_read_b128.  Nobody waits for a wave that is not late: the
+//     consumers drift apart by up to the depth of the ring and the pipe never drains;
 //   * bias + time bias are the accumulators' INITIAL value (the rows ride into LDS with the tile's first stage, as above), so the
 //     epilogue is convert, swap, stage, store.
-constexpr int PC_CNT_AT = Lds<16>::BYTES;                  // three counters x 64 copies
+constexpr int PC_CNT_AT = Lds<16>::BYTES;                  // counters (below) + a junk area the idle lanes of a signal write to
 constexpr int PC_BYTES = PC_CNT_AT + 1024;
 static_assert(PC_BYTES <= 160 * 1024, "LDS");
-constexpr int PC_READY = 0, PC_FREED = 256, PC_EDONE = 512;
+// ONE COUNTER PER WAVE, never a sum over waves: a loader that runs a step ahead of its siblings (it may: only `freed` holds it back)
+// would otherwise make up for a sibling's missing signal — `ready >= 4 (s + 1)` held with one loader's quarter of the tile still in
+// flight (seen as a rare wrong tile when the block's waves progress unevenly, e.g. next to another kernel).  ready[4] and freed[4] are
+// 16 contiguous bytes each: one ds_read_b128 returns all four, the poller takes the minimum.
+constexpr int PC_READY = 0, PC_FREED = 16, PC_EDONE = 32, PC_JUNK = 256;
 
-__device__ __forceinline__ void pc_wait_ge(unsigned addr, unsigned target) {
+// the smallest of four counters is >= target (wrap-safe signed distance)
+__device__ __forceinline__ int pc_min_dist(const u32x4& v, unsigned target) {
+    const int a = (int)(v.x - target), b = (int)(v.y - target), c = (int)(v.z - target), d = (int)(v.w - target);
+    const int m = min(min(a, b), min(c, d));
+    return __builtin_amdgcn_readfirstlane(m);
+}
+__device__ __forceinline__ void pc_wait_all_ge(unsigned addr, unsigned target) {
 #ifdef PC_ABL_NO_SYNC
     return;
 #endif
     // bounded: a protocol error must end the launch with an error the host sees (trap), never hang the GPU
+    for (unsigned spins = 0;; ++spins) {
+        u32x4 v;
+        asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(addr) : "memory");
+        if (pc_min_dist(v, target) >= 0) break;
+        if (spins > (1u << 22)) __builtin_trap();
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+__device__ __forceinline__ void pc_wait_ge(unsigned addr, unsigned target) {          // one (summed) counter: the consumers' rendezvous
+#ifdef PC_ABL_NO_SYNC
+    return;
+#endif
     for (unsigned spins = 0;; ++spins) {
         unsigned v;
         asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(addr) : "memory");
@@ -634,6 +656,8 @@ __device__ __forceinline__ void pc_wait_ge(unsigned addr, unsigned target) {
         __builtin_amdgcn_s_sleep(1);
     }
 }
+// +1 on a counter: one ds_add_u32 of the whole wave, lane 0 on the counter, every other lane on its own word of the junk area (no exec
+// masking, no bank conflict); `lane_addr` is built once per wave
 __device__ __forceinline__ void pc_signal(unsigned lane_addr) {
 #ifdef PC_ABL_NO_SYNC
     return;
@@ -682,7 +706,7 @@ void conv3x3_pc_kernel(CsArgs a) {
     };
     const int nchunks = a.C >> 6;
     const unsigned lds0 = (unsigned)(size_t)smem;
-    const unsigned cnt0 = lds0 + PC_CNT_AT, my_cnt = cnt0 + (unsigned)(lane * 4);
+    const unsigned cnt0 = lds0 + PC_CNT_AT, junk = cnt0 + PC_JUNK + (unsigned)(lane * 4);
 
     if (wave >= 4) {
         // =============================================================== loaders
@@ -751,13 +775,14 @@ void conv3x3_pc_kernel(CsArgs a) {
         issue_rows(cur, 0);
 #pragma unroll
         for (int t = 0; t < RING - 1; ++t) issue_w(cur.tn, 0, t, t);
+        const unsigned sig_ready = lane == 0 ? cnt0 + PC_READY + (unsigned)(lw * 4) : junk;
         wait_vm<8>();                                       // the halo, the rows and weight tile 0 are in; tiles 1 and 2 may be on their way
-        pc_signal(my_cnt + PC_READY);
+        pc_signal(sig_ready);
 #ifdef PC_ABL_NO_LOADERS
         return;
 #endif
         int slot = 0, hb = 0;
-        unsigned g4 = 0;                                    // 4 x (flat step index)
+        unsigned gstep = 0;                                 // flat step index
         for (int k = 0; k < my_tiles; ++k) {
             const bool more_tiles = k + 1 < my_tiles;
             TilePos nxt = cur;
@@ -774,7 +799,7 @@ void conv3x3_pc_kernel(CsArgs a) {
                 for (int tap = 0; tap < 9; ++tap) {
                     // every consumer is past step g - 1: its weight slot, the halo buffer of the chunk before this one and (when step g - 1
                     // closed a tile) the staging area of that tile's epilogue are free
-                    pc_wait_ge(cnt0 + PC_FREED, g4);
+                    pc_wait_all_ge(cnt0 + PC_FREED, gstep);
                     // requests of this step, in queue order: parts of the next halo (taps 0-5: 2 2 2 2 2 1), the next tile's rows (tap 6 of a
                     // tile's last chunk), then the weight tile three steps ahead
 #ifndef PC_ABL_NO_HALO
@@ -803,8 +828,8 @@ void conv3x3_pc_kernel(CsArgs a) {
                     } else {
                         if (tap < 6) wait_vm<8>(); else if (tap == 6) wait_vm<4>(); else wait_vm<0>();
                     }
-                    pc_signal(my_cnt + PC_READY);
-                    g4 += 4;
+                    pc_signal(sig_ready);
+                    ++gstep;
                 }
                 hb ^= 1;
             }
@@ -866,14 +891,16 @@ void conv3x3_pc_kernel(CsArgs a) {
     auto w_addr = [&](int slot_) { unsigned v = wv0 + (unsigned)(slot_ * WT_BYTES); asm volatile("" : "+v"(v)); return v; };
     u32x4 fw[2][NIB], fx[2][NJ];                           // fragment sets: K sub-step kc uses set kc & 1
     unsigned hk, wk, hkn = 0, wkn = 0;                     // this step's / the next step's addresses
-    unsigned rcp = 0;                                      // `ready` as read in the previous step's third sub-step (written by the asm read itself: no copies)
+    u32x4 rcp = {0u, 0u, 0u, 0u};                          // the loaders' `ready` counters as read in the previous step's third sub-step (written by the asm read itself: no copies)
+    const unsigned sig_freed = lane == 0 ? cnt0 + PC_FREED + (unsigned)(wave * 4) : junk;
+    const unsigned sig_edone = lane == 0 ? cnt0 + PC_EDONE : junk;
     TilePos cur = tile_pos(0);
 #ifdef C3_TIMING
     int tstep = 0;
 #endif
     PC_STAMP(0); PC_STAMP(1);
-    unsigned need = 4;                                      // `ready` value that opens the step about to start
-    pc_wait_ge(cnt0 + PC_READY, need);                     // the loaders' prologue: halo 0, rows 0 and weight tile 0 are in LDS
+    unsigned need = 1;                                      // `ready` value (of every loader) that opens the step about to start
+    pc_wait_all_ge(cnt0 + PC_READY, need);                 // the loaders' prologue: halo 0, rows 0 and weight tile 0 are in LDS
     PC_STAMP(2);
     init_acc(0);
     int slot = 0, hb = 0;
@@ -885,8 +912,10 @@ void conv3x3_pc_kernel(CsArgs a) {
             const bool last_chunk = cc + 1 == nchunks;
             u32x2 rv[2][4];                                  // residual OR previous output (the launcher admits one of them) of ONE epilogue round
             // residual / "+=" rows of round (i, jh) = 32 channels x pixel blocks 2 jh, 2 jh + 1: one address per pixel, the 4-channel runs at
-            // constant offsets.  INLINE ASM and UNCONDITIONAL (see the kernel above); waves whose 64 channels lie beyond N read the start of
-            // their row instead
+            // constant offsets.  PLAIN loads: a consumer wave has no LDS-DMA in flight, so hipcc's own vmcnt bookkeeping applies (counted
+            // waits at the first use, and a spill of a destination register — the epilogue is at the register cap — waits for the data;
+            // an inline-asm load's destination was spilled right behind the asm statement, before the data was back).  Waves whose 64
+            // channels lie beyond N read the start of their row instead (their stores are skipped).
             auto request_extra = [&](int i, int jh) {
                 const int n0 = cur.tn * 128 + wn * 64 + 4 * (lane >> 5);
 #pragma unroll
@@ -895,8 +924,7 @@ void conv3x3_pc_kernel(CsArgs a) {
                     const bf16_t* base = (a.res ? a.res : a.out) + ((long long)(cur.img * a.H + cur.py0 + (p >> 4)) * a.W + cur.px0 + (p & 15)) * (a.res ? a.res_ld : a.out_ld)
                                          + (n0 < a.N ? n0 : 0) + i * 32;
 #pragma unroll
-                    for (int g = 0; g < 4; ++g)
-                        asm volatile("global_load_dwordx2 %0, %1, off offset:%2" : "=v"(rv[jj][g]) : "v"(base), "n"(8 * g * 2) : "memory");
+                    for (int g = 0; g < 4; ++g) rv[jj][g] = *reinterpret_cast<const u32x2*>(base + 8 * g);
                 }
             };
 #pragma unroll
@@ -964,7 +992,7 @@ void conv3x3_pc_kernel(CsArgs a) {
                     mm(0, 1); rd_x(2); rd_x(3);
                     if (post == 1) {
 #ifndef PC_ABL_NO_SYNC
-                        asm volatile("ds_read_b32 %0, %1" : "=v"(rcp) : "v"(cnt0 + PC_READY) : "memory");
+                        asm volatile("ds_read_b128 %0, %1" : "=v"(rcp) : "v"(cnt0 + PC_READY) : "memory");
 #endif
                         __builtin_amdgcn_sched_barrier(0);
                     } else if (post == 2) {
@@ -982,7 +1010,6 @@ void conv3x3_pc_kernel(CsArgs a) {
                     wl(pre + 6 * rd + po);                   // x3
                     mm(0, 3); mm(1, 3);
                 };
-                if (tile_end && extra) { request_extra(0, 0); __builtin_amdgcn_sched_barrier(0); }
                 // sub-step 1: the previous step's last fragments (behind them in the queue: that step's signal) | reads kc = 0.  The `ready`
                 // counter read in the previous step's third sub-step is older than those fragments: valid once the first wait is through,
                 // and checked BEFORE this step's first read is issued
@@ -990,17 +1017,20 @@ void conv3x3_pc_kernel(CsArgs a) {
                 if (tap > 0 || pend) {
                     asm volatile("s_waitcnt lgkmcnt(5)" ::: "memory");
                     __builtin_amdgcn_sched_barrier(0);
-                    if ((int)((unsigned)__builtin_amdgcn_readfirstlane((int)rcp) - need) < 0) pc_wait_ge(cnt0 + PC_READY, need);
+                    if (pc_min_dist(rcp, need) < 0) pc_wait_all_ge(cnt0 + PC_READY, need);
                 }
 #endif
                 sub_step(tap > 0 || pend, fw[1], fx[1], 0, fw[0], fx[0], 1, 0, 0u, false);
                 sub_step(true, fw[0], fx[0], 1, fw[1], fx[1], 0, 0, 0u, false);
                 sub_step(true, fw[1], fx[1], 2, fw[0], fx[0], 0, 1, 0u, false);
                 // (a tile's last step hands its slot back AFTER the epilogue, with the staging area; here it signals the consumers' rendezvous)
-                sub_step(true, fw[0], fx[0], 3, fw[1], fx[1], 1, 2, tile_end ? my_cnt + PC_EDONE : my_cnt + PC_FREED, !tile_end);
+                sub_step(true, fw[0], fx[0], 3, fw[1], fx[1], 1, 2, tile_end ? sig_edone : sig_freed, !tile_end);
                 slot = nslot;
-                need += 4;
+                need += 1;
                 if (tile_end) {
+                    // the first residual rows are requested HERE: fragment set 0 is dead from this point on, its registers take them (requested
+                    // a step earlier they did not fit: the destination was spilled — and waited for — on the spot)
+                    if (extra) { request_extra(0, 0); __builtin_amdgcn_sched_barrier(0); }
                     sub_step(true, fw[1], fx[1], -1, fw[0], fx[0], 1, 0, 0u, false);
                     pend = false;
                     if (k == 0) PC_STAMP(3); else if (k == 1) PC_STAMP(5);
@@ -1031,18 +1061,7 @@ void conv3x3_pc_kernel(CsArgs a) {
                 for (int i = 0; i < NIB; ++i) {
 #pragma unroll
                     for (int jh = 0; jh < 2; ++jh) {
-                        if (extra) {
-                            // round 0's rows were requested in the tile's last step, every later round's behind the previous round's last use
-                            // (that round's four stores — none when the wave's channels lie beyond N — are newer than those)
-                            if ((i == 0 && jh == 0) || !live) wait_vm<0>(); else wait_vm<4>();
-                            __builtin_amdgcn_sched_barrier(0);
-                            if (!live) {
-#pragma unroll
-                                for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-                                    for (int g = 0; g < 4; ++g) rv[jj][g] = (u32x2)(0u);
-                            }
-                        }
+                        // (round 0's residual rows were requested in the tile's last step, every later round's behind the previous round's last use)
 #pragma unroll
                         for (int jj = 0; jj < 2; ++jj) {
                             const int j = 2 * jh + jj;
@@ -1088,10 +1107,10 @@ void conv3x3_pc_kernel(CsArgs a) {
                     }
                 }
                 // the staging reads are done (waited for above): slot, halo buffer and staging area go back to the loaders
-                pc_signal(my_cnt + PC_FREED);
+                pc_signal(sig_freed);
                 if (k + 1 < my_tiles) {
                     cur = tile_pos(k + 1);
-                    pc_wait_ge(cnt0 + PC_READY, need);         // the next tile's first weight tile, its halo and its rows are in
+                    pc_wait_all_ge(cnt0 + PC_READY, need);     // the next tile's first weight tile, its halo and its rows are in
                     init_acc((k + 1) & 1);
                     hk = halo_addr(0, hb ^ 1);
                     wk = w_addr(slot);

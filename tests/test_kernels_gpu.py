@@ -14,6 +14,7 @@ from tests.abi_emulator import Emulator
 pytestmark = pytest.mark.gpu
 DT = {0: torch.float32, 1: torch.bfloat16}
 TOL = {0: 2e-5, 1: 1.2e-2}
+DEV = "cuda:0"
 
 
 class A:
@@ -823,3 +824,37 @@ def test_pack_weight_multi(dt):
             assert float((dwd.cpu().float() - wd.float()).abs().max()) <= (1e-6 if dt == 0 else 2e-2) * float(wd.float().abs().max()), (N, C, "wd 4x4")
         else:
             assert torch.equal(dwd.cpu(), wd), (N, C, R, flag, "wd")
+
+
+@pytest.mark.parametrize("B,H,C,N,res", [(16, 32, 64, 128, 1), (128, 32, 128, 128, 0), (128, 16, 256, 256, 1), (72, 16, 192, 192, 0)])
+def test_conv3x3_wave_specialised_kernel_is_bit_stable_under_contention(B, H, C, N, res):
+    """conv3x3_pc_kernel synchronises its loader and consumer waves through counters in LDS, no barrier: its result must not depend on
+    how the waves of a block happen to progress.  Run alone -> reference bits; then 40 launches next to an MFMA-only kernel that holds a
+    wave on every SIMD of every CU (ddpm_mfma_probe on a second stream: the block's waves then advance unevenly) -> the same bits every
+    time.  (A first version summed the four loaders' `ready` signals in one counter: a loader running ahead stood in for one that was
+    behind, and a tile's quarter could be multiplied before it had landed — rare, and only under contention.)"""
+    dt = 1
+    M = B * H * H
+    x = r(M, C, seed=11, dt=dt).to(DEV)
+    w = r(N, 9 * C, seed=12, dt=dt, scale=1.0 / math.sqrt(9 * C)).to(DEV)
+    bias = r(N, seed=13).to(DEV)
+    resid = r(M, N, seed=14, dt=dt).to(DEV)
+    lib = _hip.lib()
+    assert lib.ddpm_conv2d_variant(C, N, B, H, H, C, H, H, N, 3, 3, 1, 1, 1, 0, 0, 0, 1, dt) == 13
+
+    def conv(y, stream):
+        _hip.call("ddpm_conv2d_nhwc", x.data_ptr(), C, w.data_ptr(), y.data_ptr(), N, bias.data_ptr(), 0, 0, resid.data_ptr() if res else 0, N if res else 0,
+                  B, H, H, C, H, H, N, 3, 3, 1, 1, 1, 0, 0, 0, 0, 1, 0, 0, dt, stream)
+    ref = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    conv(ref, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    sink = torch.zeros(256, device=DEV)
+    outs = [torch.empty_like(ref) for _ in range(40)]
+    for it in range(2):
+        _hip.call("ddpm_mfma_probe", sink.data_ptr(), 60000, 0, s1.cuda_stream)        # ~10 ms of matrix-pipe contention on every CU
+        for y in outs[it * 20:(it + 1) * 20]:
+            conv(y, s2.cuda_stream)
+        torch.cuda.synchronize()
+    bad = [i for i, y in enumerate(outs) if not torch.equal(y, ref)]
+    assert not bad, f"launches {bad} differ from the uncontended result"
