@@ -842,7 +842,6 @@ void conv3x3_pc_kernel(CsArgs a) {
     constexpr int NIB = 2, NJ = 4;
     const int wn = wave >> 1, wm = wave & 1;              // 64 channels x 128 pixels (patch rows 8 wm .. 8 wm + 7)
     if (a.flags & 1) __builtin_amdgcn_s_setprio(1);
-    const bool extra = a.res || a.accumulate;
     // Fragment addresses.  Pixel block j of the wave = patch rows 8 wm + 2 j, 2 j + 1: lane l reads pixel (2 j + (l % 32) / 16, l % 16), so the
     // four blocks sit at a CONSTANT 2 x 18 x 128 bytes from each other, their chunk key ((px + s) >> 1) is the same, and ONE address
     // register + ds_read's immediate offset serves all four; likewise the two 32-row weight blocks (4096 bytes apart).  The sub-step
@@ -910,23 +909,6 @@ void conv3x3_pc_kernel(CsArgs a) {
     for (int k = 0; k < my_tiles; ++k) {
         for (int cc = 0; cc < nchunks; ++cc) {
             const bool last_chunk = cc + 1 == nchunks;
-            u32x2 rv[2][4];                                  // residual OR previous output (the launcher admits one of them) of ONE epilogue round
-            // residual / "+=" rows of round (i, jh) = 32 channels x pixel blocks 2 jh, 2 jh + 1: one address per pixel, the 4-channel runs at
-            // constant offsets.  PLAIN loads: a consumer wave has no LDS-DMA in flight, so hipcc's own vmcnt bookkeeping applies (counted
-            // waits at the first use, and a spill of a destination register — the epilogue is at the register cap — waits for the data;
-            // an inline-asm load's destination was spilled right behind the asm statement, before the data was back).  Waves whose 64
-            // channels lie beyond N read the start of their row instead (their stores are skipped).
-            auto request_extra = [&](int i, int jh) {
-                const int n0 = cur.tn * 128 + wn * 64 + 4 * (lane >> 5);
-#pragma unroll
-                for (int jj = 0; jj < 2; ++jj) {
-                    const int p = wm * 128 + (2 * jh + jj) * 32 + (lane & 31);
-                    const bf16_t* base = (a.res ? a.res : a.out) + ((long long)(cur.img * a.H + cur.py0 + (p >> 4)) * a.W + cur.px0 + (p & 15)) * (a.res ? a.res_ld : a.out_ld)
-                                         + (n0 < a.N ? n0 : 0) + i * 32;
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) rv[jj][g] = *reinterpret_cast<const u32x2*>(base + 8 * g);
-                }
-            };
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
                 const bool tile_end = tap == 8 && last_chunk;
@@ -1028,9 +1010,6 @@ void conv3x3_pc_kernel(CsArgs a) {
                 slot = nslot;
                 need += 1;
                 if (tile_end) {
-                    // the first residual rows are requested HERE: fragment set 0 is dead from this point on, its registers take them (requested
-                    // a step earlier they did not fit: the destination was spilled — and waited for — on the spot)
-                    if (extra) { request_extra(0, 0); __builtin_amdgcn_sched_barrier(0); }
                     sub_step(true, fw[1], fx[1], -1, fw[0], fx[0], 1, 0, 0u, false);
                     pend = false;
                     if (k == 0) PC_STAMP(3); else if (k == 1) PC_STAMP(5);
@@ -1045,7 +1024,7 @@ void conv3x3_pc_kernel(CsArgs a) {
                 PC_STEP();
             }
             if (last_chunk) {
-                // ---- tile done: out = acc (+ residual | + out), staged through the finished halo buffer in wave-private slices of
+                // ---- tile done: out = acc, staged through the finished halo buffer in wave-private slices of
                 // 64 pixels x 64 bytes so that four consecutive lanes store the 64 contiguous bytes of a pixel (as above)
                 const int n0 = cur.tn * 128 + wn * 64;
                 const bool live = n0 < a.N;
@@ -1061,7 +1040,6 @@ void conv3x3_pc_kernel(CsArgs a) {
                 for (int i = 0; i < NIB; ++i) {
 #pragma unroll
                     for (int jh = 0; jh < 2; ++jh) {
-                        // (round 0's residual rows were requested in the tile's last step, every later round's behind the previous round's last use)
 #pragma unroll
                         for (int jj = 0; jj < 2; ++jj) {
                             const int j = 2 * jh + jj;
@@ -1069,11 +1047,6 @@ void conv3x3_pc_kernel(CsArgs a) {
 #pragma unroll
                             for (int g = 0; g < 4; ++g) {
                                 float v[4] = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-                                if (extra) {
-                                    const u32x2 r2 = rv[jj][g];
-                                    v[0] += __uint_as_float(r2.x << 16); v[1] += __uint_as_float(r2.x & 0xffff0000u);
-                                    v[2] += __uint_as_float(r2.y << 16); v[3] += __uint_as_float(r2.y & 0xffff0000u);
-                                }
                                 pk[g].x = pack_bf2(v[0], v[1]); pk[g].y = pack_bf2(v[2], v[3]);
                             }
 #pragma unroll
@@ -1085,11 +1058,6 @@ void conv3x3_pc_kernel(CsArgs a) {
                                 const unsigned ad = stg + (unsigned)(P * 64 + (sl << 4));
                                 asm volatile("ds_write_b128 %0, %1" :: "v"(ad), "v"(o) : "memory");
                             }
-                        }
-                        if (extra && !(i == NIB - 1 && jh == 1)) {
-                            __builtin_amdgcn_sched_barrier(0);
-                            if (jh == 0) request_extra(i, 1); else request_extra(i + 1, 0);
-                            __builtin_amdgcn_sched_barrier(0);
                         }
                         u32x4 back[4];
 #pragma unroll
@@ -1124,6 +1092,7 @@ void conv3x3_pc_kernel(CsArgs a) {
     PC_STAMP(7);
 }
 
+
 }  // namespace
 
 #ifdef C3_TRACE
@@ -1155,7 +1124,10 @@ int ddpm_conv3x3_stream_launch(const void* x, long long x_ld, const void* w, voi
     static const bool use_pc = getenv("DDPM_CONV_NO_PC") == nullptr;
 #endif
     static const int pc_flags = getenv("DDPM_C3_PC_FLAGS") ? atoi(getenv("DDPM_C3_PC_FLAGS")) : 0;
-    if (dry) return patch == 16 && use_pc ? 17 : patch;
+    // (a residual / "+=" epilogue stays on the kernel above: its rows have to be requested a K-step ahead, into registers the
+    //  wave-specialised kernel does not have — acc 128 + fragments 48 — and requested late they cost 5-12 %; the two kernels give
+    //  bit-identical results, so the choice is invisible)
+    if (dry) return patch == 16 && use_pc && !residual && !accumulate ? 17 : patch;
     CsArgs a; memset(&a, 0, sizeof(a));
     a.x = (const bf16_t*)x; a.x_ld = x_ld; a.x_extent = (unsigned)xbytes;
     a.w = (const bf16_t*)w; a.w_extent = (unsigned)wbytes;
@@ -1179,7 +1151,7 @@ int ddpm_conv3x3_stream_launch(const void* x, long long x_ld, const void* w, voi
         }                                                                                                                              \
         hipLaunchKernelGGL(conv3x3_stream_kernel<PATCHV>, dim3(grid), dim3(512), Lds<PATCHV>::BYTES, (hipStream_t)stream, a);           \
     } while (0)
-    if (patch == 16 && use_pc) {
+    if (patch == 16 && use_pc && !residual && !accumulate) {
         a.flags = pc_flags;
         static bool pc_attr_set = false;
         if (!pc_attr_set) {

@@ -1785,10 +1785,11 @@ extern "C" int ddpm_attention_fwd(const void* qkv, long long ld, void* out, long
 static const void* const FAKE = reinterpret_cast<const void*>(0x1000);
 
 extern "C" int ddpm_conv2d_variant(long long x_ld, long long y_ld, int B, int H, int W, int C, int Ho, int Wo, int N, int R, int S,
-                                   int stride, int pad_t, int pad_l, int upsample, int dilate, int out_mode, int splits, int dtype) {
+                                   int stride, int pad_t, int pad_l, int upsample, int dilate, int out_mode, int splits, int dtype, int epilogue) {
+    // epilogue: bit 0 = the call has a residual operand, bit 1 = it accumulates into y (the 3x3 dispatch depends on them)
     g_variant_query = 1;
-    const int rc = ddpm_conv2d_nhwc(FAKE, x_ld, FAKE, const_cast<void*>(FAKE), y_ld, nullptr, nullptr, 0, nullptr, 0, B, H, W, C, Ho, Wo, N, R, S, stride, pad_t, pad_l,
-                                    upsample, dilate, 0, out_mode, splits, splits > 1 ? reinterpret_cast<float*>(0x1000) : nullptr,
+    const int rc = ddpm_conv2d_nhwc(FAKE, x_ld, FAKE, const_cast<void*>(FAKE), y_ld, nullptr, nullptr, 0, (epilogue & 1) ? FAKE : nullptr, (epilogue & 1) ? y_ld : 0, B, H, W, C, Ho, Wo, N, R, S, stride, pad_t, pad_l,
+                                    upsample, dilate, (epilogue >> 1) & 1, out_mode, splits, splits > 1 ? reinterpret_cast<float*>(0x1000) : nullptr,
                                     splits > 1 ? reinterpret_cast<unsigned*>(0x1000) : nullptr, dtype, nullptr);
     const int v = g_variant_result;
     g_variant_query = 0;

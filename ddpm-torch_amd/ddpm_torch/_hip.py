@@ -37,7 +37,7 @@ PROTOTYPES = {
     "ddpm_groupnorm_silu_fwd": [P, L, P, L, P, P, P, P, I, I, I, I, F, I, F, U, P, I, P],
     "ddpm_groupnorm_silu_bwd": [P, L, P, L, P, L, P, P, P, P, P, P, I, I, I, I, I, F, U, P, I, P, L, P, L, I, P],
     "ddpm_gn_workspace_floats": [I, I, I, I, I],
-    "ddpm_conv2d_variant": [L, L] + [I] * 17,
+    "ddpm_conv2d_variant": [L, L] + [I] * 18,
     "ddpm_conv2d_wgrad_variant": [L, L] + [I] * 17,
     "ddpm_gemm_variant": [L, I, L, I, L, I, I, I, I, I, I, I],
     "ddpm_attention_fwd": [P, L, P, L, I, I, I, F, I, P],

@@ -80,7 +80,7 @@ def conv2d(x, w_ptr, y_ptr, y_ld, N, R, S, Ho, Wo, stride=1, pad_t=0, pad_l=0, u
         x.B, x.H, x.W, x.C, Ho, Wo, N, R, S, stride, pad_t, pad_l, upsample, dilate, accumulate, out_mode, splits, ws, cnt,
         x.dtype, _hip.stream()),
         f"conv M={x.B * Ho * Wo} N={N} K={R * S * x.C} {R}x{S} s{stride} u{upsample} d{dilate}",
-        lambda: _hip.lib().ddpm_conv2d_variant(x.ld, y_ld, x.B, x.H, x.W, x.C, Ho, Wo, N, R, S, stride, pad_t, pad_l, upsample, dilate, out_mode, splits, x.dtype))
+        lambda: _hip.lib().ddpm_conv2d_variant(x.ld, y_ld, x.B, x.H, x.W, x.C, Ho, Wo, N, R, S, stride, pad_t, pad_l, upsample, dilate, out_mode, splits, x.dtype, (1 if res_ptr else 0) | (2 if accumulate else 0)))
 
 
 _USE_SPLITK = bool(os.environ.get("DDPM_SPLITK"))

@@ -147,7 +147,7 @@ int ddpm_attention_bwd(const void* qkv, long long ld, const void* o, long long o
  * Pure functions of their arguments: the same dispatch code runs with launching switched off, nothing is retained between calls.
  * bench.py uses them to attribute its per-launch HIP-event timings to the kernel that ran. */
 int ddpm_conv2d_variant(long long x_ld, long long y_ld, int B, int H, int W, int C, int Ho, int Wo, int N, int R, int S,
-                        int stride, int pad_t, int pad_l, int upsample, int dilate, int out_mode, int splits, int dtype);
+                        int stride, int pad_t, int pad_l, int upsample, int dilate, int out_mode, int splits, int dtype, int epilogue);
 int ddpm_conv2d_wgrad_variant(long long dy_ld, long long x_ld, int B, int H, int W, int C, int Creal, int Ho, int Wo, int N, int Nreal,
                               int R, int S, int stride, int pad_t, int pad_l, int upsample, int splits, int dtype);
 int ddpm_gemm_variant(long long a_ld, int a_trans, long long b_ld, int b_trans, long long c_ld, int M, int N, int K, int batch,

@@ -18,7 +18,7 @@ for (H, C, N, R) in ((4, 256, 256, 3), (4, 512, 256, 3), (4, 512, 256, 1), (4, 2
     bias = torch.zeros(N, device=DEV)
     M = B * H * H
     fn = lambda: ops.conv2d(x, w.data_ptr(), y.ptr, y.ld, N, R, R, H, H, pad_t=R // 2, pad_l=R // 2, bias=bias.data_ptr(), splitk=SK)
-    var = _hip.lib().ddpm_conv2d_variant(x.ld, y.ld, B, H, H, C, H, H, N, R, R, 1, R // 2, R // 2, 0, 0, 0, 1, x.dtype)
+    var = _hip.lib().ddpm_conv2d_variant(x.ld, y.ld, B, H, H, C, H, H, N, R, R, 1, R // 2, R // 2, 0, 0, 0, 1, x.dtype, 0)
     nblk = 8192
     tbuf = torch.zeros(nblk * 8, dtype=torch.int64, device=DEV)
     for _ in range(3): fn()
