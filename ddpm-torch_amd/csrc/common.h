@@ -147,6 +147,17 @@ __device__ __forceinline__ float silu_grad_fast_(float z) {
     return s * (1.0f + z * (1.0f - s));
 }
 
+// "Done once per DEVICE" flag for the launchers' hipFuncSetAttribute(MaxDynamicSharedMemorySize) opt-ins: the attribute belongs to the
+// (function, device) pair, so a process that drives a second GPU has to set it there too.  Reads like the bool it replaces
+// (`static DevOnce set; if (!set) { ...; set = true; }`); devices are folded modulo 64, setting an attribute twice is harmless.
+#include <atomic>
+struct DevOnce {
+    std::atomic<unsigned long long> mask{0};
+    static unsigned long long bit() { int d = 0; (void)hipGetDevice(&d); return 1ull << (d & 63); }
+    bool operator!() const { return !(mask.load(std::memory_order_acquire) & bit()); }
+    DevOnce& operator=(bool) { mask.fetch_or(bit(), std::memory_order_release); return *this; }
+};
+
 static inline int check_launch() { return hipGetLastError() == hipSuccess ? DDPM_OK : DDPM_ERR_LAUNCH; }
 static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 

@@ -1143,7 +1143,7 @@ int ddpm_conv3x3_stream_launch(const void* x, long long x_ld, const void* w, voi
     const int grid = a.total_tiles < max_grid ? a.total_tiles : max_grid;
 #define C3_LAUNCH(PATCHV)                                                                                                              \
     do {                                                                                                                               \
-        static bool attr_set = false;                                                                                                  \
+        static DevOnce attr_set;                                                                                                  \
         if (!attr_set) {                                                                                                               \
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_stream_kernel<PATCHV>), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                     Lds<PATCHV>::BYTES) != hipSuccess) return DDPM_ERR_LAUNCH;                                         \
@@ -1153,7 +1153,7 @@ int ddpm_conv3x3_stream_launch(const void* x, long long x_ld, const void* w, voi
     } while (0)
     if (patch == 16 && use_pc && !residual && !accumulate) {
         a.flags = pc_flags;
-        static bool pc_attr_set = false;
+        static DevOnce pc_attr_set;
         if (!pc_attr_set) {
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_pc_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, PC_BYTES) != hipSuccess) return DDPM_ERR_LAUNCH;
             pc_attr_set = true;

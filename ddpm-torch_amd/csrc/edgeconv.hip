@@ -201,7 +201,7 @@ int ddpm_edgeconv_few_out_launch(const void* x, long long x_ld, const void* w, v
     EdgeArgs a; memset(&a, 0, sizeof(a));
     a.x = (const bf16_t*)x; a.x_ld = x_ld; a.x_extent = (unsigned)xbytes; a.w = (const bf16_t*)w; a.out = y; a.bias = bias;
     a.B = B; a.H = H; a.W = W; a.C = C; a.N = N; a.tiles_y = H / 16; a.tiles_x = W / 16;
-    static bool attr = false;
+    static DevOnce attr;
     if (!attr) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_few_out_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return DDPM_ERR_LAUNCH;
         attr = true;

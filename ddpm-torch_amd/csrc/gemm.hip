@@ -918,18 +918,20 @@ void gemm64_kernel(MatDesc A, MatDesc B, Epilogue ep, int M, int N, int K, int t
         __syncthreads();
         if (*flag == 0.f) return;
         // all the other runs' vectors are requested before the first is used (up to 7 x 2 loads in flight), then added in run order
+        // (buffer loads with the sc1 cache-policy bit, not inline asm: the compiler tracks their destination registers and places the
+        //  waits itself — an asm load whose wait sits in a separate asm statement leaves the register allocator free to move or spill
+        //  the destination before the data has landed)
         constexpr int MAXR = 8;
         f32x4 other[MAXR][2];
+        const __amdgpu_buffer_rsrc_t slab_rs = __builtin_amdgcn_make_buffer_rsrc(slabs, 0, nsplit * (T64 * T64) * 4, 0x00020000);
 #pragma unroll
         for (int sp = 0; sp < MAXR; ++sp) {
             if (sp < nsplit && sp != by) {
 #pragma unroll
                 for (int h = 0; h < 2; ++h)
-                    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(other[sp][h]) : "v"(slabs + (long long)sp * (T64 * T64) + (tid + NT * h) * 4) : "memory");
+                    other[sp][h] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(slab_rs, (sp * (T64 * T64) + (tid + NT * h) * 4) * 4, 0, 16));
             }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             f32x4 a4 = (f32x4)(0.f);
@@ -1420,7 +1422,7 @@ static int conv3x3_halo_launch(GemmArgs& g, const void* x, long long x_ld, const
     constexpr int LDS = 160 * 1024;                       // both configurations fill the CU's LDS
 #define C3_LAUNCH(RING, HROWS)                                                                                          \
     do {                                                                                                                 \
-        static bool attr_set = false;                                                                                    \
+        static DevOnce attr_set;                                                                                    \
         if (!attr_set) {                                                                                                 \
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<RING, HROWS>),                    \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return DDPM_ERR_LAUNCH; \
@@ -1433,7 +1435,7 @@ static int conv3x3_halo_launch(GemmArgs& g, const void* x, long long x_ld, const
     if (gn) {                              // GroupNorm + SiLU applied to the resident halo: single-patch geometry only
         if (NB != 1 || HP > 324) return -1;
         a.gn_stats = gn->stats; a.gn_gamma = gn->gamma; a.gn_beta = gn->beta; a.gn_G = gn->G; a.gn_cpg = C / gn->G; a.gn_silu = gn->silu;
-        static bool attr_set = false;
+        static DevOnce attr_set;
         if (!attr_set) {
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<4, 384, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return DDPM_ERR_LAUNCH;
             attr_set = true;
@@ -1498,7 +1500,7 @@ static int launch_t(GemmArgs& g, hipStream_t st) {
 #define LAUNCH64(NG)                                                                                                     \
     do {                                                                                                                 \
         constexpr int LDS64 = NG * G64 * 2 * T64 * ROW_BYTES;                                                            \
-        static bool attr_set = false;                                                                                    \
+        static DevOnce attr_set;                                                                                    \
         if (!attr_set) {                                                                                                 \
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm64_kernel<T, NG>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS64) != hipSuccess) \
                 return DDPM_ERR_LAUNCH;                                                                                  \
@@ -1522,7 +1524,7 @@ static int launch_t(GemmArgs& g, hipStream_t st) {
     do {                                                                                                                 \
         g.variant = NB != 2 ? 3 : (NWV == 8 ? 2 : 1);                                                                    \
         if (g.dry) break;                                                                                                \
-        static bool attr_set = false;   /* > 64 KiB of dynamic LDS needs the opt-in once per instantiation */            \
+        static DevOnce attr_set;   /* > 64 KiB of dynamic LDS needs the opt-in once per instantiation */            \
         if (!attr_set) {                                                                                                 \
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, TA, TB, NB, NWV>),                     \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LDS)) != hipSuccess)              \
@@ -1549,7 +1551,7 @@ static int launch_t(GemmArgs& g, hipStream_t st) {
             if (w8 && g.ep.mode >= 2 && !no_scat) {          // weight gradients: the scatter-only instantiation
                 g.variant = 2;
                 if (g.dry) return DDPM_OK;
-                static bool attr_set = false;
+                static DevOnce attr_set;
                 if (!attr_set) {
                     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, true, true, 2, 8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2) != hipSuccess)
                         return DDPM_ERR_LAUNCH;
@@ -1769,11 +1771,11 @@ extern "C" int ddpm_attention_fwd(const void* qkv, long long ld, void* out, long
     const dim3 grid(L / 128, B);
     hipStream_t st = (hipStream_t)stream;
     if (C == 256) {
-        static bool attr = false;
+        static DevOnce attr;
         if (!attr) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return DDPM_ERR_LAUNCH; attr = true; }
         hipLaunchKernelGGL(attn_fwd_kernel<8>, grid, dim3(256), lds, st, q, k, v, (bf16_t*)out, out_ld, L, scale);
     } else {
-        static bool attr = false;
+        static DevOnce attr;
         if (!attr) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return DDPM_ERR_LAUNCH; attr = true; }
         hipLaunchKernelGGL(attn_fwd_kernel<4>, grid, dim3(256), lds, st, q, k, v, (bf16_t*)out, out_ld, L, scale);
     }

@@ -1496,7 +1496,7 @@ extern "C" int ddpm_groupnorm_silu_fwd(const void* x, long long x_ld, void* y, l
     if (small) { fl = f; fl.xcd_remap = 0; lds_l = gn_lds_bytes(f.nv <= 1 ? 1 : 2, 256, f.seg_ch); }
     if (small || (!no_lds && !(reg_ok && f.nv <= 2) && gn_lds_plan(s, es, fl, lds_l))) {        // x staged in LDS: single launch, 1 read + 1 write of HBM
         const dim3 fgrid(G / fl.GPB, B);
-#define GN_LF(T, NV, NT) do { static bool attr = false; if (!attr) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_lds_fwd_kernel<T, NV, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return DDPM_ERR_LAUNCH; attr = true; } \
+#define GN_LF(T, NV, NT) do { static DevOnce attr; if (!attr) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_lds_fwd_kernel<T, NV, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return DDPM_ERR_LAUNCH; attr = true; } \
         hipLaunchKernelGGL((gn_lds_fwd_kernel<T, NV, NT>), fgrid, dim3(NT), lds_l, st, (const T*)x, (T*)y, s, fl, a); } while (0)
 #define GN_LF_NV(T) do { if (small) { if (fl.nv <= 1) GN_LF(T, 1, 256); else GN_LF(T, 2, 256); } else if (fl.nv <= 2) GN_LF(T, 2, 512); else if (fl.nv <= 4) GN_LF(T, 4, 512); else GN_LF(T, 8, 512); } while (0)
         if (dtype == DDPM_BF16) GN_LF_NV(bf16_t); else GN_LF_NV(float);
@@ -1557,7 +1557,7 @@ extern "C" int ddpm_groupnorm_silu_bwd(const void* x, long long x_ld, const void
     if (small_lds) { fl = f; fl.xcd_remap = 0; lds_l = gn_lds_bytes(f.nv <= 1 ? 1 : 2, 256, f.seg_ch); }
     if (small_lds || (!small && !no_lds && gn_lds_plan(s, es, fl, lds_l))) {
         const dim3 fgrid(G / fl.GPB, B);
-#define GN_LDS(K, NT, ...) do { static bool attr = false; if (!attr) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(&K<__VA_ARGS__>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return DDPM_ERR_LAUNCH; attr = true; } \
+#define GN_LDS(K, NT, ...) do { static DevOnce attr; if (!attr) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(&K<__VA_ARGS__>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return DDPM_ERR_LAUNCH; attr = true; } \
         hipLaunchKernelGGL((K<__VA_ARGS__>), fgrid, dim3(NT), lds_l, st, (const T_*)x, (const T_*)dy, (T_*)dx, s, fl, dy_ld, dx_ld, stats, dgamma, dbeta, a, accumulate, dx_colsum, colsum_ld, (const T_*)add, add_ld); } while (0)
 #define GN_LDS_NV() do { if (small_lds) { if (fl.nv <= 1) GN_LDS(gn_lds_bwd_kernel, 256, T_, 1, 256); else GN_LDS(gn_lds_bwd_kernel, 256, T_, 2, 256); } \
                          else if (fl.nv <= 2) GN_LDS(gn_lds_bwd_kernel, 512, T_, 2, 512); else if (fl.nv <= 4) GN_LDS(gn_lds_bwd_kernel, 512, T_, 4, 512); else GN_LDS(gn_lds_bwd8_kernel, 512, T_, 8); } while (0)

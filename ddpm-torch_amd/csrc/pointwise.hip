@@ -13,8 +13,9 @@
 //     tile's MFMAs.
 //   * a block owns whole pixel tiles and loops over the channel tiles inside: the activation tile is fetched from HBM once (the
 //     re-reads for further channel tiles hit the CU's own L2 slice), the weights (<= 1.2 MB) stay L2-resident.
-//   * 8 waves as 2 (channels) x 4 (pixels); tile = 128 channels x TM pixels, TM = 256 (64 x 64 per wave, one fragment read per
-//     MFMA as in the stationary-halo conv) or 128 when the layer has too few pixels to give every CU a 256-tile.
+//   * 8 waves; tile = TN channels x TM pixels: 256 x 128 (waves 4 x 2, 64 x 64 each — one fragment read per MFMA as in the
+//     stationary-halo conv) when N is a multiple of 256, else 128 channels x 256 pixels (waves 2 x 4), or 128 x 128 when the layer
+//     has too few pixels to give every CU a 256-pixel tile.
 #include "common.h"
 #include <string.h>
 #include <stdlib.h>
@@ -42,20 +43,23 @@ template <int N> __device__ __forceinline__ void wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory");
 }
 
-template <int TM>
+template <int TM, int TN>
 __global__ __launch_bounds__(512, 2)
 void pw_conv_kernel(PwArgs a) {
-    constexpr int MJ = TM / 128;                       // 32-pixel accumulator blocks per wave (wave = 64 channels x 32 MJ pixels)
+    constexpr int WN = TN / 64, WM = 8 / WN;           // 8 waves as WN (64 channels each) x WM (pixels)
+    constexpr int MJ = TM / (32 * WM);                 // 32-pixel accumulator blocks per wave (wave = 64 channels x 32 MJ pixels)
     constexpr int XV = TM / 64;                        // x vectors per thread per stage (TM rows x 8 chunks / 512)
-    constexpr int PER = XV + 2;                        // LDS-DMA instructions per thread per stage
-    constexpr int RING = TM == 256 ? 3 : 4;
-    constexpr int XB = TM * 128, WB = 128 * 128, STAGE = XB + WB;
+    constexpr int WV = TN / 64;                        // w vectors per thread per stage
+    constexpr int PER = XV + WV;                       // LDS-DMA instructions per thread per stage
+    constexpr int RING = TM + TN == 256 ? 4 : 3;
+    constexpr int XB = TM * 128, WB = TN * 128, STAGE = XB + WB;
+    static_assert(TN == 128 || TN == 256, "channel tile");
     constexpr int BIAS_AT = RING * STAGE;              // 4 x 1 KiB: bias rows of the tiles in flight (fetched with a tile's first stage)
     static_assert(BIAS_AT + 4096 <= 160 * 1024, "LDS");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wn = wave >> 2, wm = wave & 3;
+    const int wn = wave / WM, wm = wave % WM;
 
     auto rsrc_of = [&](const void* p, unsigned extent) {
         const unsigned long long ad = (unsigned long long)p;
@@ -67,18 +71,18 @@ void pw_conv_kernel(PwArgs a) {
     const __amdgpu_buffer_rsrc_t rb = rsrc_of(a.bias ? (const void*)a.bias : (const void*)a.w, a.bias ? (unsigned)(a.N * 4) : 0u);
 
     // DMA plan (LDS rows of 128 bytes = 64 k; 16-byte chunk c of row r sits at physical chunk c ^ ((r >> 1) & 7))
-    unsigned xoff[4], woff[2];            // (fixed bound: hipcc's host pass rejects a lambda capturing an array of template-dependent size)
+    unsigned xoff[4], woff[4];            // (fixed bound: hipcc's host pass rejects a lambda capturing an array of template-dependent size)
 #pragma unroll
     for (int i = 0; i < XV; ++i) {
         const int v = tid + 512 * i, row = v >> 3, lc = (v & 7) ^ ((row >> 1) & 7);
         xoff[i] = (unsigned)(((long long)row * a.x_ld + lc * 8) * 2);
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < WV; ++i) {
         const int v = tid + 512 * i, row = v >> 3, lc = (v & 7) ^ ((row >> 1) & 7);
         woff[i] = (unsigned)(((long long)row * a.K + lc * 8) * 2);
     }
-    const unsigned x_tile_bytes = (unsigned)((long long)TM * a.x_ld * 2), w_tile_bytes = (unsigned)((long long)128 * a.K * 2);
+    const unsigned x_tile_bytes = (unsigned)((long long)TM * a.x_ld * 2), w_tile_bytes = (unsigned)((long long)TN * a.K * 2);
 
     // the block's stage sequence: pixel tiles mt = blockIdx.x, + gridDim.x, ...; for each, channel tiles 0 .. tiles_n-1; for each, K-steps
     const int my_mt = a.tiles_m > (int)blockIdx.x ? (a.tiles_m - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
@@ -88,11 +92,11 @@ void pw_conv_kernel(PwArgs a) {
         char* dst = smem + (i_q % RING) * STAGE;
         // the tile's bias row rides with its first stage (wave 0 only; issued BEFORE the stage's loads, so it has landed when the stage
         // has).  A vector load in the epilogue instead would have to wait for every LDS-DMA issued before it — loads retire in
-        // order — and drain the ring at every tile.  Lanes >= 32 are out of range and write zeros into the slot's padding.
+        // order — and drain the ring at every tile.  Lanes >= TN / 4 are out of range and write zeros into the slot's padding.
         if (i_ks == 0) {
             if (wave == 0 && a.bias)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (__attribute__((address_space(3))) void*)(smem + BIAS_AT + (i_tile & 3) * 1024), 16,
-                                                         lane < 32 ? (unsigned)((i_nt * 128 + lane * 4) * 4) : OOB, 0, 0, 0);
+                                                         lane < TN / 4 ? (unsigned)((i_nt * TN + lane * 4) * 4) : OOB, 0, 0, 0);
             ++i_tile;
         }
         const unsigned xb = (unsigned)i_mt * x_tile_bytes + (unsigned)(i_ks * 128);
@@ -102,7 +106,7 @@ void pw_conv_kernel(PwArgs a) {
         for (int i = 0; i < XV; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(dst + (wave * 64 + 512 * i) * 16), 16, xb + xoff[i], 0, 0, 0);
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < WV; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(dst + XB + (wave * 64 + 512 * i) * 16), 16, wb + woff[i], 0, 0, 0);
         ++i_q;
         if (++i_ks == a.ksteps) { i_ks = 0; if (++i_nt == a.tiles_n) { i_nt = 0; i_mt += gridDim.x; } }
@@ -144,7 +148,7 @@ void pw_conv_kernel(PwArgs a) {
         if (pre) {
             // INLINE ASM loads: a C++ load here makes hipcc drain every pending LDS-DMA first (`s_waitcnt vmcnt(0)` in front of any
             // ordinary load while LDS-DMA is in flight).  The matching wait is issued by hand in front of the epilogue.
-            const int n0 = c_nt * 128 + wn * 64, p0 = c_mt * TM + wm * (32 * MJ);
+            const int n0 = c_nt * TN + wn * 64, p0 = c_mt * TM + wm * (32 * MJ);
 #pragma unroll
             for (int j = 0; j < MJ; ++j)
 #pragma unroll
@@ -173,7 +177,8 @@ void pw_conv_kernel(PwArgs a) {
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < MJ; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fw[i]), __builtin_bit_cast(bf16x8, fx[j]), acc[i][j], 0, 0, 0);
+                    if (!(a.ablate & 2))
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fw[i]), __builtin_bit_cast(bf16x8, fx[j]), acc[i][j], 0, 0, 0);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's LDS reads of stage q are complete before it reaches the next barrier
         if (pre) {
@@ -186,7 +191,7 @@ void pw_conv_kernel(PwArgs a) {
         if (last) {
             // ---- tile done: out[p][n] = acc + bias[n] (+ residual) (+ out), straight from the accumulators.
             // accumulator (i, j), register r, lane l: channel n0 + i*32 + 8 (r >> 2) + 4 (l >> 5) + (r & 3), pixel p0 + j*32 + (l & 31)
-            const int n0 = c_nt * 128 + wn * 64, p0 = c_mt * TM + wm * (32 * MJ);
+            const int n0 = c_nt * TN + wn * 64, p0 = c_mt * TM + wm * (32 * MJ);
 #pragma unroll
             for (int j = 0; j < MJ; ++j) {
                 const int p = p0 + j * 32 + (lane & 31);
@@ -201,7 +206,7 @@ void pw_conv_kernel(PwArgs a) {
                             // inline asm: hipcc puts `s_waitcnt vmcnt(0)` in front of a C++ LDS read it cannot prove disjoint from the
                             // pending LDS-DMA — that would drain the ring here, at every tile
                             f32x4v bv;
-                            const unsigned baddr = (unsigned)(size_t)(smem + BIAS_AT + (c_tile & 3) * 1024 + (n - c_nt * 128) * 4);
+                            const unsigned baddr = (unsigned)(size_t)(smem + BIAS_AT + (c_tile & 3) * 1024 + (n - c_nt * TN) * 4);
                             asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(bv) : "v"(baddr) : "memory");
                             v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
                         }
@@ -237,7 +242,7 @@ void pw_conv_kernel(PwArgs a) {
 #pragma unroll
                 for (int j = 0; j < MJ; ++j) acc[i][j] = (f32x16)(0.f);
             // (full 64-channel range stored by this wave -> exactly ST stores; epilogues at least RING - 1 stages apart -> one window at a time)
-            st_window = (a.ksteps >= RING - 1 && c_nt * 128 + wn * 64 + 64 <= a.N && !(a.ablate & 1)) ? RING - 1 : 0;
+            st_window = (a.ksteps >= RING - 1 && c_nt * TN + wn * 64 + 64 <= a.N && !(a.ablate & 1)) ? RING - 1 : 0;
             c_ks = 0; ++c_tile;
             if (++c_nt == a.tiles_n) { c_nt = 0; c_mt += gridDim.x; }
         } else ++c_ks;
@@ -261,24 +266,29 @@ int ddpm_pointwise_launch(const void* x, long long x_ld, const void* w, void* y,
     a.w = (const bf16_t*)w; a.w_extent = (unsigned)((long long)N * K * 2);
     a.out = (bf16_t*)y; a.out_ld = y_ld; a.bias = bias; a.res = (const bf16_t*)residual; a.res_ld = res_ld; a.accumulate = accumulate;
     { const char* e = getenv("DDPM_PW_ABLATE"); a.ablate = e ? atoi(e) : 0; }
-    a.M = M; a.N = N; a.K = K; a.tiles_n = (N + 127) / 128; a.ksteps = K / 64;
+    a.M = M; a.N = N; a.K = K; a.ksteps = K / 64;
     hipStream_t st = (hipStream_t)stream;
-    // 256-pixel tiles when they give every CU at least one; else 128-pixel tiles (twice the tiles)
+    // Tile choice.  N a multiple of 256 (the attention projections, the 2C-wide skips and their data gradients): 128 pixels x 256
+    // channels — the activation stage is fetched once for twice the channels, half as many stage hand-overs (barrier + DMA wait) per
+    // FLOP and one LDS fragment read per MFMA instead of 1.5.  Otherwise 128-channel tiles: 256 pixels when they give every CU at
+    // least one, else 128 pixels (twice the tiles).
+    static const bool no_wide = getenv("DDPM_PW_NO_WIDE") != nullptr;
+    const bool wide = !no_wide && N % 256 == 0;
     const bool big = (M + 255) / 256 >= 256;
-#define PW_LAUNCH(TM, RINGV)                                                                                                      \
+#define PW_LAUNCH(TM, TN, RINGV)                                                                                                  \
     do {                                                                                                                          \
-        constexpr int LDS = RINGV * (TM * 128 + 128 * 128) + 4096;                                                                     \
-        static bool attr_set = false;                                                                                             \
+        constexpr int LDS = RINGV * (TM * 128 + TN * 128) + 4096;                                                                 \
+        static DevOnce attr_set;                                                                                                  \
         if (!attr_set) {                                                                                                          \
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_conv_kernel<TM>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) \
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&pw_conv_kernel<TM, TN>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) \
                 return DDPM_ERR_LAUNCH;                                                                                           \
             attr_set = true;                                                                                                      \
         }                                                                                                                         \
-        a.tiles_m = (M + TM - 1) / TM;                                                                                            \
+        a.tiles_m = (M + TM - 1) / TM; a.tiles_n = (N + TN - 1) / TN;                                                             \
         const int grid = a.tiles_m < 256 ? a.tiles_m : 256;                                                                       \
-        hipLaunchKernelGGL(pw_conv_kernel<TM>, dim3(grid), dim3(512), LDS, st, a);                                                \
+        hipLaunchKernelGGL((pw_conv_kernel<TM, TN>), dim3(grid), dim3(512), LDS, st, a);                                          \
     } while (0)
-    if (big) PW_LAUNCH(256, 3); else PW_LAUNCH(128, 4);
+    if (wide) PW_LAUNCH(128, 256, 3); else if (big) PW_LAUNCH(256, 128, 3); else PW_LAUNCH(128, 128, 4);
 #undef PW_LAUNCH
     return check_launch();
 }

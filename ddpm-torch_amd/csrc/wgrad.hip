@@ -472,7 +472,7 @@ static int wgrad3x3_launch(const void* dy, long long dy_ld, const void* x, long 
         constexpr int RAW = RINGV * (SPX * 128 + XB) + (SPX == 256 ? 1024 : 0);         /* ring (+ dump): <= 160 KiB */          \
         constexpr int LDS = RAW > 147 * 1024 ? RAW : 147 * 1024;                        /* the final k-group sum needs 2 x 72 KiB + 2 KiB */ \
         static_assert(LDS <= 160 * 1024, "LDS budget");                                                                          \
-        static bool attr_set = false;                                                                                             \
+        static DevOnce attr_set;                                                                                             \
         if (!attr_set) {                                                                                                          \
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3_kernel<SPX, PWV, RINGV>),                            \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return DDPM_ERR_LAUNCH;      \

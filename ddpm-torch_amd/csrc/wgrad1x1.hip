@@ -203,7 +203,7 @@ extern "C" int ddpm_conv1x1_wgrad_nhwc(const void* dy, long long dy_ld, const vo
     a.dw = dw; a.slab_stride = slab_stride; a.dbias = dbias; a.bias_stride = bias_stride;
     a.P = P; a.C = C; a.N = N; a.tiles_c = p.tiles_c; a.tiles_n = p.tiles_n; a.ksteps = p.ksteps; a.ksteps_per_split = p.ksteps_per_split;
     constexpr int LDS = RING * STAGE;
-    static bool attr_set = false;
+    static DevOnce attr_set;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad1x1_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return DDPM_ERR_LAUNCH;
         attr_set = true;

@@ -446,7 +446,14 @@ class _Engine:
         return tb, (temb, e1, s1, t_emb, s_t, fc_w)
 
     def time_table(self):
-        """The table, rebuilt (in place: captured steps hold its address) when a parameter of the path changed."""
+        """The table, rebuilt (in place: captured steps hold its address) when a parameter of the path changed.
+
+        Built as ONE M = T = 1000 pass of the embedding MLP, not in row blocks of the sampler's batch: at M = 1000 the dispatcher
+        picks the 128 x 128-tile GEMM where the per-step MLP at M = B picks gemm64, which splits K and adds the halves in another
+        order.  A sampler reading the table therefore differs from DDPM_TIME_TABLE=0 (and from a plain ``model(x, t)`` eval call) in
+        the last bits of each fp32 time bias.  The bars: table vs no table <= 2e-5 of the sample's range after a full chain
+        (tests/test_configs_gpu.py::test_sampler_time_table_follows_weights_and_schedule_length); table-fed sampler vs the fp32
+        reference 3.9e-6 max abs after the 1000-step config-2 chain (tests/test_config2_parity_gpu.py), inside the 1e-4 parity bar."""
         self._fc_all()
         key = (self.fc_ver, self._embed_versions())
         if key != self.tt_key:
@@ -983,8 +990,9 @@ class _Engine:
                    seed_dev=st.get("seed_dev", 0), world=1, sumsq=0)
         if _SIDE_STREAM and gflat.is_cuda:
             if self._side is None:
-                # LOW priority: the weight-gradient stream has ~3.6 ms of work per 10.6 ms step and seven milliseconds of slack; the main
-                # stream is the step's critical path, so its workgroups go first whenever both queues have some ready
+                # Default priority 0 = the main stream's own: measured, a lower-priority side stream (DDPM_SIDE_PRIORITY=1..) did not move
+                # the step (the weight-gradient stream has ~3.6 ms of work per ~9.6 ms step and is confined to half the CUs by the
+                # kernels' own grids, DDPM_WGRAD3_CUS); the switch stays for experiments.
                 self._side = torch.cuda.Stream(device=self.device, priority=_SIDE_PRIORITY)
             ctx["side"] = self._side
             ctx["side_handle"] = self._side.cuda_stream
@@ -1223,8 +1231,10 @@ class _Engine:
         with self._leaf(ctx, dt_emb, s1):
             ops.gemm(dt_emb.data_ptr(), E, 0, 1, s1.data_ptr(), E, 0, 1, self._pptr(ctx, lin2.weight), E, 0, E, E, B, F, out_mode=1)
             ops.colsum(View(dt_emb, 1, B, 1, E), 0, 0, self._pptr(ctx, lin2.bias))
-        ds1 = self._f32(B, E)
-        ops.gemm(dt_emb.data_ptr(), E, 0, 0, lin2.weight.data_ptr(), E, 0, 1, ds1.data_ptr(), E, 0, B, E, E, F, out_mode=1)
+        # (K = E = 512 over 4 output tiles would leave 252 CUs idle for ~75 us at the very end of the backward: split-K with fp32 atomics
+        #  like the fc product above — 32 blocks)
+        ds1 = torch.zeros((B, E), dtype=torch.float32, device=self.device)
+        ops.gemm(dt_emb.data_ptr(), E, 0, 0, lin2.weight.data_ptr(), E, 0, 1, ds1.data_ptr(), E, 0, B, E, E, F, out_mode=2, splits=max(1, E // 64))
         de1 = self._f32(B, E)
         _hip.call("ddpm_silu_bwd", e1.data_ptr(), ds1.data_ptr(), de1.data_ptr(), B * E, 0, _hip.stream())
         with self._leaf(ctx, de1, temb):

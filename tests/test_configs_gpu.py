@@ -275,6 +275,36 @@ def test_sampler_time_table_follows_weights_and_schedule_length(golden, monkeypa
     assert bool(torch.isnan(y).any())
 
 
+def test_training_steps_after_a_sample_grid_do_not_rebuild_the_time_table(golden):
+    """upstream utils/train.py:209-216 samples an image grid between epochs; after it the table's size stays at T, and every
+    `Trainer.step` bumps the parameters' versions.  The table belongs to the samplers: the training steps that follow must not run the
+    T-row embedding MLP before each replay (nothing in training reads it) — counted here as calls of the engine's MLP with T rows —
+    and the next sampler must see the trained weights (one rebuild)."""
+    g = golden("g9_train_lr.pt")
+    m, opt, sched, tr = _g9_trainer(g)
+    tr.input_source = _reference_stream(g)
+    dif20 = ddpm_torch.GaussianDiffusion(ddpm_torch.get_beta_schedule("linear", 1e-4, 0.02, 20), "eps", "fixed-large", "mse")
+    m.eval()
+    a = dif20.p_sample(m, shape=(2, 3, 8, 8), device=DEV, seed=5)
+    eng = m.engine()
+    assert eng.tt_T == 20 and not eng.tt_on
+    rows = []
+    inner = eng._time_biases
+    eng._time_biases = lambda t, B: (rows.append(B), inner(t, B))[1]
+    try:
+        m.train()
+        for i, x in enumerate(g["xs"][:4]):                    # eager step, capture, replays
+            tr.step(x, global_steps=i + 1)
+        torch.cuda.synchronize()
+        assert 20 not in rows, rows                            # no T-row pass while training
+        m.eval()
+        b = dif20.p_sample(m, shape=(2, 3, 8, 8), device=DEV, seed=5)
+        assert rows.count(20) == 1, rows                       # the sampler rebuilt it once, for the new weights
+    finally:
+        eng._time_biases = inner
+    assert torch.isfinite(b).all() and not torch.equal(a, b)
+
+
 def test_ddim50_celeba_quadratic_eta1_vs_eager(monkeypatch):
     """BASELINE config 4 network at 64x64 (B = 2): DDIM (quadratic, eta = 1: noise is consumed) graph == eager, finite."""
     from tests.test_unet_gpu import CELEBA
