@@ -36,6 +36,7 @@ struct PwArgs {
     int accumulate;
     int ablate;                                             // timing experiments (DDPM_PW_ABLATE): 1 no stores, 2 no MFMA
     int M, N, K, tiles_m, tiles_n, ksteps;
+    int spread;                                             // 1: blocks walk (pixel tile, channel tile) pairs (fewer pixel tiles than CUs)
 };
 
 template <int N> __device__ __forceinline__ void wait_vm() {
@@ -84,10 +85,13 @@ void pw_conv_kernel(PwArgs a) {
     }
     const unsigned x_tile_bytes = (unsigned)((long long)TM * a.x_ld * 2), w_tile_bytes = (unsigned)((long long)TN * a.K * 2);
 
-    // the block's stage sequence: pixel tiles mt = blockIdx.x, + gridDim.x, ...; for each, channel tiles 0 .. tiles_n-1; for each, K-steps
-    const int my_mt = a.tiles_m > (int)blockIdx.x ? (a.tiles_m - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
-    const int total = my_mt * a.tiles_n * a.ksteps;
-    int i_mt = blockIdx.x, i_nt = 0, i_ks = 0, i_q = 0, i_tile = 0;        // issue cursor
+    // the block's stage sequence: pixel tiles mt = blockIdx.x, + gridDim.x, ...; for each, channel tiles 0 .. tiles_n-1; for each, K-steps.
+    // `spread` (layers with fewer pixel tiles than CUs): the unit is one (pixel tile, channel tile) pair instead, vt = mt * tiles_n + nt
+    const int units = a.spread ? a.tiles_m * a.tiles_n : a.tiles_m;
+    const int my_units = units > (int)blockIdx.x ? (units - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+    const int total = my_units * (a.spread ? 1 : a.tiles_n) * a.ksteps;
+    const int mt0 = a.spread ? (int)blockIdx.x / a.tiles_n : (int)blockIdx.x, nt0 = a.spread ? (int)blockIdx.x - mt0 * a.tiles_n : 0;
+    int i_vt = blockIdx.x, i_mt = mt0, i_nt = nt0, i_ks = 0, i_q = 0, i_tile = 0;        // issue cursor
     auto issue = [&]() {
         char* dst = smem + (i_q % RING) * STAGE;
         // the tile's bias row rides with its first stage (wave 0 only; issued BEFORE the stage's loads, so it has landed when the stage
@@ -109,7 +113,11 @@ void pw_conv_kernel(PwArgs a) {
         for (int i = 0; i < WV; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(dst + XB + (wave * 64 + 512 * i) * 16), 16, wb + woff[i], 0, 0, 0);
         ++i_q;
-        if (++i_ks == a.ksteps) { i_ks = 0; if (++i_nt == a.tiles_n) { i_nt = 0; i_mt += gridDim.x; } }
+        if (++i_ks == a.ksteps) {
+            i_ks = 0;
+            if (a.spread) { i_vt += gridDim.x; i_mt = i_vt / a.tiles_n; i_nt = i_vt - i_mt * a.tiles_n; }
+            else if (++i_nt == a.tiles_n) { i_nt = 0; i_mt += gridDim.x; }
+        }
     };
 
     f32x16 acc[2][MJ];
@@ -123,7 +131,7 @@ void pw_conv_kernel(PwArgs a) {
         if (t < total) issue();
 
     const int sw = (lane >> 5) ^ ((lane >> 1) & 7);
-    int c_mt = blockIdx.x, c_nt = 0, c_ks = 0, c_tile = 0;     // consume cursor
+    int c_vt = blockIdx.x, c_mt = mt0, c_nt = nt0, c_ks = 0, c_tile = 0;     // consume cursor
     constexpr int ST = 4 * MJ;                                 // 16-byte stores per lane in a tile's epilogue
     int st_window = 0;
     for (int q = 0; q < total; ++q) {
@@ -244,7 +252,8 @@ void pw_conv_kernel(PwArgs a) {
             // (full 64-channel range stored by this wave -> exactly ST stores; epilogues at least RING - 1 stages apart -> one window at a time)
             st_window = (a.ksteps >= RING - 1 && c_nt * TN + wn * 64 + 64 <= a.N && !(a.ablate & 1)) ? RING - 1 : 0;
             c_ks = 0; ++c_tile;
-            if (++c_nt == a.tiles_n) { c_nt = 0; c_mt += gridDim.x; }
+            if (a.spread) { c_vt += gridDim.x; c_mt = c_vt / a.tiles_n; c_nt = c_vt - c_mt * a.tiles_n; }
+            else if (++c_nt == a.tiles_n) { c_nt = 0; c_mt += gridDim.x; }
         } else ++c_ks;
     }
 }
@@ -256,7 +265,7 @@ void pw_conv_kernel(PwArgs a) {
 int ddpm_pointwise_launch(const void* x, long long x_ld, const void* w, void* y, long long y_ld, const float* bias, const void* residual,
                           long long res_ld, int accumulate, int M, int N, int K, int dry, void* stream) {
     static const bool off = getenv("DDPM_CONV_NO_POINTWISE") != nullptr;
-    static const int min_m = getenv("DDPM_POINTWISE_MIN_M") ? atoi(getenv("DDPM_POINTWISE_MIN_M")) : 32768;     // below: too few 128-pixel tiles for 256 CUs (the 64x64-tile kernel serves those)
+    static const int min_m = getenv("DDPM_POINTWISE_MIN_M") ? atoi(getenv("DDPM_POINTWISE_MIN_M")) : 8192;      // below: too few tiles even as (pixel, channel) pairs (the 64x64-tile kernel with its split-K serves those)
     if (off || M < min_m || K % 64 || N % 8 || x_ld % 8 || y_ld % 8 || (residual && res_ld % 4)) return -1;
     if (!aligned16(x) || !aligned16(w) || !aligned16(y) || (residual && (((uintptr_t)residual) & 7)) || (bias && !aligned16(bias))) return -1;
     if ((long long)M * x_ld * 2 > 0x7ffffff0ll || (long long)N * K * 2 > 0x7ffffff0ll) return -1;
@@ -268,13 +277,18 @@ int ddpm_pointwise_launch(const void* x, long long x_ld, const void* w, void* y,
     { const char* e = getenv("DDPM_PW_ABLATE"); a.ablate = e ? atoi(e) : 0; }
     a.M = M; a.N = N; a.K = K; a.ksteps = K / 64;
     hipStream_t st = (hipStream_t)stream;
-    // Tile choice.  N a multiple of 256 (the attention projections, the 2C-wide skips and their data gradients): 128 pixels x 256
-    // channels — the activation stage is fetched once for twice the channels, half as many stage hand-overs (barrier + DMA wait) per
-    // FLOP and one LDS fragment read per MFMA instead of 1.5.  Otherwise 128-channel tiles: 256 pixels when they give every CU at
-    // least one, else 128 pixels (twice the tiles).
-    static const bool no_wide = getenv("DDPM_PW_NO_WIDE") != nullptr;
-    const bool wide = !no_wide && N % 256 == 0;
+    // Tile choice.  N >= 256 (the attention projections, the 2C-wide skips and their data gradients): 128 pixels x 256 channels — the
+    // activation stage is fetched once for twice the channels, half as many stage hand-overs (barrier + DMA wait) per FLOP and one LDS
+    // fragment read per MFMA instead of 1.5: the 16 x 16 layers went from 19.9 / 46.4 / 50.7 us to 10.7 / 19.6 / 23.9 us (256 -> 256,
+    // 768 -> 256, 256 -> 768; isolated bursts, scripts/pw_ab.py), the step from 10.10 to 9.60 ms on the same box.  N = 384 takes two such
+    // tiles with the second half empty (16.4 vs 28.3 us at 16 x 16).  Otherwise 128-channel tiles: 256 pixels when they give every CU
+    // at least one, else 128 pixels.  Layers with fewer 128-pixel tiles than CUs (the 8 x 8 level, M = 8192) spread (pixel, channel)
+    // tile pairs over the blocks: 11.9 / 9.1 us against 13.1 / 11.3 us on the generic tile kernel (512 -> 256, 256 -> 512).
+    static const bool no_wide = getenv("DDPM_PW_NO_WIDE") != nullptr;        // A/B switch: the round-3 tiling
+    const bool small_m = (M + 127) / 128 < 256;
+    const bool wide = !no_wide && N >= 256;
     const bool big = (M + 255) / 256 >= 256;
+    a.spread = small_m ? 1 : 0;
 #define PW_LAUNCH(TM, TN, RINGV)                                                                                                  \
     do {                                                                                                                          \
         constexpr int LDS = RINGV * (TM * 128 + TN * 128) + 4096;                                                                 \
@@ -285,7 +299,8 @@ int ddpm_pointwise_launch(const void* x, long long x_ld, const void* w, void* y,
             attr_set = true;                                                                                                      \
         }                                                                                                                         \
         a.tiles_m = (M + TM - 1) / TM; a.tiles_n = (N + TN - 1) / TN;                                                             \
-        const int grid = a.tiles_m < 256 ? a.tiles_m : 256;                                                                       \
+        const int units = a.spread ? a.tiles_m * a.tiles_n : a.tiles_m;                                                           \
+        const int grid = units < 256 ? units : 256;                                                                               \
         hipLaunchKernelGGL((pw_conv_kernel<TM, TN>), dim3(grid), dim3(512), LDS, st, a);                                          \
     } while (0)
     if (wide) PW_LAUNCH(128, 256, 3); else if (big) PW_LAUNCH(256, 128, 3); else PW_LAUNCH(128, 128, 4);

@@ -12,7 +12,7 @@ h = _hip.lib()
 st = torch.cuda.current_stream().cuda_stream
 # (H, C_in, C_out, launches per step, epilogue) — epilogue: 0 plain, 1 residual, 2 "+=" (how the step calls them)
 SHAPES = ((32, 128, 256, 2, 2), (32, 128, 384, 1, 2), (32, 256, 128, 2, 0), (32, 384, 128, 1, 0), (16, 256, 256, 10, 1), (16, 256, 768, 5, 0),
-          (16, 768, 256, 5, 0), (16, 256, 512, 2, 2), (16, 512, 256, 2, 0), (16, 256, 384, 1, 2), (16, 384, 256, 1, 0))
+          (16, 768, 256, 5, 0), (16, 256, 512, 2, 2), (16, 512, 256, 2, 0), (16, 256, 384, 1, 2), (16, 384, 256, 1, 0), (8, 512, 256, 3, 0), (8, 256, 512, 3, 2))
 tot = {}
 for (H, C, N, cnt, ep) in SHAPES:
     x = torch.randn(B, H, H, C, device=DEV).to(dt)
@@ -43,7 +43,7 @@ for (H, C, N, cnt, ep) in SHAPES:
         y.zero_()
         t = burst(mode)
         mb = (M * C + M * N * (2 if mode else 1)) * 2 / 1e6
-        line += f"  {name} {t:6.1f} us {mb / t / 1e6 * 1e6 / 1e6:4.2f} TB/s"
+        line += f"  {name} {t:6.1f} us {mb / t:4.2f} TB/s"
         if mode == ep: tot["prod"] = tot.get("prod", 0.0) + t * cnt
         if mode == 0: tot["plain"] = tot.get("plain", 0.0) + t * cnt
     for ab, name in ((1, "no-stores"), (2, "no-mfma"), (3, "neither")):

@@ -204,16 +204,18 @@ def test_conv1x1_wgrad_slab_kernel(P, C, N):
 
 
 PW_CASES = [(32, 32, 128, 256), (64, 32, 128, 256), (35, 31, 64, 192), (128, 16, 256, 768), (130, 16, 320, 384), (70, 31, 192, 104), (128, 16, 768, 256),
-            (128, 16, 256, 256), (33, 32, 256, 128), (128, 16, 512, 256), (128, 16, 256, 512), (37, 31, 384, 128), (36, 31, 448, 96)]
+            (128, 16, 256, 256), (33, 32, 256, 128), (128, 16, 512, 256), (128, 16, 256, 512), (37, 31, 384, 128), (36, 31, 448, 96),
+            (35, 31, 128, 256), (35, 31, 192, 512),        # 256-channel tiles with a ragged pixel tail
+            (128, 8, 512, 256), (130, 8, 256, 512), (37, 15, 192, 384)]       # fewer pixel tiles than CUs: blocks walk (pixel, channel) tile pairs
 
 
 @pytest.mark.parametrize("B,H,C,N", PW_CASES)
 def test_conv1x1_streaming_path(B, H, C, N):
-    """bf16 1x1 / stride 1 with >= 32768 pixels takes the persistent streaming kernel (csrc/pointwise.hip): both tile heights, ragged
+    """bf16 1x1 / stride 1 with >= 8192 pixels takes the persistent streaming kernel (csrc/pointwise.hip): all three tile shapes, ragged
     pixel / channel tails, one to twelve K-steps, pitched operands, and the bias / residual / accumulate epilogues."""
     dt = 1
     M = B * H * H
-    assert M >= 32768 and _hip.lib().ddpm_conv2d_variant(C + 16, N + 32, B, H, H, C, H, H, N, 1, 1, 1, 0, 0, 0, 0, 0, 1, dt, 0) == 7
+    assert M >= 8192 and _hip.lib().ddpm_conv2d_variant(C + 16, N + 32, B, H, H, C, H, H, N, 1, 1, 1, 0, 0, 0, 0, 0, 1, dt, 0) == 7
     ld, yld = C + 16, N + 32
     x = r(M, ld, seed=1, dt=dt)
     w = r(N, C, seed=2, dt=dt, scale=1.0 / math.sqrt(C))
