@@ -111,21 +111,55 @@ __device__ __forceinline__ void pack_tensor(const float* __restrict__ w, T* __re
     constexpr int pitch = PK_T * RS + 1;                               // odd pitch: the n-fastest reads below are conflict-free
     const int tiles_c = (Cp + PK_T - 1) / PK_T, tiles_n = (Np + PK_T - 1) / PK_T;
     const int tid = threadIdx.x;
+    const bool vec_ok = ((long long)C * RS) % 4 == 0 && (((unsigned long long)w) & 15) == 0;   // every row of every tile starts on a 16-byte boundary (c0 is a multiple of 32)
     for (int t = blockIdx.x; t < tiles_c * tiles_n; t += gridDim.x) {
         const int n0 = (t / tiles_c) * PK_T, c0 = (t % tiles_c) * PK_T;
         const int cw = min(PK_T, C - c0);                              // real channels in this tile (<= 0: pure padding)
         __syncthreads();                                               // the previous tile has been consumed
-        for (int i = tid; i < PK_T * PK_T * RS; i += 256) {
-            const int nl = i / (PK_T * RS), rem = i - nl * (PK_T * RS);
-            const bool ok = n0 + nl < N && rem < cw * RS;
-            tile[nl * pitch + rem] = ok ? w[((long long)(n0 + nl) * C + c0) * RS + rem] : 0.f;
+        // Full tiles of 16-byte-aligned rows (every tile of the 3x3 / 1x1 layers but the channel tails): the 32 x 32 RS floats arrive as
+        // 16-byte vectors, ALL of a thread's requests in flight before the first is parked in LDS (scalar loads, one or two in flight per
+        // thread, left the launch at 1.9 TB/s: 153 us of every training step for 286 MB).
+        constexpr int V = PK_T * RS / 4, KV = PK_T * V / 256;          // vectors per row; vectors per thread (9 / 1 / 4 for RS = 9 / 1 / 4)
+        static_assert(PK_T * V % 256 == 0, "whole vectors per thread");
+        if (cw == PK_T && vec_ok) {
+            float4 xv[KV];
+#pragma unroll
+            for (int k = 0; k < KV; ++k) {
+                const int i = tid + 256 * k, nl = i / V, v = i - nl * V;
+                xv[k] = n0 + nl < N ? *reinterpret_cast<const float4*>(w + ((long long)(n0 + nl) * C + c0) * RS + 4 * v) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int k = 0; k < KV; ++k) {
+                const int i = tid + 256 * k, nl = i / V, v = i - nl * V;
+                float* t4 = tile + nl * pitch + 4 * v;
+                t4[0] = xv[k].x; t4[1] = xv[k].y; t4[2] = xv[k].z; t4[3] = xv[k].w;
+            }
+        } else {
+            for (int i = tid; i < PK_T * PK_T * RS; i += 256) {
+                const int nl = i / (PK_T * RS), rem = i - nl * (PK_T * RS);
+                const bool ok = n0 + nl < N && rem < cw * RS;
+                tile[nl * pitch + rem] = ok ? w[((long long)(n0 + nl) * C + c0) * RS + rem] : 0.f;
+            }
         }
         __syncthreads();
+        constexpr bool BF = sizeof(T) == 2;                            // bf16 layouts are padded to multiples of 8: 16-byte stores of 8 elements
         if (wf) {                                                      // wf[n][tap][c], c fastest
-            for (int i = tid; i < PK_T * RS * (PK_T / 2); i += 256) {
-                const int cl = (i % (PK_T / 2)) * 2, r1 = i / (PK_T / 2), tap = r1 % RS, nl = r1 / RS;
-                if (n0 + nl < N && c0 + cl < Cp)
-                    pk_store2<T>(wf + ((long long)(n0 + nl) * RS + tap) * Cp + c0 + cl, tile[nl * pitch + cl * RS + tap], tile[nl * pitch + (cl + 1) * RS + tap]);
+            if constexpr (BF) {
+                for (int i = tid; i < PK_T * RS * (PK_T / 8); i += 256) {
+                    const int cl = (i % (PK_T / 8)) * 8, r1 = i / (PK_T / 8), tap = r1 % RS, nl = r1 / RS;
+                    if (n0 + nl < N && c0 + cl < Cp) {
+                        const float* t8 = tile + nl * pitch + cl * RS + tap;
+                        u32x4 o;
+                        o.x = pack_bf2(t8[0], t8[RS]); o.y = pack_bf2(t8[2 * RS], t8[3 * RS]); o.z = pack_bf2(t8[4 * RS], t8[5 * RS]); o.w = pack_bf2(t8[6 * RS], t8[7 * RS]);
+                        *reinterpret_cast<u32x4*>(wf + ((long long)(n0 + nl) * RS + tap) * Cp + c0 + cl) = o;
+                    }
+                }
+            } else {
+                for (int i = tid; i < PK_T * RS * (PK_T / 2); i += 256) {
+                    const int cl = (i % (PK_T / 2)) * 2, r1 = i / (PK_T / 2), tap = r1 % RS, nl = r1 / RS;
+                    if (n0 + nl < N && c0 + cl < Cp)
+                        pk_store2<T>(wf + ((long long)(n0 + nl) * RS + tap) * Cp + c0 + cl, tile[nl * pitch + cl * RS + tap], tile[nl * pitch + (cl + 1) * RS + tap]);
+                }
             }
         }
         if constexpr (RS == 9) {
@@ -156,11 +190,24 @@ __device__ __forceinline__ void pack_tensor(const float* __restrict__ w, T* __re
             }
         }
         if (wd) {                                                      // wd[c][tap][n] with flipped taps, n fastest
-            for (int i = tid; i < PK_T * RS * (PK_T / 2); i += 256) {
-                const int nl = (i % (PK_T / 2)) * 2, r1 = i / (PK_T / 2), tap = r1 % RS, cl = r1 / RS;
-                if (c0 + cl < C && n0 + nl < Np)
-                    pk_store2<T>(wd + ((long long)(c0 + cl) * RS + tap) * Np + n0 + nl, tile[nl * pitch + cl * RS + (RS - 1 - tap)],
-                                 tile[(nl + 1) * pitch + cl * RS + (RS - 1 - tap)]);
+            if constexpr (BF) {
+                for (int i = tid; i < PK_T * RS * (PK_T / 8); i += 256) {
+                    const int nl = (i % (PK_T / 8)) * 8, r1 = i / (PK_T / 8), tap = r1 % RS, cl = r1 / RS;
+                    if (c0 + cl < C && n0 + nl < Np) {
+                        const float* t8 = tile + nl * pitch + cl * RS + (RS - 1 - tap);
+                        u32x4 o;
+                        o.x = pack_bf2(t8[0], t8[pitch]); o.y = pack_bf2(t8[2 * pitch], t8[3 * pitch]); o.z = pack_bf2(t8[4 * pitch], t8[5 * pitch]);
+                        o.w = pack_bf2(t8[6 * pitch], t8[7 * pitch]);
+                        *reinterpret_cast<u32x4*>(wd + ((long long)(c0 + cl) * RS + tap) * Np + n0 + nl) = o;
+                    }
+                }
+            } else {
+                for (int i = tid; i < PK_T * RS * (PK_T / 2); i += 256) {
+                    const int nl = (i % (PK_T / 2)) * 2, r1 = i / (PK_T / 2), tap = r1 % RS, cl = r1 / RS;
+                    if (c0 + cl < C && n0 + nl < Np)
+                        pk_store2<T>(wd + ((long long)(c0 + cl) * RS + tap) * Np + n0 + nl, tile[nl * pitch + cl * RS + (RS - 1 - tap)],
+                                     tile[(nl + 1) * pitch + cl * RS + (RS - 1 - tap)]);
+                }
             }
         }
     }
@@ -206,6 +253,26 @@ __global__ __launch_bounds__(256) void wgrad_unpack_kernel(const float* __restri
         for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
             const float v = src[i] * scale;
             dst[i] = v; acc += v * v;
+        }
+    } else if (RS == 9 && C % 64 == 0) {
+        // 3x3 layers: a WAVE moves one (n, 64 channels) slab — nine coalesced 256-byte row reads, all in flight together, transposed through a
+        // wave-private 2.3-KiB LDS slab (odd stride: conflict-free), nine coalesced 256-byte writes of the contiguous [64 c][9 taps] run.
+        // (The gather form below reads 28-byte runs from nine rows per wave instruction: 93 us of every step for 286 MB.)
+        __shared__ float slab[4][64 * 9];
+        const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6, ctiles = C / 64, items = (unsigned)d[2] * ctiles;
+        float* mine = slab[wave];
+        for (unsigned it = blockIdx.x * 4 + wave; it < items; it += gridDim.x * 4) {
+            const unsigned n = it / ctiles, c0 = (it - n * ctiles) * 64;
+            float v[9];
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) v[tap] = src[((unsigned long long)n * 9 + tap) * C + c0 + lane] * scale;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) { mine[lane * 9 + tap] = v[tap]; acc += v[tap] * v[tap]; }
+            __builtin_amdgcn_wave_barrier();
+            float* out = dst + ((unsigned long long)n * C + c0) * 9;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) out[k * 64 + lane] = mine[k * 64 + lane];
+            __builtin_amdgcn_wave_barrier();                                  // the slab is reused by the wave's next item
         }
     } else {
         for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {

@@ -776,7 +776,7 @@ def test_wgrad_unpack_and_fused_norm():
     """ddpm_wgrad_unpack / ddpm_wgrad_unpack_sumsq: packed [N][R*S][C] -> [N][C][R*S] (x scale) for several tensors in one launch, plain
     segment copies (R*S = 1), and — fused form — the squared norm of everything written, against float64."""
     g = torch.Generator().manual_seed(5)
-    shapes = [(64, 48, 9), (7, 24, 9), (1, 1000, 1), (33, 5, 1), (16, 16, 16)]
+    shapes = [(64, 48, 9), (7, 24, 9), (1, 1000, 1), (33, 5, 1), (16, 16, 16), (37, 128, 9), (256, 64, 9), (5, 192, 9)]     # the last three: the wave-slab path (C % 64 == 0)
     src_off, dst_off, rows = 0, 0, []
     for N, C, RS in shapes:
         rows.append([src_off, dst_off, N, C, RS])
