@@ -146,6 +146,9 @@ def settle(tr, x0, first_step, limit=40):
     steps and captures the graph in between): nothing of that may fall inside a timed region, whatever --warmup is.
     Returns the number of extra steps taken."""
     extra = 0
+    if first_step == 1:                          # --warmup 0: the direct-step objects do not exist before the first step
+        tr.step(x0, global_steps=1)
+        extra = 1
     while extra < limit and tr._direct and any(not d.settled() for d in tr._direct.values()):
         tr.step(x0, global_steps=first_step + extra)
         extra += 1
