@@ -53,6 +53,16 @@ __device__ __forceinline__ int xcd_logical(int id, int total) {
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+#ifdef WG_TIMING
+// debug builds only (scripts/wg_timeline.py): [block][wave][16] clock64 stamps (low 32 bits, scalar registers) of ONE mid-kernel stage of
+// the 16 x 16-patch kernel — taken right behind waits that leave nothing outstanding, so reading the clock does not disturb the LGKM
+// bookkeeping — plus loop begin / end and the stage count
+__device__ unsigned long long* g_wg_timing = nullptr;
+#define WG_T(k) do { if (tl) tq[k] = (unsigned)clock64(); } while (0)
+#else
+#define WG_T(k)
+#endif
+
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
@@ -122,7 +132,7 @@ void wgrad3x3_kernel(Wg3Args a) {
         dy_il_delta = 64 >> a.lPP;
         dy_delta = (unsigned)((dy_il_delta ? (long long)dy_il_delta * a.H * a.W : (long long)(64 / PW) * a.W) * a.dy_ld * 2);
     }
-    unsigned x_pos[NI_X];                                                      // (hy + 1) << 16 | (hx + 1) << 8 | il ; 0xffffffff: no pixel
+    unsigned x_pos[NI_X], x_rel[NI_X];                                         // hy << 16 | hx << 8 | il (halo coordinates; image row = py0 + hy - 1) ; 0xffffffff: no pixel
     const unsigned x_c2 = (unsigned)((tc * TC + (tid & 3) * 8) * 2);
 #pragma unroll
     for (int i = 0; i < NI_X; ++i) {
@@ -130,6 +140,11 @@ void wgrad3x3_kernel(Wg3Args a) {
         const int il = (int)fdiv((unsigned)hp, a.d_halo_img), rem = hp - il * (HH * HW);
         const int hy = (int)fdiv((unsigned)rem, a.d_halo_w), hx = rem - hy * HW;
         x_pos[i] = hp < HP ? ((unsigned)hy << 16 | (unsigned)hx << 8 | (unsigned)il) : 0xffffffffu;
+        // byte offset of this halo pixel RELATIVE to the patch origin's (img0, py0, px0 are multiples of the patch size: even, so the
+        // nearest-2x gather's shifts distribute): everything a stage adds to it is wave-uniform — no 64-bit address product per vector
+        // and stage.  Wraps modulo 2^32 for the rows above / left of the image, which are masked anyway.
+        const int dyi = (hy - 1) >> a.ups, dxi = (hx - 1) >> a.ups;
+        x_rel[i] = (unsigned)(((il * (a.H >> a.ups) + dyi) * (a.W >> a.ups) + dxi) * (int)a.x_ld * 2) + x_c2;
     }
     auto issue_stage = [&](int st, int slot) {
         const int grp = (int)fdiv((unsigned)st, a.d_tpi), pt = st - grp * tpi;
@@ -137,6 +152,7 @@ void wgrad3x3_kernel(Wg3Args a) {
         const int img0 = grp * a.NB, py0 = ty * a.PH, px0 = tx * PW;
         char* dst = smem + slot * STAGE_BYTES;
         const unsigned base = (unsigned)((((long long)(img0 * a.H + py0) * a.W + px0) * a.dy_ld) * 2);
+        const unsigned base_x = (unsigned)((((long long)(img0 * (a.H >> a.ups) + (py0 >> a.ups)) * (a.W >> a.ups) + (px0 >> a.ups)) * a.x_ld) * 2);   // wave-uniform
 #pragma unroll
         for (int i = 0; i < NI_DY; ++i) {
             const unsigned o = (img0 + dy_il0 + i * dy_il_delta < a.B) ? base + dy_rel0 + i * dy_delta : OOB;
@@ -147,7 +163,7 @@ void wgrad3x3_kernel(Wg3Args a) {
             const unsigned xp = x_pos[i];
             const int gi = img0 + (int)(xp & 0xff), iy = py0 + (int)(xp >> 16) - 1, ix = px0 + (int)((xp >> 8) & 0xff) - 1;
             const bool ok = xp != 0xffffffffu && gi < a.B && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-            const unsigned o = ok ? (unsigned)((((long long)(gi * (a.H >> a.ups) + (iy >> a.ups)) * (a.W >> a.ups) + (ix >> a.ups)) * a.x_ld) * 2) + x_c2 : OOB;
+            const unsigned o = ok ? base_x + x_rel[i] : OOB;
             const int rel = (wave * 64 + 512 * i) * 16;
             char* to = (rel + 1024 <= X_BYTES) ? dst + DY_BYTES + rel : smem + DUMP_OFF;       // wave-uniform
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)to, 16, o, 0, 0, 0);
@@ -221,33 +237,60 @@ void wgrad3x3_kernel(Wg3Args a) {
             READ_A(fa); READ_ROW(f4, 4);
             WAIT_A(fa); WAIT3(f4);
         }
+#ifdef WG_TIMING
+        unsigned tq[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) tq[q] = 0;
+        const unsigned loop_t0 = (unsigned)clock64();
+#endif
         for (int it = 0; it < nst; ++it) {
+#ifdef WG_TIMING
+            const bool tl = g_wg_timing != nullptr && it == nst / 2;
+#endif
+            WG_T(0);
             if (want_bias) { bias_add(fa[0]); bias_add(fa[1]); bias_add(fa[2]); bias_add(fa[3]); }
             Frag* f5 = f50; Frag* f0 = f50 + 3;
             READ_ROW(f5, 5); READ_ROW(f0, 0);
             MMA_ROW(fa, f4, 4);
+            WG_T(1);
             WAIT3(f5); WAIT3(f0);
+            WG_T(2);
             READ_ROW(f1, 1);
             MMA_ROW(fa, f5, 5); MMA_ROW(fa, f0, 0);
+            WG_T(3);
             WAIT3(f1);
+            WG_T(4);
             READ_ROW(f2, 2);
             MMA_ROW(fa, f1, 1);
+            WG_T(5);
             WAIT3(f2);
+            WG_T(6);
             READ_ROW(f3, 3);
             MMA_ROW(fa, f2, 2);
+            WG_T(7);
             WAIT3(f3);
+            WG_T(8);
             // every LDS read of this stage has returned: after the barrier its slot may be refilled.  Stage it+1 must have landed
             // (one newer stage, it+2, may stay in flight).
             const bool more = it + 1 < nst;
             if (more) { if (it + 2 < nst) wait_vm<PER>(); else wait_vm<0>(); }
+            WG_T(9);
             __builtin_amdgcn_s_barrier();
+            WG_T(10);
             Frag na[4], n4[3];
             if (more) {
                 bases((it + 1) % RING, abase, blo0, bhi0);
                 READ_A(na); READ_ROW(n4, 4);
             }
             MMA_ROW(fa, f3, 3);
+            WG_T(11);
+            // All eight waves issue their seven LDS-DMA instructions of the next stage HERE, together.  scripts/wg_timeline.py (round 4): that
+            // takes 800-1000 clk of a 4600-clk stage with the matrix pipe idle — an LDS-DMA instruction blocks its wave while the CU's
+            // address path (~64 B/clk) works off the queue — but both alternatives measured worse: two instructions at a time behind the
+            // MFMA groups (the waves block just as long, 4300 clk per stage at a lower clock: +3.5 % time) and the whole schedule on waves
+            // 4-7 with waves 0-3 never blocking (a wave gets ~1 instruction per 330 clk once it has ~14 in flight: 7100 clk per stage).
             if (it + RING < nst) issue_stage(st_begin + it + RING, it % RING);
+            WG_T(12);
             if (more) {
                 WAIT_A(na); WAIT3(n4);
 #pragma unroll
@@ -255,7 +298,17 @@ void wgrad3x3_kernel(Wg3Args a) {
 #pragma unroll
                 for (int sft = 0; sft < 3; ++sft) f4[sft] = n4[sft];
             }
+            WG_T(15);
         }
+#ifdef WG_TIMING
+        if (g_wg_timing && lane == 0) {
+            unsigned long long* o = g_wg_timing + ((long long)blockIdx.x * 8 + wave) * 16;
+            tq[13] = loop_t0; tq[14] = (unsigned)clock64();
+#pragma unroll
+            for (int q = 0; q < 16; ++q) o[q] = tq[q];
+            o[14] |= (unsigned long long)nst << 32;
+        }
+#endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
 #undef READ_ROW
@@ -499,3 +552,7 @@ extern "C" int ddpm_conv3x3_wgrad_up_nhwc(const void* dy, long long dy_ld, const
                                           int dtype, void* stream) {
     return wgrad3x3_launch(dy, dy_ld, x, x_ld, dw, slab_stride, dbias, bias_stride, B, H, W, C, N, Nreal, splits, dtype, 1, stream);
 }
+
+#ifdef WG_TIMING
+extern "C" int ddpm_debug_set_wg_timing(void* p) { return hipMemcpyToSymbol(HIP_SYMBOL(g_wg_timing), &p, sizeof(p)) == hipSuccess ? 0 : -1; }
+#endif
