@@ -273,6 +273,8 @@ void wgrad3x3_kernel(Wg3Args a) {
             // every LDS read of this stage has returned: after the barrier its slot may be refilled.  Stage it+1 must have landed
             // (one newer stage, it+2, may stay in flight).
             const bool more = it + 1 < nst;
+            // (waves 0-3 feed stage it + 2 HERE, see below: its slot was freed by the barrier that ended iteration it - 1)
+            if (wave < 4 && it >= 1 && it + 2 < nst) issue_stage(st_begin + it + 2, (it + 2) % RING);
             if (more) { if (it + 2 < nst) wait_vm<PER>(); else wait_vm<0>(); }
             WG_T(9);
             __builtin_amdgcn_s_barrier();
@@ -282,14 +284,18 @@ void wgrad3x3_kernel(Wg3Args a) {
                 bases((it + 1) % RING, abase, blo0, bhi0);
                 READ_A(na); READ_ROW(n4, 4);
             }
+            // Feeding the ring.  scripts/wg_timeline.py (round 4): an LDS-DMA instruction blocks its wave for ~120 clk, a stage's seven for
+            // 800-1000 clk; with all eight waves issuing here, together, that was a fifth of a 4600-clk stage with the matrix pipe idle.  The
+            // two waves of a SIMD do not multiply side by side either: the older one (waves 0-3) gets the pipe for its four MFMA groups, then
+            // idles ~950 clk at the stage barrier while its partner (waves 4-7) runs its own.  So each wave now issues where it would idle:
+            // waves 4-7 HERE, right behind the barrier, while waves 0-3 multiply; waves 0-3 at the END of their iteration (above), while
+            // waves 4-7 multiply — stage s is fed during iteration s - 2 by both, and every wave still waits for its own seven.
+            // (Measured worse: two instructions at a time behind the MFMA groups, +3.5 % time; the whole schedule on waves 4-7 — a wave gets
+            // ~1 instruction per 330 clk once ~14 are in flight — 7100 clk per stage.)
+            if (wave >= 4 && it + RING < nst) issue_stage(st_begin + it + RING, it % RING);
+            __builtin_amdgcn_sched_barrier(0);
             MMA_ROW(fa, f3, 3);
             WG_T(11);
-            // All eight waves issue their seven LDS-DMA instructions of the next stage HERE, together.  scripts/wg_timeline.py (round 4): that
-            // takes 800-1000 clk of a 4600-clk stage with the matrix pipe idle — an LDS-DMA instruction blocks its wave while the CU's
-            // address path (~64 B/clk) works off the queue — but both alternatives measured worse: two instructions at a time behind the
-            // MFMA groups (the waves block just as long, 4300 clk per stage at a lower clock: +3.5 % time) and the whole schedule on waves
-            // 4-7 with waves 0-3 never blocking (a wave gets ~1 instruction per 330 clk once it has ~14 in flight: 7100 clk per stage).
-            if (it + RING < nst) issue_stage(st_begin + it + RING, it % RING);
             WG_T(12);
             if (more) {
                 WAIT_A(na); WAIT3(n4);
