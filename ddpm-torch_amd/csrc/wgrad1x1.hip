@@ -180,8 +180,9 @@ static bool make_plan(int P, int C, int N, Plan& p) {
 // Slab copies ddpm_conv1x1_wgrad_nhwc writes for this geometry (0: geometry not covered — the caller keeps ddpm_conv2d_wgrad_nhwc).
 extern "C" int ddpm_conv1x1_wgrad_splits(int P, int C, int N) {
     static const bool off = getenv("DDPM_NO_WGRAD1X1") != nullptr;
+    static const int min_p = getenv("DDPM_WGRAD1_MIN_P") ? atoi(getenv("DDPM_WGRAD1_MIN_P")) : 16384;
     Plan p;
-    if (off || P < 16384 || !make_plan(P, C, N, p)) return 0;
+    if (off || P < min_p || !make_plan(P, C, N, p)) return 0;
     return p.splits;
 }
 
