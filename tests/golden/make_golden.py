@@ -380,8 +380,52 @@ def g10_config2():
     save("g10_config2.pt", out)
 
 
+def strided(t, n=256):
+    """n evenly spaced elements of a tensor (its flat order): a sample that reaches every region of a tensor too large to commit."""
+    f = t.detach().reshape(-1)
+    idx = torch.linspace(0, f.numel() - 1, min(n, f.numel())).round().long()
+    return f[idx].clone()
+
+
+def g11_config2_bench_batch():
+    """BASELINE config 2 AT THE BENCHMARK'S BATCH (B = 128): the geometry at which the product dispatches its hot kernels — the
+    wave-specialised / persistent 3x3 kernels need >= 16384 / 4096 pixels per layer, the streaming 1x1 kernel >= 8192, the patch-stationary
+    weight gradient whole 16 x 16 patches — which the B = 1 / B = 2 records of G10 never reach.  From the imported reference
+    (models/unet.py:205-233, diffusion.py:160-174): an eval forward, EVERY parameter gradient of sum(y * gy) (dropout inactive: eval mode,
+    the product side builds the net with drop_rate 0), and an 8-step ancestral chain.  Tensors travel as strided samples + fp64 digests;
+    inputs are seeds.  ~15 minutes on one core."""
+    B = 128
+    m, mc = _shipped_model("cifar10", 1234, 61)
+    out = dict(cfg=mc, init_seed=1234, rand_seed=61, B=B)
+    x, gy = rnd(B, 3, 32, 32, seed=71), rnd(B, 3, 32, 32, seed=72)
+    t = (torch.arange(B) * 37 + 5) % 1000
+    for q in m.parameters():
+        q.requires_grad_(True)
+    y = m(x, t)
+    (y * gy).sum().backward()
+    yd = y.detach()
+    out["fwd"] = dict(x_seed=71, t=t, y_sub=yd[:, :, ::4, ::4].clone(), y_sum=yd.double().sum((1, 2, 3)), y_abs=yd.double().abs().sum((1, 2, 3)),
+                      y_absmax=float(yd.abs().max()))
+    names, sums, abss, sqs, samples = [], [], [], [], {}
+    for k, q in m.named_parameters():
+        g = q.grad.detach()
+        names.append(k); sums.append(float(g.double().sum())); abss.append(float(g.double().abs().sum())); sqs.append(float((g.double() ** 2).sum()))
+        samples[k] = strided(g)
+    out["grads"] = dict(gy_seed=72, names=names, sum=torch.tensor(sums, dtype=torch.float64), abs_sum=torch.tensor(abss, dtype=torch.float64),
+                        sq_sum=torch.tensor(sqs, dtype=torch.float64), samples=samples)
+    for q in m.parameters():
+        q.requires_grad_(False); q.grad = None
+    steps, shape = 8, (B, 3, 32, 32)
+    short = ref.GaussianDiffusion(ref.get_beta_schedule("linear", 1e-4, 0.02, steps), "eps", "fixed-large", "mse")
+    x0 = short.p_sample(m, shape=shape, device=torch.device("cpu"), seed=73)                 # diffusion.py:160-174
+    out["ddpm8_fixed-large"] = dict(seed=73, shape=shape, timesteps=steps, x0_sub=x0[:, :, ::4, ::4].clone(), x0_sum=x0.double().sum((1, 2, 3)),
+                                    x0_abs=x0.double().abs().sum((1, 2, 3)), x0_absmax=float(x0.abs().max()))
+    save("g11_config2_b128.pt", out)
+
+
 if __name__ == "__main__":
     import sys
-    ALL = dict(g1=g1_ops, g2=g2_blocks, g3=g3_model, g4=g4_tables, g5=g5_steps, g6=g6_loops, g7=g7_train, g8=g8_toy, g9=g9_train_lr, g10=g10_config2)
+    ALL = dict(g1=g1_ops, g2=g2_blocks, g3=g3_model, g4=g4_tables, g5=g5_steps, g6=g6_loops, g7=g7_train, g8=g8_toy, g9=g9_train_lr, g10=g10_config2,
+               g11=g11_config2_bench_batch)
     for name in (sys.argv[1:] or list(ALL)):          # `make_golden.py g9` regenerates one fixture, no argument = all
         ALL[name]()

@@ -2,10 +2,12 @@
 from the imported reference): "outputs match the reference UNet forward and p_sample_loop on identical (x_t, t, noise) within 1e-3
 rel fp32" — upstream ddpm_torch/models/unet.py:205-233, ddpm_torch/diffusion.py:160-198, ddim.py:96-113.
 
-The G6 chains run on an 8 x 8 toy whose layers never reach the product's hot kernels (the persistent 3 x 3 kernel needs C % 64 == 0
-and >= 4096 pixels).  Here the nets are configs/cifar10.json at 32 x 32 and configs/celeba.json at 64 x 64: every launch of the
-chain is conv3x3_pc / conv3x3_stream<8>, pw_conv, the flash attention forward, LDS GroupNorm, gemm64 — through the GRAPH-REPLAYED
-sampler with the [T][sum Cout] time-bias table (the reference's CPU noise stream is copied into the captured step's noise buffer).
+The G6 chains run on an 8 x 8 toy.  Here the nets are configs/cifar10.json at 32 x 32 and configs/celeba.json at 64 x 64 — the real
+channel counts, K = 1152 ... 4608 reductions, the 256-token attention, LDS GroupNorm — through the GRAPH-REPLAYED sampler with the
+[T][sum Cout] time-bias table (the reference's CPU noise stream is copied into the captured step's noise buffer).  At the B = 1 / B = 2
+of these records the dispatcher still serves the convs from the small-grid kernels (gemm64 / generic tiles): the launches of the
+BENCHMARK's batch — conv3x3_pc, conv3x3_stream, pw_conv, wgrad3x3 — are pinned to the reference by fixture G11
+(tests/test_config2_bench_batch_gpu.py: forward, every parameter gradient and a short chain at B = 128).
 
 fp32 mode: <= 1e-3 of the tensor's range at every element.  bf16 mode (the throughput mode): stated, measured bars, printed."""
 import pytest

@@ -245,6 +245,29 @@ def test_g10_config2_forward_and_short_chain(golden):
         check(x, r["x_0"], 2e-4, name="g10.ddpm40")
 
 
+def test_g11_oracle_forward_and_gradients_at_the_bench_batch(golden):
+    """The oracle at the benchmark's batch (configs/cifar10.json, B = 128, eval mode) against the reference's forward and a sample of its
+    parameter gradients (fixture G11; the GPU side checks every gradient tensor: tests/test_config2_bench_batch_gpu.py)."""
+    g = golden("g11_config2_b128.pt")
+    torch.manual_seed(g["init_seed"])
+    sd = U.randomize_state_dict(U.init_state_dict(g["cfg"]), g["rand_seed"])
+    p = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    f, gr = g["fwd"], g["grads"]
+    B = g["B"]
+    y = U.unet_forward(p, g["cfg"], rnd(B, 3, 32, 32, seed=f["x_seed"]), f["t"], training=False)
+    (y * rnd(B, 3, 32, 32, seed=gr["gy_seed"])).sum().backward()
+    yd = y.detach()
+    assert float((yd[:, :, ::4, ::4] - f["y_sub"]).abs().max()) <= 2e-5 * f["y_absmax"]
+    assert float(((yd.double().sum((1, 2, 3)) - f["y_sum"]).abs() / f["y_abs"]).max()) < 1e-6
+    assert list(p) == gr["names"]
+    for i, k in enumerate(gr["names"]):
+        got = p[k].grad.reshape(-1)
+        idx = torch.linspace(0, got.numel() - 1, min(256, got.numel())).round().long()
+        want = gr["samples"][k]
+        assert float((got[idx] - want).abs().max()) <= 1e-4 * max(float(want.abs().max()), 1e-3), k
+        assert abs(float(got.double().sum()) - float(gr["sum"][i])) <= 1e-5 * float(gr["abs_sum"][i]) + 1e-9, k
+
+
 def test_g7_train_steps(golden):
     g = golden("g7_train.pt")
     torch.manual_seed(g["init_seed"])
