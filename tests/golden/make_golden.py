@@ -423,9 +423,49 @@ def g11_config2_bench_batch():
     save("g11_config2_b128.pt", out)
 
 
+def g12_config2_train_steps():
+    """Three `Trainer.step`s (utils/train.py:148-170: q_sample, loss, backward, clip_grad_norm_(1.0), Adam, EMA :300-305) of the
+    configs/cifar10.json network AT THE BENCHMARK'S BATCH (B = 128, 32 x 32), by the reference's own Trainer on its CPU (t, noise) stream.
+    Dropout is 0 here (the reference draws its masks from torch's CPU generator, which no other implementation can reproduce) and the
+    learning rate is 1e-3 without warm-up, so that the second and third loss depend on the weights the first steps wrote.  Inputs are
+    seeds; parameters and EMA shadows travel as fp64 sums + 64 strided entries per tensor.  ~8 minutes on one core."""
+    B = 128
+    cfg = json.load(open(os.path.join(LR.REFERENCE_ROOT, "configs", "cifar10.json")))
+    mc = dict(cfg["model"]); mc.pop("block_size", None)
+    mc["out_channels"] = mc["in_channels"]; mc["drop_rate"] = 0.0
+    torch.manual_seed(1234)
+    m = ref.UNet(**mc)
+    randomized(m, 61)
+    dif = ref.GaussianDiffusion(ref.get_beta_schedule("linear", 1e-4, 0.02, 1000), "eps", "fixed-large", "mse")
+    lr = 1e-3
+    opt = torch.optim.Adam(m.parameters(), lr=lr, betas=(0.9, 0.999))
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lr_lambda=lambda t: 1.0)
+    tr = ref.Trainer(m, opt, dif, epochs=1, trainloader=None, scheduler=sched, use_ema=True, grad_norm=1.0,
+                     shape=(3, 32, 32), device=torch.device("cpu"), ema_decay=0.9999)
+    m.train()
+    x_seeds = [121, 122, 123]
+    losses = []
+    for i, sd in enumerate(x_seeds):
+        x = torch.rand(B, 3, 32, 32, generator=torch.Generator().manual_seed(sd)) * 2 - 1
+        tr.stats.reset()
+        tr.step(x, global_steps=i + 1)
+        losses.append(tr.current_stats["loss"])
+        print("step", i + 1, losses[-1], flush=True)
+
+    def digest_state(state):
+        names = list(state)
+        return dict(names=names, sum=torch.tensor([float(state[k].double().sum()) for k in names], dtype=torch.float64),
+                    abs_sum=torch.tensor([float(state[k].double().abs().sum()) for k in names], dtype=torch.float64),
+                    samples={k: strided(state[k], 64) for k in names})
+    params = {k: v.detach() for k, v in m.named_parameters()}
+    out = dict(cfg=mc, init_seed=1234, rand_seed=61, B=B, lr=lr, gen_seed=8191, x_seeds=x_seeds, losses=torch.tensor(losses, dtype=torch.float64),
+               params=digest_state(params), shadow=digest_state({k: tr.ema.shadow[k] for k in params}), num_updates=tr.ema.num_updates)
+    save("g12_config2_train_b128.pt", out)
+
+
 if __name__ == "__main__":
     import sys
     ALL = dict(g1=g1_ops, g2=g2_blocks, g3=g3_model, g4=g4_tables, g5=g5_steps, g6=g6_loops, g7=g7_train, g8=g8_toy, g9=g9_train_lr, g10=g10_config2,
-               g11=g11_config2_bench_batch)
+               g11=g11_config2_bench_batch, g12=g12_config2_train_steps)
     for name in (sys.argv[1:] or list(ALL)):          # `make_golden.py g9` regenerates one fixture, no argument = all
         ALL[name]()

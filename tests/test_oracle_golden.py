@@ -268,6 +268,35 @@ def test_g11_oracle_forward_and_gradients_at_the_bench_batch(golden):
         assert abs(float(got.double().sum()) - float(gr["sum"][i])) <= 1e-5 * float(gr["abs_sum"][i]) + 1e-9, k
 
 
+def test_g12_oracle_train_steps_at_the_bench_batch(golden):
+    """oracle/train_ref.py against the reference's own Trainer on configs/cifar10.json at B = 128 (fixture G12: three steps at lr 1e-3,
+    dropout 0, the reference's CPU (t, noise) stream): the losses and the sampled parameters / EMA shadows after the third step."""
+    g = golden("g12_config2_train_b128.pt")
+    torch.manual_seed(g["init_seed"])
+    sd0 = U.randomize_state_dict(U.init_state_dict(g["cfg"]), g["rand_seed"])
+    st = train_ref.TrainState(sd0, g["cfg"], lr=g["lr"], warmup=1, grad_norm=1.0, ema_decay=0.9999)
+    T = D.ddpm_tables(D.beta_schedule("linear", 1e-4, 0.02, 1000), "fixed-large")
+    gen = torch.Generator("cpu").manual_seed(g["gen_seed"])
+    losses = []
+    for sd in g["x_seeds"]:
+        x = torch.rand(g["B"], 3, 32, 32, generator=torch.Generator().manual_seed(sd)) * 2 - 1
+        t = torch.empty((g["B"],), dtype=torch.int64).random_(to=1000, generator=gen)
+        noise = torch.empty_like(x).normal_(generator=gen)
+        losses.append(st.step(T, x, t, noise))
+    assert torch.allclose(torch.tensor(losses, dtype=torch.float64), g["losses"], rtol=2e-4), (losses, g["losses"])
+    assert st.num_updates == g["num_updates"]
+    for state, dg in ((st.params, g["params"]), (st.shadow, g["shadow"])):
+        beyond = total = 0
+        for i, k in enumerate(dg["names"]):
+            f = state[k].detach().reshape(-1)
+            idx = torch.linspace(0, f.numel() - 1, min(64, f.numel())).round().long()
+            d = (f[idx] - dg["samples"][k]).abs()
+            beyond += int((d > 1e-3 * max(float(dg["samples"][k].abs().max()), 1e-3)).sum()); total += d.numel()
+            assert float(d.max()) <= 2.0 * g["lr"] * len(g["x_seeds"]) + 1e-6, k          # inside Adam's reach
+            assert abs(float(f.double().sum()) - float(dg["sum"][i])) <= 2e-3 * float(dg["abs_sum"][i]) + 1e-9, k
+        assert beyond <= 0.02 * total, (beyond, total)
+
+
 def test_g7_train_steps(golden):
     g = golden("g7_train.pt")
     torch.manual_seed(g["init_seed"])
