@@ -463,9 +463,43 @@ def g12_config2_train_steps():
     save("g12_config2_train_b128.pt", out)
 
 
+def g13_config5_and_4_at_their_batches():
+    """BASELINE config 5's per-GPU work — configs/celebahq.json (113.7 M parameters, six levels, 512-channel attention at 16 x 16) at
+    256 x 256, B = 2 — forward and EVERY parameter gradient of sum(y * gy) from the imported reference (dropout is 0 in this config), and
+    config 4's network (configs/celeba.json) at 64 x 64 and B = 32, where its layers reach the large-grid kernels: eval forward.
+    Strided samples + fp64 sums, inputs as seeds.  ~5 minutes on one core."""
+    out = {}
+    m, mc = _shipped_model("celebahq", 2345, 64)
+    m.train()
+    B = 2
+    x, gy, t = rnd(B, 3, 256, 256, seed=131), rnd(B, 3, 256, 256, seed=132), torch.tensor([417, 36])
+    for q in m.parameters():
+        q.requires_grad_(True)
+    y = m(x, t)
+    (y * gy).sum().backward()
+    yd = y.detach()
+    names = [k for k, _ in m.named_parameters()]
+    grads = {k: q.grad.detach() for k, q in m.named_parameters()}
+    out["celebahq"] = dict(cfg=mc, init_seed=2345, rand_seed=64, B=B, x_seed=131, gy_seed=132, t=t,
+                           y_sub=yd[:, :, ::16, ::16].clone(), y_sum=yd.double().sum((1, 2, 3)), y_abs=yd.double().abs().sum((1, 2, 3)), y_absmax=float(yd.abs().max()),
+                           grads=dict(names=names, sum=torch.tensor([float(grads[k].double().sum()) for k in names], dtype=torch.float64),
+                                      abs_sum=torch.tensor([float(grads[k].double().abs().sum()) for k in names], dtype=torch.float64),
+                                      sq_sum=torch.tensor([float((grads[k].double() ** 2).sum()) for k in names], dtype=torch.float64),
+                                      samples={k: strided(grads[k], 64) for k in names}))
+    del m, grads, y
+    m2, mc2 = _shipped_model("celeba", 4321, 63)
+    B2 = 32
+    x2, t2 = rnd(B2, 3, 64, 64, seed=133), (torch.arange(B2) * 31 + 7) % 1000
+    with torch.no_grad():
+        y2 = m2(x2, t2)
+    out["celeba"] = dict(cfg=mc2, init_seed=4321, rand_seed=63, B=B2, x_seed=133, t=t2, y_sub=y2[:, :, ::8, ::8].clone(),
+                         y_sum=y2.double().sum((1, 2, 3)), y_abs=y2.double().abs().sum((1, 2, 3)), y_absmax=float(y2.abs().max()))
+    save("g13_config5_config4.pt", out)
+
+
 if __name__ == "__main__":
     import sys
     ALL = dict(g1=g1_ops, g2=g2_blocks, g3=g3_model, g4=g4_tables, g5=g5_steps, g6=g6_loops, g7=g7_train, g8=g8_toy, g9=g9_train_lr, g10=g10_config2,
-               g11=g11_config2_bench_batch, g12=g12_config2_train_steps)
+               g11=g11_config2_bench_batch, g12=g12_config2_train_steps, g13=g13_config5_and_4_at_their_batches)
     for name in (sys.argv[1:] or list(ALL)):          # `make_golden.py g9` regenerates one fixture, no argument = all
         ALL[name]()
