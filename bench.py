@@ -161,14 +161,14 @@ def timed_steps(tr, x0, steps, warmup, sync):
     warmup += settle(tr, x0, warmup + 1)
     tr.current_stats
     sync()
-    before = [(d.choice, id(d.graph), d.captures) for d in tr._direct.values()]
+    before = [(d.choice, id(d.graph), id(d.plan), d.captures) for d in tr._direct.values()]
     t0 = time.perf_counter()
     for i in range(steps):
         tr.step(x0, global_steps=warmup + i + 1)
     tr.current_stats                     # every step's loss read-back is collected INSIDE the timed region (the last one is still pending)
     sync()
     el = time.perf_counter() - t0
-    after = [(d.choice, id(d.graph), d.captures) for d in tr._direct.values()]
+    after = [(d.choice, id(d.graph), id(d.plan), d.captures) for d in tr._direct.values()]
     assert before == after, f"the step changed form inside the timed region: {before} -> {after}"
     return el
 
@@ -268,9 +268,17 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     imgs_per_s = B_PER_GPU * world * args.steps / elapsed
     loss = tr.current_stats["loss"]
-    replayed = any((d.choice == "graph") if d.choice is not None else (d.graph is not None and d.last_kind == "graph") for d in tr._direct.values())
-    step_mode = "direct step, " + ("hipGraph replay" if replayed else "eager launches") + (" (chosen by measurement)" if any(d.choice for d in tr._direct.values()) else "") \
+    kinds = {d.last_kind for d in tr._direct.values()}
+    form = "graph" if "graph" in kinds else ("plan" if "plan" in kinds else "eager")
+    step_mode = "direct step, " + {"graph": "hipGraph replay", "plan": "launch plan (ddpm_plan_run: the step's C-ABI calls re-issued from C on both streams)",
+                                   "eager": "eager launches"}[form] + (" (chosen by measurement)" if any(d.choice for d in tr._direct.values()) else "") \
         if tr._direct else "autograd step"
+    # what the auto-probe measured for each form of the step on THIS box (ms per step, 4 pipelined steps each, before the timed region)
+    step_probe = {}
+    for d in tr._direct.values():
+        step_probe = {k + "_ms": round(v * 1e3, 3) for k, v in d.times.items()}
+        if d.plan is not None:
+            step_probe["plan_launches"] = d.plan.launches
 
     # ---- roofline of the dominant kernel: per-launch HIP events (recorded on the stream each kernel is launched on) over
     # one more training step.  The product runs the weight-gradient kernels on a side stream NEXT to the critical path, so
@@ -444,7 +452,7 @@ def main():
                "config": {"workload": "configs/cifar10.json UNet (35.7M params), full Trainer.step, B=128 per GPU, 32x32, T=1000, dropout 0.1, Adam+clip+EMA",
                           "global_batch": B_PER_GPU * world, "rccl_ranks": ranks_seen, "dp": dp,
                           "parallelism": f"dp{world}" + ("" if world == 1 else (" (native chunked RCCL all-reduce inside backward)" if native else " (torch DDP)")),
-                          "step_execution": step_mode, "imgs_per_s_per_gpu": round(imgs_per_s / world, 2),
+                          "step_execution": step_mode, "step_probe": step_probe, "imgs_per_s_per_gpu": round(imgs_per_s / world, 2),
                           "train_model_tflops_per_gpu": round(imgs_per_s / world * 3 * FWD_GFLOP["cifar"] / 1e3, 1),
                           "train_model_frac_of_peak": round(imgs_per_s / world * 3 * FWD_GFLOP["cifar"] / 1e3 / peak, 4), "final_loss": round(loss, 4)},
                "roofline": roofline}

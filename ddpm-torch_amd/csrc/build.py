@@ -10,7 +10,7 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["gemm.hip", "wgrad.hip", "wgrad1x1.hip", "attention.hip", "pointwise.hip", "conv3x3.hip", "edgeconv.hip", "norm.hip", "elementwise.hip", "optim.hip", "probe.hip"]
+SOURCES = ["gemm.hip", "wgrad.hip", "wgrad1x1.hip", "attention.hip", "pointwise.hip", "conv3x3.hip", "edgeconv.hip", "norm.hip", "elementwise.hip", "optim.hip", "probe.hip", "plan.hip"]
 OUT = os.path.join(HERE, "libddpm_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-fPIC"]
 

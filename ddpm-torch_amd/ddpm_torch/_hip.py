@@ -71,7 +71,20 @@ PROTOTYPES = {
     "ddpm_mt_gather_f32": [P, I, P],
     "ddpm_sumsq_accumulate": [P, L, P, P, P],
     "ddpm_adam_ema_step": [P, P, P, P, P, L, P, F, F, F, F, F, F, F, F, P],
+    # launch plans (csrc/plan.hip; driven by _plan.LaunchPlan)
+    "ddpm_stream_order": [P, P],
+    "ddpm_fill_zero": [P, L, P],
+    "ddpm_plan_create": [],
+    "ddpm_plan_destroy": [P],
+    "ddpm_plan_append": [P, ctypes.c_char_p, P, I],
+    "ddpm_plan_cut": [P],
+    "ddpm_plan_segments": [P],
+    "ddpm_plan_entries": [P],
+    "ddpm_plan_run": [P, I],
+    "ddpm_plan_failed_entry": [P, P],
+    "ddpm_plan_entry_arity": [ctypes.c_char_p],
 }
+RESTYPES = {"ddpm_gn_workspace_floats": c_longlong, "ddpm_plan_create": c_void_p, "ddpm_plan_failed_entry": ctypes.c_char_p}
 
 _lib = None
 
@@ -91,15 +104,40 @@ def lib():
             except AttributeError as e:
                 raise RuntimeError(f"{LIB_PATH} does not export {name}; rebuild it") from e
             fn.argtypes = argtypes
-            fn.restype = c_longlong if name == "ddpm_gn_workspace_floats" else c_int
+            fn.restype = RESTYPES.get(name, c_int)
         _lib = handle
     return _lib
 
 
-def call(name, *args):
+def _invoke(name, args):
     rc = getattr(lib(), name)(*args)
     if rc != 0:
         raise RuntimeError(f"{name} failed: {_ERR.get(rc, rc)}")
+
+
+_recorder = None        # a _plan.LaunchPlan while a step is being recorded: every call is executed AND appended to it
+
+
+def call(name, *args):
+    """Enqueue one launching entry point (raises on a non-zero status).  While a launch plan records, the call is also appended to it."""
+    if _recorder is not None:
+        _recorder.add(name, args)
+    _invoke(name, args)
+
+
+def record_into(plan):
+    """Route a copy of every call() to ``plan`` (None: stop).  Returns the previous recorder."""
+    global _recorder
+    prev, _recorder = _recorder, plan
+    return prev
+
+
+def retain(t):
+    """Called by the engine for every tensor it allocates: while a plan records, the plan keeps them alive — its entries address them
+    by raw pointer (host-emulated runs; on the GPU the recording also runs inside a private allocator pool, see _plan.py)."""
+    if _recorder is not None:
+        _recorder.keep.append(t)
+    return t
 
 
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)

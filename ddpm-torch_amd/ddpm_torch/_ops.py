@@ -48,7 +48,7 @@ class View:
 
     @staticmethod
     def new(B, H, W, C, dtype, device):
-        return View(torch.empty((B, H, W, C), dtype=dtype, device=device), B, H, W, C)
+        return View(_hip.retain(torch.empty((B, H, W, C), dtype=dtype, device=device)), B, H, W, C)
 
     def chan_slice(self, c0, c1):
         v = View.__new__(View)

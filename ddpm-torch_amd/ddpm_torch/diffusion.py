@@ -151,7 +151,7 @@ class GaussianDiffusion:
             noise = torch.randn_like(x_0)
         x_0, noise = self._prep(x_0, noise)
         t = t.contiguous()
-        out = torch.empty_like(x_0)
+        out = _hip.retain(torch.empty_like(x_0))
         B = x_0.shape[0]
         _hip.call("ddpm_q_sample", x_0.data_ptr(), noise.data_ptr(), t.data_ptr(), self._tab("sqrt_alphas_bar", x_0.device).data_ptr(),
              self._tab("sqrt_one_minus_alphas_bar", x_0.device).data_ptr(), out.data_ptr(), B, x_0[0].numel(), len(self.sqrt_alphas_bar), _hip.stream())

@@ -508,7 +508,13 @@ class _Engine:
         return View.new(B, H, W, C, self.T, self.device)
 
     def _f32(self, *shape):
-        return torch.empty(shape, dtype=torch.float32, device=self.device)
+        return _hip.retain(torch.empty(shape, dtype=torch.float32, device=self.device))
+
+    def _zeros(self, *shape):
+        """fp32 zeros by a stream-ordered C-ABI fill (a launch-plan records it; torch.zeros would be invisible to the plan)."""
+        t = self._f32(*shape)
+        _hip.call("ddpm_fill_zero", t.data_ptr(), t.numel() * 4, _hip.stream())
+        return t
 
     def _gptr(self, gflat, p):
         return gflat.data_ptr() + 4 * self.goff[id(p)]
@@ -582,9 +588,7 @@ class _Engine:
             yield
             return
         ctx["keep"].extend(views)
-        ev = torch.cuda.Event()
-        ev.record(ctx["main"])                       # inputs are final on the main stream here
-        side.wait_event(ev)
+        _hip.call("ddpm_stream_order", ctx["side_handle"], ctx["main_handle"])     # inputs are final on the main stream here
         # The kernels take their stream as an argument: routing _hip.stream() to the side stream's handle is all a leaf needs (no
         # torch.cuda.stream() context: two stream switches and several device look-ups per leaf, ~190 leaves per step).  Nothing
         # inside a leaf allocates temporaries (the slab copies are persistent), so the allocator's stream bookkeeping is not involved.
@@ -596,11 +600,8 @@ class _Engine:
 
     def _join_side(self, ctx):
         """Main stream waits for everything queued on the side stream so far."""
-        side = ctx.get("side")
-        if side is not None:
-            ev = torch.cuda.Event()
-            ev.record(side)
-            ctx["main"].wait_event(ev)
+        if ctx.get("side") is not None:
+            _hip.call("ddpm_stream_order", ctx["main_handle"], ctx["side_handle"])
 
     def _wgrad(self, ctx, weight, dy, x, Creal, Nreal, R, S, splits=1, bias=None, **kw):
         """Weight gradient into the staging buffer; then hand finished all-reduce chunks to the communicator.  ``bias`` = staging
@@ -848,7 +849,7 @@ class _Engine:
                 self._conv(st, mods[n + 1][1], cur, dst, 3, upsample=1)
                 cur = dst
         # ---- head: GN + SiLU + conv -> NCHW fp32
-        out = torch.empty((B, m.out_channels, H, W), dtype=torch.float32, device=self.device)
+        out = self._f32(B, m.out_channels, H, W)
         act = self._new(B, H, W, self.hid)
         stats = self._f32(B, ops.GN_GROUPS, 2) if save else None
         norm, conv = m.out_conv[0], m.out_conv[2]
@@ -966,7 +967,7 @@ class _Engine:
             logits = self._f32(B, Lk, Lk)                       # S = Q K^T / sqrt(C)   (unet.py:46-48)
             ops.gemm(q, 3 * C, bs, 0, kk, 3 * C, bs, 0, logits.data_ptr(), Lk, Lk * Lk, Lk, Lk, C, self.dcode, batch=B,
                      alpha=scale, out_mode=1)
-            prob = torch.empty((B, Lk, Lk), dtype=self.T, device=self.device)
+            prob = _hip.retain(torch.empty((B, Lk, Lk), dtype=self.T, device=self.device))
             _hip.call("ddpm_softmax_fwd", logits.data_ptr(), prob.data_ptr(), B * Lk, Lk, self.dcode, _hip.stream())
             ops.gemm(prob.data_ptr(), Lk, Lk * Lk, 0, v, 3 * C, bs, 1, o.ptr, C, Lk * C, Lk, C, Lk, self.dcode, batch=B)   # O = P V (unet.py:50)
         co = self._packed(ab.project_out, save)
@@ -980,12 +981,14 @@ class _Engine:
         """Gradient staging buffers + stream / communicator bookkeeping of one backward pass."""
         B, ws = st["B"], st["ws"]
         if gflat is None:
-            gflat = torch.empty(self.gtotal, dtype=torch.float32, device=self.device)   # written only by the final unpack
-        dtb = torch.zeros((B, self.tb_total), dtype=torch.float32, device=self.device)
+            gflat = self._f32(self.gtotal)   # written only by the final unpack
+        dtb = self._zeros(B, self.tb_total)
         self._wgrad_table()
         if self._gpack is None or self._gpack.numel() != self.ptotal:
             self._gpack = torch.empty(self.ptotal, dtype=torch.float32, device=self.device)
-        gpack = self._gpack.zero_()           # persistent (stable addresses for the slab-reduce tables): packed conv weight grads [N][RS][C] + tail
+        gpack = self._gpack
+        _hip.call("ddpm_fill_zero", gpack.data_ptr(), gpack.numel() * 4, _hip.stream())
+        # persistent (stable addresses for the slab-reduce tables): packed conv weight grads [N][RS][C] + tail
         ctx = dict(gflat=gflat, gpack=gpack, ws=ws, B=B, dtb=dtb, pending=None, works=self._works, slab_rows=[], side=None, keep=[], cut=cut,
                    seed_dev=st.get("seed_dev", 0), world=1, sumsq=0)
         if _SIDE_STREAM and gflat.is_cuda:
@@ -997,9 +1000,8 @@ class _Engine:
             ctx["side"] = self._side
             ctx["side_handle"] = self._side.cuda_stream
             ctx["main"] = torch.cuda.current_stream()
-            ev0 = torch.cuda.Event()
-            ev0.record()                              # the staging buffer is zeroed on the main stream
-            self._side.wait_event(ev0)
+            ctx["main_handle"] = _hip.stream()
+            _hip.call("ddpm_stream_order", ctx["side_handle"], ctx["main_handle"])   # the staging buffer is zeroed on the main stream
         if self.pg is not None:
             import torch.distributed as dist
             ctx["world"] = dist.get_world_size(self.pg)
@@ -1196,7 +1198,7 @@ class _Engine:
             ops.gemm(do.ptr, C, Lk * C, 0, v, 3 * C, bs, 0, dp.data_ptr(), Lk, Lk * Lk, Lk, Lk, C, self.dcode, batch=B, out_mode=1)
             # dV = P^T dO
             ops.gemm(prob.data_ptr(), Lk, Lk * Lk, 1, do.ptr, C, Lk * C, 1, dv, 3 * C, bs, Lk, C, Lk, self.dcode, batch=B)
-            ds = torch.empty((B, Lk, Lk), dtype=self.T, device=self.device)
+            ds = _hip.retain(torch.empty((B, Lk, Lk), dtype=self.T, device=self.device))
             _hip.call("ddpm_softmax_bwd", prob.data_ptr(), dp.data_ptr(), ds.data_ptr(), B * Lk, Lk, self.dcode, _hip.stream())
             ops.gemm(ds.data_ptr(), Lk, Lk * Lk, 0, kk, 3 * C, bs, 1, dq, 3 * C, bs, Lk, C, Lk, self.dcode, batch=B, alpha=scale)   # dQ = dS K
             ops.gemm(ds.data_ptr(), Lk, Lk * Lk, 1, q, 3 * C, bs, 1, dk, 3 * C, bs, Lk, C, Lk, self.dcode, batch=B, alpha=scale)    # dK = dS^T Q
@@ -1222,7 +1224,7 @@ class _Engine:
         with self._leaf(ctx, dtb, s_t):
             ops.gemm(dtb.data_ptr(), Ct, 0, 1, s_t.data_ptr(), E, 0, 1, self._pptr(ctx, "fc_w"), E, 0, Ct, E, B, F, out_mode=1)
             ops.colsum(View(dtb, 1, B, 1, Ct), 0, 0, self._pptr(ctx, "fc_b"))
-        ds_t = torch.zeros((B, E), dtype=torch.float32, device=self.device)     # K = sum Cout (~5000): split-K with fp32 atomics
+        ds_t = self._zeros(B, E)     # K = sum Cout (~5000): split-K with fp32 atomics
         ops.gemm(dtb.data_ptr(), Ct, 0, 0, fc_w.data_ptr(), E, 0, 1, ds_t.data_ptr(), E, 0, B, E, Ct, F, out_mode=2, splits=max(1, Ct // 256))
         dt_emb = self._f32(B, E)
         _hip.call("ddpm_silu_bwd", t_emb.data_ptr(), ds_t.data_ptr(), dt_emb.data_ptr(), B * E, 0, _hip.stream())
@@ -1233,7 +1235,7 @@ class _Engine:
             ops.colsum(View(dt_emb, 1, B, 1, E), 0, 0, self._pptr(ctx, lin2.bias))
         # (K = E = 512 over 4 output tiles would leave 252 CUs idle for ~75 us at the very end of the backward: split-K with fp32 atomics
         #  like the fc product above — 32 blocks)
-        ds1 = torch.zeros((B, E), dtype=torch.float32, device=self.device)
+        ds1 = self._zeros(B, E)
         ops.gemm(dt_emb.data_ptr(), E, 0, 0, lin2.weight.data_ptr(), E, 0, 1, ds1.data_ptr(), E, 0, B, E, E, F, out_mode=2, splits=max(1, E // 64))
         de1 = self._f32(B, E)
         _hip.call("ddpm_silu_bwd", e1.data_ptr(), ds1.data_ptr(), de1.data_ptr(), B * E, 0, _hip.stream())

@@ -35,12 +35,13 @@ from torch.nn.parallel import DistributedDataParallel as DDP
 
 from .. import _hip
 from .._graphs import SegmentedGraph
+from .._plan import LaunchPlan
 
 __all__ = ["Trainer", "EMA", "ModelWrapper", "DummyScheduler", "RunningStatistics"]
 
 # "auto" (default): the captured step is used when it measures faster than the eager one on this workload; "1" / "0" force it
 _ASYNC_LOSS = os.environ.get("DDPM_TORCH_AMD_ASYNC_LOSS", "1") != "0"     # 0: read the loss back synchronously in every step
-_TRAIN_GRAPH = {"0": False, "1": True}.get(os.environ.get("DDPM_TORCH_AMD_TRAIN_GRAPH", "auto"), "auto")
+_TRAIN_GRAPH = {"0": False, "1": True, "plan": "plan"}.get(os.environ.get("DDPM_TORCH_AMD_TRAIN_GRAPH", "auto"), "auto")
 
 
 class DummyScheduler:
@@ -351,7 +352,10 @@ class _DirectStep:
         self.calls = 0
         self.graph = None
         self.graph_failed = False
-        self.captures = 0                    # graph captures so far (bench.py asserts none happens inside a timed region)
+        self.plan = None                     # _plan.LaunchPlan of this step (recorded once, replayed from C)
+        self.plan_failed = False
+        self._plan_baked = None
+        self.captures = 0                    # graph captures + plan recordings so far (bench.py asserts none happens inside a timed region)
         self._baked = None                   # identity of everything whose ADDRESS the captured graph holds (see _identity)
         self._warm = None                    # serial of the engine that has run an EAGER step here (lazy tables / slabs / workspaces exist)
         # auto mode: wall times (Trainer.step reports them) of a few eager and a few replayed steps decide which one stays
@@ -371,49 +375,85 @@ class _DirectStep:
         host[2] = eng.next_dropout_seed() if self.unet.training and self.unet.drop_rate > 0 else 0
         self.hyper_dev.copy_(host, non_blocking=True)
 
-    def body(self, cut=None):
-        """One training step on the persistent buffers (x0 and the hyper words are already in place)."""
-        tr, dif, eng = self.tr, self.tr.diffusion, self.unet.engine()
-        B, n = self.x0.shape[0], self.x0[0].numel()
-        s = _hip.stream
+    def draw(self):
+        """This step's (t, noise) into the persistent buffers: t first, then noise (utils/train.py:138-140)."""
+        tr = self.tr
         if tr.input_source is not None:
             tr.input_source(self.t, self.noise)                                # parity tests: an injected (t, noise) stream
         else:
-            self.t.random_(to=tr.timesteps, generator=tr.generator)            # draw order: t, then noise (utils/train.py:138-140)
+            self.t.random_(to=tr.timesteps, generator=tr.generator)
             self.noise.normal_(generator=tr.generator)
+
+    def body(self, cut=None, draw=True):
+        """One training step on the persistent buffers (x0 and the hyper words are already in place).  Apart from the draw, every device
+        operation is a C-ABI call (fills and stream edges included), which is what lets a launch plan record it."""
+        tr, dif, eng = self.tr, self.tr.diffusion, self.unet.engine()
+        B, n = self.x0.shape[0], self.x0[0].numel()
+        s = _hip.stream
+        if draw:
+            self.draw()
         x_t = dif.q_sample(self.x0, self.t, noise=self.noise)
         target = dif.loss_target(self.x0, x_t, self.t, self.noise)
         tape = []
         out = eng.forward(x_t, self.t, self.unet.training, tape, seed_dev=self.hyper_dev.data_ptr() + 16)
-        losses = torch.empty(B, dtype=torch.float32, device=out.device)
+        losses = _hip.retain(torch.empty(B, dtype=torch.float32, device=out.device))
         _hip.call("ddpm_mse_fwd", out.data_ptr(), target.data_ptr(), losses.data_ptr(), B, n, s())
         _hip.call("ddpm_weighted_sum_f32", losses.data_ptr(), self.gloss.data_ptr(), self.loss.data_ptr(), B, s())   # mean over the batch
-        gout = torch.empty_like(out)
+        gout = _hip.retain(torch.empty_like(out))
         _hip.call("ddpm_mse_bwd", out.data_ptr(), target.data_ptr(), self.gloss.data_ptr(), gout.data_ptr(), B, n, s())
         clip = bool(tr.grad_norm) and tr.grad_norm > 0
         if clip:
-            tr._fused.total.zero_()
+            _hip.call("ddpm_fill_zero", tr._fused.total.data_ptr(), tr._fused.total.numel() * 4, s())
         # (the backward's last launch, which rewrites the staging buffer into the flat gradient, also accumulates its squared norm)
         eng.backward(tape, gout, gflat=self.gflat, cut=cut, want_views=False, sumsq=tr._fused.total.data_ptr() if clip else 0)
         tr._fused.launch(tr.grad_norm, hyper_dev=self.hyper_dev.data_ptr(), have_sumsq=clip)
         eng.refresh_unconditionally()                                          # the next forward reads the re-derived copies
 
     PROBE = 4
+    FORMS = ("plan", "eager", "graph")          # order of preference among forms that measure within 2 % of the fastest
 
-    # ---- auto mode: which form of the step is faster HERE?  Both are timed the way they will run — launches pipelined, the loss read
-    # back a step late — over PROBE consecutive steps bracketed by device synchronisations: eager launches keep the overlap of the
-    # weight-gradient stream but cost ~7 ms of host time per step (on a slow or busy host that is the bound), the replayed graph
-    # costs the host next to nothing but its executor overlaps the two branches less well.
-    def _wants_graph(self):
+    # ---- auto mode: which form of the step is fastest HERE?  Each is timed the way it will run — launches pipelined, the loss read
+    # back a step late — over PROBE consecutive steps bracketed by device synchronisations:
+    #   eager  every launch issued from Python: ~7 ms of host time per step (on a slow or busy host that is the bound);
+    #   plan   the same launches on the same two streams, walked by ddpm_plan_run in C (csrc/plan.hip): eager semantics, no interpreter;
+    #   graph  hipGraph replay: no host cost either, but the executor overlaps the two stream branches less well.
+    def _available(self):
+        """Forms this step can take here, in probing order."""
+        forms = ["eager"]
+        if self._plan_ok() and (self.x0.is_cuda or _TRAIN_GRAPH == "plan"):     # (host-emulated runs: only when asked for)
+            forms.append("plan")
+        if self.x0.is_cuda and not self.graph_failed and self.tr.input_source is None:
+            forms.append("graph")
+        return forms
+
+    def _plan_ok(self):
+        # loss_target of model_mean_type "mean" gathers its coefficients with torch ops: invisible to a plan
+        return not self.plan_failed and self.tr.diffusion.model_mean_type in ("eps", "x_0")
+
+    def _form(self):
+        """The form the NEXT step takes."""
+        forms = self._available()
         if _TRAIN_GRAPH != "auto":
-            return bool(_TRAIN_GRAPH)
+            want = {False: "eager", True: "graph", "plan": "plan"}[_TRAIN_GRAPH]
+            return want if want in forms else "eager"
         if self.choice is not None:
-            return self.choice == "graph"
-        return "eager" in self.times                       # eager phase measured: the graph phase is next (or running)
+            return self.choice if self.choice in forms else "eager"
+        for f in forms:
+            if f not in self.times:
+                return f
+        self._decide()
+        return self.choice
+
+    def _decide(self):
+        best = min(self.times.values())
+        self.choice = next(f for f in self.FORMS if f in self.times and self.times[f] <= 1.02 * best)
+
+    def _wants_graph(self):
+        return self._form() == "graph"
 
     def _probe_begin(self, kind):
         if _TRAIN_GRAPH == "auto" and self.choice is None and not self.x0.is_cuda:
-            self.choice = "eager"                           # (host-emulated runs: nothing to capture)
+            self.choice = "eager"                           # (host-emulated runs: nothing to measure)
         if _TRAIN_GRAPH == "auto" and self.choice is None and kind not in self.times and self._phase is None:
             torch.cuda.synchronize()
             self._phase = [kind, 0, time.perf_counter()]
@@ -427,30 +467,33 @@ class _DirectStep:
             torch.cuda.synchronize()
             self.times[kind] = (time.perf_counter() - ph[2]) / self.PROBE
             self._phase = None
-            if "graph" in self.times:
-                self.choice = "graph" if self.times["graph"] < 0.98 * self.times["eager"] else "eager"
+            if all(f in self.times for f in self._available()):
+                self._decide()
 
     def observe(self, seconds):
         """Kept for callers of the earlier interface: the probe now times whole phases itself."""
 
     def settled(self):
-        """True once the form of the step (eager launches or graph replay) is final and, for the replayed form, captured."""
+        """True once the form of the step (eager launches, launch plan or graph replay) is final and recorded / captured."""
         if not self.x0.is_cuda:
             return True
-        if _TRAIN_GRAPH == "auto":
-            if self.choice is None:
-                return False
-            return self.choice == "eager" or self.graph is not None or self.graph_failed
-        return not _TRAIN_GRAPH or self.graph is not None or self.graph_failed
+        if _TRAIN_GRAPH == "auto" and self.choice is None:
+            return False
+        form = self._form()
+        if form == "graph":
+            return self.graph is not None
+        if form == "plan":
+            return self.plan is not None
+        return True
 
     def _identity(self):
-        """Everything a captured step addresses by a raw pointer baked into its kernel arguments and that can be RE-CREATED behind
-        its back: the fused update's pointer table (``optimizer.load_state_dict`` / ``load_checkpoint`` re-create the Adam moments
+        """Everything a captured or recorded step addresses by a raw pointer baked into its kernel arguments and that can be RE-CREATED
+        behind its back: the fused update's pointer table (``optimizer.load_state_dict`` / ``load_checkpoint`` re-create the Adam moments
         and with them the table), the engine (``model.to()`` / ``.float()`` drop it: packed weights, workspaces, staging buffers)
         and the engine's derived-copy tables.  A replay after any of these changed would write through dangling pointers."""
         eng, fused = self.unet.engine(), self.tr._fused
         return (eng.serial, fused.generation, fused.table.data_ptr(), eng.pack_table.data_ptr(), eng.fc_table.data_ptr(),
-                self.gflat.data_ptr(), self.unet.training)
+                self.gflat.data_ptr(), self.unet.training, eng.pg is not None)
 
     def run(self, x):
         tr, eng = self.tr, self.unet.engine()
@@ -461,44 +504,71 @@ class _DirectStep:
         params = tr._fused.prepare(grad_ptrs=self.grad_ptrs, stable_grads=True)
         assert len(params) == len(eng.params)
         self._write_hyper()
-        if self.graph is not None and self._baked != self._identity():
-            self.graph = None                                   # stale addresses: capture again (or run eagerly) instead of replaying
-        # capture only what has run eagerly once with THIS engine: its first backward builds descriptor tables with host -> device
-        # copies (illegal under stream capture) and allocates the persistent slabs / staging buffers
-        can_graph = (not self.graph_failed and self.x0.is_cuda and self._warm == eng.serial and tr.input_source is None
-                     and not torch.cuda.is_current_stream_capturing())
-        use_graph = can_graph and self._wants_graph()
+        ident = None
+        if self.graph is not None or self.plan is not None:
+            ident = self._identity()
+            if self.graph is not None and self._baked != ident:
+                self.graph = None                               # stale addresses: capture again (or run eagerly) instead of replaying
+            if self.plan is not None and self._plan_baked != (ident, _hip.stream()):
+                self.plan = None                                # ... and a plan also holds the stream handle it was recorded on
+        # capture / record only what has run eagerly once with THIS engine: its first backward builds descriptor tables with host ->
+        # device copies (illegal under stream capture, invisible to a plan) and allocates the persistent slabs / staging buffers
+        warm = self._warm == eng.serial and not (self.x0.is_cuda and torch.cuda.is_current_stream_capturing())
+        form = self._form() if warm else "eager"
         self.last_kind = None
-        if use_graph and self.graph is None:
+        fresh = False                                           # this step paid for a capture / recording: not a probe sample
+        if form == "graph" and self.graph is None:
             g = SegmentedGraph(self.x0.device)
             g.register_generator(tr.generator)
             try:
                 self.graph = g.capture(self.body)
                 self.captures += 1
                 self._baked = self._identity()
-            except Exception as e:                        # capture not possible here: keep training eagerly
+            except Exception as e:                        # capture not possible here: keep training without it
                 warnings.warn(f"hipGraph capture of the training step failed ({type(e).__name__}: {e}); running it eagerly")
                 torch.cuda.synchronize()
                 self.graph_failed, self.graph = True, None
-                if _TRAIN_GRAPH == "auto":
-                    self.choice = "eager"
-            captured_now = True
-        else:
-            captured_now = False
-        if use_graph and self.graph is not None:
-            if not captured_now:
-                self._probe_begin("graph")                  # (the step that paid for the capture is not a sample)
+                if self.choice == "graph":
+                    self.choice = None
+                    self.times.pop("graph", None)
+                form = "eager"
+            fresh = True
+        if form == "plan" and self.plan is None:
+            # recording IS a step: the body runs eagerly once more while every call is copied into the plan
+            self.draw()
+            plan = LaunchPlan(self.x0.device)
+            plan.record(lambda cut: self.body(cut, draw=False))          # (an exception of the body itself propagates, as it would eagerly)
+            self.last_kind = "eager"
+            if plan.build_error is None:
+                self.plan = plan
+                self.captures += 1
+                self._plan_baked = (self._identity(), _hip.stream())
+            else:                                                        # the step is done; only its replays are not to be had
+                warnings.warn(f"the training step could not be turned into a launch plan ({plan.build_error}); running it eagerly")
+                self.plan_failed = True
+                if self.choice == "plan":
+                    self.choice = None
+                    self.times.pop("plan", None)
+        elif form == "plan":
+            self._probe_begin("plan")
+            self.draw()
+            self.plan.replay()
+            self.last_kind = "plan"
+            self._probe_end("plan")
+        elif form == "graph" and self.graph is not None:
+            if not fresh:
+                self._probe_begin("graph")
             self.graph.replay()
             self.last_kind = "graph"
-            if not captured_now:
+            if not fresh:
                 self._probe_end("graph")
         else:
-            if self.calls >= 1:
+            if self.calls >= 1 and not fresh:
                 self._probe_begin("eager")                  # (nor is the very first step: lazy initialisation)
             self.body()
             self.last_kind = "eager"
             self._warm = eng.serial
-            if self.calls >= 1:
+            if self.calls >= 1 and not fresh:
                 self._probe_end("eager")
         self.calls += 1
         tr._fused.committed()

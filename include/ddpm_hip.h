@@ -258,6 +258,31 @@ int ddpm_mfma_probe(float* sink, int iters, int zero_operands, void* stream);
 /* test hook: the keep-mask (1/0) the GroupNorm kernels regenerate for element indices 0..n-1 */
 int ddpm_dropout_mask(float* mask, long long n, float p, unsigned long long seed, void* stream);
 
+/* ---- launch plans (no upstream counterpart: the reference issues its step op by op from Python, ddpm_torch/utils/train.py:148-170).
+ * The training step is a fixed sequence of the calls above; a plan records it once — entry-point name + argument words + the
+ * hipStream_t each call was given — and ddpm_plan_run re-issues a whole segment from C: eager semantics (two concurrent streams,
+ * host work such as RCCL calls between segments) without the interpreter between launches.  Step-varying scalars must live in
+ * device memory (hyper_dev, seed_dev), exactly as for a captured hipGraph; every pointer recorded must stay valid while the plan lives.
+ *
+ * ddpm_stream_order(waiter, signaller): everything enqueued on hipStream_t `waiter` after the call runs after everything enqueued on
+ * `signaller` before it (event record + stream wait on a pooled event) — the fork / join edges of the weight-gradient stream.
+ * ddpm_fill_zero: stream-ordered memset(0) (torch.zeros / Tensor.zero_ of the gradient staging buffers).
+ * ddpm_plan_append: words[i] = argument i of `entry` as a 64-bit word (pointers / 64-bit integers as they are, int in the low half,
+ * float as its IEEE-754 bits in the low half); returns the entry index or -(status) (unknown name or wrong argument count: -1).
+ * ddpm_plan_cut closes the current segment (returns its index).  ddpm_plan_run issues segment `segment` and returns 0 or the status of
+ * the first failing call (ddpm_plan_failed_entry names it).  A plan is not thread-safe; distinct plans are independent. */
+int ddpm_stream_order(void* waiter, void* signaller);
+int ddpm_fill_zero(void* p, long long bytes, void* stream);
+void* ddpm_plan_create(void);
+int ddpm_plan_destroy(void* plan);
+int ddpm_plan_append(void* plan, const char* entry, const unsigned long long* words, int n_words);
+int ddpm_plan_cut(void* plan);
+int ddpm_plan_segments(void* plan);
+int ddpm_plan_entries(void* plan);
+int ddpm_plan_run(void* plan, int segment);
+const char* ddpm_plan_failed_entry(void* plan, int* index);
+int ddpm_plan_entry_arity(const char* entry);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,44 +1,57 @@
-"""How much of a step is host (Python + ctypes launch) time?  Times eval forward and a full train step at B=128 and B=4:
-at B=4 the GPU work is tiny, so the wall time ~= host time per step."""
+"""Host time per training step, by form of the step (eager launches | launch plan | hipGraph replay), CIFAR-10 UNet, bf16, B = 128.
+
+Method: the GPU is parked behind a spin kernel while the host enqueues N whole steps, so the time until ``Trainer.step`` returns is pure
+host work (interpreter + ctypes + HIP runtime enqueue), not GPU back-pressure; the loss read-back of the previous step is dropped before
+each call (it would wait for the parked GPU).  Then the same N steps are timed end to end with the GPU running (wall per step, pipelined).
+Output is committed as profiles/r05_host_overhead.txt.
+"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "ddpm-torch_amd")]
 import torch
 import ddpm_torch
+from ddpm_torch.utils import train as train_mod
 from bench import CIFAR
-dev = "cuda:0"
-torch.manual_seed(0)
-m = ddpm_torch.UNet(**CIFAR).to(dev).set_compute_dtype("bf16")
-dif = ddpm_torch.GaussianDiffusion(ddpm_torch.get_beta_schedule("linear", 1e-4, 0.02, 1000), "eps", "fixed-large", "mse")
-opt = torch.optim.Adam(m.parameters(), lr=2e-4)
-tr = ddpm_torch.Trainer(m, opt, dif, epochs=1, trainloader=None, use_ema=True, shape=(3, 32, 32), device=torch.device(dev))
-for B in (128, 4):
-    x = torch.rand(B, 3, 32, 32, device=dev) * 2 - 1
-    t = torch.randint(0, 1000, (B,), device=dev)
-    m.eval()
-    with torch.inference_mode():
-        for _ in range(5): m(x, t)
-        torch.cuda.synchronize(); t0 = time.perf_counter()
-        for _ in range(30): m(x, t)
-        t_issue = time.perf_counter() - t0
-        torch.cuda.synchronize(); t_all = time.perf_counter() - t0
-    print(f"B={B:4d} eval forward: host issue {t_issue / 30 * 1e3:6.2f} ms, wall {t_all / 30 * 1e3:6.2f} ms per call")
-    m.train()
-    for _ in range(3): tr.step(x)
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    for _ in range(10): tr.step(x)
-    torch.cuda.synchronize(); t_all = time.perf_counter() - t0
-    print(f"B={B:4d} train step  : wall {t_all / 10 * 1e3:6.2f} ms per step")
 
-if os.environ.get("HOST_PROFILE"):
-    import cProfile, pstats
-    x = torch.rand(4, 3, 32, 32, device=dev) * 2 - 1
+dev = "cuda:0"
+N = int(os.environ.get("HOST_STEPS", "6"))
+B = int(os.environ.get("HOST_BATCH", "128"))
+torch.cuda.synchronize()
+t0 = time.perf_counter(); torch.cuda._sleep(20_000_000); torch.cuda.synchronize()
+cycles_per_ms = 20_000_000 / ((time.perf_counter() - t0) * 1e3)
+
+for form in (False, "plan", True):
+    train_mod._TRAIN_GRAPH = form
+    torch.manual_seed(0)
+    m = ddpm_torch.UNet(**CIFAR).to(dev).set_compute_dtype("bf16")
+    dif = ddpm_torch.GaussianDiffusion(ddpm_torch.get_beta_schedule("linear", 1e-4, 0.02, 1000), "eps", "fixed-large", "mse")
+    opt = torch.optim.Adam(m.parameters(), lr=2e-4)
+    tr = ddpm_torch.Trainer(m, opt, dif, epochs=1, trainloader=None, use_ema=True, grad_norm=1.0, shape=(3, 32, 32), device=torch.device(dev))
+    x = torch.rand(B, 3, 32, 32, device=dev) * 2 - 1
     m.train()
-    for _ in range(3): tr.step(x)
-    pr = cProfile.Profile()
-    pr.enable()
-    for _ in range(10): tr.step(x)
+    for i in range(6):
+        tr.step(x, global_steps=i + 1)
     torch.cuda.synchronize()
-    pr.disable()
-    st = pstats.Stats(pr)
-    st.sort_stats("tottime").print_stats(28)
+    ds = next(iter(tr._direct.values()))
+    # (1) host only: GPU parked for ~N * 12 ms + slack
+    tr._collect_loss()
+    torch.cuda._sleep(int(cycles_per_ms * (N * 14 + 40)))
+    t0 = time.perf_counter()
+    for i in range(N):
+        tr._loss_pending = None
+        tr.step(x, global_steps=7 + i)
+    host = (time.perf_counter() - t0) / N
+    tr._loss_pending = None
+    torch.cuda.synchronize()
+    # (2) wall, pipelined
+    for i in range(3):
+        tr.step(x, global_steps=20 + i)
+    tr.current_stats; torch.cuda.synchronize(); t0 = time.perf_counter()
+    for i in range(20):
+        tr.step(x, global_steps=30 + i)
+    tr.current_stats; torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / 20
+    name = {False: "eager launches", "plan": "launch plan", True: "hipGraph replay"}[form]
+    extra = f", {ds.plan.launches} recorded calls in {len(ds.plan.segments)} segment(s)" if ds.plan is not None else ""
+    print(f"B={B} {name:16s}: host {host * 1e3:6.2f} ms per step, wall {wall * 1e3:6.2f} ms per step (form run: {ds.last_kind}{extra})", flush=True)
+    del tr, opt, m

@@ -22,7 +22,7 @@ def install_emulator():
     from ddpm_torch import _hip
     from tests.abi_emulator import Emulator
     emu = Emulator(_hip.lib())
-    _hip.call = emu.call
+    _hip._invoke = lambda name, args: emu.call(name, *args)
     _hip.stream = lambda: 0
     _hip.require_cuda = lambda *a: None
     _hip.on_device = lambda t: True
@@ -65,20 +65,24 @@ def run(rank, world, port, mode, out_dir, kind="cpu"):
         # full distributed Trainer.steps on top (loss reduce to rank 0 included).  "native": the direct step, captured into
         # graph segments on a GPU (the all-reduces run between the segments); "native_eager": same step without capture
         from ddpm_torch.utils import train as train_mod
-        train_mod._TRAIN_GRAPH = mode != "native_eager"             # force the captured / the eager form (the default picks by measurement)
+        # force the captured / the eager / the launch-plan form (the default picks by measurement)
+        train_mod._TRAIN_GRAPH = {"native_eager": False, "native_eager4": False, "native_plan": "plan"}.get(mode, True)
         dif = ddpm_torch.GaussianDiffusion(ddpm_torch.get_beta_schedule("linear", 1e-4, 0.02, 1000), "eps", "fixed-large", "mse")
         opt = torch.optim.Adam(model.parameters(), lr=1e-3)
         tr = ddpm_torch.Trainer(model, opt, dif, epochs=1, trainloader=None, sampler=object(), use_ema=True, shape=SHAPE[1:],
                                 device=dev, distributed=True, rank=rank)
         model.zero_grad(set_to_none=True)
         losses = []
-        for i in range(4 if kind == "cuda" else 1):
+        for i in range(4 if kind == "cuda" or mode in ("native_plan", "native_eager4") else 1):
             tr.stats.reset()
             tr.step(x.clamp(-1, 1).to(dev), global_steps=i + 1)
             losses.append(tr.current_stats["loss"])
         ds = tr._direct.get((SHAPE, True))
         torch.save(dict(sd=cpu(model.state_dict()), shadow=cpu(tr.ema.shadow), losses=losses,
                         segments=None if ds is None or ds.graph is None else ds.graph.launches,
+                        plan_segments=None if ds is None or ds.plan is None else len(ds.plan.segments),
+                        plan_launches=None if ds is None or ds.plan is None else ds.plan.launches,
+                        last_kind=None if ds is None else ds.last_kind,
                         direct=ds is not None), os.path.join(out_dir, f"after_step_{mode}_{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()

@@ -498,11 +498,20 @@ class Emulator:
         f32(mask, n)[...] = _keep_mask(seed, np.arange(n, dtype=np.uint64), _thresh(p)).astype(np.float32)
 
 
+    # ------------------------------------------------------------------ plan helpers (csrc/plan.hip)
+    def ddpm_stream_order(self, waiter, signaller):
+        pass                                             # host memory: everything is already in program order
+
+    def ddpm_fill_zero(self, p, nbytes, st):
+        if nbytes:
+            ctypes.memset(p, 0, nbytes)
+
+
 def install(monkeypatch, hip_module):
     """Route the product's ABI calls to the emulator for the duration of a test."""
     real_lib = hip_module.lib()                      # the real .so still answers host-side geometry queries
     emu = Emulator(real_lib)
-    monkeypatch.setattr(hip_module, "call", emu.call)
+    monkeypatch.setattr(hip_module, "_invoke", lambda name, args: emu.call(name, *args))
     monkeypatch.setattr(hip_module, "stream", lambda: 0)
     monkeypatch.setattr(hip_module, "require_cuda", lambda *a: None)
     monkeypatch.setattr(hip_module, "on_device", lambda t: True)

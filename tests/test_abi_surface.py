@@ -15,8 +15,8 @@ HEADER = os.path.join(ROOT, "include", "ddpm_hip.h")
 def declared():
     src = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
     out = {}
-    for m in re.finditer(r"\b(?:int|long long)\s+(ddpm_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
-        args = [a for a in m.group(2).split(",") if a.strip()]
+    for m in re.finditer(r"\b(?:int|long long|void\s*\*|const char\s*\*)\s*(ddpm_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
+        args = [a for a in m.group(2).split(",") if a.strip() and a.strip() != "void"]
         out[m.group(1)] = len(args)
     return out
 
@@ -43,3 +43,44 @@ def test_argument_validation_returns_status_codes_without_a_gpu():
     assert lib.ddpm_gn_workspace_floats(2, 64, 128, 32, 1) > 0
     with pytest.raises(RuntimeError, match="null pointer"):
         _hip.call("ddpm_silu_fwd", 0, 0, 10, 0)
+
+
+QUERIES = {"ddpm_wgrad_effective_splits", "ddpm_conv3x3_wgrad_splits", "ddpm_conv1x1_wgrad_splits", "ddpm_gn_workspace_floats",
+           "ddpm_conv2d_variant", "ddpm_conv2d_wgrad_variant", "ddpm_gemm_variant"}
+
+
+@pytest.mark.skipif(not os.path.exists(_hip.LIB_PATH), reason="libddpm_hip.so not built")
+def test_plan_executor_knows_every_launching_entry_point_with_the_declared_arity():
+    """csrc/plan.hip generates its call thunks from the header's declarations; the ctypes table is what the recorder converts arguments
+    with — the two must agree for every entry point a step can record."""
+    lib = _hip.lib()
+    for name, argtypes in _hip.PROTOTYPES.items():
+        arity = lib.ddpm_plan_entry_arity(name.encode())
+        if name in QUERIES or name.startswith("ddpm_plan_"):
+            assert arity == -1, name                               # pure queries / the plan API itself enqueue nothing: not recordable
+        else:
+            assert arity == len(argtypes), (name, arity, len(argtypes))
+
+
+@pytest.mark.skipif(not os.path.exists(_hip.LIB_PATH), reason="libddpm_hip.so not built")
+def test_plan_api_validates_on_the_host():
+    lib = _hip.lib()
+    h = ctypes.c_void_p(lib.ddpm_plan_create())
+    assert h.value
+    words = (ctypes.c_ulonglong * 4)(0, 0, 10, 0)
+    as_ptr = ctypes.cast(words, ctypes.c_void_p)
+    assert lib.ddpm_plan_append(h, b"ddpm_silu_fwd", as_ptr, 4) == 0            # first entry
+    assert lib.ddpm_plan_append(h, b"ddpm_silu_fwd", as_ptr, 3) == -1           # wrong argument count
+    assert lib.ddpm_plan_append(h, b"ddpm_no_such_entry", as_ptr, 4) == -1
+    assert lib.ddpm_plan_append(h, b"ddpm_gemm_variant", as_ptr, 4) == -1       # a query is not a launch
+    assert lib.ddpm_plan_entries(h) == 1 and lib.ddpm_plan_segments(h) == 1
+    assert lib.ddpm_plan_cut(h) == 0 and lib.ddpm_plan_segments(h) == 1
+    assert lib.ddpm_plan_append(h, b"ddpm_silu_fwd", as_ptr, 4) == 1 and lib.ddpm_plan_segments(h) == 2
+    # running it calls ddpm_silu_fwd(NULL, NULL, 10, stream 0): rejected on the host (null pointer = 5) before any launch, and reported
+    assert lib.ddpm_plan_run(h, 0) == 5
+    idx = ctypes.c_int(-1)
+    name = lib.ddpm_plan_failed_entry(h, ctypes.cast(ctypes.pointer(idx), ctypes.c_void_p))
+    assert name == b"ddpm_silu_fwd" and idx.value == 0
+    assert lib.ddpm_plan_run(h, 7) == 1                                         # no such segment
+    assert lib.ddpm_fill_zero(0, 16, 0) == 5 and lib.ddpm_fill_zero(0, 0, 0) == 0 and lib.ddpm_fill_zero(0, -1, 0) == 1
+    assert lib.ddpm_plan_destroy(h) == 0

@@ -162,14 +162,14 @@ def test_steps_that_move_the_weights_vs_reference_fixture(golden, monkeypatch, p
 
 @pytest.mark.parametrize("cfg_name,dtype", [("tiny3", torch.float32), ("cifar", torch.bfloat16)])
 def test_captured_training_step_equals_the_eager_step(monkeypatch, cfg_name, dtype):
-    """The hipGraph-replayed step consumes the generator, the dropout seeds, the LR schedule and the bias corrections exactly
-    like the eager direct step: after 6 steps (1 eager + capture + 5 replays) losses / parameters / EMA / Adam state agree
+    """The hipGraph-replayed step and the launch-plan step (the same C-ABI calls re-issued by csrc/plan.hip) consume the generator, the dropout seeds, the LR schedule and the bias corrections exactly
+    like the eager direct step: after 6 steps (1 eager + capture / recording + replays) losses / parameters / EMA / Adam state agree
     (tolerance = atomic-order noise of the weight gradients), and the replayed forward sees the updated weights."""
     from tests.test_unet_gpu import TINY3
     cfg = TINY3 if cfg_name == "tiny3" else CIFAR
     hw, B = (16, 4) if cfg_name == "tiny3" else (32, 8)
     runs = []
-    for graph in (True, False):
+    for graph in (True, "plan", False):
         monkeypatch.setattr(train_mod, "_TRAIN_GRAPH", graph)
         torch.manual_seed(11)
         m, _ = make(cfg, dtype=dtype)
@@ -185,23 +185,27 @@ def test_captured_training_step_equals_the_eager_step(monkeypatch, cfg_name, dty
             tr.step(x, global_steps=i + 1)
             losses.append(tr.current_stats["loss"])
         ds = next(iter(tr._direct.values()))
-        assert (ds.graph is not None) == graph and not ds.graph_failed
-        if graph:
+        assert (ds.graph is not None) == (graph is True) and not ds.graph_failed
+        assert (ds.plan is not None) == (graph == "plan") and not ds.plan_failed
+        if graph is True:
             assert ds.graph.launches == 1                        # single GPU: the whole step is ONE graph launch
+        if graph == "plan":                                      # ... or one ddpm_plan_run over the recorded calls (csrc/plan.hip)
+            assert len(ds.plan.segments) == 1 and ds.plan.launches > 100 and ds.last_kind == "plan" and ds.plan._c is not None
         first = next(iter(m.parameters()))
         runs.append(dict(losses=losses, params={k: v.detach().cpu().clone() for k, v in m.named_parameters()},
                          shadow={k: v.cpu().clone() for k, v in tr.ema.shadow.items()}, step=int(opt.state[first]["step"]),
                          m1=opt.state[first]["exp_avg"].cpu().clone(), lr=sched.get_last_lr()[0], upd=tr.ema.num_updates))
-    a, b = runs
-    print(cfg_name, a["losses"], b["losses"])
-    tol = 2e-4 if dtype == torch.float32 else 3e-2
-    assert a["step"] == b["step"] == 6 and a["lr"] == b["lr"] and a["upd"] == b["upd"] == 5
-    assert torch.allclose(torch.tensor(a["losses"]), torch.tensor(b["losses"]), rtol=tol)
-    assert a["losses"][-1] < a["losses"][0]                      # it trains
-    for k in a["params"]:
-        scale = float(b["params"][k].abs().max()) or 1.0
-        assert float((a["params"][k] - b["params"][k]).abs().max()) <= (tol * scale + 6 * 1e-3 * 0.3), k
-    check(a["m1"], b["m1"], tol * 10, atol=1e-6, name="exp_avg")
+    b = runs[-1]
+    for a in runs[:-1]:
+        print(cfg_name, a["losses"], b["losses"])
+        tol = 2e-4 if dtype == torch.float32 else 3e-2
+        assert a["step"] == b["step"] == 6 and a["lr"] == b["lr"] and a["upd"] == b["upd"] == 5
+        assert torch.allclose(torch.tensor(a["losses"]), torch.tensor(b["losses"]), rtol=tol)
+        assert a["losses"][-1] < a["losses"][0]                      # it trains
+        for k in a["params"]:
+            scale = float(b["params"][k].abs().max()) or 1.0
+            assert float((a["params"][k] - b["params"][k]).abs().max()) <= (tol * scale + 6 * 1e-3 * 0.3), k
+        check(a["m1"], b["m1"], tol * 10, atol=1e-6, name="exp_avg")
 
 
 def test_sampler_graph_is_cached_and_follows_weight_changes(golden, monkeypatch):
@@ -321,7 +325,7 @@ def test_ddim50_celeba_quadratic_eta1_vs_eager(monkeypatch):
 
 
 def test_auto_mode_picks_a_step_execution_and_keeps_training(monkeypatch):
-    """Default (auto): a few eager and a few replayed steps are timed, one form is kept; the loss keeps decreasing through the
+    """Default (auto): a few eager, a few launch-plan and a few graph-replayed steps are timed, one form is kept; the loss keeps decreasing through the
     hand-over and both probes were real training steps."""
     from tests.test_unet_gpu import TINY3
     monkeypatch.setattr(train_mod, "_TRAIN_GRAPH", "auto")
@@ -333,14 +337,15 @@ def test_auto_mode_picks_a_step_execution_and_keeps_training(monkeypatch):
     tr = ddpm_torch.Trainer(m, opt, dif, epochs=1, trainloader=None, use_ema=True, shape=(3, 16, 16), device=torch.device(DEV))
     x = (torch.rand(4, 3, 16, 16, generator=torch.Generator().manual_seed(1)) * 2 - 1).to(DEV)
     losses = []
-    for i in range(14):
+    for i in range(20):
         tr.stats.reset()
         tr.step(x, global_steps=i + 1)
         losses.append(tr.current_stats["loss"])
     ds = next(iter(tr._direct.values()))
-    assert ds.choice in ("eager", "graph") and set(ds.times) == {"eager", "graph"} and min(ds.times.values()) > 0
-    assert ds.graph is not None and not ds.graph_failed
-    assert int(opt.state[next(iter(m.parameters()))]["step"]) == 14 and tr.ema.num_updates == 13
+    assert ds.choice in ("eager", "plan", "graph") and set(ds.times) == {"eager", "plan", "graph"} and min(ds.times.values()) > 0
+    assert ds.graph is not None and not ds.graph_failed and ds.plan is not None and not ds.plan_failed and ds.settled()
+    assert ds.last_kind == ds.choice
+    assert int(opt.state[next(iter(m.parameters()))]["step"]) == 20 and tr.ema.num_updates == 19
     assert sum(losses[-4:]) < sum(losses[:4])
 
 
@@ -350,7 +355,7 @@ def test_captured_step_is_recaptured_when_baked_addresses_move(monkeypatch):
     step must notice, capture again and give what the eager step gives — never replay through the stale pointers."""
     from tests.test_unet_gpu import TINY3
     runs = {}
-    for graph in (True, False):
+    for graph in (True, "plan", False):
         monkeypatch.setattr(train_mod, "_TRAIN_GRAPH", graph)
         torch.manual_seed(11)
         m, _ = make(TINY3, dtype=torch.float32)
@@ -381,17 +386,19 @@ def test_captured_step_is_recaptured_when_baked_addresses_move(monkeypatch):
         assert ds.captures == (3 if graph else 0) and not ds.graph_failed
         torch.cuda.synchronize()
         runs[graph] = ({k: v.detach().cpu().clone() for k, v in m.named_parameters()}, tr.current_stats["loss"])
-    for k, v in runs[True][0].items():
-        scale = float(runs[False][0][k].abs().max()) or 1.0
-        assert float((v - runs[False][0][k]).abs().max()) <= 2e-4 * scale + 9 * 1e-3 * 0.3, k
-    assert abs(runs[True][1] - runs[False][1]) <= 2e-4 * abs(runs[False][1])
+    for form in (True, "plan"):
+        for k, v in runs[form][0].items():
+            scale = float(runs[False][0][k].abs().max()) or 1.0
+            assert float((v - runs[False][0][k]).abs().max()) <= 2e-4 * scale + 9 * 1e-3 * 0.3, (form, k)
+        assert abs(runs[form][1] - runs[False][1]) <= 2e-4 * abs(runs[False][1])
 
 
-def test_training_graph_survives_a_sampling_pass_at_another_batch_size(monkeypatch):
+@pytest.mark.parametrize("form", [True, "plan"])
+def test_training_graph_survives_a_sampling_pass_at_another_batch_size(monkeypatch, form):
     """Trainer.train() samples a grid between epochs (another batch size -> another GroupNorm workspace requirement); the captured
     training step still points at the workspace it was captured with, which therefore must stay alive and in place."""
     from tests.test_unet_gpu import TINY3
-    monkeypatch.setattr(train_mod, "_TRAIN_GRAPH", True)
+    monkeypatch.setattr(train_mod, "_TRAIN_GRAPH", form)
     torch.manual_seed(5)
     m, _ = make(TINY3, dtype=torch.float32)
     dif = ddpm_torch.GaussianDiffusion(ddpm_torch.get_beta_schedule("linear", 1e-4, 0.02, 20), "eps", "fixed-large", "mse")

@@ -60,3 +60,21 @@ def test_two_rank_gradients_are_averaged(tmp_path, mode):
         assert a["direct"] and b["direct"]                    # the autograd-free step ran (its backward issues the same all-reduces)
         for k in a["sd"]:
             assert float((a["sd"][k] - b["sd"][k]).abs().max()) < 1e-7, f"{k}: replicas diverged after a distributed Trainer.step"
+
+
+def test_two_rank_launch_plan_steps_equal_eager_steps(tmp_path):
+    """The recorded form of the distributed step (csrc/plan.hip's table, here replayed through the emulator): the RCCL / gloo all-reduces sit
+    BETWEEN plan segments as host callbacks.  Four steps (eager warm-up, recording, two replays) must leave both ranks exactly where four
+    eager steps leave them."""
+    _launch("native_plan", tmp_path)
+    _launch("native_eager4", tmp_path)
+    for r in range(2):
+        p = torch.load(os.path.join(tmp_path, f"after_step_native_plan_{r}.pt"), weights_only=True)
+        e = torch.load(os.path.join(tmp_path, f"after_step_native_eager4_{r}.pt"), weights_only=True)
+        assert p["direct"] and p["last_kind"] == "plan" and e["last_kind"] == "eager"
+        assert p["plan_segments"] >= 2 and p["plan_launches"] > 100           # at least one exchange inside the backward + the tail
+        assert p["losses"] == e["losses"]
+        for k in e["sd"]:
+            assert torch.equal(p["sd"][k], e["sd"][k]), k
+        for k in e["shadow"]:
+            assert torch.equal(p["shadow"][k], e["shadow"][k]), k

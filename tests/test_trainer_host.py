@@ -46,6 +46,32 @@ def _run_g9(tr, g):
     return losses
 
 
+def test_launch_plan_replays_reproduce_the_reference_steps(emu, golden, monkeypatch):
+    """The direct step recorded as a launch plan (ddpm_torch/_plan.py; here the table is replayed through the emulator, on the GPU by
+    csrc/plan.hip): step 1 eager, step 2 records, steps 3-6 are replays — against the reference Trainer's losses and final state (G9:
+    the learning rate changes at step 4, so the replays must read it from the device block, and every forward must see the weights the
+    previous replay wrote)."""
+    g = golden("g9_train_lr.pt")
+    monkeypatch.setattr(train_mod, "_TRAIN_GRAPH", "plan")
+    m, opt, sched, tr = _g9_trainer(g)
+    losses = _run_g9(tr, g)
+    ds = next(iter(tr._direct.values()))
+    assert ds.plan is not None and ds.last_kind == "plan" and ds.captures == 1 and ds.plan.launches > 100
+    names = {n for seg in ds.plan.segments for n, _ in seg}
+    assert {"ddpm_fill_zero", "ddpm_q_sample", "ddpm_mse_bwd", "ddpm_mt_adam_ema", "ddpm_pack_weight_multi"} <= names
+    assert torch.allclose(torch.tensor(losses, dtype=torch.float64), g["losses"], rtol=5e-4), (losses, g["losses"])
+    slack = 0.25 * g["lr"] * len(g["xs"])
+    _check_state(m.state_dict(), g["params"], 1e-3, "param", adam_slack=slack)
+    _check_state(tr.ema.shadow, g["shadow"], 1e-3, "shadow", adam_slack=slack)
+    # ... and bit for bit against the same steps issued eagerly
+    monkeypatch.setattr(train_mod, "_TRAIN_GRAPH", False)
+    m2, _, _, tr2 = _g9_trainer(g)
+    losses2 = _run_g9(tr2, g)
+    assert losses == losses2
+    for (k, a), b in zip(m.state_dict().items(), m2.state_dict().values()):
+        assert torch.equal(a, b), k
+
+
 @pytest.mark.parametrize("direct", [True, False])
 def test_steps_that_move_the_weights_match_the_reference(emu, golden, monkeypatch, direct):
     g = golden("g9_train_lr.pt")
