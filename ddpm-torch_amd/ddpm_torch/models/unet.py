@@ -478,8 +478,17 @@ class _Engine:
         self._launch_pack()
         self._launch_fc()
 
-    def mark_fresh(self):
-        """The derived copies match the current parameter versions (after a replay whose tail re-derived them)."""
+    def mark_fresh(self, bumped=False):
+        """The derived copies match the current parameter versions (after a step whose tail re-derived them).  ``bumped``: the caller
+        knows that every parameter's version counter went up by exactly one since ``ensure_fresh`` verified the keys (the fused
+        update's ``increment_version``) — the keys are advanced arithmetically instead of re-read (~350 attribute reads, 0.25 ms)."""
+        if bumped and self.pack_key is not None and self.fc_ver is not None:
+            pack_key = tuple(v + 1 for v in self.pack_key)
+            fc_ver = tuple((a + 1, b + 1, c + 1, ptr) for a, b, c, ptr in self.fc_ver)
+            first, last = next(iter(self.convs.values())), self.res_blocks[-1]
+            if first.mod.weight._version == pack_key[0] and last.fc.weight._version == fc_ver[-1][0]:     # spot check; else re-read everything
+                self.pack_key, self.fc_ver = pack_key, fc_ver
+                return
         self.pack_key = self._pack_versions()
         self.fc_ver = self._fc_versions()
 

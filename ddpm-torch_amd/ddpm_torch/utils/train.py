@@ -216,6 +216,7 @@ class _FusedUpdate:
     def __init__(self, optimizer, ema):
         self.opt, self.ema = optimizer, ema
         self.table = self.key = self.sig = None
+        self.step_block = None
         self.total = None
         self.generation = 0                  # bumped whenever the pointer table is rebuilt (captured steps compare it)
 
@@ -279,13 +280,23 @@ class _FusedUpdate:
                 self.total = torch.zeros(64, dtype=torch.float32, device=dev)      # striped ||g||^2 accumulators
             self.key, self.params = key, params
             self.generation += 1
+            # Adam keeps one 0-dim CPU "step" tensor per parameter; bumping ~300 of them costs the host 1.3 ms per step.  Re-bind them as
+            # views of ONE block (same dtype, same values, still tensors in state_dict()): the bookkeeping of a step is one add_.
+            steps = [self.opt.state[p]["step"] for p in params]
+            if all(torch.is_tensor(t) and not t.is_cuda and t.dtype == steps[0].dtype for t in steps):
+                block = torch.stack([t.detach().reshape(()) for t in steps])
+                for i, p in enumerate(params):
+                    self.opt.state[p]["step"] = block[i]
+                self.step_block = block
+            else:
+                self.step_block = None
         self.sig = self._signature(grad_ptrs) if stable_grads else None
         return self.params
 
     def step_count(self):
         """Optimiser steps taken so far, read from the optimiser's own state (survives load_state_dict and fallbacks)."""
-        params = [p for p in self.opt.param_groups[0]["params"] if p.requires_grad]
-        st = self.opt.state.get(params[0], {})
+        first = next(p for p in self.opt.param_groups[0]["params"] if p.requires_grad)
+        st = self.opt.state.get(first, {})
         return int(st["step"]) if "step" in st else 0
 
     def launch(self, max_norm, scalars=None, hyper_dev=0, have_sumsq=False):
@@ -311,7 +322,11 @@ class _FusedUpdate:
 
     def committed(self):
         """Host-side bookkeeping after the update kernels were enqueued (eagerly or by a graph replay)."""
-        torch._foreach_add_([self.opt.state[p]["step"] for p in self.params], 1)
+        block = getattr(self, "step_block", None)
+        if block is not None and self.opt.state[self.params[0]]["step"].untyped_storage().data_ptr() == block.untyped_storage().data_ptr():
+            block.add_(1)
+        else:                                          # (state re-created behind our back and not yet re-bound by prepare())
+            torch._foreach_add_([self.opt.state[p]["step"] for p in self.params], 1)
         torch.autograd.graph.increment_version(self.params)
         self.opt._opt_called = True                    # what LR schedulers check before their own step()
 
@@ -572,7 +587,7 @@ class _DirectStep:
                 self._probe_end("eager")
         self.calls += 1
         tr._fused.committed()
-        eng.mark_fresh()
+        eng.mark_fresh(bumped=True)
         return self.loss
 
 
@@ -649,6 +664,21 @@ class Trainer:
         """The UNet behind ``self.model`` when the autograd-free step applies, else None."""
         from ..models.unet import UNet
         m = self.model
+        group = self.optimizer.param_groups[0] if self.optimizer.param_groups else None
+        # (the scans below walk ~300 parameters: 0.25 ms per step — done once per (model, engine, optimizer, parameter list, hyper-flags))
+        key = (id(m), id(getattr(m, "_eng", None)), id(self.optimizer), len(self.optimizer.param_groups), id(group["params"]) if group else 0,
+               len(group["params"]) if group else 0, self.num_accum, type(self.optimizer),
+               tuple(bool(group.get(k)) for k in ("amsgrad", "maximize", "weight_decay", "capturable", "differentiable", "fused")) if group else (),
+               "get_input" in self.__dict__, "loss" in self.__dict__, id(self.diffusion), getattr(self.diffusion, "loss_type", None),
+               getattr(self.diffusion, "model_mean_type", None))
+        cached = getattr(self, "_direct_unet_cache", None)
+        if cached is not None and cached[0] == key:
+            return cached[1]
+        result = self._direct_unet_scan(m, UNet)
+        self._direct_unet_cache = (key, result)
+        return result
+
+    def _direct_unet_scan(self, m, UNet):
         if not isinstance(m, UNet) or self.num_accum != 1 or not self._fused.eligible():
             return None
         if "get_input" in self.__dict__ or "loss" in self.__dict__ or type(self).get_input is not Trainer.get_input or type(self).loss is not Trainer.loss:
