@@ -161,6 +161,9 @@ struct DevOnce {
 static inline int check_launch() { return hipGetLastError() == hipSuccess ? DDPM_OK : DDPM_ERR_LAUNCH; }
 static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
+// probe.hip: compute units the persistent launchers leave to a concurrent collective (ddpm_set_reserved_cus); 0 by default
+int ddpm_reserved_cus();
+static inline int ddpm_cu_budget(int wanted) { const int left = 256 - ddpm_reserved_cus(); return wanted < left ? wanted : (left > 1 ? left : 1); }
 // pointwise.hip: launcher of the persistent 1x1-conv kernel (-1: geometry not covered)
 int ddpm_pointwise_launch(const void* x, long long x_ld, const void* w, void* y, long long y_ld, const float* bias, const void* residual,
                           long long res_ld, int accumulate, int M, int N, int K, int dry, void* stream);

@@ -631,16 +631,36 @@ __device__ __forceinline__ int pc_min_dist(const u32x4& v, unsigned target) {
     const int m = min(min(a, b), min(c, d));
     return __builtin_amdgcn_readfirstlane(m);
 }
+// ---- what a timed-out semaphore wait leaves behind (see pc_wait_all_ge)
+__device__ unsigned g_pc_fault[4];
+constexpr unsigned long long PC_WAIT_TICKS = 500000000ull;          // 5 s of the 100 MHz s_memrealtime clock
+__device__ __forceinline__ bool pc_expired(unsigned long long& t_first) {
+    const unsigned long long now = wall_clock64();
+    if (t_first == 0) { t_first = now | 1ull; return false; }
+    return now - t_first > PC_WAIT_TICKS;
+}
+__device__ __forceinline__ void pc_fault(unsigned addr, unsigned target, unsigned kind) {
+    if ((threadIdx.x & 63) == 0) {
+        g_pc_fault[0] = blockIdx.x; g_pc_fault[1] = addr; g_pc_fault[2] = target; g_pc_fault[3] = 1u + kind;
+        __threadfence_system();
+    }
+    __builtin_trap();
+}
 __device__ __forceinline__ void pc_wait_all_ge(unsigned addr, unsigned target) {
 #ifdef PC_ABL_NO_SYNC
     return;
 #endif
-    // bounded: a protocol error must end the launch with an error the host sees (trap), never hang the GPU
+    // bounded: a protocol error must end the launch with an error the host sees (trap), never hang the GPU.  The bound is WALL time
+    // (s_memrealtime, 100 MHz): ~5 s, so that a profiler's thread trace, a debugger or a stalled co-tenant cannot turn a slow wait into
+    // a fault; the clock is looked at every 4096 polls only.  pc_fault() leaves {block, counter address, target, 1 + kind} in
+    // g_pc_fault before the trap (rocgdb / a core file name the wait that tripped; ddpm_conv3x3_pc_last_fault reads it where the
+    // context survives).  DDPM_CONV_NO_PC=1 runs every call on conv3x3_stream_kernel<16>, which has no such waits.
+    unsigned long long t_first = 0;
     for (unsigned spins = 0;; ++spins) {
         u32x4 v;
         asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(addr) : "memory");
         if (pc_min_dist(v, target) >= 0) break;
-        if (spins > (1u << 22)) __builtin_trap();
+        if ((spins & 4095u) == 4095u && pc_expired(t_first)) pc_fault(addr, target, 0u);
         __builtin_amdgcn_s_sleep(1);
     }
 }
@@ -648,11 +668,12 @@ __device__ __forceinline__ void pc_wait_ge(unsigned addr, unsigned target) {    
 #ifdef PC_ABL_NO_SYNC
     return;
 #endif
+    unsigned long long t_first = 0;
     for (unsigned spins = 0;; ++spins) {
         unsigned v;
         asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(addr) : "memory");
         if ((int)((unsigned)__builtin_amdgcn_readfirstlane((int)v) - target) >= 0) break;
-        if (spins > (1u << 22)) __builtin_trap();
+        if ((spins & 4095u) == 4095u && pc_expired(t_first)) pc_fault(addr, target, 1u);
         __builtin_amdgcn_s_sleep(1);
     }
 }
@@ -1105,6 +1126,13 @@ extern "C" int ddpm_debug_set_c3_timing(void* p) { return hipMemcpyToSymbol(HIP_
 // Launcher behind ddpm_conv2d_nhwc (gemm.hip) for 3x3 / stride 1 / pad 1, bf16 -> bf16 (H, W = output image; upsample: x stored at H/2 x W/2): 16 x 16 patches for images of 16 x 16 and up with
 // >= 16384 pixels, 8 x 8 patches for 8 x 8-divisible images with >= 4096 pixels.  -1: geometry / epilogue not covered (the caller keeps
 // its other kernels), else a status code.  dry: decide only, and return the patch edge (16 / 8) that would run.
+// Diagnostic: the record a timed-out semaphore wait of conv3x3_pc_kernel left before it trapped — out4 (HOST memory) receives
+// {block, LDS address of the counter, value waited for, 0 = none | 1 = a loader / consumer counter | 2 = the consumers' rendezvous}.
+extern "C" int ddpm_conv3x3_pc_last_fault(unsigned* out4) {
+    if (!out4) return DDPM_ERR_NULL;
+    return hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_pc_fault), 4 * sizeof(unsigned)) == hipSuccess ? DDPM_OK : DDPM_ERR_LAUNCH;
+}
+
 int ddpm_conv3x3_stream_launch(const void* x, long long x_ld, const void* w, void* y, long long y_ld, const float* bias, const float* rowbias,
                                long long rowbias_ld, const void* residual, long long res_ld, int accumulate, int B, int H, int W, int C, int N,
                                int upsample, int xcd, int dry, void* stream) {
@@ -1140,7 +1168,8 @@ int ddpm_conv3x3_stream_launch(const void* x, long long x_ld, const void* w, voi
     a.xcd = xcd;
     a.d_tiles_n = make_fastdiv((unsigned)a.tiles_n); a.d_tpi = make_fastdiv((unsigned)(a.tiles_y * a.tiles_x)); a.d_tiles_x = make_fastdiv((unsigned)a.tiles_x);
     static const int max_grid = getenv("DDPM_C3_GRID") ? atoi(getenv("DDPM_C3_GRID")) : 256;      // (timing experiments: > 256 = fewer tiles per block)
-    const int grid = a.total_tiles < max_grid ? a.total_tiles : max_grid;
+    const int cus = max_grid == 256 ? ddpm_cu_budget(256) : max_grid;                             // (256 - DDPM_DP_RESERVED_CUS when a collective runs beside the step)
+    const int grid = a.total_tiles < cus ? a.total_tiles : cus;
 #define C3_LAUNCH(PATCHV)                                                                                                              \
     do {                                                                                                                               \
         static DevOnce attr_set;                                                                                                  \

@@ -300,7 +300,8 @@ int ddpm_pointwise_launch(const void* x, long long x_ld, const void* w, void* y,
         }                                                                                                                         \
         a.tiles_m = (M + TM - 1) / TM; a.tiles_n = (N + TN - 1) / TN;                                                             \
         const int units = a.spread ? a.tiles_m * a.tiles_n : a.tiles_m;                                                           \
-        const int grid = units < 256 ? units : 256;                                                                               \
+        const int cus = ddpm_cu_budget(256);                                                                                      \
+        const int grid = units < cus ? units : cus;                                                                               \
         hipLaunchKernelGGL((pw_conv_kernel<TM, TN>), dim3(grid), dim3(512), LDS, st, a);                                          \
     } while (0)
     if (wide) PW_LAUNCH(128, 256, 3); else if (big) PW_LAUNCH(256, 128, 3); else PW_LAUNCH(128, 128, 4);

@@ -44,7 +44,36 @@ __global__ __launch_bounds__(256) void mfma_probe_kernel(float* sink, int iters,
     if (s == 12345.678f) sink[threadIdx.x] = s;          // keeps the accumulators alive; never true in practice
 }
 
+// Stand-in for a collective's copy kernel (bench.py's one-rank data-parallel trace): `blocks` workgroups of 512 threads stream `bytes`
+// from src to dst with 16-byte accesses, grid-strided — the shape of an RCCL ring step (few workgroups, memory-bound).  What it measures
+// is whether such a kernel, issued from inside the backward, GETS compute units while the persistent MFMA kernels hold theirs.
+__global__ __launch_bounds__(512) void copy_probe_kernel(u32x4* dst, const u32x4* src, long long vecs) {
+    for (long long i = (long long)blockIdx.x * 512 + threadIdx.x; i < vecs; i += (long long)gridDim.x * 512)
+        __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
+}
+
 }  // namespace
+
+// ---- compute units left to a concurrent collective.  The persistent kernels size their grids to the chip (one block per CU: 160 KiB of
+// LDS, 512 threads x ~250 registers), so a kernel of another stream — RCCL's all-reduce issued from inside the backward — only finds
+// a CU at a block boundary.  With n > 0 every persistent launcher (3x3 conv, 1x1 conv, both weight-gradient kernels) plans for 256 - n
+// compute units instead.  Process-wide; the engine sets it when a process group is attached (DDPM_DP_RESERVED_CUS).
+static std::atomic<int> g_reserved_cus{0};
+int ddpm_reserved_cus() { return g_reserved_cus.load(std::memory_order_relaxed); }
+extern "C" int ddpm_set_reserved_cus(int n) {
+    if (n < 0 || n > 192) return DDPM_ERR_SHAPE;
+    g_reserved_cus.store(n, std::memory_order_relaxed);
+    return DDPM_OK;
+}
+extern "C" int ddpm_get_reserved_cus(void) { return ddpm_reserved_cus(); }
+
+extern "C" int ddpm_copy_probe(void* dst, const void* src, long long bytes, int blocks, void* stream) {
+    if (!dst || !src) return DDPM_ERR_NULL;
+    if (bytes <= 0 || bytes % 16 || blocks <= 0 || blocks > 4096) return DDPM_ERR_SHAPE;
+    if (!aligned16(dst) || !aligned16(src)) return DDPM_ERR_ALIGN;
+    hipLaunchKernelGGL(copy_probe_kernel, dim3(blocks), dim3(512), 0, (hipStream_t)stream, (u32x4*)dst, (const u32x4*)src, bytes / 16);
+    return check_launch();
+}
 
 // One launch of the MFMA-only loop on every CU (256 blocks x 4 waves: one wave per SIMD, 8 accumulator blocks each):
 // 16 * iters MFMAs per wave = iters * 16 * 32768 * 1024 FLOP per launch.  sink: >= 256 floats.  zero_operands: the zero-data ceiling.

@@ -166,7 +166,7 @@ static bool make_plan(int P, int C, int N, Plan& p) {
     p.ksteps = (P + 63) / 64;                                   // pixels beyond P: out-of-range offsets (zeros)
     const int tiles = p.tiles_c * p.tiles_n;
     static const int cu_budget = getenv("DDPM_WGRAD1_CUS") ? atoi(getenv("DDPM_WGRAD1_CUS")) : 256;
-    int splits = cu_budget / tiles;                             // one block per CU
+    int splits = ddpm_cu_budget(cu_budget) / tiles;             // one block per CU
     if (splits < 1) splits = 1;
     const int max_splits = p.ksteps / 4 > 0 ? p.ksteps / 4 : 1; // a slice keeps >= 4 K-steps
     if (splits > max_splits) splits = max_splits;

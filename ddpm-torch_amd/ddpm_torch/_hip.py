@@ -11,7 +11,9 @@ from ctypes import c_float, c_int, c_longlong, c_ulonglong, c_void_p
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libddpm_hip.so")
+# DDPM_HIP_LIB: load another build of the library instead (A/B and ablation drivers point it at csrc/libddpm_hip_<name>.so — they must
+# never overwrite the product library; scripts/build_variant.sh builds such variants)
+LIB_PATH = os.environ.get("DDPM_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "csrc", "libddpm_hip.so")
 
 F32, BF16 = 0, 1
 _ERR = {1: "bad shape / divisibility", 2: "unsupported dtype", 3: "misaligned pointer or pitch",
@@ -71,6 +73,10 @@ PROTOTYPES = {
     "ddpm_mt_gather_f32": [P, I, P],
     "ddpm_sumsq_accumulate": [P, L, P, P, P],
     "ddpm_adam_ema_step": [P, P, P, P, P, L, P, F, F, F, F, F, F, F, F, P],
+    "ddpm_conv3x3_pc_last_fault": [P],
+    "ddpm_set_reserved_cus": [I],
+    "ddpm_get_reserved_cus": [],
+    "ddpm_copy_probe": [P, P, L, I, P],
     # launch plans (csrc/plan.hip; driven by _plan.LaunchPlan)
     "ddpm_stream_order": [P, P],
     "ddpm_fill_zero": [P, L, P],

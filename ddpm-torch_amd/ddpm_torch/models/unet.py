@@ -182,6 +182,7 @@ class UNet(nn.Module):
                     dist.broadcast(p.detach(), src=dist.get_global_rank(self._pg, 0), group=self._pg)   # detach() shares the version counter, .data does not
         if self._eng is not None:
             self._eng.pg = self._pg
+            self._eng.apply_reserved_cus()
         return self
 
     def _apply(self, fn, *a, **k):
@@ -192,6 +193,7 @@ class UNet(nn.Module):
         if self._eng is None:
             self._eng = _Engine(self)
             self._eng.pg = getattr(self, "_pg", None)
+            self._eng.apply_reserved_cus()
         return self._eng
 
     def forward(self, x, t):
@@ -309,10 +311,27 @@ class _Engine:
         self.debug_keep_tape = False               # tests set it to look at the tape after a step; costs the activations' lifetime
         self.splitk = ops.SplitK(self.device)
         self.pg = None                              # process group of the native data-parallel path (set_process_group)
+        self.dp_standin = None                      # callable(chunk) run where an all-reduce is issued (bench.py's one-rank stand-in measurement)
         self.dp_trace = None                        # list -> (what, bytes, event) records of one backward's exchange (bench.py's config.dp)
         self.pack_table = self.pack_ptrs = self.pack_key = None
         self.pack_has_dgrad = False
         _hip.lib()
+
+    def apply_reserved_cus(self):
+        """Data-parallel runs: leave DDPM_DP_RESERVED_CUS compute units to the communicator's kernels (the persistent kernels otherwise
+        take every CU whole and an all-reduce issued inside the backward finds one only at a block boundary).  Process-wide switch of the
+        library; the slab counts of the weight-gradient kernels depend on it, so the cached plans are dropped when it changes.
+        Default 0: on one GPU a stand-in copy kernel issued where the all-reduces are gets its CUs within one block of the
+        persistent kernels either way (profiles/r05_dp_reserved_cus.txt); the right value for 8 ranks over xGMI is
+        to be swept on the node."""
+        want = int(os.environ.get("DDPM_DP_RESERVED_CUS", "0")) if self.pg is not None else 0
+        lib = _hip.lib()
+        if int(lib.ddpm_get_reserved_cus()) != want:
+            if lib.ddpm_set_reserved_cus(want) != 0:
+                raise ValueError(f"DDPM_DP_RESERVED_CUS={want}: must be in [0, 192]")
+            self._eff_splits.clear()
+            self._slabs.clear()
+            self._slab_tables.clear()
 
     # ---------------------------------------------------------------- topology helpers
     def _split(self, blk):
@@ -730,6 +749,8 @@ class _Engine:
             ev = torch.cuda.Event(enable_timing=True)
             ev.record()
             self.dp_trace.append(("all_reduce", t.numel() * 4, ev))
+        if self.dp_standin is not None:                    # bench.py, one rank: a copy kernel of the chunk's size stands in for the ring step
+            self.dp_standin(t)
         return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
 
     def _dp_mark(self, what):
@@ -1233,8 +1254,12 @@ class _Engine:
         with self._leaf(ctx, dtb, s_t):
             ops.gemm(dtb.data_ptr(), Ct, 0, 1, s_t.data_ptr(), E, 0, 1, self._pptr(ctx, "fc_w"), E, 0, Ct, E, B, F, out_mode=1)
             ops.colsum(View(dtb, 1, B, 1, Ct), 0, 0, self._pptr(ctx, "fc_b"))
-        ds_t = self._zeros(B, E)     # K = sum Cout (~5000): split-K with fp32 atomics
-        ops.gemm(dtb.data_ptr(), Ct, 0, 0, fc_w.data_ptr(), E, 0, 1, ds_t.data_ptr(), E, 0, B, E, Ct, F, out_mode=2, splits=max(1, Ct // 256))
+        # K = sum Cout (~5000): split-K with fp32 atomics (run-to-run summation order) — unless the deterministic-reduction mode is on
+        # (DDPM_WGRAD_SLABS=1: bit-reproducible gradients), where this product and the lin2 one below run as single-pass GEMMs
+        det = _WGRAD_SLABS
+        ds_t = self._f32(B, E) if det else self._zeros(B, E)
+        ops.gemm(dtb.data_ptr(), Ct, 0, 0, fc_w.data_ptr(), E, 0, 1, ds_t.data_ptr(), E, 0, B, E, Ct, F, out_mode=1 if det else 2,
+                 splits=1 if det else max(1, Ct // 256))
         dt_emb = self._f32(B, E)
         _hip.call("ddpm_silu_bwd", t_emb.data_ptr(), ds_t.data_ptr(), dt_emb.data_ptr(), B * E, 0, _hip.stream())
         ctx["dt_emb"] = dt_emb                                  # d/d(t_emb): what the reference's ResidualBlock hands back to the embedding MLP
@@ -1243,9 +1268,10 @@ class _Engine:
             ops.gemm(dt_emb.data_ptr(), E, 0, 1, s1.data_ptr(), E, 0, 1, self._pptr(ctx, lin2.weight), E, 0, E, E, B, F, out_mode=1)
             ops.colsum(View(dt_emb, 1, B, 1, E), 0, 0, self._pptr(ctx, lin2.bias))
         # (K = E = 512 over 4 output tiles would leave 252 CUs idle for ~75 us at the very end of the backward: split-K with fp32 atomics
-        #  like the fc product above — 32 blocks)
-        ds1 = self._zeros(B, E)
-        ops.gemm(dt_emb.data_ptr(), E, 0, 0, lin2.weight.data_ptr(), E, 0, 1, ds1.data_ptr(), E, 0, B, E, E, F, out_mode=2, splits=max(1, E // 64))
+        #  like the fc product above — output tiles x E / 64 K slices)
+        ds1 = self._f32(B, E) if det else self._zeros(B, E)
+        ops.gemm(dt_emb.data_ptr(), E, 0, 0, lin2.weight.data_ptr(), E, 0, 1, ds1.data_ptr(), E, 0, B, E, E, F, out_mode=1 if det else 2,
+                 splits=1 if det else max(1, E // 64))
         de1 = self._f32(B, E)
         _hip.call("ddpm_silu_bwd", e1.data_ptr(), ds1.data_ptr(), de1.data_ptr(), B * E, 0, _hip.stream())
         with self._leaf(ctx, de1, temb):

@@ -255,6 +255,21 @@ int ddpm_mt_gather_f32(const long long* table, int n_tensors, void* stream);
  * budget (~1.7 PFLOP/s on random operands, ~2.5 on zeros).  sink: >= 256 floats, never written in practice. */
 int ddpm_mfma_probe(float* sink, int iters, int zero_operands, void* stream);
 
+/* diagnostic (no upstream counterpart): the wave-specialised 3x3 kernel's LDS-semaphore waits are bounded in wall time (~5 s); one that
+ * expires records {block, counter address, value waited for, kind} and traps (the launch fails instead of hanging the GPU).  out4 is HOST
+ * memory; kind 0 = no wait has ever expired.  Setting DDPM_CONV_NO_PC=1 runs those calls on the barrier-synchronised kernel instead. */
+int ddpm_conv3x3_pc_last_fault(unsigned* out4);
+
+/* Data-parallel training (upstream: DistributedDataParallel's all-reduce beside the backward, train.py:110): the persistent kernels size
+ * their grids to the whole chip, one block per compute unit, so a collective's kernel issued from inside the backward finds a CU only at
+ * a block boundary.  ddpm_set_reserved_cus(n) makes every persistent launcher (3x3 / 1x1 conv, both weight-gradient kernels) plan for
+ * 256 - n compute units (0 <= n <= 192; process-wide; 0 = default).  Changes the slab counts ddpm_conv3x3_wgrad_splits /
+ * ddpm_conv1x1_wgrad_splits report: set it before asking.  ddpm_copy_probe: `blocks` workgroups streaming `bytes` (a multiple of 16)
+ * from src to dst — a stand-in for a ring step's copy kernel, used by bench.py to measure what a collective gets on one GPU. */
+int ddpm_set_reserved_cus(int n);
+int ddpm_get_reserved_cus(void);
+int ddpm_copy_probe(void* dst, const void* src, long long bytes, int blocks, void* stream);
+
 /* test hook: the keep-mask (1/0) the GroupNorm kernels regenerate for element indices 0..n-1 */
 int ddpm_dropout_mask(float* mask, long long n, float p, unsigned long long seed, void* stream);
 

@@ -6,7 +6,7 @@ import torch
 from ddpm_torch import _hip, _ops as ops
 from ddpm_torch._ops import View
 DEV, dt, B = "cuda:0", torch.bfloat16, 128
-lib = ctypes.CDLL(os.path.join(ROOT, "ddpm-torch_amd", "csrc", "libddpm_hip.so"))
+lib = ctypes.CDLL(os.environ.get("DDPM_HIP_LIB") or os.path.join(ROOT, "ddpm-torch_amd", "csrc", "libddpm_hip.so"))
 ZERO = os.environ.get("ZERO_DATA") == "1"
 for (H, C, N) in ((32, 128, 128), (16, 256, 256), (16, 512, 256)):
     xt = torch.randn(B, H, H, C, device=DEV).to(dt)

@@ -14,8 +14,11 @@ TINY = dict(in_channels=3, hid_channels=32, out_channels=3, ch_multipliers=[1, 2
 CIFAR = dict(in_channels=3, hid_channels=128, out_channels=3, ch_multipliers=[1, 2, 2, 2], num_res_blocks=2, apply_attn=[False, True, False, False], drop_rate=0.0)
 # DDP_WORKER_CFG=cifar: the configs/cifar10.json geometry at B = 4 per rank (tests/test_multi_gpu.py) — the chunk plan, the packed gradient
 # staging buffer and the hot kernels of BASELINE config 3 instead of the 8 x 8 toy
-BIG = os.environ.get("DDP_WORKER_CFG") == "cifar"
-CFG, SHAPE = (CIFAR, (4, 3, 32, 32)) if BIG else (TINY, (2, 3, 8, 8))
+# DDP_WORKER_CFG=celebahq: the configs/celebahq.json geometry (113.7 M parameters, 454.7 MB of gradients per exchange) at 256 x 256, B = 1 per rank
+HQ = dict(in_channels=3, hid_channels=128, out_channels=3, ch_multipliers=[1, 1, 2, 2, 4, 4], num_res_blocks=2,
+          apply_attn=[False, False, False, False, True, False], drop_rate=0.0)
+BIG = os.environ.get("DDP_WORKER_CFG")
+CFG, SHAPE = {"cifar": (CIFAR, (4, 3, 32, 32)), "celebahq": (HQ, (1, 3, 256, 256))}.get(BIG, (TINY, (2, 3, 8, 8)))
 
 
 def install_emulator():

@@ -31,8 +31,9 @@ _SREG = re.compile(r"^s(\d+)$")
 
 def kernel_bodies(asm_text):
     lines = asm_text.split("\n")
+    functions = set(re.findall(r"^\s*\.type\s+(_Z\w+),@function", asm_text, flags=re.M))      # (data symbols have labels too)
     for i, l in enumerate(lines):
-        if re.match(r"^_Z\w+:", l):
+        if re.match(r"^_Z\w+:", l) and l.split(":")[0] in functions:
             end = next(j for j in range(i, len(lines)) if lines[j].strip().startswith(".amdhsa_kernel") or lines[j].startswith(".Lfunc_end"))
             yield l.split(":")[0], lines[i + 1:end]
 

@@ -105,3 +105,44 @@ def test_cifar_geometry_native_exchange_equals_torch_ddp(tmp_path):
     for r in range(1, world):
         for k in after[0]["sd"]:
             assert float((after[0]["sd"][k] - after[r]["sd"][k]).abs().max()) < 1e-7, f"{k}: replicas diverged"
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs at least two GPUs")
+def test_celebahq_geometry_native_exchange_equals_torch_ddp(tmp_path):
+    """BASELINE config 5's geometry (configs/celebahq.json at 256 x 256, B = 1 per rank here): 454.7 MB of packed gradients per exchange,
+    cut into chunks and all-reduced from inside the backward — every rank ends with the gradients torch's DistributedDataParallel gives
+    (upstream train.py:110), the ranks agree bit for bit, and distributed Trainer.steps keep the replicas in lock-step."""
+    world = _world()
+    (tmp_path / "n").mkdir(); (tmp_path / "d").mkdir()
+    nat = _launch("native", tmp_path / "n", world, DDP_WORKER_CFG="celebahq", DDPM_TORCH_AMD_COMPUTE="fp32")
+    ddp = _launch("ddp", tmp_path / "d", world, DDP_WORKER_CFG="celebahq", DDPM_TORCH_AMD_COMPUTE="fp32")
+    for k, g0 in nat[0]["grads"].items():
+        for r in nat[1:]:
+            assert torch.equal(g0, r["grads"][k]), f"{k}: ranks disagree after the all-reduce"
+        scale = max(float(ddp[0]["grads"][k].abs().max()), 1e-6)
+        assert float((g0 - ddp[0]["grads"][k]).abs().max()) <= 1e-4 * scale + 1e-7, k
+    after = [torch.load(os.path.join(tmp_path / "n", f"after_step_native_{r}.pt"), weights_only=True) for r in range(world)]
+    for r in range(1, world):
+        for k in after[0]["sd"]:
+            assert float((after[0]["sd"][k] - after[r]["sd"][k]).abs().max()) < 1e-7, f"{k}: replicas diverged"
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs at least two GPUs")
+@pytest.mark.parametrize("reserved", ["0", "16"])
+def test_launch_plan_data_parallel_step_equals_eager(tmp_path, reserved):
+    """The launch-plan form of the distributed step (csrc/plan.hip; the RCCL all-reduces are host callbacks between plan segments), also
+    with compute units held back for the communicator (DDPM_DP_RESERVED_CUS): same parameters as the eager step, replicas in lock-step."""
+    world = _world()
+    (tmp_path / "p").mkdir(); (tmp_path / "e").mkdir()
+    _launch("native_plan", tmp_path / "p", world, DDPM_DP_RESERVED_CUS=reserved)
+    _launch("native_eager4", tmp_path / "e", world, DDPM_DP_RESERVED_CUS=reserved)
+    p = [torch.load(os.path.join(tmp_path / "p", f"after_step_native_plan_{r}.pt"), weights_only=True) for r in range(world)]
+    e = [torch.load(os.path.join(tmp_path / "e", f"after_step_native_eager4_{r}.pt"), weights_only=True) for r in range(world)]
+    assert p[0]["direct"] and p[0]["last_kind"] == "plan" and p[0]["plan_segments"] >= 2
+    for r in range(1, world):
+        for k in p[0]["sd"]:
+            assert float((p[0]["sd"][k] - p[r]["sd"][k]).abs().max()) < 1e-7, f"{k}: replicas diverged"
+    for k in p[0]["sd"]:
+        scale = float(e[0]["sd"][k].abs().max()) or 1.0
+        assert float((p[0]["sd"][k] - e[0]["sd"][k]).abs().max()) <= 2e-3 * scale + 2e-4, k
+    assert p[0]["losses"] == pytest.approx(e[0]["losses"], rel=1e-3)

@@ -346,8 +346,10 @@ def test_toy_config_plumbing_on_device(golden):
 def test_native_data_parallel_path_on_rccl_single_rank():
     """world_size 1 over the "nccl" (= RCCL) backend: exercises the in-backward async all-reduce / wait / scaled unpack on the
     real device and streams (the 2-rank arithmetic is covered on CPU by tests/test_ddp_gloo.py)."""
+    import os
     import socket
     import torch.distributed as dist
+    from ddpm_torch import _hip
     with socket.socket() as sck:
         sck.bind(("127.0.0.1", 0))
         port = sck.getsockname()[1]
@@ -368,5 +370,43 @@ def test_native_data_parallel_path_on_rccl_single_rank():
         for k, p in m.named_parameters():
             scale = max(float(ref[k].abs().max()), 1e-4)
             assert float((p.grad - ref[k]).abs().max()) <= 1e-4 * scale + 1e-6, k
+        # ... and whole distributed Trainer.steps in the launch-plan form (the all-reduce calls are host callbacks between the plan's
+        # segments), with compute units held back for the communicator: same parameters as the eager form
+        from ddpm_torch import _hip
+        from ddpm_torch.utils import train as train_mod
+        import os
+        finals = {}
+        for form, reserved in ((False, "0"), ("plan", "0"), ("plan", "24")):
+            os.environ["DDPM_DP_RESERVED_CUS"] = reserved
+            was, train_mod._TRAIN_GRAPH = train_mod._TRAIN_GRAPH, form
+            try:
+                torch.manual_seed(21)
+                m2, _ = make(TINY3, dtype=torch.float32)
+                m2.set_process_group()
+                m2.engine()                                     # (the switch is applied when the engine exists)
+                assert int(_hip.lib().ddpm_get_reserved_cus()) == int(reserved)
+                m2.train()
+                dif = ddpm_torch.GaussianDiffusion(ddpm_torch.get_beta_schedule("linear", 1e-4, 0.02, 1000), "eps", "fixed-large", "mse")
+                opt = torch.optim.Adam(m2.parameters(), lr=1e-3)
+                tr = ddpm_torch.Trainer(m2, opt, dif, epochs=1, trainloader=None, sampler=object(), use_ema=True, shape=(3, 16, 16),
+                                        device=torch.device(DEV), distributed=True, rank=0)
+                xs = [(torch.rand(4, 3, 16, 16, generator=torch.Generator().manual_seed(90 + i)) * 2 - 1).to(DEV) for i in range(5)]
+                for i, xb in enumerate(xs):
+                    tr.step(xb, global_steps=i + 1)
+                torch.cuda.synchronize()
+                ds = next(iter(tr._direct.values()))
+                assert ds.last_kind == ("plan" if form == "plan" else "eager")
+                if form == "plan":
+                    assert len(ds.plan.segments) >= 2 and len(ds.plan.callbacks) == len(ds.plan.segments) - 1
+                finals[(form, reserved)] = {k: v.detach().cpu().clone() for k, v in m2.named_parameters()}
+            finally:
+                train_mod._TRAIN_GRAPH = was
+        base = finals[(False, "0")]
+        for key, got in finals.items():
+            for k, v in got.items():
+                scale = float(base[k].abs().max()) or 1.0
+                assert float((v - base[k]).abs().max()) <= 2e-4 * scale + 5 * 1e-3 * 0.3, (key, k)
     finally:
+        os.environ.pop("DDPM_DP_RESERVED_CUS", None)
+        _hip.lib().ddpm_set_reserved_cus(0)
         dist.destroy_process_group()
