@@ -8,7 +8,7 @@ Differences that follow from the platform, not from taste: there is no CPU path 
 ``--distributed`` uses the engine's own data parallelism (``UNet.set_process_group``: gradient all-reduce over RCCL issued
 from inside the hand-written backward) unless ``--ddp-wrapper`` asks for ``DistributedDataParallel``; ``--compute``
 chooses the arithmetic (bf16 throughput mode or exact-fp32 MFMA); images come from a tensor file or synthetic data
-(``ddpm_torch/datasets.py``); ``--eval`` is refused (no FID network here).
+(``ddpm_torch/datasets.py``); ``--eval`` scores FID through ``ddpm_torch.metrics`` when a feature network is provisioned (``DDPM_TORCH_AMD_INCEPTION`` = TorchScript file, ``precomputed/fid_stats_<dataset>.npz``) and is refused otherwise.
 """
 import argparse
 import json

@@ -69,3 +69,43 @@ def load():
         for k, v in saved.items():
             if v is not None:
                 sys.modules[k] = v
+
+
+def load_metrics():
+    """The reference's evaluation arithmetic (``ddpm_torch/metrics/fid_score.py``, ``precision_recall.py``) for fixture G15.  Those modules
+    import torchvision and the Inception wrapper at module level; both are stubbed (nothing of them is called: the fixture drives the
+    statistics merge, the Fréchet distance and the manifold functions with synthetic features)."""
+    if not available():
+        raise RuntimeError("reference not mounted at " + REFERENCE_ROOT)
+    pkg_dir = os.path.join(REFERENCE_ROOT, "ddpm_torch")
+    saved = {k: sys.modules.get(k) for k in list(sys.modules) if k.startswith(("ddpm_torch", "torchvision"))}
+    for k in saved:
+        sys.modules.pop(k, None)
+    try:
+        def stub(name, path=None):
+            m = types.ModuleType(name)
+            if path:
+                m.__path__ = [path]
+            sys.modules[name] = m
+            return m
+
+        stub("ddpm_torch", pkg_dir)
+        stub("ddpm_torch.metrics", os.path.join(pkg_dir, "metrics"))
+        inc = stub("ddpm_torch.metrics.inception")
+        inc.InceptionV3 = type("InceptionV3", (), {"BLOCK_INDEX_BY_DIM": {2048: 3}})
+        tv = stub("torchvision")
+        tf = stub("torchvision.transforms")
+        tv.transforms = tf
+        for name in ("Compose", "Resize", "Normalize", "ToTensor"):
+            setattr(tf, name, type(name, (), {"__init__": lambda self, *a, **k: None}))
+        tf.InterpolationMode = types.SimpleNamespace(BILINEAR="bilinear")
+        ns = types.SimpleNamespace()
+        ns.fid_score = importlib.import_module("ddpm_torch.metrics.fid_score")
+        ns.precision_recall = importlib.import_module("ddpm_torch.metrics.precision_recall")
+        return ns
+    finally:
+        for k in [k for k in sys.modules if k.startswith(("ddpm_torch", "torchvision"))]:
+            sys.modules.pop(k, None)
+        for k, v in saved.items():
+            if v is not None:
+                sys.modules[k] = v

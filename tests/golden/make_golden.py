@@ -497,9 +497,79 @@ def g13_config5_and_4_at_their_batches():
     save("g13_config5_config4.pt", out)
 
 
+def g14_config4_ddim50_at_its_batch():
+    """BASELINE config 4 AT ITS BATCH: configs/celeba.json at 64 x 64, the 50-step eta = 0 DDIM chain (ddim.py:96-113 on top of
+    diffusion.py:160-174) for B = 128 samples at once — the geometry at which the product serves the chain from its large-grid kernels
+    (G10 pins the same chain at B = 1, where the small-grid kernels run).  From the imported reference on its CPU noise stream; the result
+    travels as an 8 x 8-strided sample of every image + per-image fp64 sums.  50 x 128 forwards of 46.7 GFLOP: ~45 minutes on 6 cores."""
+    B = 128
+    torch.set_num_threads(int(os.environ.get("G14_THREADS", "6")))      # (the other fixtures are written single-threaded; this one is 300 TFLOP)
+    m2, mc2 = _shipped_model("celeba", 4321, 63)
+    betas = ref.get_beta_schedule("linear", 1e-4, 0.02, 1000)
+    base = ref.GaussianDiffusion(betas, "eps", "fixed-small", "mse")
+    ddim = ref.DDIM.from_ddpm(base, eta=0.0, subsequence=ref.get_selection_schedule("linear", 50, 1000))
+    shape = (B, 3, 64, 64)
+    with torch.no_grad():
+        x0 = ddim.p_sample(m2, shape=shape, device=torch.device("cpu"), seed=141)
+    out = dict(cfg=mc2, init_seed=4321, rand_seed=63, B=B, seed=141, shape=shape, steps=50, x0_sub=x0[:, :, ::8, ::8].clone(),
+               x0_sum=x0.double().sum((1, 2, 3)), x0_abs=x0.double().abs().sum((1, 2, 3)), x0_absmax=float(x0.abs().max()),
+               x0_first=x0[0].clone())
+    save("g14_config4_ddim50_b128.pt", out)
+
+
+def g15_metrics():
+    """The evaluation arithmetic from the reference's own functions on synthetic features:
+    * `InceptionStatistics.forward` / `get_statistics` (metrics/fid_score.py:109-139) fed through an identity "network" in three unequal
+      batches; `calculate_frechet_distance` (:264-316) between two such statistics;
+    * `ManifoldBuilder.compute_kth` (metrics/precision_recall.py:159-168) and `calc_pr` (:177-206) on two feature clouds.
+    The feature networks themselves (pretrained Inception-v3 / VGG-16) cannot be fetched here; everything around them is pinned."""
+    import numpy as np
+    rm = LR.load_metrics()
+    from tests.golden.recipes import g15_inputs
+    D = 48
+    gen, real = g15_inputs(D, 151)
+
+    def stats(x, sizes):
+        st = object.__new__(rm.fid_score.InceptionStatistics)          # (its __init__ loads the pretrained network)
+        st.input_transform = lambda v: v
+        st.activation_dim = D
+        st.model = lambda v: v
+        st.running_mean = np.zeros((D,), dtype=np.float64)
+        st.running_var = np.zeros((D, D), dtype=np.float64)
+        st.count = 0
+        o = 0
+        for n in sizes:
+            st.forward(x[o:o + n].reshape(n, D, 1, 1))
+            o += n
+        assert o == x.shape[0]
+        return st.get_statistics()
+    mu_g, cov_g = stats(gen, (256, 256, 188))
+    mu_r, cov_r = stats(real, (100, 500, 300))
+    fd = rm.fid_score.calc_fd(mu_g, cov_g, mu_r, cov_r)
+    fd_self = rm.fid_score.calc_fd(mu_g, cov_g, mu_g, cov_g)
+    pr = rm.precision_recall
+    fa, fb = gen[:400].contiguous(), real[:500].contiguous() * 0.9
+
+    def kth_of(f, k):
+        b = object.__new__(pr.ManifoldBuilder)                          # (its __init__ casts to fp16, which torch.cdist lacks on the host)
+        b.nhood_size, b.row_batch_size, b.col_batch_size, b.op_device = k, 128, 200, torch.device("cpu")
+        return b.compute_kth(f)
+    ka, kb = kth_of(fa, 3), kth_of(fb, 3)
+    precision, recall = pr.calc_pr(pr.Manifold(fa, ka), pr.Manifold(fb, kb), row_batch_size=128, col_batch_size=200, device=torch.device("cpu"))
+    k5 = kth_of(fa, 5)
+    out = dict(D=D, seed=151, gen_sum=gen.double().sum(), real_sum=real.double().sum(), gen_batches=(256, 256, 188), real_batches=(100, 500, 300),
+               mu_g=torch.from_numpy(mu_g), cov_g=torch.from_numpy(cov_g), mu_r=torch.from_numpy(mu_r), cov_r=torch.from_numpy(cov_r),
+               fd=float(fd), fd_self=float(fd_self), kth_a=ka, kth_b=kb, kth_a5=k5,
+               precision=float(precision), recall=float(recall),
+               to_uint8_in=torch.linspace(-1.2, 1.2, 41), to_uint8_out=pr.to_uint8(torch.linspace(-1.2, 1.2, 41)))
+    print("G15: fd", fd, "fd_self", fd_self, "precision", float(precision), "recall", float(recall))
+    save("g15_metrics.pt", out)
+
+
 if __name__ == "__main__":
     import sys
     ALL = dict(g1=g1_ops, g2=g2_blocks, g3=g3_model, g4=g4_tables, g5=g5_steps, g6=g6_loops, g7=g7_train, g8=g8_toy, g9=g9_train_lr, g10=g10_config2,
-               g11=g11_config2_bench_batch, g12=g12_config2_train_steps, g13=g13_config5_and_4_at_their_batches)
+               g11=g11_config2_bench_batch, g12=g12_config2_train_steps, g13=g13_config5_and_4_at_their_batches,
+               g14=g14_config4_ddim50_at_its_batch, g15=g15_metrics)
     for name in (sys.argv[1:] or list(ALL)):          # `make_golden.py g9` regenerates one fixture, no argument = all
         ALL[name]()

@@ -82,3 +82,12 @@ def check_state(actual, expected, tol, name, adam_slack=0.0):
         assert int(bad.sum()) <= 0.02 * bad.numel() * (adam_slack > 0), f"{name}.{k}: {int(bad.sum())}/{bad.numel()} elements beyond {tol:g}"
 
 
+
+
+def g15_inputs(D=48, seed=151):
+    """Synthetic feature clouds of fixture G15 (evaluation arithmetic): recreated from the seed on both sides instead of being committed."""
+    g = torch.Generator().manual_seed(seed)
+    mix = torch.randn(D, D, generator=g) / D ** 0.5
+    gen = torch.randn(700, D, generator=g) @ mix + 0.3
+    real = torch.randn(900, D, generator=g) @ (mix * 1.1) + torch.linspace(-0.2, 0.4, D)
+    return gen, real

@@ -82,12 +82,37 @@ def test_train_then_generate_round_trip(emu, workdir):
     assert len(glob.glob(os.path.join(out2, "*.png"))) == 1
 
 
-def test_eval_flag_is_refused_loudly(emu, workdir):
+def test_eval_flag_without_a_feature_network_is_refused_loudly(emu, workdir, monkeypatch):
     tmp, cfg = workdir
     train = _import_cli("train")
-    with pytest.raises(NotImplementedError, match="FID"):
+    monkeypatch.delenv("DDPM_TORCH_AMD_INCEPTION", raising=False)
+    with pytest.raises(RuntimeError, match="feature network"):
         train.main(["--config-path", cfg, "--train-device", "cpu", "--dry-run", "--num-samples", "0", "--eval", "--num-workers", "0",
                     "--chkpt-dir", str(tmp / "c"), "--image-dir", str(tmp / "i")])
+
+
+def test_eval_flag_scores_fid_with_a_provisioned_feature_network(emu, workdir, monkeypatch):
+    """--eval as the reference wires it (train.py:204-211, utils/train.py:225-226): the Evaluator samples eval_total_size images through
+    the trainer's sample_fn and the FID lands in the checkpoint.  The feature network is a TorchScript file named by
+    DDPM_TORCH_AMD_INCEPTION (here a toy stand-in with the 2048-wide output of the real one) and the dataset statistics come from
+    precomputed/fid_stats_cifar10_train.npz, the file the reference would download."""
+    import numpy as np
+    tmp, cfg = workdir
+
+    class Head(torch.nn.Module):
+        def forward(self, x):
+            return x.mean(dim=(2, 3)).repeat(1, 683)[:, :2048]
+
+    torch.jit.script(Head()).save(str(tmp / "head.pt"))
+    monkeypatch.setenv("DDPM_TORCH_AMD_INCEPTION", str(tmp / "head.pt"))
+    os.makedirs(tmp / "precomputed")
+    np.savez(tmp / "precomputed" / "fid_stats_cifar10_train.npz", mu=np.zeros(2048), sigma=np.eye(2048))
+    train = _import_cli("train")
+    train.main(["--config-path", cfg, "--train-device", "cpu", "--eval-device", "cpu", "--dry-run", "--num-samples", "0", "--eval", "--use-ddim",
+                "--subseq-size", "4", "--eval-total-size", "6", "--eval-batch-size", "4", "--num-workers", "0", "--compute", "fp32",
+                "--chkpt-dir", str(tmp / "c"), "--image-dir", str(tmp / "i")])
+    saved = torch.load(tmp / "c" / "tiny" / "tiny_1.pt", weights_only=False)
+    assert "fid" in saved and saved["fid"] is not None and saved["fid"] > 0 and saved["fid"] == saved["fid"]
 
 
 @pytest.mark.skipif(not os.path.exists("/root/reference/train.py"), reason="the reference checkout only exists in the build container")
