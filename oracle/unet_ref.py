@@ -163,6 +163,17 @@ def group_norm(x, w, b):
     return F.group_norm(x, GN_GROUPS, w, b, eps=GN_EPS)
 
 
+# ---- storage-rounding hooks (error-budget studies only: scripts/bf16_error_budget.py).  The MI355X engine's bf16 mode keeps fp32
+# accumulators and rounds a tensor when it is STORED: "conv" = a convolution's output after its fused epilogue (bias, time bias,
+# residual), "gn" = a GroupNorm(+SiLU) output, "attn" = the attention core's output and its probability tile, "input" = the image.
+# None (the default) leaves the restatement exactly as the reference computes it.
+ROUND = None
+
+
+def _st(kind, x):
+    return x if ROUND is None or kind not in ROUND else ROUND[kind](x)
+
+
 def same_pad_s2(x):
     """modules.py:145-160 for kernel 3, stride 2 (TF SAME)."""
     h, w = x.shape[-2:]
@@ -178,37 +189,37 @@ def attention_core(q, k, v):
     B, C, H, W = q.shape
     qf, kf, vf = (z.reshape(B, C, H * W) for z in (q, k, v))
     logits = torch.einsum("bcq,bck->bqk", qf, kf) / math.sqrt(C)
-    p = torch.softmax(logits, dim=-1)
+    p = _st("attn", torch.softmax(logits, dim=-1))
     out = torch.einsum("bqk,bck->bcq", p, vf)
-    return out.reshape(B, C, H, W)
+    return _st("attn", out.reshape(B, C, H, W))
 
 
 def attention_block(sd, p, x):
     """unet.py:53-60 (skip is Identity: in == out everywhere in the UNet)."""
-    h = group_norm(x, sd[p + "norm.weight"], sd[p + "norm.bias"])
-    qkv = F.conv2d(h, sd[p + "project_in.weight"], sd[p + "project_in.bias"])
+    h = _st("gn", group_norm(x, sd[p + "norm.weight"], sd[p + "norm.bias"]))
+    qkv = _st("conv", F.conv2d(h, sd[p + "project_in.weight"], sd[p + "project_in.bias"]))
     q, k, v = qkv.chunk(3, dim=1)
     h = attention_core(q, k, v)
     h = F.conv2d(h, sd[p + "project_out.weight"], sd[p + "project_out.bias"])
-    return h + x
+    return _st("conv", h + x)
 
 
 def residual_block(sd, p, x, t_emb, drop_p=0.0, training=False, mask=None):
     """unet.py:83-89.  ``mask`` (0/1, shape of the conv2 input) overrides torch's dropout RNG."""
     skip = x
     if p + "skip.weight" in sd:
-        skip = F.conv2d(x, sd[p + "skip.weight"], sd[p + "skip.bias"])
-    h = F.conv2d(F.silu(group_norm(x, sd[p + "norm1.weight"], sd[p + "norm1.bias"])),
+        skip = _st("conv", F.conv2d(x, sd[p + "skip.weight"], sd[p + "skip.bias"]))
+    h = F.conv2d(_st("gn", F.silu(group_norm(x, sd[p + "norm1.weight"], sd[p + "norm1.bias"]))),
                  sd[p + "conv1.weight"], sd[p + "conv1.bias"], padding=1)
-    h = h + F.linear(F.silu(t_emb), sd[p + "fc.weight"], sd[p + "fc.bias"])[:, :, None, None]
-    h = F.silu(group_norm(h, sd[p + "norm2.weight"], sd[p + "norm2.bias"]))
+    h = _st("conv", h + F.linear(F.silu(t_emb), sd[p + "fc.weight"], sd[p + "fc.bias"])[:, :, None, None])
+    h = _st("gn", F.silu(group_norm(h, sd[p + "norm2.weight"], sd[p + "norm2.bias"])))
     if training and drop_p > 0:
         if mask is not None:
             h = h * mask.to(h.dtype) / (1.0 - drop_p)
         else:
             h = F.dropout(h, drop_p, training=True)
     h = F.conv2d(h, sd[p + "conv2.weight"], sd[p + "conv2.bias"], padding=1)
-    return h + skip
+    return _st("conv", h + skip)
 
 
 def _block(sd, p, x, t_emb, attn, **kw):
@@ -247,14 +258,14 @@ def unet_forward(sd, cfg, x, t, training=False, masks=None):
     t_emb = F.linear(t_emb, sd["embed.0.weight"], sd["embed.0.bias"])
     t_emb = F.linear(F.silu(t_emb), sd["embed.2.weight"], sd["embed.2.bias"])
 
-    hs = [F.conv2d(x, sd["in_conv.weight"], sd["in_conv.bias"], padding=1)]
+    hs = [_st("conv", F.conv2d(_st("input", x), sd["in_conv.weight"], sd["in_conv.bias"], padding=1))]
     for i in range(L):
         p = f"downsamples.level_{i}."
         a = c["apply_attn"][i]
         for j in range(n):
             hs.append(_block(sd, p + f"{j}.", hs[-1], t_emb, a, mask=mk(p + f"{j}.", a), **kw))
         if i != L - 1:
-            hs.append(F.conv2d(same_pad_s2(hs[-1]), sd[p + f"{n}.1.weight"], sd[p + f"{n}.1.bias"], stride=2))
+            hs.append(_st("conv", F.conv2d(same_pad_s2(hs[-1]), sd[p + f"{n}.1.weight"], sd[p + f"{n}.1.bias"], stride=2)))
 
     h = residual_block(sd, "middle.0.", hs[-1], t_emb, mask=masks.get("middle.0."), **kw)
     h = attention_block(sd, "middle.1.", h)
@@ -267,9 +278,9 @@ def unet_forward(sd, cfg, x, t, training=False, masks=None):
             h = _block(sd, p + f"{j}.", torch.cat([h, hs.pop()], dim=1), t_emb, a, mask=mk(p + f"{j}.", a), **kw)
         if i != 0:
             h = F.interpolate(h, scale_factor=2, mode="nearest")              # unet.py:199
-            h = F.conv2d(h, sd[p + f"{n + 1}.1.weight"], sd[p + f"{n + 1}.1.bias"], padding=1)
+            h = _st("conv", F.conv2d(h, sd[p + f"{n + 1}.1.weight"], sd[p + f"{n + 1}.1.bias"], padding=1))
     assert not hs
-    h = F.silu(group_norm(h, sd["out_conv.0.weight"], sd["out_conv.0.bias"]))
+    h = _st("gn", F.silu(group_norm(h, sd["out_conv.0.weight"], sd["out_conv.0.bias"])))
     return F.conv2d(h, sd["out_conv.2.weight"], sd["out_conv.2.bias"], padding=1)
 
 

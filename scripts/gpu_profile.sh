@@ -3,7 +3,7 @@
 #   usage: gpu_profile.sh TAG      -> gpurun_out/TAG/{kernel_stats.csv, hbm_traffic.json, mfma_busy.csv, bench_default.json}
 cd "$GRAFT_REPO_ROOT" || exit 1
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${1:-prof}; mkdir -p $O
-export TMPDIR=/tmp DDPM_TORCH_AMD_TRAIN_GRAPH=0
+export TMPDIR=/tmp DDPM_TORCH_AMD_TRAIN_GRAPH=${PROFILE_STEP_FORM:-plan}
 CMD="python $R/bench.py --steps 10 --warmup 3 --sample-steps 0 --no-cpu-baseline --no-extras"
 cd /tmp
 rm -rf /tmp/kt; timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- $CMD > $O/kt.log 2>&1
@@ -11,7 +11,7 @@ cp $(find /tmp/kt -name "*kernel_stats.csv" | head -1) $O/kernel_stats.csv
 rm -rf /tmp/pf /tmp/pw /tmp/pm
 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/pf -- $CMD > $O/pf.log 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/pw -- $CMD > $O/pw.log 2>&1
-python $R/scripts/pmc_traffic.py /tmp/pf /tmp/pw $O/hbm_traffic.json "bench.py --steps 10 --warmup 3 --sample-steps 0 --no-cpu-baseline --no-extras (DDPM_TORCH_AMD_TRAIN_GRAPH=0)"
+python $R/scripts/pmc_traffic.py /tmp/pf /tmp/pw $O/hbm_traffic.json "bench.py --steps 10 --warmup 3 --sample-steps 0 --no-cpu-baseline --no-extras (DDPM_TORCH_AMD_TRAIN_GRAPH=plan: the launch-plan form of the step)"
 timeout 600 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES --kernel-trace --output-format csv -d /tmp/pm -- $CMD > $O/pm.log 2>&1
 python - $O/mfma_busy.csv <<'PY'
 import csv, glob, sys, collections

@@ -183,5 +183,6 @@ def test_three_trainer_steps_at_batch_128_vs_reference_fixture(golden, dtype):
     else:
         # lr 1e-3 from a randomised start is an AMPLIFYING regime (the loss climbs 1.64 -> 2.15 -> 2.84 in the reference too): the bf16 mode's
         # 1e-3 on the first loss grows to a few percent by the third.  Every element stays inside Adam's reach (<= 2 lr per step).
-        assert rel[0] < 5e-3 and rel[1] < 2e-2 and rel[2] < 1.5e-1
+        # Bars = 2 x the measured 9.8e-4 / 3.7e-3 / 6.0e-2 (round 4 and 5 runs; the values are printed above).
+        assert rel[0] < 2e-3 and rel[1] < 7.5e-3 and rel[2] < 1.2e-1
         assert pe[1] <= 2.0 and pe[2] < 5e-2

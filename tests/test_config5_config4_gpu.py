@@ -85,3 +85,40 @@ def test_celeba_64_forward_at_batch_32_vs_reference_fixture(g13, dtype, bar):
     s = float(((yd.double().sum((1, 2, 3)) - rec["y_sum"]).abs() / rec["y_abs"]).max())
     print(f"G13 celeba 64x64 B=32 {dtype}: forward {e:.3e}, per-image sums {s:.3e}")
     assert e < bar
+
+
+# ---------------------------------------------------------------------------------------------- G14: config 4's chain AT ITS BATCH
+def _ddim50_b128(rec, dtype):
+    """configs/celeba.json at 64 x 64, DDIM-50 (eta = 0, linear subsequence; upstream ddim.py:96-113) for 128 samples at once through the
+    graph-replayed sampler, on the reference's CPU noise stream (x_T, then one draw per step — consumed and multiplied by zero)."""
+    import ddim as ddim_mod
+    m = shipped(rec, dtype).eval()
+    shape = tuple(rec["shape"])
+    dd = ddim_mod.DDIM(ddpm_torch.get_beta_schedule("linear", 1e-4, 0.02, 1000), "eps", "fixed-small", "mse", eta=0.0,
+                       subsequence=ddim_mod.get_selection_schedule("linear", rec["steps"], 1000))
+    g = torch.Generator("cpu").manual_seed(rec["seed"])
+    x_T = torch.empty(shape).normal_(generator=g)
+    zs = (torch.empty(shape).normal_(generator=g) for _ in range(rec["steps"]))
+    with torch.inference_mode():
+        x = dd._sample_loop(m, shape, DEV, x_T, None, z_stream=zs)
+    x = x.float().cpu()
+    d = (x[:, :, ::8, ::8] - rec["x0_sub"]).abs() / rec["x0_absmax"]
+    sums = ((x.double().sum((1, 2, 3)) - rec["x0_sum"]).abs() / rec["x0_abs"])
+    first = (x[0] - rec["x0_first"]).abs() / rec["x0_absmax"]
+    return float(d.max()), float(d.mean()), float((d > 5e-2).float().mean()), float(sums.max()), float(first.max())
+
+
+def test_celeba_ddim50_at_batch_128_fp32_vs_reference_fixture(golden):
+    """BASELINE config 4 at its batch: the north-star bar (1e-3 of the range at every compared element) in the fp32 mode."""
+    e_max, e_mean, _, s, f = _ddim50_b128(golden("g14_config4_ddim50_b128.pt"), torch.float32)
+    print(f"G14 celeba 64x64 DDIM-50 B=128 fp32: max {e_max:.3e}, mean {e_mean:.3e}, per-image sums {s:.3e}, image 0 (every pixel) {f:.3e}")
+    assert e_max < 1e-3 and f < 1e-3 and s < 1e-4
+
+
+def test_celeba_ddim50_at_batch_128_bf16_with_stated_bars(golden):
+    """The throughput mode on the same chain.  An eta = 0 DDIM chain is a deterministic map with nothing to forget an error (no fresh
+    noise, 50 compounding steps): bars as for the B = 1 chain of G10 — mean < 3e-2 of the range, at most 10 % of the compared elements
+    further than 5e-2 off.  The measured values are printed."""
+    e_max, e_mean, frac, s, f = _ddim50_b128(golden("g14_config4_ddim50_b128.pt"), torch.bfloat16)
+    print(f"G14 celeba 64x64 DDIM-50 B=128 bf16: max {e_max:.3e}, mean {e_mean:.3e}, share beyond 5e-2: {frac:.3%}, per-image sums {s:.3e}")
+    assert e_mean < 3e-2 and frac < 0.10
