@@ -258,7 +258,7 @@ _WGRAD_MINSTEPS = int(os.environ.get("DDPM_WGRAD_MINSTEPS", "20"))
 _WGRAD_SLABS = os.environ.get("DDPM_WGRAD_SLABS", "0") != "0"      # deterministic slab reduction instead of atomics
 _WGRAD3 = os.environ.get("DDPM_WGRAD3", "1") != "0"                # patch-stationary kernel for the 3x3 / stride-1 weight gradients
 _WGRAD3_UP = os.environ.get("DDPM_WGRAD3_UP", "1") != "0"          # ... also for the Upsample blocks' conv (nearest-2x gather folded into the halo loads)
-_SLAB_FLUSH_ROWS = int(os.environ.get("DDPM_SLAB_FLUSH_ROWS", "6"))   # slab reductions queued on the side stream every so many rows
+_SLAB_FLUSH_ROWS = int(os.environ.get("DDPM_SLAB_FLUSH_ROWS", "3"))   # slab reductions queued on the side stream every so many rows
 _WGRAD1 = os.environ.get("DDPM_WGRAD1", "1") != "0"                # slab kernel for the 1x1 weight gradients
 _WGRAD3_ATOMIC = os.environ.get("DDPM_WGRAD3_ATOMIC", "0") != "0"  # ... with fp32 atomics instead of slab copies
 

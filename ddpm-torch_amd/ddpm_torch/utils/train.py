@@ -462,6 +462,11 @@ class _DirectStep:
     def _decide(self):
         best = min(self.times.values())
         self.choice = next(f for f in self.FORMS if f in self.times and self.times[f] <= 1.02 * best)
+        # the forms that lost own a private allocator pool with a full set of the step's activations each: give that memory back
+        if self.choice != "graph":
+            self.graph = None
+        if self.choice != "plan":
+            self.plan = None
 
     def _wants_graph(self):
         return self._form() == "graph"

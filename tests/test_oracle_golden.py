@@ -245,6 +245,26 @@ def test_g10_config2_forward_and_short_chain(golden):
         check(x, r["x_0"], 2e-4, name="g10.ddpm40")
 
 
+def test_g14_oracle_ddim50_chain_of_config4_first_samples(golden):
+    """The oracle on BASELINE config 4's chain (configs/celeba.json at 64 x 64, DDIM-50, eta = 0) against fixture G14, which the reference
+    wrote at B = 128: eval-mode samples are independent, so the first TWO samples of the batch — x_T drawn for the whole batch, as the
+    reference does — must come out the same (all 128 are compared on the GPU side: tests/test_config5_config4_gpu.py)."""
+    g = golden("g14_config4_ddim50_b128.pt")
+    torch.manual_seed(g["init_seed"])
+    sd = U.randomize_state_dict(U.init_state_dict(g["cfg"]), g["rand_seed"])
+    fn = lambda x, t: U.unet_forward(sd, g["cfg"], x, t)
+    shape, n = tuple(g["shape"]), 2
+    gen = torch.Generator("cpu").manual_seed(g["seed"])
+    x_T = torch.empty(shape).normal_(generator=gen)[:n].clone()
+    sub = D.selection_schedule("linear", g["steps"], 1000)
+    T = D.ddim_tables(D.beta_schedule("linear", 1e-4, 0.02, 1000), "fixed-small", 0.0, sub)
+    with torch.no_grad():
+        x = D.sample_loop(T, fn, x_T, [torch.zeros_like(x_T)] * g["steps"], timestep_map=sub)     # (eta = 0: the per-step draws are multiplied by zero)
+    assert float((x[0] - g["x0_first"]).abs().max()) <= 2e-4 * g["x0_absmax"]
+    assert float((x[:, :, ::8, ::8] - g["x0_sub"][:n]).abs().max()) <= 2e-4 * g["x0_absmax"]
+    assert float(((x.double().sum((1, 2, 3)) - g["x0_sum"][:n]).abs() / g["x0_abs"][:n]).max()) < 1e-5
+
+
 def test_g11_oracle_forward_and_gradients_at_the_bench_batch(golden):
     """The oracle at the benchmark's batch (configs/cifar10.json, B = 128, eval mode) against the reference's forward and a sample of its
     parameter gradients (fixture G11; the GPU side checks every gradient tensor: tests/test_config2_bench_batch_gpu.py)."""
