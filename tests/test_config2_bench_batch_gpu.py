@@ -139,11 +139,14 @@ def _state_errors(actual, dg, lr_steps):
     return beyond / total, worst_lr, worst_sum
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_three_trainer_steps_at_batch_128_vs_reference_fixture(golden, dtype):
+@pytest.mark.parametrize("dtype,form", [(torch.float32, False), (torch.bfloat16, False), (torch.float32, "plan"), (torch.bfloat16, "plan")])
+def test_three_trainer_steps_at_batch_128_vs_reference_fixture(golden, monkeypatch, dtype, form):
     """utils/train.py:148-170 + EMA :300-305 by the reference's own Trainer (fixture G12) vs `ddpm_torch.Trainer.step` — the direct step with
     its side stream, slab reductions, fused clip + Adam + EMA — on the configs/cifar10.json network at B = 128, dropout 0, lr 1e-3 without
-    warm-up (losses 2 and 3 depend on the weights written by the steps before), same CPU (t, noise) stream."""
+    warm-up (losses 2 and 3 depend on the weights written by the steps before), same CPU (t, noise) stream.  form "plan": step 2 records the
+    launch plan, step 3 is a replay by csrc/plan.hip (the form the benchmark runs); form False: eager launches."""
+    from ddpm_torch.utils import train as train_mod
+    monkeypatch.setattr(train_mod, "_TRAIN_GRAPH", form)
     g = golden("g12_config2_train_b128.pt")
     torch.manual_seed(g["init_seed"])
     m = ddpm_torch.UNet(**g["cfg"])
@@ -168,12 +171,14 @@ def test_three_trainer_steps_at_batch_128_vs_reference_fixture(golden, dtype):
         tr.step(x, global_steps=i + 1)
         losses.append(tr.current_stats["loss"])
     torch.cuda.synchronize()
+    ds = next(iter(tr._direct.values()))
+    assert ds.last_kind == ("plan" if form == "plan" else "eager")
     losses = torch.tensor(losses, dtype=torch.float64)
     rel = ((losses - g["losses"]).abs() / g["losses"]).tolist()
     steps = len(g["x_seeds"])
     pe = _state_errors({k: v.detach() for k, v in m.named_parameters()}, g["params"], g["lr"] * steps)
     se = _state_errors({k: tr.ema.shadow[k].detach() for k in g["shadow"]["names"]}, g["shadow"], g["lr"] * steps)
-    print(f"G12 {dtype} B=128: losses {[round(v, 5) for v in losses.tolist()]} vs {[round(v, 5) for v in g['losses'].tolist()]} (rel {['%.1e' % v for v in rel]}); "
+    print(f"G12 {dtype} B=128 {'launch plan' if form else 'eager'}: losses {[round(v, 5) for v in losses.tolist()]} vs {[round(v, 5) for v in g['losses'].tolist()]} (rel {['%.1e' % v for v in rel]}); "
           f"parameters: {pe[0]:.2%} of the sampled entries beyond 1e-3, worst {pe[1]:.2f} x lr x steps, sums {pe[2]:.1e}; EMA shadow: {se[0]:.2%}, {se[1]:.3f}, {se[2]:.1e}")
     assert tr.ema.num_updates == g["num_updates"]
     if dtype == torch.float32:

@@ -127,15 +127,17 @@ def _reference_stream(g):
     return fill
 
 
-@pytest.mark.parametrize("path", ["direct", "autograd"])
+@pytest.mark.parametrize("path", ["direct", "plan", "autograd"])
 def test_steps_that_move_the_weights_vs_reference_fixture(golden, monkeypatch, path):
     """G9 on the GPU (fp32 mode): lr 3e-3 without warm-up — losses after the first step depend on every derived weight copy
-    being re-derived from the updated parameters."""
+    being re-derived from the updated parameters.  "plan": the same six steps with the direct step recorded as a launch plan at step 2
+    and replayed by csrc/plan.hip from step 3 on (the learning rate changes at step 4: read from the device block)."""
     g = golden("g9_train_lr.pt")
-    monkeypatch.setenv("DDPM_TORCH_AMD_DIRECT_STEP", "1" if path == "direct" else "0")
+    monkeypatch.setenv("DDPM_TORCH_AMD_DIRECT_STEP", "0" if path == "autograd" else "1")
+    monkeypatch.setattr(train_mod, "_TRAIN_GRAPH", "plan" if path == "plan" else False)
     m, opt, sched, tr = _g9_trainer(g)
     fill = _reference_stream(g)
-    if path == "direct":
+    if path != "autograd":
         tr.input_source = fill
     else:
         def get_input(x):
@@ -148,6 +150,9 @@ def test_steps_that_move_the_weights_vs_reference_fixture(golden, monkeypatch, p
         tr.stats.reset()
         tr.step(x, global_steps=i + 1)
         losses.append(tr.current_stats["loss"])
+    if path == "plan":
+        ds = next(iter(tr._direct.values()))
+        assert ds.plan is not None and ds.last_kind == "plan" and ds.captures == 1
     print(path, losses)
     assert torch.allclose(torch.tensor(losses, dtype=torch.float64), g["losses"], rtol=1e-3), (losses, g["losses"])
     slack = 0.25 * g["lr"] * len(g["xs"])
