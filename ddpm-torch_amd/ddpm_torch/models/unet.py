@@ -561,14 +561,52 @@ class _Engine:
                 off += (n + 3) // 4 * 4
                 return self.poff[key]
 
-            for cw in self.convs.values():
+            # ---- conv weights in execution order, cut into the all-reduce chunks of the native data-parallel path as they are laid out:
+            # a chunk = a run of conv weights + the rows of the time-projection gradient d(fc.weight) of the residual blocks whose conv1
+            # lies in it (contiguous columns of the concatenated projection: ONE product per chunk).  Chunks become final one after another
+            # as the backward walks the network in reverse; the chunk holding the network's FIRST layers is final LAST (the backward ends at
+            # in_conv) and whatever travels after the backward has ended is exposed, so the first two chunks in execution order are capped
+            # at 1/16 and 1/4 of the target (round 5; uniform chunks put 23 MB of the CIFAR net and 80 MB of the CelebA-HQ net — deep-
+            # encoder weights that had been final for milliseconds — behind in_conv's gradient: profiles/r05_dp_one_rank.json), and the
+            # 10-18 MB of d(fc.weight), which round 4 produced in one piece after the backward, travel with the chunks.
+            # ~6 chunks of ~24 MB for the CIFAR / CelebA nets (143 MB of gradients); DDPM_DP_CHUNK_MB overrides the chunk size — xGMI rings
+            # are per-link bound, so the right size is a property of the node and is to be swept there (bench.py prints config.dp);
+            # DDPM_DP_CHUNK_RAMP=0: uniform chunks.
+            E = self.E
+            convs = list(self.convs.values())
+            conv_floats = sum((cw.mod.weight.numel() + 3) // 4 * 4 for cw in convs) + self.tb_total * E
+            target = max(conv_floats // 6, 1 << 20)
+            if os.environ.get("DDPM_DP_CHUNK_MB"):
+                target = max(int(float(os.environ["DDPM_DP_CHUNK_MB"]) * (1 << 18)), 1 << 16)
+            ramp = [16, 4] if os.environ.get("DDPM_DP_CHUNK_RAMP", "1") != "0" else []
+            rb_of_conv1 = {id(rb.conv1): rb for rb in self.res_blocks}
+            self.chunks, self.chunk_fc, start, members, blocks = [], [], 0, [], []
+            for i, cw in enumerate(convs):
                 w = cw.mod.weight
                 rows.append([slot(id(w), w.numel()), self.goff[id(w)], cw.N, cw.C, cw.R * cw.R])
-            E = self.E
-            fw, fb = slot("fc_w", self.tb_total * E), slot("fc_b", self.tb_total)
+                members.append(id(w))
+                if id(cw.mod) in rb_of_conv1:
+                    blocks.append(rb_of_conv1[id(cw.mod)])
+                k = len(self.chunks)
+                limit = max(target // ramp[k], 1 << 16) if k < len(ramp) else target
+                pending_fc = sum(rb.out_channels for rb in blocks) * E
+                if off + pending_fc - start >= limit or i + 1 == len(convs):
+                    fc = None
+                    if blocks:                                   # rows [o0, o0 + n) of the concatenated projection, stored at fbase
+                        o0, n = self.tb_off[id(blocks[0])], sum(rb.out_channels for rb in blocks)
+                        assert all(self.tb_off[id(rb)] == o0 + sum(q.out_channels for q in blocks[:j]) for j, rb in enumerate(blocks))
+                        fbase = slot(("fc_w", k), n * E)
+                        for rb in blocks:
+                            rows.append([fbase + (self.tb_off[id(rb)] - o0) * E, self.goff[id(rb.fc.weight)], 1, rb.out_channels * E, 1])
+                        fc = (o0, n, fbase)
+                        members.append(("fc_w", k))
+                    self.chunks.append((start, off, members))
+                    self.chunk_fc.append(fc)
+                    start, members, blocks = off, [], []
+            conv_end = off
+            fb = slot("fc_b", self.tb_total)
             for rb in self.res_blocks:
                 o, c = self.tb_off[id(rb)], rb.out_channels
-                rows.append([fw + o * E, self.goff[id(rb.fc.weight)], 1, c * E, 1])
                 rows.append([fb + o, self.goff[id(rb.fc.bias)], 1, c, 1])
                 rows.append([fb + o, self.goff[id(rb.conv1.bias)], 1, c, 1])
                 if rb.has_skip:
@@ -585,22 +623,6 @@ class _Engine:
                     rows.append([slot(id(prm), prm.numel()), self.goff[id(prm)], 1, prm.numel(), 1])
             self.ptotal = off
             self.wdesc = torch.tensor(rows, dtype=torch.int64, device=self.device)
-            # all-reduce plan for the native data-parallel path: the conv-weight region (execution order) in chunks that
-            # become final one after another as the backward walks the network in reverse; the small tail goes last.
-            convs = list(self.convs.values())
-            conv_end = self.poff[id(convs[-1].mod.weight)] + (convs[-1].mod.weight.numel() + 3) // 4 * 4
-            # ~6 chunks of ~24 MB for the CIFAR / CelebA nets (143 MB of gradients); DDPM_DP_CHUNK_MB overrides the chunk size — xGMI rings
-            # are per-link bound, so the right size is a property of the node and is to be swept there (bench.py prints config.dp)
-            target = max(conv_end // 6, 1 << 20)
-            if os.environ.get("DDPM_DP_CHUNK_MB"):
-                target = max(int(float(os.environ["DDPM_DP_CHUNK_MB"]) * (1 << 18)), 1 << 16)
-            self.chunks, start, members = [], 0, []
-            for i, cw in enumerate(convs):
-                members.append(id(cw.mod.weight))
-                end = self.poff[id(convs[i + 1].mod.weight)] if i + 1 < len(convs) else conv_end
-                if end - start >= target or i + 1 == len(convs):
-                    self.chunks.append((start, end, members))
-                    start, members = end, []
             self.tail = (conv_end, self.ptotal)
         return self.wdesc
 
@@ -711,13 +733,29 @@ class _Engine:
         if ctx.get("pending") is not None:
             for ch in ctx["pending"]:
                 ch[2].discard(id(weight))
-            while ctx["pending"] and not ctx["pending"][-1][2]:
-                a, b, _ = ctx["pending"].pop()
+            while ctx["pending"]:
+                a, b, mem, k = ctx["pending"][-1]
+                if mem - {("fc_w", k)}:
+                    break                                    # conv gradients of this chunk are still to come
+                if ("fc_w", k) in mem:                       # its residual blocks are through their backward: their time-projection rows
+                    self._fc_wgrad(ctx, k)
+                ctx["pending"].pop()
                 self._flush_slabs(ctx)                       # the chunk's conv gradients must be summed before they travel
                 self._join_side(ctx)                         # ... and produced: the communicator orders itself after the main stream
                 works, chunk = ctx["works"], ctx["gpack"][a:b]
                 self._comm(ctx, lambda works=works, chunk=chunk: works.append(self._all_reduce(chunk)))
         return did_bias
+
+    def _fc_wgrad(self, ctx, k):
+        """d(fc.weight) of the residual blocks of chunk k: rows [o0, o0 + n) of dW = dtb^T s_t (all of them one product: the blocks'
+        columns of the concatenated projection are contiguous), into the chunk's own region of the staging buffer.  A leaf."""
+        if self.chunk_fc[k] is None:
+            return
+        o0, n, fbase = self.chunk_fc[k]
+        dtb, s_t, E, Ct = ctx["dtb"], ctx["s_t"], self.E, self.tb_total
+        with self._leaf(ctx, dtb, s_t):
+            ops.gemm(dtb.data_ptr() + 4 * o0, Ct, 0, 1, s_t.data_ptr(), E, 0, 1, ctx["gpack"].data_ptr() + 4 * fbase, E, 0, n, E, ctx["B"],
+                     _hip.F32, out_mode=1)
 
     def _flush_slabs(self, ctx, on_side=False):
         """Sum the slab copies recorded since the last flush into the staging buffer (one launch).  ``on_side``: queue it on the side
@@ -1019,7 +1057,7 @@ class _Engine:
         gpack = self._gpack
         _hip.call("ddpm_fill_zero", gpack.data_ptr(), gpack.numel() * 4, _hip.stream())
         # persistent (stable addresses for the slab-reduce tables): packed conv weight grads [N][RS][C] + tail
-        ctx = dict(gflat=gflat, gpack=gpack, ws=ws, B=B, dtb=dtb, pending=None, works=self._works, slab_rows=[], side=None, keep=[], cut=cut,
+        ctx = dict(gflat=gflat, gpack=gpack, ws=ws, B=B, dtb=dtb, s_t=st["temb_saved"][4], pending=None, works=self._works, slab_rows=[], side=None, keep=[], cut=cut,
                    seed_dev=st.get("seed_dev", 0), world=1, sumsq=0)
         if _SIDE_STREAM and gflat.is_cuda:
             if self._side is None:
@@ -1036,7 +1074,7 @@ class _Engine:
             import torch.distributed as dist
             ctx["world"] = dist.get_world_size(self.pg)
             # chunks in execution order; the backward finishes them from the last one backwards
-            ctx["pending"] = [(a, b, set(mem)) for a, b, mem in self.chunks]
+            ctx["pending"] = [(a, b, set(mem), k) for k, (a, b, mem) in enumerate(self.chunks)]
         return ctx
 
     def _close_backward(self, ctx, st):
@@ -1251,8 +1289,10 @@ class _Engine:
         # unpack table fans out to every fc.weight / fc.bias / conv1.bias.
         # (parameter gradients are leaves: on the side stream, next to the chain d(s_t) -> d(t_emb) -> d(s1) -> d(e1) that is the very
         #  end of the backward's critical path)
+        if ctx["pending"] is None:                      # (data-parallel runs produced these rows chunk by chunk, inside the backward)
+            for k in range(len(self.chunks)):
+                self._fc_wgrad(ctx, k)
         with self._leaf(ctx, dtb, s_t):
-            ops.gemm(dtb.data_ptr(), Ct, 0, 1, s_t.data_ptr(), E, 0, 1, self._pptr(ctx, "fc_w"), E, 0, Ct, E, B, F, out_mode=1)
             ops.colsum(View(dtb, 1, B, 1, Ct), 0, 0, self._pptr(ctx, "fc_b"))
         # K = sum Cout (~5000): split-K with fp32 atomics (run-to-run summation order) — unless the deterministic-reduction mode is on
         # (DDPM_WGRAD_SLABS=1: bit-reproducible gradients), where this product and the lin2 one below run as single-pass GEMMs

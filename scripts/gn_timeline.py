@@ -5,7 +5,7 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "ddpm-torch_amd")]
 import torch
 from ddpm_torch import _hip, _ops as ops
 from ddpm_torch._ops import View
-lib = ctypes.CDLL(os.path.join(ROOT, "ddpm-torch_amd", "csrc", "libddpm_hip.so"))
+lib = ctypes.CDLL(_hip.LIB_PATH)          # (DDPM_HIP_LIB selects the instrumented build: scripts/gn_timeline.sh)
 B = 128
 def report(t, names):
     t = t[t[:, 0] > 0]
