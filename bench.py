@@ -452,7 +452,10 @@ def main():
                "config": {"workload": "configs/cifar10.json UNet (35.7M params), full Trainer.step, B=128 per GPU, 32x32, T=1000, dropout 0.1, Adam+clip+EMA",
                           "global_batch": B_PER_GPU * world, "rccl_ranks": ranks_seen, "dp": dp,
                           "parallelism": f"dp{world}" + ("" if world == 1 else (" (native chunked RCCL all-reduce inside backward)" if native else " (torch DDP)")),
-                          "step_execution": step_mode, "step_probe": step_probe, "imgs_per_s_per_gpu": round(imgs_per_s / world, 2),
+                          "step_execution": step_mode, "step_probe": step_probe,
+                          "hbm_gb": {"reserved": round(torch.cuda.memory_reserved() / 2 ** 30, 2), "allocated_peak": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
+                                     "of": 288, "note": "whole bench process at the end of the run (training state + the step form's private pool + the sampler's graphs + the other-configs legs)"},
+                          "imgs_per_s_per_gpu": round(imgs_per_s / world, 2),
                           "train_model_tflops_per_gpu": round(imgs_per_s / world * 3 * FWD_GFLOP["cifar"] / 1e3, 1),
                           "train_model_frac_of_peak": round(imgs_per_s / world * 3 * FWD_GFLOP["cifar"] / 1e3 / peak, 4), "final_loss": round(loss, 4)},
                "roofline": roofline}

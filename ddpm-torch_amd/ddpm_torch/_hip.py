@@ -141,7 +141,7 @@ def record_into(plan):
 def retain(t):
     """Called by the engine for every tensor it allocates: while a plan records, the plan keeps them alive — its entries address them
     by raw pointer (host-emulated runs; on the GPU the recording also runs inside a private allocator pool, see _plan.py)."""
-    if _recorder is not None:
+    if _recorder is not None and _recorder.retains:
         _recorder.keep.append(t)
     return t
 

@@ -53,6 +53,8 @@ class LaunchPlan:
         self.segments = [[]]            # [[(entry point, args), ...], ...]
         self.callbacks = []             # callbacks[i] runs after segment i
         self.keep = []                  # tensors whose addresses the entries hold (see _hip.retain)
+        self.retains = self.device.type != "cuda"     # on the GPU the private pool keeps the memory: holding every tensor alive until the
+                                                       # recording ends would make the pool as large as the SUM of the step's allocations
         self.pool = None
         self._c = None                  # handle of the C-side copy (GPU only)
         self.recorded = False
@@ -83,7 +85,6 @@ class LaunchPlan:
         finally:
             _hip.record_into(prev)
         if on_gpu:
-            self.keep = []                   # the pool holds the memory; no need to pin every activation as a live tensor
             try:
                 self._build_native()
             except Exception as e:           # (the body has run: the step is complete either way)

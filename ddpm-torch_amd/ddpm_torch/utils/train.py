@@ -11,9 +11,11 @@ global-norm clip, Adam step, ``zero_grad(set_to_none)``, LR-schedule step, EMA u
   backward are called back to back, the eps-MSE and its gradient are two kernels, clip + Adam + EMA are two multi-tensor
   launches over a pointer table, and the packed weight copies are re-derived at the end of the step.  All step-dependent
   scalars (learning rate, Adam bias corrections, EMA weight, the per-step part of the dropout seed) are read by the
-  kernels from a small device buffer, so the whole step is shape-static and is **captured once into hipGraphs and
-  replayed** (``_graphs.SegmentedGraph``): ~1000 launches per step become one graph launch (plus one per gradient
-  all-reduce chunk in data-parallel runs: the RCCL calls stay outside the graphs, between segments).
+  kernels from a small device buffer, so the whole step is shape-static.  It runs in one of three forms, chosen by measurement on the
+  box (``DDPM_TORCH_AMD_TRAIN_GRAPH=auto``): eager launches from Python; a **launch plan** (``_plan.LaunchPlan`` / ``csrc/plan.hip``:
+  the step's ~500 C-ABI calls recorded once and re-issued from C on both streams — the eager step without the interpreter; the
+  default wherever it has been measured); or **hipGraphs** (``_graphs.SegmentedGraph``).  In data-parallel runs the RCCL calls stay
+  outside the plan / the graphs, between segments.
 * **autograd step** (anything else: DDP-wrapped or user-wrapped models, gradient accumulation, other optimisers):
   ``loss.backward()`` through the engine's single autograd node, then the fused multi-tensor update when the optimiser
   qualifies, else the plain torch calls.

@@ -260,7 +260,13 @@ def test_graph_replayed_sampler_equals_eager_loop(golden, monkeypatch):
         assert torch.equal(outs["1d"], outs["0d"]), float((outs["1d"] - outs["0d"]).abs().max())
 
 
-def test_trainer_steps_vs_reference_fixture(golden):
+@pytest.mark.parametrize("path", ["autograd", "plan"])
+def test_trainer_steps_vs_reference_fixture(golden, monkeypatch, path):
+    """G7: three steps of the reference's Trainer (Adam + clip + warm-up + EMA).  "autograd": a customised get_input keeps the generic
+    loss.backward() step (the engine behind one autograd node + the fused update); "plan": the direct step with the reference's (t, noise)
+    stream injected, recorded as a launch plan at step 2 and replayed by csrc/plan.hip at step 3."""
+    from ddpm_torch.utils import train as train_mod
+    monkeypatch.setattr(train_mod, "_TRAIN_GRAPH", "plan" if path == "plan" else False)
     g = golden("g7_train.pt")
     torch.manual_seed(g["init_seed"])
     m = ddpm_torch.UNet(**g["cfg"])
@@ -278,13 +284,23 @@ def test_trainer_steps_vs_reference_fixture(golden):
         noise = torch.empty_like(x.cpu()).normal_(generator=gen)
         return {"x_0": x.to(DEV), "t": t.to(DEV), "noise": noise.to(DEV)}
 
-    tr.get_input = get_input
+    def fill(t_buf, noise_buf):
+        t_buf.copy_(torch.empty(t_buf.shape, dtype=torch.int64).random_(to=1000, generator=gen))
+        noise_buf.copy_(torch.empty(noise_buf.shape).normal_(generator=gen))
+
+    if path == "plan":
+        tr.input_source = fill
+    else:
+        tr.get_input = get_input
     m.train()
     losses = []
     for i, x in enumerate(g["xs"]):
         tr.stats.reset()
         tr.step(x, global_steps=i + 1)
         losses.append(tr.current_stats["loss"])
+    if path == "plan":
+        ds = next(iter(tr._direct.values()))
+        assert ds.plan is not None and ds.last_kind == "plan"
     assert torch.allclose(torch.tensor(losses, dtype=torch.float64), g["losses"], rtol=1e-4)
     for k, v in g["params"].items():
         check(m.state_dict()[k], v, 1e-4, name="param." + k)
