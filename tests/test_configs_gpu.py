@@ -165,14 +165,15 @@ def test_steps_that_move_the_weights_vs_reference_fixture(golden, monkeypatch, p
         check(m(x.to(DEV), t.to(DEV)).cpu(), U.unet_forward({k: v.cpu() for k, v in m.state_dict().items()}, g["cfg"], x, t), 1e-3, name="fwd after steps")
 
 
-@pytest.mark.parametrize("cfg_name,dtype", [("tiny3", torch.float32), ("cifar", torch.bfloat16)])
+@pytest.mark.parametrize("cfg_name,dtype", [("tiny3", torch.float32), ("cifar", torch.bfloat16), ("celebahq", torch.bfloat16)])
 def test_captured_training_step_equals_the_eager_step(monkeypatch, cfg_name, dtype):
     """The hipGraph-replayed step and the launch-plan step (the same C-ABI calls re-issued by csrc/plan.hip) consume the generator, the dropout seeds, the LR schedule and the bias corrections exactly
     like the eager direct step: after 6 steps (1 eager + capture / recording + replays) losses / parameters / EMA / Adam state agree
     (tolerance = atomic-order noise of the weight gradients), and the replayed forward sees the updated weights."""
     from tests.test_unet_gpu import TINY3
-    cfg = TINY3 if cfg_name == "tiny3" else CIFAR
-    hw, B = (16, 4) if cfg_name == "tiny3" else (32, 8)
+    cfg = {"tiny3": TINY3, "cifar": CIFAR, "celebahq": CELEBAHQ}[cfg_name]
+    # (celebahq: BASELINE config 5's per-GPU work, 256 x 256 at B = 2 — the two-launch GroupNorm path, K-run small-grid convs, C = 512 attention)
+    hw, B = {"tiny3": (16, 4), "cifar": (32, 8), "celebahq": (256, 2)}[cfg_name]
     runs = []
     for graph in (True, "plan", False):
         monkeypatch.setattr(train_mod, "_TRAIN_GRAPH", graph)
@@ -206,7 +207,7 @@ def test_captured_training_step_equals_the_eager_step(monkeypatch, cfg_name, dty
         tol = 2e-4 if dtype == torch.float32 else 3e-2
         assert a["step"] == b["step"] == 6 and a["lr"] == b["lr"] and a["upd"] == b["upd"] == 5
         assert torch.allclose(torch.tensor(a["losses"]), torch.tensor(b["losses"]), rtol=tol)
-        assert a["losses"][-1] < a["losses"][0]                      # it trains
+        assert cfg_name == "celebahq" or a["losses"][-1] < a["losses"][0]      # it trains (six steps of the 114 M-parameter net need not show it)
         for k in a["params"]:
             scale = float(b["params"][k].abs().max()) or 1.0
             assert float((a["params"][k] - b["params"][k]).abs().max()) <= (tol * scale + 6 * 1e-3 * 0.3), k
