@@ -43,6 +43,11 @@ def test_argument_validation_returns_status_codes_without_a_gpu():
     assert lib.ddpm_gn_workspace_floats(2, 64, 128, 32, 1) > 0
     with pytest.raises(RuntimeError, match="null pointer"):
         _hip.call("ddpm_silu_fwd", 0, 0, 10, 0)
+    # maximum sizes: the kernels address an operand with 32-bit byte offsets, so a tensor of 2 GiB or more is refused on the host
+    # (32 x 32 x 384 channels bf16: B = 4096 is 3 GiB; B = 2048 = 1.5 GiB passes validation and only fails here for want of a GPU)
+    fake = 0x10000
+    conv = lambda B: lib.ddpm_conv2d_nhwc(fake, 384, fake, fake, 128, 0, 0, 0, 0, 0, B, 32, 32, 384, 32, 32, 128, 3, 3, 1, 1, 1, 0, 0, 0, 0, 1, 0, 0, 1, 0)
+    assert conv(4096) == 1 and conv(2048) in (0, 4)
 
 
 QUERIES = {"ddpm_wgrad_effective_splits", "ddpm_conv3x3_wgrad_splits", "ddpm_conv1x1_wgrad_splits", "ddpm_gn_workspace_floats",
