@@ -488,7 +488,7 @@ def main():
             # batch sweep (SURVEY.md §8d "M2: B=128 and a sweep"): 50-step chains (identical per-step work), scaled to 1000 steps
             swdif = ddpm_torch.GaussianDiffusion(ddpm_torch.get_beta_schedule("linear", 1e-4, 0.02, 50), "eps", "fixed-large", "mse")
             sweep = {}
-            for sb in (32, 256, 512):
+            for sb in (32, 256, 512, 2048):            # (2048: the largest power of two whose 384-channel tensors stay under the 2-GiB operand limit; 8 GiB of HBM)
                 w_el = chain(swdif, model, (sb, 3, 32, 32), 4, 50) / 50
                 sweep[str(sb)] = {"ms_per_step": round(w_el * 1e3, 3), "samples_per_s_1000_steps": round(sb / (w_el * 1000), 3)}
             samp["batch_sweep"] = sweep
