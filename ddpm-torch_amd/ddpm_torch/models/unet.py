@@ -1031,6 +1031,11 @@ class _Engine:
             _hip.call("ddpm_attention_fwd_lse", qkv.ptr, qkv.ld, o.ptr, o.ld, lse.data_ptr() if save else 0, B, Lk, C, scale,
                       self.dcode, _hip.stream())
         else:
+            if Lk % self.vec:
+                # (the probability matrix [B][L][L] is an operand of the second product: its rows must be 16-byte multiples.  No shipped
+                #  configuration attends over fewer than 16 tokens; the reference itself has no such limit)
+                raise NotImplementedError(f"attention over {Lk} tokens in the {'bf16' if self.T == torch.bfloat16 else 'fp32'} mode: the token "
+                                          f"count must be a multiple of {self.vec} (use a larger image, or the fp32 mode for multiples of 4)")
             q, kk, v = qkv.ptr, qkv.ptr + C * es, qkv.ptr + 2 * C * es
             logits = self._f32(B, Lk, Lk)                       # S = Q K^T / sqrt(C)   (unet.py:46-48)
             ops.gemm(q, 3 * C, bs, 0, kk, 3 * C, bs, 0, logits.data_ptr(), Lk, Lk * Lk, Lk, Lk, C, self.dcode, batch=B,

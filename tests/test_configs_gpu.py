@@ -425,3 +425,44 @@ def test_training_graph_survives_a_sampling_pass_at_another_batch_size(monkeypat
         tr.step(x, global_steps=i + 1)
     torch.cuda.synchronize()
     assert next(iter(tr._direct.values())).captures == 1 and all(torch.isfinite(p).all() for p in m.parameters())
+
+
+@pytest.mark.parametrize("cfg_name,hw,B", [("cifar", 32, 8), ("celebahq", 128, 2)])
+def test_recorded_step_contains_no_torch_arithmetic_on_the_device(monkeypatch, cfg_name, hw, B):
+    """The launch plan replays what went through the C ABI and nothing else (ddpm_torch/_plan.py): on the device — side stream, bf16 kernels,
+    flash attention, the fused update — the recorded body may issue no ATen operation beyond allocations and views.  (The CPU twin of
+    this test covers the emulated path: tests/test_trainer_host.py.)"""
+    import collections
+    from torch.utils._python_dispatch import TorchDispatchMode
+    monkeypatch.setattr(train_mod, "_TRAIN_GRAPH", "plan")
+    torch.manual_seed(2)
+    m, _ = make({"cifar": CIFAR, "celebahq": CELEBAHQ}[cfg_name], dtype=torch.bfloat16)
+    m.train()
+    dif = ddpm_torch.GaussianDiffusion(ddpm_torch.get_beta_schedule("linear", 1e-4, 0.02, 1000), "eps", "fixed-large", "mse")
+    opt = torch.optim.Adam(m.parameters(), lr=1e-4)
+    tr = ddpm_torch.Trainer(m, opt, dif, epochs=1, trainloader=None, use_ema=True, grad_norm=1.0, shape=(3, hw, hw), device=torch.device(DEV))
+    x = (torch.rand(B, 3, hw, hw, generator=torch.Generator().manual_seed(5)) * 2 - 1).to(DEV)
+    tr.step(x, global_steps=1)
+    ds = next(iter(tr._direct.values()))
+    seen = collections.Counter()
+
+    class Log(TorchDispatchMode):
+        def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+            seen[str(func)] += 1
+            return func(*args, **(kwargs or {}))
+
+    body = ds.body
+
+    def logged(cut=None, draw=True):
+        with Log():
+            return body(cut, draw)
+    ds.body = logged
+    tr.step(x, global_steps=2)                                   # the recording step
+    ds.body = body
+    tr.step(x, global_steps=3)                                   # a replay
+    torch.cuda.synchronize()
+    assert ds.plan is not None and ds.last_kind == "plan" and ds.plan.launches > 300
+    allowed = {"aten.empty.memory_format", "aten.empty_like.default", "aten.empty_strided.default", "aten.select.int", "aten.view.default",
+               "aten.slice.Tensor", "aten.as_strided.default", "aten.detach.default", "aten.alias.default", "aten._unsafe_view.default"}
+    assert set(seen) <= allowed, sorted(set(seen) - allowed)
+    assert all(torch.isfinite(p).all() for p in m.parameters())

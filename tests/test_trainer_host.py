@@ -72,6 +72,44 @@ def test_launch_plan_replays_reproduce_the_reference_steps(emu, golden, monkeypa
         assert torch.equal(a, b), k
 
 
+def test_recorded_step_contains_no_torch_arithmetic(emu, monkeypatch):
+    """A launch plan replays only what went through ``_hip.call``: a torch operation inside the recorded body would run once (at
+    recording) and silently be missing from every replay.  Guard: the body of the direct step is run under a TorchDispatchMode while it
+    is being recorded — the only ATen calls it may make are allocations and views (the (t, noise) draw sits in front of the recorded
+    region; fills and stream edges are C-ABI calls)."""
+    import collections
+    from torch.utils._python_dispatch import TorchDispatchMode
+    monkeypatch.setattr(train_mod, "_TRAIN_GRAPH", "plan")
+    torch.manual_seed(0)
+    m = ddpm_torch.UNet(**dict(TINY, drop_rate=0.1))
+    dif = ddpm_torch.GaussianDiffusion(ddpm_torch.get_beta_schedule("linear", 1e-4, 0.02, 1000), "eps", "fixed-large", "mse")
+    opt = torch.optim.Adam(m.parameters(), lr=2e-4)
+    tr = ddpm_torch.Trainer(m, opt, dif, epochs=1, trainloader=None, use_ema=True, grad_norm=1.0, shape=(3, 8, 8), device=torch.device("cpu"))
+    m.train()
+    x = torch.rand(2, 3, 8, 8) * 2 - 1
+    tr.step(x, global_steps=1)                                   # eager warm-up: lazy tables, slabs, workspaces
+    ds = next(iter(tr._direct.values()))
+    seen = collections.Counter()
+
+    class Log(TorchDispatchMode):
+        def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+            seen[str(func)] += 1
+            return func(*args, **(kwargs or {}))
+
+    monkeypatch.setattr(_hip, "_invoke", lambda name, args: None)     # (the emulator computes with torch: keep it out of the log)
+    body = ds.body
+
+    def logged(cut=None, draw=True):
+        with Log():
+            return body(cut, draw)
+    ds.body = logged
+    tr.step(x, global_steps=2)                                   # the recording step
+    assert ds.plan is not None and ds.plan.launches > 100
+    allowed = {"aten.empty.memory_format", "aten.empty_like.default", "aten.empty_strided.default", "aten.select.int", "aten.view.default",
+               "aten.slice.Tensor", "aten.as_strided.default", "aten.detach.default", "aten.alias.default", "aten._unsafe_view.default"}
+    assert set(seen) <= allowed, sorted(set(seen) - allowed)
+
+
 @pytest.mark.parametrize("direct", [True, False])
 def test_steps_that_move_the_weights_match_the_reference(emu, golden, monkeypatch, direct):
     g = golden("g9_train_lr.pt")
