@@ -672,9 +672,10 @@ class Trainer:
         from ..models.unet import UNet
         m = self.model
         group = self.optimizer.param_groups[0] if self.optimizer.param_groups else None
-        # (the scans below walk ~300 parameters: 0.25 ms per step — done once per (model, engine, optimizer, parameter list, hyper-flags))
+        # (the scans below walk ~300 parameters several times: 0.25 ms per step — done once per (model, engine, optimizer, parameter list,
+        #  number of trainable parameters, hyper-flags))
         key = (id(m), id(getattr(m, "_eng", None)), id(self.optimizer), len(self.optimizer.param_groups), id(group["params"]) if group else 0,
-               len(group["params"]) if group else 0, self.num_accum, type(self.optimizer),
+               len(group["params"]) if group else 0, sum(1 for q in group["params"] if q.requires_grad) if group else 0, self.num_accum, type(self.optimizer),
                tuple(bool(group.get(k)) for k in ("amsgrad", "maximize", "weight_decay", "capturable", "differentiable", "fused")) if group else (),
                "get_input" in self.__dict__, "loss" in self.__dict__, id(self.diffusion), getattr(self.diffusion, "loss_type", None),
                getattr(self.diffusion, "model_mean_type", None))
