@@ -6,5 +6,5 @@ export TMPDIR=/tmp DDPM_TORCH_AMD_TRAIN_GRAPH=${GRAPH:-0}
 cd /tmp; rm -rf /tmp/kt
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- python $R/bench.py --steps 12 --warmup 4 --sample-steps 0 --no-cpu-baseline --no-extras > $O/kt.log 2>&1
 cp $(find /tmp/kt -name "*kernel_stats.csv" | head -1) $O/kernel_stats.csv
-python $R/scripts/step_timeline.py /tmp/kt | tee $O/timeline.txt
+python $R/scripts/step_timeline.py /tmp/kt ${TL_FIRST:-} ${TL_LAST:-} | tee $O/timeline.txt
 python $R/scripts/kstats.py /tmp/kt 18 30 | tee $O/kstats.txt
