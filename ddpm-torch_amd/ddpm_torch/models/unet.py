@@ -259,6 +259,11 @@ _WGRAD_SLABS = os.environ.get("DDPM_WGRAD_SLABS", "0") != "0"      # determinist
 _WGRAD3 = os.environ.get("DDPM_WGRAD3", "1") != "0"                # patch-stationary kernel for the 3x3 / stride-1 weight gradients
 _WGRAD3_UP = os.environ.get("DDPM_WGRAD3_UP", "1") != "0"          # ... also for the Upsample blocks' conv (nearest-2x gather folded into the halo loads)
 _SLAB_FLUSH_ROWS = int(os.environ.get("DDPM_SLAB_FLUSH_ROWS", "3"))   # slab reductions queued on the side stream every so many rows
+# The backward ends at the network's first layers, and the step ends when the side stream has drained: the weight gradients of the LAST
+# residual blocks of the backward (the first in execution order) find the main stream with little left to run — they take the whole chip
+# instead of the usual half (twice the K slices).  0 = off.
+_TAIL_BLOCKS = int(os.environ.get("DDPM_WGRAD3_TAIL_BLOCKS", "0"))
+_ABL_NO_LEAF_ORDER = os.environ.get("DDPM_ABL_NO_LEAF_ORDER", "0") != "0"   # TIMING-ONLY ablation (wrong results): leaves are not ordered behind the main stream
 _WGRAD1 = os.environ.get("DDPM_WGRAD1", "1") != "0"                # slab kernel for the 1x1 weight gradients
 _WGRAD3_ATOMIC = os.environ.get("DDPM_WGRAD3_ATOMIC", "0") != "0"  # ... with fp32 atomics instead of slab copies
 
@@ -638,7 +643,8 @@ class _Engine:
             yield
             return
         ctx["keep"].extend(views)
-        _hip.call("ddpm_stream_order", ctx["side_handle"], ctx["main_handle"])     # inputs are final on the main stream here
+        if not _ABL_NO_LEAF_ORDER:
+            _hip.call("ddpm_stream_order", ctx["side_handle"], ctx["main_handle"])     # inputs are final on the main stream here
         # The kernels take their stream as an argument: routing _hip.stream() to the side stream's handle is all a leaf needs (no
         # torch.cuda.stream() context: two stream switches and several device look-ups per leaf, ~190 leaves per step).  Nothing
         # inside a leaf allocates temporaries (the slab copies are persistent), so the allocator's stream bookkeeping is not involved.
@@ -666,13 +672,18 @@ class _Engine:
         (DDPM_WGRAD_SLABS=1) store slab copies as above."""
         did_bias = False
         patch = 0
+        boost_req = kw.pop("boost", False)
         up = bool(kw.get("upsample"))                    # Upsample block: x stored at half of dy's size, gathered in place by the kernel
         if (_WGRAD3 and self.T == torch.bfloat16 and R == 3 and S == 3 and (not up or (_WGRAD3_UP and dy.H == 2 * x.H and dy.W == 2 * x.W))
                 and kw.get("stride", 1) == 1 and kw.get("pad_t") == 1 and kw.get("pad_l") == 1 and Creal == x.C):
-            pkey = ("w3", x.B, dy.H, dy.W, x.C, dy.C)
+            boost = bool(boost_req)
+            pkey = ("w3", x.B, dy.H, dy.W, x.C, dy.C, boost)
             patch = self._eff_splits.get(pkey)
             if patch is None:
-                patch = self._eff_splits[pkey] = ops.conv3x3_wgrad_splits(x.B, dy.H, dy.W, x.C, dy.C)
+                patch = ops.conv3x3_wgrad_splits(x.B, dy.H, dy.W, x.C, dy.C)
+                if boost and patch:                     # the whole chip instead of half of it (see _TAIL_BLOCKS)
+                    patch = ops.conv3x3_wgrad_splits(x.B, dy.H, dy.W, x.C, dy.C, 2 * patch)
+                self._eff_splits[pkey] = patch
         point = 0
         if (not patch and _WGRAD1 and self.T == torch.bfloat16 and R == 1 and S == 1 and not kw.get("upsample") and kw.get("stride", 1) == 1
                 and not kw.get("pad_t") and not kw.get("pad_l") and Creal == x.C and Nreal == dy.C):
@@ -730,16 +741,18 @@ class _Engine:
                     ctx["slab_rows"].append((slab.data_ptr(), self._pptr(ctx, weight), n, eff, stride))
                 else:
                     ops.conv2d_wgrad(dy, x, self._pptr(ctx, weight), Creal, Nreal, R, S, splits=eff, **kw)
-        if ctx.get("pending") is not None:
-            for ch in ctx["pending"]:
-                ch[2].discard(id(weight))
-            while ctx["pending"]:
-                a, b, mem, k = ctx["pending"][-1]
-                if mem - {("fc_w", k)}:
-                    break                                    # conv gradients of this chunk are still to come
-                if ("fc_w", k) in mem:                       # its residual blocks are through their backward: their time-projection rows
-                    self._fc_wgrad(ctx, k)
-                ctx["pending"].pop()
+        # chunk bookkeeping (also without a process group: a chunk whose convolutions are through their backward gets its time-projection
+        # rows NOW, on the side stream, instead of on the tail of the step)
+        for ch in ctx["pending"]:
+            ch[2].discard(id(weight))
+        while ctx["pending"]:
+            a, b, mem, k = ctx["pending"][-1]
+            if mem - {("fc_w", k)}:
+                break                                        # conv gradients of this chunk are still to come
+            if ("fc_w", k) in mem:                           # its residual blocks are through their backward: their time-projection rows
+                self._fc_wgrad(ctx, k)
+            ctx["pending"].pop()
+            if ctx["dp"]:
                 self._flush_slabs(ctx)                       # the chunk's conv gradients must be summed before they travel
                 self._join_side(ctx)                         # ... and produced: the communicator orders itself after the main stream
                 works, chunk = ctx["works"], ctx["gpack"][a:b]
@@ -1062,7 +1075,7 @@ class _Engine:
         gpack = self._gpack
         _hip.call("ddpm_fill_zero", gpack.data_ptr(), gpack.numel() * 4, _hip.stream())
         # persistent (stable addresses for the slab-reduce tables): packed conv weight grads [N][RS][C] + tail
-        ctx = dict(gflat=gflat, gpack=gpack, ws=ws, B=B, dtb=dtb, s_t=st["temb_saved"][4], pending=None, works=self._works, slab_rows=[], side=None, keep=[], cut=cut,
+        ctx = dict(gflat=gflat, gpack=gpack, ws=ws, B=B, dtb=dtb, s_t=st["temb_saved"][4], pending=None, dp=self.pg is not None, works=self._works, slab_rows=[], side=None, keep=[], cut=cut,
                    seed_dev=st.get("seed_dev", 0), world=1, sumsq=0)
         if _SIDE_STREAM and gflat.is_cuda:
             if self._side is None:
@@ -1075,11 +1088,11 @@ class _Engine:
             ctx["main"] = torch.cuda.current_stream()
             ctx["main_handle"] = _hip.stream()
             _hip.call("ddpm_stream_order", ctx["side_handle"], ctx["main_handle"])   # the staging buffer is zeroed on the main stream
+        # chunks in execution order; the backward finishes them from the last one backwards
+        ctx["pending"] = [(a, b, set(mem), k) for k, (a, b, mem) in enumerate(self.chunks)]
         if self.pg is not None:
             import torch.distributed as dist
             ctx["world"] = dist.get_world_size(self.pg)
-            # chunks in execution order; the backward finishes them from the last one backwards
-            ctx["pending"] = [(a, b, set(mem), k) for k, (a, b, mem) in enumerate(self.chunks)]
         return ctx
 
     def _close_backward(self, ctx, st):
@@ -1136,7 +1149,7 @@ class _Engine:
         # ---- the rest of the tape in reverse
         for rec in reversed(tape[:-1]):
             kind = rec[0]
-            if ctx["pending"] is None and len(ctx["slab_rows"]) >= _SLAB_FLUSH_ROWS:
+            if not ctx["dp"] and len(ctx["slab_rows"]) >= _SLAB_FLUSH_ROWS:
                 self._flush_slabs(ctx, on_side=True)
             if kind == "res":
                 self._res_bwd(ctx, rec)
@@ -1216,7 +1229,9 @@ class _Engine:
         da2 = self._new(B, x.H, x.W, Cout)
         ops.conv2d(dout, c2.wd.data_ptr(), da2.ptr, da2.ld, Cout, 3, 3, x.H, x.W, pad_t=1, pad_l=1, splitk=self.splitk)
         b2 = ("b2", id(rb)) if rb.has_skip else rb.conv2.bias
-        if not self._wgrad(ctx, rb.conv2.weight, dout, a2, Cout, Cout, 3, 3, pad_t=1, pad_l=1, splits=self._splits(Cout, 9 * Cout, dout.rows), bias=b2):
+        boost = _TAIL_BLOCKS > 0 and any(rb is q for q in self.res_blocks[:_TAIL_BLOCKS])
+
+        if not self._wgrad(ctx, rb.conv2.weight, dout, a2, Cout, Cout, 3, 3, pad_t=1, pad_l=1, splits=self._splits(Cout, 9 * Cout, dout.rows), bias=b2, boost=boost):
             self._bias_grad(ctx, dout, [rb.conv2.bias], Cout, slot=("b2", id(rb)) if rb.has_skip else None)
         # GN2 + SiLU + dropout
         dh1 = self._new(B, x.H, x.W, Cout)
@@ -1228,7 +1243,7 @@ class _Engine:
         # conv1
         da1 = self._new(B, x.H, x.W, Cin)
         ops.conv2d(dh1, c1.wd.data_ptr(), da1.ptr, da1.ld, Cin, 3, 3, x.H, x.W, pad_t=1, pad_l=1, splitk=self.splitk)
-        self._wgrad(ctx, rb.conv1.weight, dh1, a1, Cin, Cout, 3, 3, pad_t=1, pad_l=1, splits=self._splits(Cout, 9 * Cin, dh1.rows))
+        self._wgrad(ctx, rb.conv1.weight, dh1, a1, Cin, Cout, 3, 3, pad_t=1, pad_l=1, splits=self._splits(Cout, 9 * Cin, dh1.rows), boost=boost)
         # GN1 + SiLU, then the skip path, into d(x)
         g, acc = self._grad_target(x)
         # (identity skip: the block's output gradient joins d(x) inside the same kernel)
@@ -1294,9 +1309,12 @@ class _Engine:
         # unpack table fans out to every fc.weight / fc.bias / conv1.bias.
         # (parameter gradients are leaves: on the side stream, next to the chain d(s_t) -> d(t_emb) -> d(s1) -> d(e1) that is the very
         #  end of the backward's critical path)
-        if ctx["pending"] is None:                      # (data-parallel runs produced these rows chunk by chunk, inside the backward)
-            for k in range(len(self.chunks)):
+        # (the rows of d(fc.weight) were produced chunk by chunk inside the backward: _fc_wgrad.  A PARTIAL backward — a harness that
+        #  runs one block's routines — leaves chunks open: their rows are produced here)
+        for _, _, mem, k in ctx["pending"]:
+            if ("fc_w", k) in mem:
                 self._fc_wgrad(ctx, k)
+                mem.discard(("fc_w", k))
         with self._leaf(ctx, dtb, s_t):
             ops.colsum(View(dtb, 1, B, 1, Ct), 0, 0, self._pptr(ctx, "fc_b"))
         # K = sum Cout (~5000): split-K with fp32 atomics (run-to-run summation order) — unless the deterministic-reduction mode is on

@@ -42,6 +42,7 @@ from .._plan import LaunchPlan
 __all__ = ["Trainer", "EMA", "ModelWrapper", "DummyScheduler", "RunningStatistics"]
 
 # "auto" (default): the captured step is used when it measures faster than the eager one on this workload; "1" / "0" force it
+_MAIN_PRIORITY = os.environ.get("DDPM_MAIN_PRIORITY", "0") != "0"        # run the direct step's main chain on a high-priority stream
 _ASYNC_LOSS = os.environ.get("DDPM_TORCH_AMD_ASYNC_LOSS", "1") != "0"     # 0: read the loss back synchronously in every step
 _TRAIN_GRAPH = {"0": False, "1": True, "plan": "plan"}.get(os.environ.get("DDPM_TORCH_AMD_TRAIN_GRAPH", "auto"), "auto")
 
@@ -627,6 +628,7 @@ class Trainer:
         self._loss_pending, self._loss_host, self._loss_slot = None, None, 0
         self._fused = _FusedUpdate(optimizer, self.ema)
         self._direct = {}                               # (input shape, train/eval) -> _DirectStep
+        self._hi_stream = None                          # high-priority stream of the direct step (DDPM_MAIN_PRIORITY)
         self.input_source = None                        # optional fn(t_buf, noise_buf) filling the step's (t, noise) in place (parity tests)
 
     # ------------------------------------------------------------------ the reference's small accessors
@@ -709,7 +711,19 @@ class Trainer:
             if key not in self._direct:
                 self._direct[key] = _DirectStep(self, unet, key[0])
             direct = self._direct[key]
-            loss = direct.run(x).clone()
+            if _MAIN_PRIORITY and x.is_cuda:
+                # The step's critical chain on a HIGH-priority HIP stream (the priority range of this part is 0 .. -1, so the weight-
+                # gradient stream cannot be made lower than a default stream — the main chain has to be made higher): when a leaf
+                # kernel of the side stream and the next kernel of the chain become ready together, the chain gets the compute units.
+                if self._hi_stream is None:
+                    self._hi_stream = torch.cuda.Stream(device=x.device, priority=-1)
+                cur = torch.cuda.current_stream(x.device)
+                self._hi_stream.wait_stream(cur)
+                with torch.cuda.stream(self._hi_stream):
+                    loss = direct.run(x).clone()
+                cur.wait_stream(self._hi_stream)
+            else:
+                loss = direct.run(x).clone()
             if self._ema_on:
                 self.ema.num_updates += 1
             self.scheduler.step()

@@ -51,3 +51,18 @@ for key, d in perq.items():
     print(f"--- queue {key[0]} stream {key[1]}: {sum(v[0] for v in d.values()) / nsteps:.0f} launches/step")
     for name, (n, t) in sorted(d.items(), key=lambda kv: -kv[1][1])[:40]:
         print(f"  {t / nsteps / 1e3:8.1f} us/step  n/step={n / nsteps:5.1f}  avg {t / n / 1e3:6.1f} us  {name}")
+
+# gaps of the BUSIEST queue (the critical stream) while it waits — for the other stream, or for the host: where does the step's span exceed
+# that stream's kernel time?
+main = max(busy.items(), key=lambda kv: kv[1])[0]
+mk = sorted((s_, e_, k) for s_, e_, k, q, st in win if (q, st) == main)
+mg = collections.defaultdict(lambda: [0, 0])
+tot = 0
+for (s0, e0, k0), (s1, e1, k1) in zip(mk, mk[1:]):
+    if s1 - e0 > 3000:
+        short = lambda k: k.split("(")[0].replace("void ", "").replace("(anonymous namespace)::", "")[-48:]
+        mg[(short(k0), short(k1))][0] += 1; mg[(short(k0), short(k1))][1] += s1 - e0
+        tot += s1 - e0
+print(f"--- gaps > 3 us on queue {main[0]} stream {main[1]} (the critical stream): {tot / nsteps / 1e3:.1f} us/step")
+for (a, b), (n_, g) in sorted(mg.items(), key=lambda kv: -kv[1][1])[:16]:
+    print(f"  {g / nsteps / 1e3:7.1f} us/step  n/step={n_ / nsteps:5.1f}  after [{a}] before [{b}]")
