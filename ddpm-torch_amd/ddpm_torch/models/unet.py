@@ -261,8 +261,9 @@ _WGRAD3_UP = os.environ.get("DDPM_WGRAD3_UP", "1") != "0"          # ... also fo
 _SLAB_FLUSH_ROWS = int(os.environ.get("DDPM_SLAB_FLUSH_ROWS", "3"))   # slab reductions queued on the side stream every so many rows
 # The backward ends at the network's first layers, and the step ends when the side stream has drained: the weight gradients of the LAST
 # residual blocks of the backward (the first in execution order) find the main stream with little left to run — they take the whole chip
-# instead of the usual half (twice the K slices).  0 = off.
-_TAIL_BLOCKS = int(os.environ.get("DDPM_WGRAD3_TAIL_BLOCKS", "0"))
+# instead of the usual half (twice the K slices).  Same-box sweeps on two boxes (profiles/r05_tail_boost_sweep.txt): 0 / 4 / 8 blocks ->
+# 9.87 / 9.81 / 9.83 ms per step (every one of nine 0-vs-4 pairs in favour of 4); 0 = off.
+_TAIL_BLOCKS = int(os.environ.get("DDPM_WGRAD3_TAIL_BLOCKS", "4"))
 _ABL_NO_LEAF_ORDER = os.environ.get("DDPM_ABL_NO_LEAF_ORDER", "0") != "0"   # TIMING-ONLY ablation (wrong results): leaves are not ordered behind the main stream
 _WGRAD1 = os.environ.get("DDPM_WGRAD1", "1") != "0"                # slab kernel for the 1x1 weight gradients
 _WGRAD3_ATOMIC = os.environ.get("DDPM_WGRAD3_ATOMIC", "0") != "0"  # ... with fp32 atomics instead of slab copies
