@@ -470,7 +470,8 @@ static Plan make_plan(int B, int H, int W, int C, int N, int want_splits) {
         // 96 -> 10.3, 64 -> 11.0 ms; CelebA-HQ B = 2: 12.36 -> 11.97 ms), which also halves the slab copies ddpm_wgrad_reduce sums.
         // Keep >= 4 stages per slice so that the block's prologue / final reduction amortise.
         static const int cu_budget = getenv("DDPM_WGRAD3_CUS") ? atoi(getenv("DDPM_WGRAD3_CUS")) : 128;
-        splits = ddpm_cu_budget(cu_budget) / tiles;
+        static const int cu_budget_small = getenv("DDPM_WGRAD3_CUS_SMALL") ? atoi(getenv("DDPM_WGRAD3_CUS_SMALL")) : cu_budget;   // the 8 x 8 / 4 x 4 levels
+        splits = ddpm_cu_budget(W <= 8 ? cu_budget_small : cu_budget) / tiles;
         const int cap = p.stages >= 4 ? p.stages / 4 : 1;
         if (splits > cap) splits = cap;
         if (splits < 1) splits = 1;

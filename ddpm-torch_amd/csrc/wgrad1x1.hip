@@ -165,7 +165,9 @@ static bool make_plan(int P, int C, int N, Plan& p) {
     p.tiles_c = (C + 127) / 128; p.tiles_n = (N + 127) / 128;
     p.ksteps = (P + 63) / 64;                                   // pixels beyond P: out-of-range offsets (zeros)
     const int tiles = p.tiles_c * p.tiles_n;
-    static const int cu_budget = getenv("DDPM_WGRAD1_CUS") ? atoi(getenv("DDPM_WGRAD1_CUS")) : 256;
+    // half the chip, like the 3x3 weight-gradient kernel: a launch on every CU makes the main stream's next kernel wait for a whole
+    // block of this one (round 5, under the launch-plan step: 256 -> 9.81, 192 -> 9.66, 128 -> 9.65 / 9.73, 96 -> 9.70, 64 -> 9.86 ms per step)
+    static const int cu_budget = getenv("DDPM_WGRAD1_CUS") ? atoi(getenv("DDPM_WGRAD1_CUS")) : 128;
     int splits = ddpm_cu_budget(cu_budget) / tiles;             // one block per CU
     if (splits < 1) splits = 1;
     const int max_splits = p.ksteps / 4 > 0 ? p.ksteps / 4 : 1; // a slice keeps >= 4 K-steps
