@@ -182,7 +182,9 @@ static bool make_plan(int P, int C, int N, Plan& p) {
 // Slab copies ddpm_conv1x1_wgrad_nhwc writes for this geometry (0: geometry not covered — the caller keeps ddpm_conv2d_wgrad_nhwc).
 extern "C" int ddpm_conv1x1_wgrad_splits(int P, int C, int N) {
     static const bool off = getenv("DDPM_NO_WGRAD1X1") != nullptr;
-    static const int min_p = getenv("DDPM_WGRAD1_MIN_P") ? atoi(getenv("DDPM_WGRAD1_MIN_P")) : 16384;
+    // (round 5, under the launch-plan step: the 8 x 8 and 4 x 4 levels' 1x1 weight gradients — P = 8192 / 2048 — on this kernel too:
+    //  16384 -> 9.41, 8192 -> 9.39, 2048 -> 9.34 ms per step; the generic kernel's 512-block grids held the main stream up more)
+    static const int min_p = getenv("DDPM_WGRAD1_MIN_P") ? atoi(getenv("DDPM_WGRAD1_MIN_P")) : 2048;
     Plan p;
     if (off || P < min_p || !make_plan(P, C, N, p)) return 0;
     return p.splits;

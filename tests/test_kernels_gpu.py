@@ -172,7 +172,8 @@ def test_conv_small_grid_split_k(B, H, C, N, R, dt):
     assert torch.equal(outs[0], outs[1]) and int(cntd.abs().sum()) == 0
 
 
-WG1_CASES = [(32768, 256, 256), (32768, 256, 768), (131072, 128, 256), (33635, 192, 104), (32768, 768, 256), (16384, 64, 64), (40000, 384, 128)]
+WG1_CASES = [(32768, 256, 256), (32768, 256, 768), (131072, 128, 256), (33635, 192, 104), (32768, 768, 256), (16384, 64, 64), (40000, 384, 128),
+             (8192, 512, 256), (2048, 512, 256), (2048, 256, 256), (2050, 192, 104)]      # the 8 x 8 / 4 x 4 levels (round 5: P >= 2048 takes the slab kernel)
 
 
 @pytest.mark.parametrize("P,C,N", WG1_CASES)
@@ -200,7 +201,7 @@ def test_conv1x1_wgrad_slab_kernel(P, C, N):
     assert float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max()) + 1e-3, float((got - ref).abs().max())
     assert float((gotb - refb).abs().max()) <= 2e-5 * float(refb.abs().max()) + 1e-3
     # the geometry query refuses what the kernel does not serve
-    assert _hip.lib().ddpm_conv1x1_wgrad_splits(8192, C, N) == 0 and _hip.lib().ddpm_conv1x1_wgrad_splits(P, C + 4, N) == 0
+    assert _hip.lib().ddpm_conv1x1_wgrad_splits(1024, C, N) == 0 and _hip.lib().ddpm_conv1x1_wgrad_splits(P, C + 4, N) == 0
 
 
 PW_CASES = [(32, 32, 128, 256), (64, 32, 128, 256), (35, 31, 64, 192), (128, 16, 256, 768), (130, 16, 320, 384), (70, 31, 192, 104), (128, 16, 768, 256),
