@@ -463,6 +463,58 @@ extern "C" int ddpm_weighted_sum_f32(const float* x, const float* w, float* out,
     return check_launch();
 }
 
+// C[m][n] = sum_k A[k][m] * B[k][n]  (fp32; A is [K][lda], B is [K][ldb], C is [M][ldc]) for SHORT reductions — K = the batch (128):
+// the weight gradients of the time-embedding path, dW = d(out)^T in: the 22 ResidualBlock.fc projections (per all-reduce chunk), UNet.embed's
+// two Linears (ddpm_torch/models/unet.py:77,122-126 through autograd).  The generic GEMM spends ~34 us on each of these (both operands
+// k-strided, four K-steps of work behind its whole prologue); here a block owns a 64 x 64 tile of C, stages 32 rows of A and B at a time
+// in LDS and every thread accumulates a 4 x 4 patch: the products are microseconds.  Plain stores, fixed order: bit-deterministic.
+__global__ __launch_bounds__(256) void atb_f32_kernel(const float* __restrict__ A, long long lda, const float* __restrict__ Bm, long long ldb,
+                                                      float* __restrict__ C, long long ldc, int M, int N, int K) {
+    __shared__ float sa[32][64 + 4], sb[32][64 + 4];
+    const int tid = threadIdx.x, tm = tid >> 4, tn = tid & 15;            // 16 x 16 threads, 4 x 4 outputs each
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    float acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+    for (int k0 = 0; k0 < K; k0 += 32) {
+        for (int e = tid; e < 32 * 64; e += 256) {                         // coalesced along m / n
+            const int kk = e >> 6, c = e & 63, k = k0 + kk;
+            sa[kk][c] = (k < K && m0 + c < M) ? A[(long long)k * lda + m0 + c] : 0.f;
+            sb[kk][c] = (k < K && n0 + c < N) ? Bm[(long long)k * ldb + n0 + c] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int kk = 0; kk < 32; ++kk) {
+            float a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { a[i] = sa[kk][tm * 4 + i]; b[i] = sb[kk][tn * 4 + i]; }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + tm * 4 + i;
+        if (m >= M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + tn * 4 + j;
+            if (n < N) C[(long long)m * ldc + n] = acc[i][j];
+        }
+    }
+}
+extern "C" int ddpm_atb_f32(const float* a, long long lda, const float* b, long long ldb, float* c, long long ldc, int M, int N, int K, void* stream) {
+    if (!a || !b || !c) return DDPM_ERR_NULL;
+    if (M <= 0 || N <= 0 || K <= 0 || lda < M || ldb < N || ldc < N) return DDPM_ERR_SHAPE;
+    hipLaunchKernelGGL(atb_f32_kernel, dim3((N + 63) / 64, (M + 63) / 64), dim3(256), 0, (hipStream_t)stream, a, lda, b, ldb, c, ldc, M, N, K);
+    return check_launch();
+}
+
 // One fused sampling step for model_mean_type in {eps, x_0, mean} with a fixed variance table
 // (diffusion.py:107-158): pred_x0 -> clamp -> posterior mean -> + 1[t>0]*exp(0.5*logvar)*z.
 // tab = 7 fp32 tables of length T, concatenated: recip, recip_m1, coef1, coef2, logvar, (unused), (unused)

@@ -55,6 +55,7 @@ PROTOTYPES = {
     "ddpm_mse_fwd": [P, P, P, I, I, P],
     "ddpm_mse_bwd": [P, P, P, P, I, I, P],
     "ddpm_weighted_sum_f32": [P, P, P, I, P],
+    "ddpm_atb_f32": [P, L, P, L, P, L, I, I, I, P],
     "ddpm_p_sample_step": [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, P],
     "ddpm_gather_i64": [P, P, P, I, P],
     "ddpm_add_i64": [P, I, L, P],

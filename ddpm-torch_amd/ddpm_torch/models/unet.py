@@ -768,8 +768,7 @@ class _Engine:
         o0, n, fbase = self.chunk_fc[k]
         dtb, s_t, E, Ct = ctx["dtb"], ctx["s_t"], self.E, self.tb_total
         with self._leaf(ctx, dtb, s_t):
-            ops.gemm(dtb.data_ptr() + 4 * o0, Ct, 0, 1, s_t.data_ptr(), E, 0, 1, ctx["gpack"].data_ptr() + 4 * fbase, E, 0, n, E, ctx["B"],
-                     _hip.F32, out_mode=1)
+            _hip.call("ddpm_atb_f32", dtb.data_ptr() + 4 * o0, Ct, s_t.data_ptr(), E, ctx["gpack"].data_ptr() + 4 * fbase, E, n, E, ctx["B"], _hip.stream())
 
     def _flush_slabs(self, ctx, on_side=False):
         """Sum the slab copies recorded since the last flush into the staging buffer (one launch).  ``on_side``: queue it on the side
@@ -1329,7 +1328,7 @@ class _Engine:
         ctx["dt_emb"] = dt_emb                                  # d/d(t_emb): what the reference's ResidualBlock hands back to the embedding MLP
         lin2, lin1 = m.embed[2], m.embed[0]
         with self._leaf(ctx, dt_emb, s1):
-            ops.gemm(dt_emb.data_ptr(), E, 0, 1, s1.data_ptr(), E, 0, 1, self._pptr(ctx, lin2.weight), E, 0, E, E, B, F, out_mode=1)
+            _hip.call("ddpm_atb_f32", dt_emb.data_ptr(), E, s1.data_ptr(), E, self._pptr(ctx, lin2.weight), E, E, E, B, _hip.stream())
             ops.colsum(View(dt_emb, 1, B, 1, E), 0, 0, self._pptr(ctx, lin2.bias))
         # (K = E = 512 over 4 output tiles would leave 252 CUs idle for ~75 us at the very end of the backward: split-K with fp32 atomics
         #  like the fc product above — output tiles x E / 64 K slices)
@@ -1339,5 +1338,5 @@ class _Engine:
         de1 = self._f32(B, E)
         _hip.call("ddpm_silu_bwd", e1.data_ptr(), ds1.data_ptr(), de1.data_ptr(), B * E, 0, _hip.stream())
         with self._leaf(ctx, de1, temb):
-            ops.gemm(de1.data_ptr(), E, 0, 1, temb.data_ptr(), self.hid, 0, 1, self._pptr(ctx, lin1.weight), self.hid, 0, E, self.hid, B, F, out_mode=1)
+            _hip.call("ddpm_atb_f32", de1.data_ptr(), E, temb.data_ptr(), self.hid, self._pptr(ctx, lin1.weight), self.hid, E, self.hid, B, _hip.stream())
             ops.colsum(View(de1, 1, B, 1, E), 0, 0, self._pptr(ctx, lin1.bias))

@@ -195,6 +195,10 @@ int ddpm_mse_fwd(const float* pred, const float* target, float* loss, int B, int
 int ddpm_mse_bwd(const float* pred, const float* target, const float* gloss, float* gpred, int B, int n, void* stream);
 /* out[0] = sum_i x[i]*w[i], one block, fixed order: the batch mean of the per-sample losses (utils/train.py:151 `loss.mean()`) */
 int ddpm_weighted_sum_f32(const float* x, const float* w, float* out, int n, void* stream);
+/* C[m][n] = sum_k A[k][m] * B[k][n] in fp32 for short reductions (K = the batch): the weight gradients of the time-embedding path —
+ * autograd of F.linear (ddpm_torch/modules.py:58-59) at ResidualBlock.fc (models/unet.py:77,86) and UNet.embed (:122-126): dW = d(out)^T in.
+ * A is [K][lda], B is [K][ldb], C is [M][ldc]; plain stores in a fixed order (bit-deterministic). */
+int ddpm_atb_f32(const float* a, long long lda, const float* b, long long ldb, float* c, long long ldc, int M, int N, int K, void* stream);
 /* p_mean_var + p_sample_step (diffusion.py:107-158; ddim.py inherits it): one fused update
  *   x0 = clamp(recip[t]*x_t - recip_m1[t]*out)   (mean_type 0 = eps; 1: x0 = out; 2: out is the mean)
  *   x_prev = coef1[t]*x0 + coef2[t]*x_t + 1[t>0]*exp(0.5*logvar[t])*z ;  pred_x0 optional.

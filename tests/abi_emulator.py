@@ -498,6 +498,12 @@ class Emulator:
         f32(mask, n)[...] = _keep_mask(seed, np.arange(n, dtype=np.uint64), _thresh(p)).astype(np.float32)
 
 
+    def ddpm_atb_f32(self, a, lda, b, ldb, c, ldc, M, N, K, st):
+        A = np.lib.stride_tricks.as_strided(f32(a, (K - 1) * lda + M), (K, M), (lda * 4, 4))
+        Bm = np.lib.stride_tricks.as_strided(f32(b, (K - 1) * ldb + N), (K, N), (ldb * 4, 4))
+        C = np.lib.stride_tricks.as_strided(f32(c, (M - 1) * ldc + N), (M, N), (ldc * 4, 4), writeable=True)
+        C[...] = (A.astype(np.float64).T @ Bm.astype(np.float64)).astype(np.float32)
+
     # ------------------------------------------------------------------ plan helpers (csrc/plan.hip)
     def ddpm_stream_order(self, waiter, signaller):
         pass                                             # host memory: everything is already in program order

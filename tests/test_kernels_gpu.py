@@ -864,3 +864,25 @@ def test_conv3x3_wave_specialised_kernel_is_bit_stable_under_contention(B, H, C,
         torch.cuda.synchronize()
     bad = [i for i, y in enumerate(outs) if not torch.equal(y, ref)]
     assert not bad, f"launches {bad} differ from the uncontended result"
+
+
+@pytest.mark.parametrize("M,N,K", [(1024, 512, 128), (256, 512, 128), (512, 128, 128), (2048, 512, 2), (130, 70, 37)])
+def test_atb_f32_short_reduction_product(M, N, K):
+    """C = A^T B in fp32 for short reductions (csrc/elementwise.hip `atb_f32_kernel`: the time-embedding path's weight gradients, K = the
+    batch) against float64, with pitched operands and ragged tile edges; two launches are bit-identical (plain stores, fixed order)."""
+    lda, ldb, ldc = M + 12, N + 4, N + 8
+    g = torch.Generator().manual_seed(11)
+    a = torch.randn(K, lda, generator=g)
+    b = torch.randn(K, ldb, generator=g)
+    ad, bd = a.cuda(), b.cuda()
+    outs = []
+    for _ in range(2):
+        c = torch.full((M, ldc), float("nan"), device="cuda")
+        _hip.call("ddpm_atb_f32", ad.data_ptr(), lda, bd.data_ptr(), ldb, c.data_ptr(), ldc, M, N, K, _hip.stream())
+        torch.cuda.synchronize()
+        outs.append(c.cpu())
+    got = outs[0][:, :N]
+    ref = a[:, :M].double().t() @ b[:, :N].double()
+    assert torch.equal(outs[0][:, :N], outs[1][:, :N]) and torch.isnan(outs[0][:, N:]).all()      # nothing written beyond column N
+    assert float((got.double() - ref).abs().max()) <= 2e-6 * float(ref.abs().max()) * max(K, 8) ** 0.5
+    assert _hip.lib().ddpm_atb_f32(0, lda, bd.data_ptr(), ldb, 1, ldc, M, N, K, 0) == 5 and _hip.lib().ddpm_atb_f32(ad.data_ptr(), M - 1, bd.data_ptr(), ldb, 1, ldc, M, N, K, 0) == 1
