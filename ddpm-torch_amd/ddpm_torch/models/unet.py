@@ -264,6 +264,7 @@ _SLAB_FLUSH_ROWS = int(os.environ.get("DDPM_SLAB_FLUSH_ROWS", "3"))   # slab red
 # instead of the usual half (twice the K slices).  Same-box sweeps on two boxes (profiles/r05_tail_boost_sweep.txt): 0 / 4 / 8 blocks ->
 # 9.87 / 9.81 / 9.83 ms per step (every one of nine 0-vs-4 pairs in favour of 4); 0 = off.
 _TAIL_BLOCKS = int(os.environ.get("DDPM_WGRAD3_TAIL_BLOCKS", "4"))
+_TAIL_ANY = os.environ.get("DDPM_WGRAD3_TAIL_ANY", "0") != "0"
 _ABL_NO_LEAF_ORDER = os.environ.get("DDPM_ABL_NO_LEAF_ORDER", "0") != "0"   # TIMING-ONLY ablation (wrong results): leaves are not ordered behind the main stream
 _WGRAD1 = os.environ.get("DDPM_WGRAD1", "1") != "0"                # slab kernel for the 1x1 weight gradients
 _WGRAD3_ATOMIC = os.environ.get("DDPM_WGRAD3_ATOMIC", "0") != "0"  # ... with fp32 atomics instead of slab copies
@@ -1229,7 +1230,9 @@ class _Engine:
         da2 = self._new(B, x.H, x.W, Cout)
         ops.conv2d(dout, c2.wd.data_ptr(), da2.ptr, da2.ld, Cout, 3, 3, x.H, x.W, pad_t=1, pad_l=1, splitk=self.splitk)
         b2 = ("b2", id(rb)) if rb.has_skip else rb.conv2.bias
-        boost = _TAIL_BLOCKS > 0 and any(rb is q for q in self.res_blocks[:_TAIL_BLOCKS])
+        # (... on images up to 64 x 64 only: on the CelebA-HQ step the same boost COSTS 1.4 % — 11.71 against 11.55 ms — its first blocks sit
+        #  at 256 x 256 / 128 x 128 with a long main-stream chain still to come; DDPM_WGRAD3_TAIL_ANY=1 lifts the limit)
+        boost = _TAIL_BLOCKS > 0 and (x.H * x.W <= 4096 or _TAIL_ANY) and any(rb is q for q in self.res_blocks[:_TAIL_BLOCKS])
 
         if not self._wgrad(ctx, rb.conv2.weight, dout, a2, Cout, Cout, 3, 3, pad_t=1, pad_l=1, splits=self._splits(Cout, 9 * Cout, dout.rows), bias=b2, boost=boost):
             self._bias_grad(ctx, dout, [rb.conv2.bias], Cout, slot=("b2", id(rb)) if rb.has_skip else None)
