@@ -10,6 +10,8 @@ else — ~1000 kernel launches per step — is replayed from a handful of graph 
 All segments share one private memory pool and are always replayed in capture order on one stream, so activations
 allocated in one segment and released in a later one keep their addresses from replay to replay.
 """
+import gc
+
 import torch
 
 __all__ = ["SegmentedGraph"]
@@ -57,6 +59,18 @@ class SegmentedGraph:
         """Run ``body(cut)`` once under stream capture (nothing executes).  On failure the partial capture is discarded and
         the exception propagates; the caller falls back to eager execution."""
         assert not self.segments and self._open is None
+        # (an allocator pool released in the middle of a capture — by the cyclic collector freeing an earlier graph or launch plan —
+        #  trips an internal assertion of the caching allocator: collect first, keep the collector off while capturing)
+        gc.collect()
+        gc_was_on = gc.isenabled()
+        gc.disable()
+        try:
+            return self._capture(body)
+        finally:
+            if gc_was_on:
+                gc.enable()
+
+    def _capture(self, body):
         torch.cuda.synchronize(self.device)
         cur = torch.cuda.current_stream(self.device)
         self.stream.wait_stream(cur)

@@ -20,6 +20,7 @@ out of the replays: the direct step draws (t, noise) outside the recorded region
 """
 import contextlib
 import ctypes
+import gc
 import struct
 
 import torch
@@ -78,12 +79,21 @@ class LaunchPlan:
             scope = torch.cuda.use_mem_pool(self.pool, device=self.device)
         else:
             scope = contextlib.nullcontext()
+        # Releasing an allocator pool (an earlier plan's, a captured graph's) while allocations are routed to another one trips an
+        # internal assertion of the caching allocator — and such owners usually sit in reference cycles (trainer <-> step object), so
+        # it is the cyclic collector that frees them, whenever it happens to run.  Collect NOW, then keep the collector off for the
+        # duration of the recording (what torch.cuda.graph() does around a capture, for the same reason).
+        gc.collect()
+        gc_was_on = gc.isenabled()
+        gc.disable()
         prev = _hip.record_into(self)
         try:
             with scope:
                 body(self.cut)
         finally:
             _hip.record_into(prev)
+            if gc_was_on:
+                gc.enable()
         if on_gpu:
             try:
                 self._build_native()

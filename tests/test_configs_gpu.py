@@ -466,3 +466,49 @@ def test_recorded_step_contains_no_torch_arithmetic_on_the_device(monkeypatch, c
                "aten.slice.Tensor", "aten.as_strided.default", "aten.detach.default", "aten.alias.default", "aten._unsafe_view.default"}
     assert set(seen) <= allowed, sorted(set(seen) - allowed)
     assert all(torch.isfinite(p).all() for p in m.parameters())
+
+
+def test_recording_a_plan_while_an_earlier_one_awaits_the_garbage_collector(monkeypatch):
+    """A trainer and its step object reference each other, so a dropped trainer's launch plan (and the allocator pool it owns) is freed by
+    the CYCLIC collector, whenever that runs.  Releasing a pool while allocations are routed to another one — i.e. in the middle of the next
+    recording or capture — aborts the process inside the caching allocator (seen in round 5: `Fatal Python error: Aborted ... Garbage-
+    collecting` under `LaunchPlan.record`).  `record` / `capture` therefore collect first and keep the collector off while they run: here a
+    collection is forced in the MIDDLE of the second recording, with the first trainer left as garbage just before."""
+    import gc
+    from tests.test_unet_gpu import TINY3
+    monkeypatch.setattr(train_mod, "_TRAIN_GRAPH", "plan")
+
+    def trainer(seed):
+        torch.manual_seed(seed)
+        m, _ = make(TINY3, dtype=torch.float32)
+        m.train()
+        dif = ddpm_torch.GaussianDiffusion(ddpm_torch.get_beta_schedule("linear", 1e-4, 0.02, 1000), "eps", "fixed-large", "mse")
+        return m, ddpm_torch.Trainer(m, torch.optim.Adam(m.parameters(), lr=1e-3), dif, epochs=1, trainloader=None, use_ema=True, shape=(3, 16, 16),
+                                     device=torch.device(DEV))
+    x = (torch.rand(4, 3, 16, 16, generator=torch.Generator().manual_seed(1)) * 2 - 1).to(DEV)
+    gc.collect()
+    gc.disable()                                                 # nothing may free the first trainer before the second recording starts
+    try:
+        m1, t1 = trainer(1)
+        for i in range(3):
+            t1.step(x, global_steps=i + 1)
+        assert next(iter(t1._direct.values())).plan is not None
+        torch.cuda.synchronize()
+        del m1, t1                                               # garbage now: a cycle that owns a launch plan and its pool
+        m2, t2 = trainer(2)
+        t2.step(x, global_steps=1)
+        ds = None
+        orig_fwd = m2.engine().forward
+
+        def forward_with_collection(*a, **k):                    # runs inside the recorded body
+            gc.collect()
+            return orig_fwd(*a, **k)
+        m2.engine().forward = forward_with_collection
+        t2.step(x, global_steps=2)                               # records
+        m2.engine().forward = orig_fwd
+        t2.step(x, global_steps=3)
+        torch.cuda.synchronize()
+        ds = next(iter(t2._direct.values()))
+        assert ds.plan is not None and ds.last_kind == "plan"
+    finally:
+        gc.enable()
