@@ -161,6 +161,8 @@ struct DevOnce {
 static inline int check_launch() { return hipGetLastError() == hipSuccess ? DDPM_OK : DDPM_ERR_LAUNCH; }
 static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
+// optim.hip: total_sq[0] = sum of partial[0 .. n) in a fixed order, total_sq[1 .. 63] = 0 (one 1024-thread block)
+int ddpm_sumsq_finish_launch(const float* partial, int n, float* total_sq, void* stream);
 // probe.hip: compute units the persistent launchers leave to a concurrent collective (ddpm_set_reserved_cus); 0 by default
 int ddpm_reserved_cus();
 static inline int ddpm_cu_budget(int wanted) { const int left = 256 - ddpm_reserved_cus(); return wanted < left ? wanted : (left > 1 ? left : 1); }

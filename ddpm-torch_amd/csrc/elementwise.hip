@@ -238,7 +238,8 @@ extern "C" int ddpm_pack_weight_multi(const long long* descs, int n_tensors, int
 
 // packed conv weight gradients [N][R*S][C] -> parameter layout [N][C][R*S], all layers in one launch.
 // descs[i] = {src offset (floats) in gpack, dst offset in gflat, N, C, R*S}; grid = (blocks, n_tensors).
-// sumsq (optional): bank of 64 fp32 accumulators that receives the sum of squares of everything written — the global gradient norm of
+// sumsq (optional): one slot per block that receives the block's sum of squares of everything it wrote (added up in a fixed order by
+// sumsq_finish_kernel: optim.hip) — was: a bank of 64 fp32 accumulators fed by atomics — the global gradient norm of
 // nn.utils.clip_grad_norm_ (ddpm_torch/utils/train.py:159) falls out of this pass instead of costing another read of all gradients.
 __global__ __launch_bounds__(256) void wgrad_unpack_kernel(const float* __restrict__ gpack, float* __restrict__ gflat, const long long* __restrict__ descs, float scale,
                                                             float* __restrict__ sumsq) {
@@ -286,10 +287,7 @@ __global__ __launch_bounds__(256) void wgrad_unpack_kernel(const float* __restri
         acc = wave_sum(acc);
         if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
         __syncthreads();
-        if (threadIdx.x == 0) {
-            const float t = (sh[0] + sh[1]) + (sh[2] + sh[3]);
-            if (t != 0.f) atomicAdd(sumsq + ((blockIdx.y * gridDim.x + blockIdx.x) & 63), t);
-        }
+        if (threadIdx.x == 0) sumsq[blockIdx.y * gridDim.x + blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);      // this block's slot (fixed-order finish: optim.hip)
     }
 }
 extern "C" int ddpm_wgrad_unpack(const float* gpack, float* gflat, const long long* descs, int n_tensors, float scale, void* stream) {
@@ -301,8 +299,9 @@ extern "C" int ddpm_wgrad_unpack(const float* gpack, float* gflat, const long lo
 extern "C" int ddpm_wgrad_unpack_sumsq(const float* gpack, float* gflat, const long long* descs, int n_tensors, float scale, float* total_sq, void* stream) {
     if (!gpack || !gflat || !descs || !total_sq) return DDPM_ERR_NULL;
     if (n_tensors <= 0) return DDPM_OK;
-    hipLaunchKernelGGL(wgrad_unpack_kernel, dim3(64, n_tensors), dim3(256), 0, (hipStream_t)stream, gpack, gflat, descs, scale, total_sq);
-    return check_launch();
+    hipLaunchKernelGGL(wgrad_unpack_kernel, dim3(64, n_tensors), dim3(256), 0, (hipStream_t)stream, gpack, gflat, descs, scale, total_sq + 64);
+    const int rc = check_launch();
+    return rc ? rc : ddpm_sumsq_finish_launch(total_sq + 64, 64 * n_tensors, total_sq, stream);
 }
 
 // sum of the split-K slab copies of the packed weight gradients, many tensors in one launch (fixed order: deterministic).

@@ -76,7 +76,30 @@ extern "C" int ddpm_adam_ema_step(float* p, const float* g, float* m, float* v, 
 // total_sq is a bank of MT_SUMSQ_LANES accumulators: ~5000 blocks ending in an atomic on ONE address serialise at ~27 ns each
 // (the kernel took 127 us for 143 MB); striped over 64 addresses the atomics vanish under the streaming read.
 constexpr int MT_SUMSQ_LANES = 64;
-__global__ void mt_sumsq_kernel(const long long* __restrict__ table, float* __restrict__ total_sq) {
+// Round 5: the squared gradient norm is BIT-DETERMINISTIC.  Earlier the blocks added their partial sums to the bank with fp32 atomics:
+// whatever order they arrived in decided the last bits of the norm, hence of the clip coefficient — and two data-parallel replicas holding
+// identical (all-reduced) gradients could step to parameters one ulp apart (seen on the CIFAR geometry with two ranks: 1.2e-7 after four
+// steps, and nothing ever pulls replicas back together).  Now every block STORES its partial in its own slot behind the bank and one
+// 1024-thread block adds the slots in a fixed order into total_sq[0] (the other 63 lanes are zeroed, so consumers that add the bank up are
+// unchanged).  total_sq therefore needs MT_SUMSQ_LANES + (blocks of the producing launch) floats; ddpm_mt_sumsq_slots() says how many.
+__global__ __launch_bounds__(1024) void sumsq_finish_kernel(const float* __restrict__ partial, int n, float* __restrict__ total_sq) {
+    __shared__ float sh[1024];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < n; i += 1024) acc += partial[i];                 // thread t owns slots t, t + 1024, ...: a fixed order
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int w = 512; w > 0; w >>= 1) {                                            // fixed tree
+        if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x < MT_SUMSQ_LANES) total_sq[threadIdx.x] = threadIdx.x == 0 ? sh[0] : 0.f;
+}
+int ddpm_sumsq_finish_launch(const float* partial, int n, float* total_sq, void* stream) {
+    hipLaunchKernelGGL(sumsq_finish_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, partial, n, total_sq);
+    return check_launch();
+}
+constexpr int MT_SUMSQ_BLOCKS = 16;                     // blocks per tensor of mt_sumsq_kernel
+__global__ void mt_sumsq_kernel(const long long* __restrict__ table, float* __restrict__ partial) {
     __shared__ float sh[4];
     const long long* row = table + 6 * (long long)blockIdx.y;
     const float* g = reinterpret_cast<const float*>(row[1]);
@@ -91,10 +114,7 @@ __global__ void mt_sumsq_kernel(const long long* __restrict__ table, float* __re
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        const float s = sh[0] + sh[1] + sh[2] + sh[3];
-        if (s != 0.f) atomicAdd(total_sq + ((blockIdx.y * gridDim.x + blockIdx.x) & (MT_SUMSQ_LANES - 1)), s);
-    }
+    if (threadIdx.x == 0) partial[blockIdx.y * gridDim.x + blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
 // hyper (optional, device memory): {lr, bias_corr1, bias_corr2, ema_w} — overrides the by-value arguments, so that a hipGraph
 // captured once can be replayed with the step-dependent scalars of every training step (LR schedule, bias corrections, EMA
@@ -146,12 +166,16 @@ __global__ void mt_adam_ema_kernel(const long long* __restrict__ table, const fl
         if (shadow) shadow[i] = si;
     }
 }
-// the total_sq bank must be zero on entry to the norm pass.
+// floats a total_sq buffer needs for a producing launch over n_tensors rows (the 64-lane bank + one slot per block; the unpack kernel
+// runs 64 blocks per row, the norm pass 16)
+extern "C" int ddpm_mt_sumsq_slots(int n_tensors) { return MT_SUMSQ_LANES + 64 * (n_tensors > 0 ? n_tensors : 0); }
+// total_sq: ddpm_mt_sumsq_slots(n_tensors) floats; on return (stream-ordered) total_sq[0] holds the sum, lanes 1..63 are zero.
 extern "C" int ddpm_mt_grad_sumsq(const long long* table, int n_tensors, float* total_sq, void* stream) {
     if (!table || !total_sq) return DDPM_ERR_NULL;
     if (n_tensors <= 0) return DDPM_OK;
-    hipLaunchKernelGGL(mt_sumsq_kernel, dim3(16, n_tensors), dim3(256), 0, (hipStream_t)stream, table, total_sq);
-    return check_launch();
+    hipLaunchKernelGGL(mt_sumsq_kernel, dim3(MT_SUMSQ_BLOCKS, n_tensors), dim3(256), 0, (hipStream_t)stream, table, total_sq + MT_SUMSQ_LANES);
+    const int rc = check_launch();
+    return rc ? rc : ddpm_sumsq_finish_launch(total_sq + MT_SUMSQ_LANES, MT_SUMSQ_BLOCKS * n_tensors, total_sq, stream);
 }
 extern "C" int ddpm_mt_adam_ema(const long long* table, int n_tensors, const float* total_sq, float max_norm, float lr, float beta1,
                                 float beta2, float eps, float bias_corr1, float bias_corr2, float ema_w, const float* hyper_dev, void* stream) {

@@ -69,6 +69,7 @@ PROTOTYPES = {
     "ddpm_softmax_bwd": [P, P, P, L, I, I, P],
     "ddpm_dropout_mask": [P, L, F, U, P],
     "ddpm_mfma_probe": [P, I, I, P],
+    "ddpm_mt_sumsq_slots": [I],
     "ddpm_mt_grad_sumsq": [P, I, P, P],
     "ddpm_mt_adam_ema": [P, I, P, F, F, F, F, F, F, F, F, P, P],
     "ddpm_mt_gather_f32": [P, I, P],
@@ -114,6 +115,12 @@ def lib():
             fn.restype = RESTYPES.get(name, c_int)
         _lib = handle
     return _lib
+
+
+# ||g||^2 buffers (ddpm_mt_grad_sumsq / ddpm_wgrad_unpack_sumsq): a 64-float bank + one slot per block of the producing launch
+# (64 per tensor row) — sized once for SUMSQ_MAX_TENSORS rows (2 MB); callers check their row count against it.
+SUMSQ_MAX_TENSORS = 8192
+SUMSQ_FLOATS = 64 + 64 * SUMSQ_MAX_TENSORS
 
 
 def _invoke(name, args):

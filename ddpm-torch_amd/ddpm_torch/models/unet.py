@@ -1116,7 +1116,9 @@ class _Engine:
                 self._dp_mark("exchange_done")
             self._comm(ctx, finish)
         wdesc = self._wgrad_table()
-        if ctx["sumsq"]:           # the caller's squared-norm accumulators: the clip norm comes out of this pass (no second read of all gradients)
+        if ctx["sumsq"]:           # the caller's squared-norm buffer (_hip.SUMSQ_FLOATS): the clip norm comes out of this pass (no second read of all gradients)
+            if wdesc.shape[0] > _hip.SUMSQ_MAX_TENSORS:
+                raise ValueError(f"{wdesc.shape[0]} gradient rows exceed the squared-norm buffer ({_hip.SUMSQ_MAX_TENSORS})")
             _hip.call("ddpm_wgrad_unpack_sumsq", gpack.data_ptr(), gflat.data_ptr(), wdesc.data_ptr(), wdesc.shape[0], 1.0 / ctx["world"], ctx["sumsq"], _hip.stream())
         else:
             _hip.call("ddpm_wgrad_unpack", gpack.data_ptr(), gflat.data_ptr(), wdesc.data_ptr(), wdesc.shape[0], 1.0 / ctx["world"], _hip.stream())
@@ -1134,7 +1136,7 @@ class _Engine:
         gout = gout.contiguous().float()
         H, W = gout.shape[2], gout.shape[3]
         ctx = self._open_backward(st, gflat, cut)
-        ctx["sumsq"] = sumsq             # device address of a zeroed bank of 64 fp32 accumulators for ||grad||^2 (0: not wanted)
+        ctx["sumsq"] = sumsq             # device address of _hip.SUMSQ_FLOATS floats that receive ||grad||^2 in lane 0 (0: not wanted)
         # ---- head
         _, cur, act, stats, _ = head
         norm, conv = m.out_conv[0], m.out_conv[2]

@@ -280,7 +280,8 @@ class _FusedUpdate:
             dev = params[0].device
             self.table = torch.tensor(rows, dtype=torch.int64).to(dev)
             if self.total is None or self.total.device != dev:
-                self.total = torch.zeros(64, dtype=torch.float32, device=dev)      # striped ||g||^2 accumulators
+                # ||g||^2: bank of 64 (lane 0 = the norm, fixed-order sum) + the per-block partial slots behind it
+                self.total = torch.zeros(_hip.SUMSQ_FLOATS, dtype=torch.float32, device=dev)
             self.key, self.params = key, params
             self.generation += 1
             # Adam keeps one 0-dim CPU "step" tensor per parameter; bumping ~300 of them costs the host 1.3 ms per step.  Re-bind them as
@@ -311,7 +312,8 @@ class _FusedUpdate:
         n, s = len(self.params), _hip.stream()
         clip = bool(max_norm) and max_norm > 0
         if clip and not have_sumsq:
-            self.total.zero_()
+            if n > _hip.SUMSQ_MAX_TENSORS:
+                raise ValueError(f"{n} parameter tensors exceed the squared-norm buffer ({_hip.SUMSQ_MAX_TENSORS})")
             _hip.call("ddpm_mt_grad_sumsq", self.table.data_ptr(), n, self.total.data_ptr(), s)
         lr, bc1, bc2, ema_w = scalars if scalars is not None else (0.0, 1.0, 1.0, 0.0)
         _hip.call("ddpm_mt_adam_ema", self.table.data_ptr(), n, self.total.data_ptr() if clip else 0, float(max_norm or 0.0),
@@ -420,9 +422,8 @@ class _DirectStep:
         gout = _hip.retain(torch.empty_like(out))
         _hip.call("ddpm_mse_bwd", out.data_ptr(), target.data_ptr(), self.gloss.data_ptr(), gout.data_ptr(), B, n, s())
         clip = bool(tr.grad_norm) and tr.grad_norm > 0
-        if clip:
-            _hip.call("ddpm_fill_zero", tr._fused.total.data_ptr(), tr._fused.total.numel() * 4, s())
-        # (the backward's last launch, which rewrites the staging buffer into the flat gradient, also accumulates its squared norm)
+        # (the backward's last launch, which rewrites the staging buffer into the flat gradient, also produces its squared norm: per-block
+        # partials added in a fixed order, so two replicas with the same gradients clip by the same coefficient, bit for bit)
         eng.backward(tape, gout, gflat=self.gflat, cut=cut, want_views=False, sumsq=tr._fused.total.data_ptr() if clip else 0)
         tr._fused.launch(tr.grad_norm, hyper_dev=self.hyper_dev.data_ptr(), have_sumsq=clip)
         eng.refresh_unconditionally()                                          # the next forward reads the re-derived copies

@@ -92,9 +92,11 @@ int ddpm_conv1x1_wgrad_nhwc(const void* dy, long long dy_ld, const void* x, long
 int ddpm_wgrad_reduce(const long long* table, int n_tensors, void* stream);
 
 int ddpm_wgrad_unpack(const float* gpack, float* gflat, const long long* descs, int n_tensors, float scale, void* stream);
-/* ... the same pass, also accumulating the sum of squares of everything it writes into total_sq (the bank of 64 fp32 accumulators that
- * ddpm_mt_grad_sumsq fills and ddpm_mt_adam_ema reads; zero on entry): the global gradient norm of nn.utils.clip_grad_norm_
- * (ddpm_torch/utils/train.py:159) without another read of all gradients */
+/* ... the same pass, also producing the sum of squares of everything it writes: the global gradient norm of nn.utils.clip_grad_norm_
+ * (ddpm_torch/utils/train.py:159) without another read of all gradients.  total_sq: ddpm_mt_sumsq_slots(n_tensors) floats; every block
+ * stores its partial in its own slot behind the 64-float bank and a second launch adds the slots in a FIXED order: on return
+ * (stream-ordered) total_sq[0] is the sum and lanes 1..63 are zero — bit-deterministic, so data-parallel replicas holding identical
+ * gradients derive the identical clip coefficient (fp32 atomics into the bank, as before round 5, let them drift apart by ulps). */
 int ddpm_wgrad_unpack_sumsq(const float* gpack, float* gflat, const long long* descs, int n_tensors, float scale, float* total_sq, void* stream);
 
 /* F.linear (modules.py:58-59; unet.py:77,123,125) and torch.einsum in AttentionBlock.qkv (unet.py:46,50):
@@ -240,9 +242,10 @@ int ddpm_adam_ema_step(float* p, const float* g, float* m, float* v, float* shad
                        float ema_w, void* stream);
 
 /* multi-tensor forms: ONE launch over every parameter tensor.  table[i] = {p, g, m, v, shadow (0 = none), numel} (int64).
- * ddpm_mt_grad_sumsq: total_sq is a bank of 64 floats (zero on entry) whose SUM receives sum ||g_i||^2 (striped so that the
- * final atomics of ~5000 blocks do not serialise on one address).  ddpm_mt_adam_ema: the fused update above for all i, with the
- * clipping norm taken from the sum of that bank. */
+ * ddpm_mt_grad_sumsq: total_sq holds ddpm_mt_sumsq_slots(n_tensors) floats; on return total_sq[0] = sum ||g_i||^2 (lanes 1..63 zero),
+ * added up in a fixed order (see ddpm_wgrad_unpack_sumsq).  ddpm_mt_adam_ema: the fused update above for all i, with the clipping norm
+ * taken from the sum of the 64-float bank at total_sq. */
+int ddpm_mt_sumsq_slots(int n_tensors);
 int ddpm_mt_grad_sumsq(const long long* table, int n_tensors, float* total_sq, void* stream);
 /* hyper_dev (optional, 4 device floats {lr, bias_corr1, bias_corr2, ema_w}) overrides the by-value scalars: the values of the
  * current step are read from memory, so one captured hipGraph serves every training step. */

@@ -38,6 +38,12 @@ def run(rank, world, port, mode, out_dir, kind="cpu"):
         torch.cuda.set_device(rank)
         dev = torch.device("cuda", rank)
         dist.init_process_group("nccl", rank=rank, world_size=world)            # "nccl" is RCCL on ROCm
+    elif kind == "cuda_shared":
+        # every rank on GPU 0, collectives over gloo (RCCL refuses two ranks on one device): the REAL kernels, streams and launch plan
+        # under a world size > 1 on a one-GPU box — the exchange logic on device, not the xGMI transport (tests/test_ddp_one_gpu.py)
+        torch.cuda.set_device(0)
+        dev = torch.device("cuda", 0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     else:
         dev = torch.device("cpu")
         dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -57,7 +63,7 @@ def run(rank, world, port, mode, out_dir, kind="cpu"):
         model.set_process_group()                         # broadcast + chunked all-reduce inside the hand-written backward
         net = model
     else:
-        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[rank] if kind == "cuda" else None)     # the reference's wrapper (train.py:110) must keep working
+        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev.index] if dev.type == "cuda" else None)     # the reference's wrapper (train.py:110) must keep working
     net.train()
     y = net(x.to(dev), t.to(dev))
     (y * gy.to(dev)).sum().backward()
@@ -76,7 +82,7 @@ def run(rank, world, port, mode, out_dir, kind="cpu"):
                                 device=dev, distributed=True, rank=rank)
         model.zero_grad(set_to_none=True)
         losses = []
-        for i in range(4 if kind == "cuda" or mode in ("native_plan", "native_eager4") else 1):
+        for i in range(4 if kind.startswith("cuda") or mode in ("native_plan", "native_eager4") else 1):
             tr.stats.reset()
             tr.step(x.clamp(-1, 1).to(dev), global_steps=i + 1)
             losses.append(tr.current_stats["loss"])

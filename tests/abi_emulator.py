@@ -206,7 +206,9 @@ class Emulator:
         for src, dst, N, C, RS in i64(descs, 5 * n).reshape(n, 5):
             g = f32(gflat + 4 * int(dst), int(N * C * RS)).astype(np.float64)
             tot += float((g * g).sum())
-        f32(total, 64)[0] += np.float32(tot)
+        bank = f32(total, 64)
+        bank[...] = 0
+        bank[0] = np.float32(tot)
 
     def _operand(self, p, ld, bs, trans, rows, K, batch, dt):
         es = 2 if dt == BF16 else 4
@@ -373,7 +375,9 @@ class Emulator:
         for row in i64(table, 6 * n).reshape(n, 6):
             g = f32(int(row[1]), int(row[5])).astype(np.float64)
             tot += float((g * g).sum())
-        f32(total, 64)[0] += np.float32(tot)
+        bank = f32(total, 64)
+        bank[...] = 0
+        bank[0] = np.float32(tot)
 
     def ddpm_mt_adam_ema(self, table, n, total, max_norm, lr, b1, b2, eps, bc1, bc2, ema_w, hyper, st):
         if hyper:
