@@ -14,9 +14,9 @@ import math
 import torch
 
 from .fid_score import InceptionStatistics, calc_fd, get_precomputed
-from .precision_recall import Manifold, ManifoldBuilder, calc_pr
+from .precision_recall import Manifold, ManifoldBuilder, calc_pr, load_manifold
 
-__all__ = ["InceptionStatistics", "get_precomputed", "calc_fd", "ManifoldBuilder", "Manifold", "calc_pr", "Evaluator"]
+__all__ = ["InceptionStatistics", "get_precomputed", "calc_fd", "ManifoldBuilder", "Manifold", "calc_pr", "load_manifold", "Evaluator"]
 
 
 class Evaluator:

@@ -97,9 +97,12 @@ def get_precomputed(dataset, download_dir="precomputed"):
     """(mu, sigma) of the dataset's reference activations from ``<download_dir>/fid_stats_<...>.npz`` (keys "mu", "sigma") — the file the
     reference downloads on first use (fid_score.py:160-183).  No network here: a missing file is an error that names the URL."""
     url = PRECOMPUTED_URLS.get(dataset, f"fid_stats_{dataset}.npz")
-    path = os.path.join(download_dir or ".", os.path.basename(url))
-    if not os.path.exists(path):
-        raise FileNotFoundError(f"{path} not found: place the precomputed statistics of '{dataset}' there ({url}); this build does not download")
+    # the published file's name first, then the name eval.py saves statistics computed from the raw data under (eval.py:96)
+    names = [os.path.basename(url), f"fid_stats_{dataset}.npz"]
+    path = next((p for p in (os.path.join(download_dir or ".", n) for n in names) if os.path.exists(p)), None)
+    if path is None:
+        raise FileNotFoundError(f"{os.path.join(download_dir or '.', names[0])} not found: place the precomputed statistics of '{dataset}' there "
+                                f"({url}); this build does not download")
     with np.load(path) as data:
         return data["mu"], data["sigma"]
 

@@ -9,7 +9,7 @@ from collections import namedtuple
 import numpy as np
 import torch
 
-__all__ = ["Manifold", "ManifoldBuilder", "calc_pr", "compute_distance", "to_uint8"]
+__all__ = ["Manifold", "ManifoldBuilder", "calc_pr", "compute_distance", "to_uint8", "load_manifold"]
 
 Manifold = namedtuple("Manifold", ["features", "kth"])
 
@@ -109,6 +109,14 @@ class ManifoldBuilder:
     def save(self, fpath):
         os.makedirs(os.path.dirname(fpath) or ".", exist_ok=True)
         torch.save(self.manifold, fpath)
+
+
+def load_manifold(fpath):
+    """A manifold file written by ``ManifoldBuilder.save`` — here or by the reference (the same namedtuple under the same module path) —
+    opened with the tensors-only unpickler plus that one class."""
+    with torch.serialization.safe_globals([Manifold]):
+        features, kth = torch.load(fpath, map_location="cpu", weights_only=True)
+    return Manifold(features=features, kth=kth)
 
 
 def _coverage(probe, support, row_batch_size, col_batch_size, device):

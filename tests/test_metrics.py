@@ -132,3 +132,63 @@ def test_evaluator_runs_the_reference_protocol_with_a_pluggable_extractor(tmp_pa
     monkeypatch.delenv("DDPM_TORCH_AMD_INCEPTION", raising=False)
     with pytest.raises(RuntimeError, match="feature network"):
         ddpm_torch.Evaluator("cifar10", target_stats=target)
+
+
+def test_eval_cli_scores_a_sample_folder(tmp_path, monkeypatch):
+    """``eval.py`` end to end (reference: eval.py:72-141) with stand-in feature networks: a folder of PNG samples against a dataset read from
+    its own on-disk format; statistics / manifold computed from the raw data on the first run, loaded from ``--precomputed-dir`` on the
+    second; results appended to metrics.txt; refused without a network."""
+    import importlib.util
+    import os
+    import pickle
+    from PIL import Image
+    spec = importlib.util.spec_from_file_location("eval_cli", os.path.join(os.path.dirname(ddpm_torch.__file__), "..", "eval.py"))
+    cli = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cli)
+    rng = np.random.RandomState(0)
+    folder = tmp_path / "data" / "cifar-10-batches-py"
+    folder.mkdir(parents=True)
+    real = []
+    for fn in [f"data_batch_{i}" for i in range(1, 6)]:
+        arr = rng.randint(0, 256, (12, 3072), dtype=np.uint8)
+        real.append(arr.reshape(-1, 3, 32, 32))
+        with open(folder / fn, "wb") as f:
+            pickle.dump({"data": arr, "labels": [0] * 12}, f, protocol=2)
+    real = torch.from_numpy(np.concatenate(real))
+    gen = torch.from_numpy(np.concatenate([rng.randint(0, 256, (20, 32, 32, 3), dtype=np.uint8),       # half like the data,
+                                           rng.randint(0, 160, (20, 32, 32, 3), dtype=np.uint8)]))     # half darker: 0 < precision < 1
+    run = tmp_path / "images" / "run1"
+    run.mkdir(parents=True)
+    for i, g in enumerate(gen):
+        Image.fromarray(g.numpy()).save(run / f"{i:03d}.png")
+    D = 5
+    fid_net = lambda x: torch.stack([x[:, 0].mean(dim=(1, 2)), x[:, 1].mean(dim=(1, 2)), x[:, 2].mean(dim=(1, 2)), x[:, :, :16].mean(dim=(1, 2, 3)),
+                                     x[:, :, :, :16].mean(dim=(1, 2, 3))], dim=1) * 10     # noqa: E731  ([-1, 1] floats in)
+    pr_net = lambda x: x.float().reshape(x.shape[0], 3, 4, 8, 4, 8).mean(dim=(3, 5)).reshape(x.shape[0], -1) / 16      # noqa: E731  (uint8 in)
+    monkeypatch.setattr(M.InceptionStatistics.__init__, "__defaults__", (None, D, torch.device("cpu"), None))
+    argv = ["--root", str(tmp_path / "data"), "--dataset", "cifar10", "--sample-folder", str(run) + "/", "--device", "cpu", "--num-workers", "0",
+            "--eval-batch-size", "16", "--eval-total-size", "1000", "--precomputed-dir", str(tmp_path / "pre"), "--nhood-size", "2"]
+    out = cli.main(argv, extractors={"fid": fid_net, "pr": pr_net})
+    # the same numbers from the library, directly
+    to_float = lambda u: (u.float() - 127.5) / 127.5                                      # noqa: E731
+    sa, sb = M.InceptionStatistics(activation_dim=D, feature_extractor=fid_net), M.InceptionStatistics(activation_dim=D, feature_extractor=fid_net)
+    sa(to_float(real)); sb(to_float(gen.permute(0, 3, 1, 2)))
+    want_fid = M.calc_fd(*sb.get_statistics(), *sa.get_statistics())
+    assert out["folder_name"] == "run1" and abs(out["fid"] - want_fid) <= 1e-6 * max(1.0, want_fid) and out["fid"] > 0.1     # (batches of 16 vs one: fp64 merge order)
+    mt, mg = (M.ManifoldBuilder(features=pr_net(v), nhood_size=2).manifold for v in (real, gen.permute(0, 3, 1, 2)))
+    p, r = M.calc_pr(mg, mt, 10000, 10000, torch.device("cpu"))
+    assert out["pr"] == f"{float(p):.3f}/{float(r):.3f}" and 0.0 < float(p) < 1.0
+    assert (tmp_path / "pre" / "fid_stats_cifar10.npz").exists() and (tmp_path / "pre" / "pr_manifold_cifar10.pt").exists()
+    loaded = M.load_manifold(tmp_path / "pre" / "pr_manifold_cifar10.pt")
+    assert torch.equal(loaded.features, mt.features) and torch.equal(loaded.kth, mt.kth)
+    # second run: the dataset is gone, the precomputed files answer
+    for fn in os.listdir(folder):
+        os.remove(folder / fn)
+    again = cli.main(argv, extractors={"fid": fid_net, "pr": pr_net})
+    assert again == out
+    lines = (tmp_path / "images" / "metrics.txt").read_text()
+    assert lines.count("'folder_name': 'run1'") == 2 and "'fid'" in lines and "'pr'" in lines
+    # no network given: refused
+    monkeypatch.delenv("DDPM_TORCH_AMD_INCEPTION", raising=False)
+    with pytest.raises(RuntimeError, match="feature network"):
+        cli.main(argv + ["--metrics", "fid"])
