@@ -29,7 +29,7 @@ def _launch(mode, out_dir, **extra_env):
     outs = []
     for p in procs:
         try:
-            outs.append(p.communicate(timeout=900)[0].decode())
+            outs.append(p.communicate(timeout=300)[0].decode())
         except subprocess.TimeoutExpired:
             for q in procs:
                 q.kill()
