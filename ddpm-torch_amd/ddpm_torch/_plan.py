@@ -16,7 +16,8 @@ Everything a recorded call addresses must keep its address:
 Step-varying scalars must be device-resident (learning rate / bias corrections / EMA weight / dropout seed word: ``hyper_dev``), the
 contract the captured-graph form already imposed.  Anything in the body that is NOT a ``_hip.call`` (a torch op) would silently be left
 out of the replays: the direct step draws (t, noise) outside the recorded region and has no other torch arithmetic
-(``tests/test_plan_gpu.py`` holds replayed steps to eager steps bit for bit).
+(``tests/test_configs_gpu.py::test_captured_training_step_equals_the_eager_step`` holds replayed steps to eager steps; the host-emulated
+suite checks that a recorded body contains no torch arithmetic).
 """
 import contextlib
 import ctypes
