@@ -218,6 +218,13 @@ def main():
         if rank == 0:
             print(json.dumps({"launch_probe": True, "n_gpus": world, "ranks_in_collective": int(seen)}))
         return
+    # The JSON line must be the only thing on stdout.  RCCL prints a version banner ("RCCL version : ... / Librccl path : ...") through C
+    # stdio when a communicator comes up; on a pipe or a file that buffer is flushed at process exit, i.e. AFTER Python's own line — seen on
+    # the one-rank RCCL run (profiles/r05h_bench_ddp1.json was followed by five banner lines), and with N ranks every rank would add its own.
+    # So the process-level stdout (fd 1) of every rank is pointed at stderr from here on and Python keeps the original for its one print.
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     ranks_seen = 1
@@ -550,7 +557,7 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), file=json_out, flush=True)
 
 
 if __name__ == "__main__":
