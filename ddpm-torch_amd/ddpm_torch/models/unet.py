@@ -265,6 +265,7 @@ _SLAB_FLUSH_ROWS = int(os.environ.get("DDPM_SLAB_FLUSH_ROWS", "3"))   # slab red
 # 9.87 / 9.81 / 9.83 ms per step (every one of nine 0-vs-4 pairs in favour of 4); 0 = off.
 _TAIL_BLOCKS = int(os.environ.get("DDPM_WGRAD3_TAIL_BLOCKS", "4"))
 _TAIL_ANY = os.environ.get("DDPM_WGRAD3_TAIL_ANY", "0") != "0"
+_DP_ISSUE_ON_SIDE = os.environ.get("DDPM_DP_ISSUE_ON_SIDE", "1") != "0"      # data parallel: chunk exchanges ordered behind the side stream, no main-stream joins (0: round-4 form)
 _ABL_NO_LEAF_ORDER = os.environ.get("DDPM_ABL_NO_LEAF_ORDER", "0") != "0"   # TIMING-ONLY ablation (wrong results): leaves are not ordered behind the main stream
 _WGRAD1 = os.environ.get("DDPM_WGRAD1", "1") != "0"                # slab kernel for the 1x1 weight gradients
 _WGRAD3_ATOMIC = os.environ.get("DDPM_WGRAD3_ATOMIC", "0") != "0"  # ... with fp32 atomics instead of slab copies
@@ -755,10 +756,25 @@ class _Engine:
                 self._fc_wgrad(ctx, k)
             ctx["pending"].pop()
             if ctx["dp"]:
-                self._flush_slabs(ctx)                       # the chunk's conv gradients must be summed before they travel
-                self._join_side(ctx)                         # ... and produced: the communicator orders itself after the main stream
-                works, chunk = ctx["works"], ctx["gpack"][a:b]
-                self._comm(ctx, lambda works=works, chunk=chunk: works.append(self._all_reduce(chunk)))
+                works, chunk, side = ctx["works"], ctx["gpack"][a:b], ctx.get("side")
+                if side is not None and _DP_ISSUE_ON_SIDE and not torch.cuda.is_current_stream_capturing():
+                    # Everything in a chunk is produced on the SIDE stream (weight gradients, their slab sums, the time-projection rows).
+                    # torch's communicators order a collective behind the stream that is current when it is issued: issued with the side
+                    # stream current, the exchange waits for exactly its producers and the MAIN stream — the critical path — waits for
+                    # nothing.  (Round 5, found on the one-rank RCCL bench line: joining the side stream into the main stream at every
+                    # chunk, as below, cost 1.0 ms per step — nine stalls of the chain that the exchange is supposed to hide under.)
+                    self._flush_slabs(ctx, on_side=True)
+
+                    def issue(works=works, chunk=chunk, side=side):
+                        with torch.cuda.stream(side):
+                            works.append(self._all_reduce(chunk))
+                    self._comm(ctx, issue)
+                else:
+                    # (single-stream runs, and steps being captured as hipGraph segments: a segment ends with its side branch joined, and
+                    #  at replay the whole segment is work of the stream the graph is launched on)
+                    self._flush_slabs(ctx)                   # the chunk's conv gradients must be summed before they travel
+                    self._join_side(ctx)                     # ... and produced: the communicator orders itself after the main stream
+                    self._comm(ctx, lambda works=works, chunk=chunk: works.append(self._all_reduce(chunk)))
         return did_bias
 
     def _fc_wgrad(self, ctx, k):
@@ -1152,7 +1168,9 @@ class _Engine:
         # ---- the rest of the tape in reverse
         for rec in reversed(tape[:-1]):
             kind = rec[0]
-            if not ctx["dp"] and len(ctx["slab_rows"]) >= _SLAB_FLUSH_ROWS:
+            # (the same grouping of rows whether the step runs eagerly, is being recorded or is being captured: the reduce tables are
+            #  cached per group and built with a host -> device copy, which a stream capture does not allow)
+            if len(ctx["slab_rows"]) >= _SLAB_FLUSH_ROWS and (not ctx["dp"] or (_DP_ISSUE_ON_SIDE and ctx["side"] is not None)):
                 self._flush_slabs(ctx, on_side=True)
             if kind == "res":
                 self._res_bwd(ctx, rec)
