@@ -626,7 +626,7 @@ class Trainer:
         self.use_ema = use_ema
         self.ema = EMA(model.module if isinstance(model, DDP) else model, decay=ema_decay) if use_ema else nullcontext()
         self.stats = _StepStatistics(self._collect_loss, loss=None)
-        self._loss_pending, self._loss_host, self._loss_slot = None, None, 0
+        self._loss_pending, self._loss_host, self._loss_slot, self._stat_stream = None, None, 0, None
         self._fused = _FusedUpdate(optimizer, self.ema)
         self._direct = {}                               # (input shape, train/eval) -> _DirectStep
         self._hi_stream = None                          # high-priority stream of the direct step (DDPM_MAIN_PRIORITY)
@@ -744,7 +744,8 @@ class Trainer:
                 self.optimizer.zero_grad(set_to_none=True)
                 self.scheduler.step()
             loss = loss.detach()
-        if self.distributed:
+        off_chain = self.distributed and _ASYNC_LOSS and loss.is_cuda
+        if self.distributed and not off_chain:
             dist.reduce(loss, dst=0, op=dist.ReduceOp.SUM)
             loss.div_(self.world_size)
         if _ASYNC_LOSS and loss.is_cuda:
@@ -757,9 +758,25 @@ class Trainer:
                 self._loss_host = [torch.zeros((), dtype=torch.float32).pin_memory() for _ in range(2)]
             buf = self._loss_host[self._loss_slot]
             self._loss_slot ^= 1
-            buf.copy_(loss, non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record()
+            if off_chain:
+                # Data parallel: the loss reduce of the reference (utils/train.py:166-169) is a collective at the END of every step; waited
+                # for on the step's own stream, its latency sits between this step's update and the next step's forward.  Nothing on the
+                # chain needs the reduced value: the collective is issued asynchronously (the communicator orders it behind the step),
+                # and the division + read-back follow it on a stream of their own.
+                if self._stat_stream is None:
+                    self._stat_stream = torch.cuda.Stream(device=loss.device)
+                work = dist.reduce(loss, dst=0, op=dist.ReduceOp.SUM, async_op=True)
+                with torch.cuda.stream(self._stat_stream):
+                    work.wait()                              # (this stream waits for the communicator; the host and the step's stream do not)
+                    loss.div_(self.world_size)
+                    buf.copy_(loss, non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record()
+                loss.record_stream(self._stat_stream)
+            else:
+                buf.copy_(loss, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
             self._loss_pending = (x.shape[0], ev, buf)
         else:
             self._collect_loss()
