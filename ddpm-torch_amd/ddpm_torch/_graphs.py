@@ -24,6 +24,7 @@ class SegmentedGraph:
         self.pool = torch.cuda.graph_pool_handle()
         self.segments = []              # [(CUDAGraph, callback or None)]
         self._open = None
+        self._on_abort = None
         self._generators = []
 
     def register_generator(self, gen):
@@ -55,9 +56,13 @@ class SegmentedGraph:
         self._end(callback)
         self._begin()
 
-    def capture(self, body):
+    def capture(self, body, on_abort=None):
         """Run ``body(cut)`` once under stream capture (nothing executes).  On failure the partial capture is discarded and
-        the exception propagates; the caller falls back to eager execution."""
+        the exception propagates; the caller falls back to eager execution.  ``on_abort()``: called on the capture stream before the
+        broken capture is ended — the body's owner joins whatever streams it had forked into the capture (a capture with unjoined work
+        cannot be ended: the streams would stay in capture mode, the registered generators in their in-graph mode, and the caching
+        allocator would keep routing allocations to this graph's pool)."""
+        self._on_abort = on_abort
         assert not self.segments and self._open is None
         # (an allocator pool released in the middle of a capture — by the cyclic collector freeing an earlier graph or launch plan —
         #  trips an internal assertion of the caching allocator: collect first, keep the collector off while capturing)
@@ -81,10 +86,21 @@ class SegmentedGraph:
                 self._end(None)
             except BaseException:
                 if self._open is not None:
+                    if self._on_abort is not None:
+                        try:
+                            self._on_abort()
+                        except Exception:
+                            pass
                     try:
                         self._open.capture_end()
                     except Exception:
-                        pass
+                        # the capture was invalidated: capture_end stops at hipStreamEndCapture and never tells the caching allocator
+                        # that allocations are no longer routed to this graph's pool (the process would then abort at exit on the
+                        # allocator's "captures_underway.empty()" assertion, after an otherwise successful fallback)
+                        try:
+                            torch._C._cuda_endAllocateToPool(self.device.index if self.device.index is not None else torch.cuda.current_device(), self.pool)
+                        except Exception:
+                            pass
                     self._open = None
                 self.segments.clear()
                 raise

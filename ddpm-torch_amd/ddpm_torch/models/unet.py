@@ -657,6 +657,17 @@ class _Engine:
         finally:
             _hip.route_stream(prev)
 
+    def join_forked_streams(self):
+        """The CURRENT stream waits for the weight-gradient stream if that one is part of a stream capture (a capture being abandoned
+        half-way: see SegmentedGraph.capture)."""
+        side = self._side
+        if side is None:
+            return
+        with torch.cuda.stream(side):
+            forked = torch.cuda.is_current_stream_capturing()
+        if forked:
+            _hip._invoke("ddpm_stream_order", (_hip.stream(), side.cuda_stream))
+
     def _join_side(self, ctx):
         """Main stream waits for everything queued on the side stream so far."""
         if ctx.get("side") is not None:

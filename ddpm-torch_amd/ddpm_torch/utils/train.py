@@ -348,6 +348,25 @@ class _FusedUpdate:
         return True
 
 
+def _end_generator_capture(gen, device):
+    """A capture that dies half-way never reaches the epilogue that switches a registered generator back from its in-graph offset to
+    the ordinary one; the next eager draw from it then raises "Offset increment outside graph capture encountered unexpectedly" — the
+    fallback to the eager step would crash exactly when it is needed (seen once in round 5).  A complete, EMPTY capture with the generator
+    registered runs prologue and epilogue and leaves it usable; its seed and offset outside graphs were never touched."""
+    if gen is None or gen.device.type != "cuda":
+        return
+    try:
+        graph, stream = torch.cuda.CUDAGraph(), torch.cuda.Stream(device=device)
+        graph.register_generator_state(gen)
+        with torch.cuda.stream(stream), warnings.catch_warnings():
+            warnings.simplefilter("ignore")                 # ("The CUDA Graph is empty")
+            graph.capture_begin(capture_error_mode="thread_local")
+            graph.capture_end()
+        torch.cuda.synchronize(device)
+    except Exception as e:                                  # best effort: the eager step will report what is still wrong
+        warnings.warn(f"could not return the training generator to eager use after the failed capture ({type(e).__name__}: {e})")
+
+
 # ========================================================================================== the direct / captured step
 class _DirectStep:
     """State of the autograd-free training step for ONE input shape: persistent buffers, the pointer table of the fused
@@ -449,12 +468,23 @@ class _DirectStep:
         # loss_target of model_mean_type "mean" gathers its coefficients with torch ops: invisible to a plan
         return not self.plan_failed and self.tr.diffusion.model_mean_type in ("eps", "x_0")
 
+    def _candidates(self):
+        """Forms the auto-probe measures.  With a process group the hipGraph form is not a candidate: between its segments sit the
+        communicator calls, its replay serialises the two stream branches the exchange overlaps with (one-rank RCCL: 11.2 ms against 9.9
+        for the plan), and a capture next to a live communicator is the one form whose failure modes cannot be exercised on one GPU.
+        DDPM_TORCH_AMD_TRAIN_GRAPH=1 still forces it."""
+        forms = self._available()
+        if self.unet.engine().pg is not None:
+            forms = [f for f in forms if f != "graph"]
+        return forms
+
     def _form(self):
         """The form the NEXT step takes."""
         forms = self._available()
         if _TRAIN_GRAPH != "auto":
             want = {False: "eager", True: "graph", "plan": "plan"}[_TRAIN_GRAPH]
             return want if want in forms else "eager"
+        forms = self._candidates()
         if self.choice is not None:
             return self.choice if self.choice in forms else "eager"
         for f in forms:
@@ -491,7 +521,7 @@ class _DirectStep:
             torch.cuda.synchronize()
             self.times[kind] = (time.perf_counter() - ph[2]) / self.PROBE
             self._phase = None
-            if all(f in self.times for f in self._available()):
+            if all(f in self.times for f in self._candidates()):
                 self._decide()
 
     def observe(self, seconds):
@@ -545,12 +575,14 @@ class _DirectStep:
             g = SegmentedGraph(self.x0.device)
             g.register_generator(tr.generator)
             try:
-                self.graph = g.capture(self.body)
+                self.graph = g.capture(self.body, on_abort=eng.join_forked_streams)
                 self.captures += 1
                 self._baked = self._identity()
             except Exception as e:                        # capture not possible here: keep training without it
                 warnings.warn(f"hipGraph capture of the training step failed ({type(e).__name__}: {e}); running it eagerly")
                 torch.cuda.synchronize()
+                del g
+                _end_generator_capture(tr.generator, self.x0.device)
                 self.graph_failed, self.graph = True, None
                 if self.choice == "graph":
                     self.choice = None
