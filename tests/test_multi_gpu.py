@@ -31,7 +31,7 @@ def _launch(mode, out_dir, world, **extra_env):
     outs = []
     for p in procs:
         try:
-            outs.append(p.communicate(timeout=900)[0].decode())
+            outs.append(p.communicate(timeout=300)[0].decode())
         except subprocess.TimeoutExpired:
             for q in procs:
                 q.kill()
