@@ -296,9 +296,11 @@ extern "C" int ddpm_wgrad_unpack(const float* gpack, float* gflat, const long lo
     hipLaunchKernelGGL(wgrad_unpack_kernel, dim3(64, n_tensors), dim3(256), 0, (hipStream_t)stream, gpack, gflat, descs, scale, (float*)nullptr);
     return check_launch();
 }
-extern "C" int ddpm_wgrad_unpack_sumsq(const float* gpack, float* gflat, const long long* descs, int n_tensors, float scale, float* total_sq, void* stream) {
+extern "C" int ddpm_wgrad_unpack_sumsq(const float* gpack, float* gflat, const long long* descs, int n_tensors, float scale, float* total_sq,
+                                       long long total_sq_floats, void* stream) {
     if (!gpack || !gflat || !descs || !total_sq) return DDPM_ERR_NULL;
     if (n_tensors <= 0) return DDPM_OK;
+    if (total_sq_floats < 64 + 64ll * n_tensors) return DDPM_ERR_SHAPE;         // == ddpm_mt_sumsq_slots(n_tensors), optim.hip
     hipLaunchKernelGGL(wgrad_unpack_kernel, dim3(64, n_tensors), dim3(256), 0, (hipStream_t)stream, gpack, gflat, descs, scale, total_sq + 64);
     const int rc = check_launch();
     return rc ? rc : ddpm_sumsq_finish_launch(total_sq + 64, 64 * n_tensors, total_sq, stream);

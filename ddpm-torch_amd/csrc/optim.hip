@@ -170,9 +170,10 @@ __global__ void mt_adam_ema_kernel(const long long* __restrict__ table, const fl
 // runs 64 blocks per row, the norm pass 16)
 extern "C" int ddpm_mt_sumsq_slots(int n_tensors) { return MT_SUMSQ_LANES + 64 * (n_tensors > 0 ? n_tensors : 0); }
 // total_sq: ddpm_mt_sumsq_slots(n_tensors) floats; on return (stream-ordered) total_sq[0] holds the sum, lanes 1..63 are zero.
-extern "C" int ddpm_mt_grad_sumsq(const long long* table, int n_tensors, float* total_sq, void* stream) {
+extern "C" int ddpm_mt_grad_sumsq(const long long* table, int n_tensors, float* total_sq, long long total_sq_floats, void* stream) {
     if (!table || !total_sq) return DDPM_ERR_NULL;
     if (n_tensors <= 0) return DDPM_OK;
+    if (total_sq_floats < ddpm_mt_sumsq_slots(n_tensors)) return DDPM_ERR_SHAPE;
     hipLaunchKernelGGL(mt_sumsq_kernel, dim3(MT_SUMSQ_BLOCKS, n_tensors), dim3(256), 0, (hipStream_t)stream, table, total_sq + MT_SUMSQ_LANES);
     const int rc = check_launch();
     return rc ? rc : ddpm_sumsq_finish_launch(total_sq + MT_SUMSQ_LANES, MT_SUMSQ_BLOCKS * n_tensors, total_sq, stream);

@@ -34,7 +34,7 @@ PROTOTYPES = {
     "ddpm_conv1x1_wgrad_nhwc": [P, L, P, L, P, L, P, L, I, I, I, I, I, P],
     "ddpm_wgrad_reduce": [P, I, P],
     "ddpm_wgrad_unpack": [P, P, P, I, F, P],
-    "ddpm_wgrad_unpack_sumsq": [P, P, P, I, F, P, P],
+    "ddpm_wgrad_unpack_sumsq": [P, P, P, I, F, P, L, P],
     "ddpm_gemm": [P, L, L, I, P, L, L, I, P, L, L, P, P, L, L, I, I, I, I, F, I, I, I, I, P],
     "ddpm_groupnorm_silu_fwd": [P, L, P, L, P, P, P, P, I, I, I, I, F, I, F, U, P, I, P],
     "ddpm_groupnorm_silu_bwd": [P, L, P, L, P, L, P, P, P, P, P, P, I, I, I, I, I, F, U, P, I, P, L, P, L, I, P],
@@ -70,7 +70,7 @@ PROTOTYPES = {
     "ddpm_dropout_mask": [P, L, F, U, P],
     "ddpm_mfma_probe": [P, I, I, P],
     "ddpm_mt_sumsq_slots": [I],
-    "ddpm_mt_grad_sumsq": [P, I, P, P],
+    "ddpm_mt_grad_sumsq": [P, I, P, L, P],
     "ddpm_mt_adam_ema": [P, I, P, F, F, F, F, F, F, F, F, P, P],
     "ddpm_mt_gather_f32": [P, I, P],
     "ddpm_sumsq_accumulate": [P, L, P, P, P],

@@ -265,7 +265,10 @@ _SLAB_FLUSH_ROWS = int(os.environ.get("DDPM_SLAB_FLUSH_ROWS", "3"))   # slab red
 # 9.87 / 9.81 / 9.83 ms per step (every one of nine 0-vs-4 pairs in favour of 4); 0 = off.
 _TAIL_BLOCKS = int(os.environ.get("DDPM_WGRAD3_TAIL_BLOCKS", "4"))
 _TAIL_ANY = os.environ.get("DDPM_WGRAD3_TAIL_ANY", "0") != "0"
-_DP_ISSUE_ON_SIDE = os.environ.get("DDPM_DP_ISSUE_ON_SIDE", "1") != "0"      # data parallel: chunk exchanges ordered behind the side stream, no main-stream joins (0: round-4 form)
+# Data parallel: 1 = chunk exchanges ordered behind the side stream, no main-stream joins (-7.5 % on the one-rank RCCL step, round 5).
+# Default 0 = the round-4 form (join + issue on the main stream): a one-rank all-reduce is the identity and gloo stages through the host, so
+# the ordering of the fast form has never been observable on this one-GPU pool.  Opt in after tests/test_multi_gpu.py passed on >= 2 GPUs.
+_DP_ISSUE_ON_SIDE = os.environ.get("DDPM_DP_ISSUE_ON_SIDE", "0") != "0"
 _ABL_NO_LEAF_ORDER = os.environ.get("DDPM_ABL_NO_LEAF_ORDER", "0") != "0"   # TIMING-ONLY ablation (wrong results): leaves are not ordered behind the main stream
 _WGRAD1 = os.environ.get("DDPM_WGRAD1", "1") != "0"                # slab kernel for the 1x1 weight gradients
 _WGRAD3_ATOMIC = os.environ.get("DDPM_WGRAD3_ATOMIC", "0") != "0"  # ... with fp32 atomics instead of slab copies
@@ -1146,7 +1149,7 @@ class _Engine:
         if ctx["sumsq"]:           # the caller's squared-norm buffer (_hip.SUMSQ_FLOATS): the clip norm comes out of this pass (no second read of all gradients)
             if wdesc.shape[0] > _hip.SUMSQ_MAX_TENSORS:
                 raise ValueError(f"{wdesc.shape[0]} gradient rows exceed the squared-norm buffer ({_hip.SUMSQ_MAX_TENSORS})")
-            _hip.call("ddpm_wgrad_unpack_sumsq", gpack.data_ptr(), gflat.data_ptr(), wdesc.data_ptr(), wdesc.shape[0], 1.0 / ctx["world"], ctx["sumsq"], _hip.stream())
+            _hip.call("ddpm_wgrad_unpack_sumsq", gpack.data_ptr(), gflat.data_ptr(), wdesc.data_ptr(), wdesc.shape[0], 1.0 / ctx["world"], ctx["sumsq"], _hip.SUMSQ_FLOATS, _hip.stream())
         else:
             _hip.call("ddpm_wgrad_unpack", gpack.data_ptr(), gflat.data_ptr(), wdesc.data_ptr(), wdesc.shape[0], 1.0 / ctx["world"], _hip.stream())
         return gflat

@@ -44,6 +44,9 @@ __all__ = ["Trainer", "EMA", "ModelWrapper", "DummyScheduler", "RunningStatistic
 # "auto" (default): the captured step is used when it measures faster than the eager one on this workload; "1" / "0" force it
 _MAIN_PRIORITY = os.environ.get("DDPM_MAIN_PRIORITY", "0") != "0"        # run the direct step's main chain on a high-priority stream
 _ASYNC_LOSS = os.environ.get("DDPM_TORCH_AMD_ASYNC_LOSS", "1") != "0"     # 0: read the loss back synchronously in every step
+# distributed runs: 1 = the per-step loss reduce is issued asynchronously and read back on a stream of its own (round 5).  Default 0 = the
+# reference's synchronous reduce on the step's stream (utils/train.py:166-169): opt in after tests/test_multi_gpu.py passed on >= 2 GPUs.
+_ASYNC_LOSS_REDUCE = os.environ.get("DDPM_TORCH_AMD_ASYNC_LOSS_REDUCE", "0") != "0"
 _TRAIN_GRAPH = {"0": False, "1": True, "plan": "plan"}.get(os.environ.get("DDPM_TORCH_AMD_TRAIN_GRAPH", "auto"), "auto")
 
 
@@ -314,7 +317,7 @@ class _FusedUpdate:
         if clip and not have_sumsq:
             if n > _hip.SUMSQ_MAX_TENSORS:
                 raise ValueError(f"{n} parameter tensors exceed the squared-norm buffer ({_hip.SUMSQ_MAX_TENSORS})")
-            _hip.call("ddpm_mt_grad_sumsq", self.table.data_ptr(), n, self.total.data_ptr(), s)
+            _hip.call("ddpm_mt_grad_sumsq", self.table.data_ptr(), n, self.total.data_ptr(), self.total.numel(), s)
         lr, bc1, bc2, ema_w = scalars if scalars is not None else (0.0, 1.0, 1.0, 0.0)
         _hip.call("ddpm_mt_adam_ema", self.table.data_ptr(), n, self.total.data_ptr() if clip else 0, float(max_norm or 0.0),
                   float(lr), b1, b2, g["eps"], float(bc1), float(bc2), float(ema_w), hyper_dev, s)
@@ -776,7 +779,7 @@ class Trainer:
                 self.optimizer.zero_grad(set_to_none=True)
                 self.scheduler.step()
             loss = loss.detach()
-        off_chain = self.distributed and _ASYNC_LOSS and loss.is_cuda
+        off_chain = self.distributed and _ASYNC_LOSS and _ASYNC_LOSS_REDUCE and loss.is_cuda
         if self.distributed and not off_chain:
             dist.reduce(loss, dst=0, op=dist.ReduceOp.SUM)
             loss.div_(self.world_size)

@@ -96,8 +96,11 @@ int ddpm_wgrad_unpack(const float* gpack, float* gflat, const long long* descs, 
  * (ddpm_torch/utils/train.py:159) without another read of all gradients.  total_sq: ddpm_mt_sumsq_slots(n_tensors) floats; every block
  * stores its partial in its own slot behind the 64-float bank and a second launch adds the slots in a FIXED order: on return
  * (stream-ordered) total_sq[0] is the sum and lanes 1..63 are zero — bit-deterministic, so data-parallel replicas holding identical
- * gradients derive the identical clip coefficient (fp32 atomics into the bank, as before round 5, let them drift apart by ulps). */
-int ddpm_wgrad_unpack_sumsq(const float* gpack, float* gflat, const long long* descs, int n_tensors, float scale, float* total_sq, void* stream);
+ * gradients derive the identical clip coefficient (fp32 atomics into the bank, as before round 5, let them drift apart by ulps).
+ * total_sq_floats: the capacity of total_sq in floats; DDPM_ERR_SHAPE when it is below ddpm_mt_sumsq_slots(n_tensors) (the buffer was a
+ * 64-float bank before round 5: a caller that still passes one is refused instead of being written past). */
+int ddpm_wgrad_unpack_sumsq(const float* gpack, float* gflat, const long long* descs, int n_tensors, float scale, float* total_sq,
+                            long long total_sq_floats, void* stream);
 
 /* F.linear (modules.py:58-59; unet.py:77,123,125) and torch.einsum in AttentionBlock.qkv (unet.py:46,50):
  *   C[b][m][n] = alpha * sum_k A[b][m][k] * B[b][n][k] + bias[n] + residual[b][m][n]   (+ C when accumulate)
@@ -243,10 +246,11 @@ int ddpm_adam_ema_step(float* p, const float* g, float* m, float* v, float* shad
 
 /* multi-tensor forms: ONE launch over every parameter tensor.  table[i] = {p, g, m, v, shadow (0 = none), numel} (int64).
  * ddpm_mt_grad_sumsq: total_sq holds ddpm_mt_sumsq_slots(n_tensors) floats; on return total_sq[0] = sum ||g_i||^2 (lanes 1..63 zero),
- * added up in a fixed order (see ddpm_wgrad_unpack_sumsq).  ddpm_mt_adam_ema: the fused update above for all i, with the clipping norm
- * taken from the sum of the 64-float bank at total_sq. */
+ * added up in a fixed order (see ddpm_wgrad_unpack_sumsq; total_sq_floats < ddpm_mt_sumsq_slots(n_tensors) -> DDPM_ERR_SHAPE).
+ * ddpm_mt_adam_ema: the fused update above for all i, with the clipping norm taken from the sum of the 64-float bank at total_sq — it
+ * reads total_sq[0..63] and nothing behind them, so a 64-float buffer is enough for this call. */
 int ddpm_mt_sumsq_slots(int n_tensors);
-int ddpm_mt_grad_sumsq(const long long* table, int n_tensors, float* total_sq, void* stream);
+int ddpm_mt_grad_sumsq(const long long* table, int n_tensors, float* total_sq, long long total_sq_floats, void* stream);
 /* hyper_dev (optional, 4 device floats {lr, bias_corr1, bias_corr2, ema_w}) overrides the by-value scalars: the values of the
  * current step are read from memory, so one captured hipGraph serves every training step. */
 int ddpm_mt_adam_ema(const long long* table, int n_tensors, const float* total_sq, float max_norm, float lr, float beta1,

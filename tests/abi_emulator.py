@@ -200,7 +200,8 @@ class Emulator:
             v = f32(gpack + 4 * int(src), int(N * C * RS)).reshape(N, RS, C).transpose(0, 2, 1)
             f32(gflat + 4 * int(dst), int(N * C * RS)).reshape(N, C, RS)[...] = v * np.float32(scale)
 
-    def ddpm_wgrad_unpack_sumsq(self, gpack, gflat, descs, n, scale, total, st):
+    def ddpm_wgrad_unpack_sumsq(self, gpack, gflat, descs, n, scale, total, total_floats, st):
+        assert total_floats >= 64 + 64 * n
         self.ddpm_wgrad_unpack(gpack, gflat, descs, n, scale, st)
         tot = 0.0
         for src, dst, N, C, RS in i64(descs, 5 * n).reshape(n, 5):
@@ -370,7 +371,8 @@ class Emulator:
                 v += f32(int(b), int(numel))
             f32(int(dst), int(numel))[...] = v
 
-    def ddpm_mt_grad_sumsq(self, table, n, total, st):
+    def ddpm_mt_grad_sumsq(self, table, n, total, total_floats, st):
+        assert total_floats >= 64 + 64 * n
         tot = 0.0
         for row in i64(table, 6 * n).reshape(n, 6):
             g = f32(int(row[1]), int(row[5])).astype(np.float64)

@@ -676,10 +676,10 @@ def test_multi_tensor_update_with_scalars_from_device_memory():
                 sr += (1 - d) * (q.detach() - sr)
             for g_dev, g_ in zip(G, gs):
                 g_dev.copy_(g_)
-            _hip.call("ddpm_mt_grad_sumsq", table.data_ptr(), len(P), total.data_ptr(), _hip.stream())
+            _hip.call("ddpm_mt_grad_sumsq", table.data_ptr(), len(P), total.data_ptr(), total.numel(), _hip.stream())
             first = total[:64].clone()
             assert abs(float(first.sum().sqrt()) - float(norm)) < 1e-4 * float(norm) and float(first[1:].abs().max()) == 0.0
-            _hip.call("ddpm_mt_grad_sumsq", table.data_ptr(), len(P), total.data_ptr(), _hip.stream())
+            _hip.call("ddpm_mt_grad_sumsq", table.data_ptr(), len(P), total.data_ptr(), total.numel(), _hip.stream())
             assert torch.equal(total[:64], first)                              # fixed-order sum: the same bits every time
             sc = (3e-3, 1 - 0.9 ** step, 1 - 0.999 ** step, 1 - d)
             if hyper_mode:
@@ -792,15 +792,19 @@ def test_wgrad_unpack_and_fused_norm():
         slots = _hip.lib().ddpm_mt_sumsq_slots(len(rows))
         total = torch.zeros(slots)
         if fused:
-            both("ddpm_wgrad_unpack_sumsq", A(gpack), A(gflat, out=True, name="gflat"), A(descs), len(rows), 0.5, A(total), tol=0.0)
+            both("ddpm_wgrad_unpack_sumsq", A(gpack), A(gflat, out=True, name="gflat"), A(descs), len(rows), 0.5, A(total), slots, tol=0.0)
             dp, df, dd, dtot = gpack.cuda(), torch.zeros(dst_off).cuda(), descs.cuda(), torch.full((slots,), 7.0).cuda()     # dirty on entry
             ref = sum(float((0.5 * gpack[s:s + N * C * RS].double()).pow(2).sum()) for s, _, N, C, RS in rows)
             seen = []
             for _ in range(3):
-                _hip.call("ddpm_wgrad_unpack_sumsq", dp.data_ptr(), df.data_ptr(), dd.data_ptr(), len(rows), 0.5, dtot.data_ptr(), _hip.stream())
+                _hip.call("ddpm_wgrad_unpack_sumsq", dp.data_ptr(), df.data_ptr(), dd.data_ptr(), len(rows), 0.5, dtot.data_ptr(), slots, _hip.stream())
                 seen.append(dtot[:64].clone())
                 assert abs(float(dtot[0].double()) - ref) <= 1e-5 * ref and float(dtot[1:64].abs().max()) == 0.0
             assert torch.equal(seen[0], seen[1]) and torch.equal(seen[0], seen[2])       # fixed-order sum: the same bits every launch
+            # a buffer sized for the pre-round-5 contract (a 64-float bank) is refused, not written past
+            lib = _hip.lib()
+            assert lib.ddpm_wgrad_unpack_sumsq(dp.data_ptr(), df.data_ptr(), dd.data_ptr(), len(rows), 0.5, dtot.data_ptr(), 64, _hip.stream()) == 1
+            assert lib.ddpm_mt_grad_sumsq(dd.data_ptr(), len(rows), dtot.data_ptr(), slots - 1, _hip.stream()) == 1
         else:
             both("ddpm_wgrad_unpack", A(gpack), A(gflat, out=True, name="gflat"), A(descs), len(rows), 0.5, tol=0.0)
 
