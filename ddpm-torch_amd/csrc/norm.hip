@@ -540,6 +540,58 @@ __device__ __forceinline__ void gn_lane_reduce(float (&v)[CNT], int sv, int lane
     }
 }
 
+// The same wave stage without the LDS crossbar (gfx950): lanes l and l ^ 32 / l ^ 16 trade HALF their payload with v_permlane32_swap /
+// v_permlane16_swap — one swap + one add retire two values, for both partners at once — and the in-row steps (lanes of a 16-lane row
+// that hold the same vector column: l, l + sv, l + 2 sv, ...) are v_add_f32 with a row_ror DPP operand.  16 values: 12 swaps + 12 adds,
+// then 4 x log2(16 / sv) DPP adds — against 15 ds_bpermute round trips with two selects each.  Lane l ends with the wave totals of
+// the values base .. base + CNT' - 1 for its column (base = bit 5 of the lane selects the upper half, bit 4 the upper quarter).
+typedef unsigned gn_u32x2 __attribute__((ext_vector_type(2)));
+template <int CTRL>
+__device__ __forceinline__ float gn_dpp_add(float v) {
+    return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+template <int CNT, typename W>
+__device__ __forceinline__ void gn_lane_reduce_hw(float (&v)[CNT], int sv, int lane, W&& write) {
+    static_assert(CNT % 4 == 0, "two halvings");
+    float h[CNT / 2];
+#pragma unroll
+    for (int k = 0; k < CNT / 2; ++k) {
+        const gn_u32x2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[k]), __float_as_uint(v[k + CNT / 2]), false, false);
+        h[k] = __uint_as_float(r.x) + __uint_as_float(r.y);
+    }
+    int base = (lane & 32) ? CNT / 2 : 0;
+    if (sv > 16) {                                   // 32 vector columns: rows 0-1 / 2-3 hold different columns, nothing else to add
+#pragma unroll
+        for (int k = 0; k < CNT / 2; ++k) write(base + k, h[k]);
+        return;
+    }
+    float q[CNT / 4];
+#pragma unroll
+    for (int k = 0; k < CNT / 4; ++k) {
+        const gn_u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(h[k]), __float_as_uint(h[k + CNT / 4]), false, false);
+        q[k] = __uint_as_float(r.x) + __uint_as_float(r.y);
+    }
+    base += (lane & 16) ? CNT / 4 : 0;
+    if (sv <= 8) {
+#pragma unroll
+        for (int k = 0; k < CNT / 4; ++k) q[k] = gn_dpp_add<0x128>(q[k]);          // row_ror:8
+    }
+    if (sv <= 4) {
+#pragma unroll
+        for (int k = 0; k < CNT / 4; ++k) q[k] = gn_dpp_add<0x124>(q[k]);          // row_ror:4
+    }
+    if (sv <= 2) {
+#pragma unroll
+        for (int k = 0; k < CNT / 4; ++k) q[k] = gn_dpp_add<0x122>(q[k]);          // row_ror:2
+    }
+    if (sv <= 1) {
+#pragma unroll
+        for (int k = 0; k < CNT / 4; ++k) q[k] = gn_dpp_add<0x121>(q[k]);          // row_ror:1
+    }
+#pragma unroll
+    for (int k = 0; k < CNT / 4; ++k) write(base + k, q[k]);
+}
+
 // NARR partial vectors at once (same barriers): sh_row holds NARR x [NW waves][seg_ch], sh_ch NARR x [seg_ch]
 // sum over the cpg consecutive lanes of a channel group (cpg a power of two <= 64, groups aligned to it)
 __device__ __forceinline__ float gn_group_lanes_sum(float v, int cpg) {
@@ -551,10 +603,17 @@ template <int VEC, int NARR, int NW = 8>
 __device__ __forceinline__ void gn_wave_partials(float (&v)[NARR * VEC], const GnFused& f, int j, int tid, float* sh_row) {
     const int lane = tid & 63, wave = tid >> 6;
     if ((f.seg_vecs & (f.seg_vecs - 1)) == 0) {
+        if constexpr ((NARR * VEC) % 4 == 0) {
+            gn_lane_reduce_hw<NARR * VEC>(v, f.seg_vecs, lane, [&](int gi, float val) {
+                const int m = gi / VEC, e = gi - m * VEC;        // VEC is a compile-time power of two
+                sh_row[(m * NW + wave) * f.seg_ch + j * VEC + e] = val;      // lanes holding copies of a total store the same value
+            });
+        } else {
         gn_lane_reduce<NARR * VEC, 32>(v, f.seg_vecs, lane, 0, [&](int gi, float val) {
             const int m = gi / VEC, e = gi - m * VEC;        // VEC is a compile-time power of two
             sh_row[(m * NW + wave) * f.seg_ch + j * VEC + e] = val;      // lanes holding copies of a total store the same value
         });
+        }
     } else {
         // lanes l, l + seg_vecs, l + 2 seg_vecs, ... hold the same vector column (3 / 6 / 12 vectors per pixel of the 384-channel
         // tensors): strided tree, after which lanes < seg_vecs hold their column's wave total
@@ -824,12 +883,20 @@ __device__ __forceinline__ void gn_lds_barrier() {
 //   pass 2  dx = dz*ca + xhat*k2 + k3 (xhat = x*rs + ms, k2 = -rstd*c1, k3 = -rstd*c2) folded to dz*ca + x*q2 + q3 — two fmas per element.
 // (NV <= 4; eight vectors per thread run gn_lds_bwd8_kernel above.)  NT = 512 for the 16 - 64 KiB slices, 256 for the small ones
 // (<= 8 KiB: the 8 x 8 and 4 x 4 tensors).
-template <typename T, int NV, int NT>
+// P2 (round 6): cpg is a power of two >= VEC / 2, so the lower and the upper half of a thread's vector column lie in ONE group each:
+// mean and the pass-2 coefficients q2, q3 are two scalars per thread instead of VEC-wide arrays — with them the eight-vector form
+// (the 32 x 32 tensors) fits 128 registers without spilling and replaces gn_lds_bwd8_kernel for bf16.
+// FL >= 0: SiLU (bit 0) and dropout (bit 1) are compile-time facts — straight-line passes (with run-time flags hipcc keeps the unpacked
+// operands of a vector alive across the flag branches: 33 spilled registers at NV = 8); FL < 0: read from the arguments.
+// FL >= 0: SiLU (bit 0) and dropout (bit 1) are compile-time facts, so that a vector's four element pairs are ONE basic block and their
+// dependent chains (exp -> rcp -> fma ...) interleave; FL < 0: read from the arguments (a branch per pair: 64 per pass).
+template <typename T, int NV, int NT, bool P2, int FL = -1>
 __global__ __launch_bounds__(NT, NT == 512 ? 4 : 2)
 void gn_lds_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __restrict__ dx, GnShape s, GnFused f, long long dy_ld,
                        long long dx_ld, const float* __restrict__ stats, float* __restrict__ dgamma, float* __restrict__ dbeta, GnApply a,
                        int accumulate, float* __restrict__ dx_colsum, long long colsum_ld, const T* __restrict__ addp, long long add_ld) {
     constexpr int VEC = Elem<T>::VEC, ES = (int)sizeof(T);
+    const bool do_silu = FL < 0 ? a.silu != 0 : (FL & 1) != 0, do_drop = FL < 0 ? a.drop_p > 0.f : (FL & 2) != 0;
     extern __shared__ __attribute__((aligned(16))) char lsm[];
     constexpr int NW = NT / 64;
     char* xs = lsm;                                               // [NV][NT] vectors of x
@@ -880,11 +947,19 @@ void gn_lds_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __r
         gn_lds_wr4(ad + K_CA * kstride, ca); gn_lds_wr4(ad + K_CB * kstride, in_b - mean * ca); gn_lds_wr4(ad + K_GAM * kstride, in_g);
     }
     gn_lds_barrier();
-    float ca[VEC], cb[VEC], mean[VEC];
+    constexpr int NM = P2 ? 2 : VEC;                   // distinct means / pass-2 coefficients of a vector column
+    constexpr int MS = VEC / NM;                       // element e uses entry e / MS
+    float ca[VEC], cb[VEC], mean[NM];
     gn_lds_rd_consts<VEC>(kcol + K_CA * kstride, ca);
     gn_lds_rd_consts<VEC>(kcol + K_CB * kstride, cb);
-    gn_lds_rd_consts<VEC>(kcol + K_MEAN * kstride, mean);
-    const float keep_scale = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
+    if constexpr (P2) {
+        float m8[VEC];
+        gn_lds_rd_consts<VEC>(kcol + K_MEAN * kstride, m8);
+        mean[0] = m8[0]; mean[1] = m8[VEC / 2];
+    } else {
+        gn_lds_rd_consts<VEC>(kcol + K_MEAN * kstride, mean);
+    }
+    const float keep_scale = do_drop ? 1.0f / (1.0f - a.drop_p) : 1.0f;
     const unsigned idx0 = (unsigned)(((unsigned)b * (unsigned)s.HW) * (unsigned)s.C + (unsigned)(c0 + j * VEC));   // < 2^32: checked by the host
     float a1[VEC], a2[VEC];
 #pragma unroll
@@ -892,16 +967,63 @@ void gn_lds_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __r
     const unsigned myx_ad = lds0 + (unsigned)(tid * 16);
     static_for_gn<NV>([&](auto ic) {
         constexpr int i = decltype(ic)::v;
-        gn_wait_vm<2 * (NV - 1 - i)>(0);
+        // (the wait takes the previous vector's last sums as operands: in straight-line code hipcc otherwise retires ALL waits and LDS
+        //  reads first, unpacks every vector and spills the lot — 100 registers at NV = 8)
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * (NV - 1 - i)), "v"(a1[VEC - 1]), "v"(a2[VEC - 1]) : "memory");
         const int p = prow + i * f.rows_per_iter;
+        if constexpr (VEC == 8) {
+            // bf16: element PAIRS in 2-wide float vectors from the unpack on, so that the arithmetic is v_pk_fma / v_pk_mul / v_pk_add on
+            // register pairs that never have to be assembled (hipcc's own SLP pass packed the scalar form too, but paid for it with
+            // ~33 v_mov per vector: 252 instructions per vector, now ~150).  silu'(z) = s + s (z - z s), s = 1 / (1 + 2^(-z log2 e)).
+            const u32x4 xv = gn_lds_rd16(myx_ad + i * (NT * 16)), dv = vd[i];
+            const unsigned xw[4] = {xv.x, xv.y, xv.z, xv.w}, dw[4] = {dv.x, dv.y, dv.z, dv.w};
+            unsigned q0 = (idx0 + (unsigned)p * (unsigned)s.C) >> 1;
+            asm volatile("" : "+v"(q0));                // (opaque: ordered behind this vector's wait)
+            unsigned dzw[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                gn_f32x2 x2, d2, g2;
+                x2.x = __uint_as_float(xw[k] << 16); x2.y = __uint_as_float(xw[k] & 0xffff0000u);
+                d2.x = __uint_as_float(dw[k] << 16); d2.y = __uint_as_float(dw[k] & 0xffff0000u);
+                gn_f32x2 ca2, cb2, mn2;
+                ca2.x = ca[2 * k]; ca2.y = ca[2 * k + 1]; cb2.x = cb[2 * k]; cb2.y = cb[2 * k + 1];
+                mn2.x = mean[(2 * k) / MS]; mn2.y = mean[(2 * k + 1) / MS];
+                g2.x = g2.y = keep_scale;
+                if (do_silu) {
+                    const gn_f32x2 z = x2 * ca2 + cb2, nz = z * (-1.4426950408889634f);
+                    gn_f32x2 t;
+                    t.x = __builtin_amdgcn_exp2f(nz.x); t.y = __builtin_amdgcn_exp2f(nz.y);
+                    t = t + 1.0f;
+                    gn_f32x2 sg;
+                    sg.x = __builtin_amdgcn_rcpf(t.x); sg.y = __builtin_amdgcn_rcpf(t.y);
+                    const gn_f32x2 w = z - z * sg;
+                    g2 = (sg + sg * w) * keep_scale;
+                }
+                if (do_drop) {
+                    const unsigned wd = dropout_word32(h0, q0 + k);
+                    g2.x = (wd & 0xffffu) >= a.thresh16 ? g2.x : 0.f;
+                    g2.y = (wd >> 16) >= a.thresh16 ? g2.y : 0.f;
+                }
+                const gn_f32x2 dz = d2 * g2;
+                gn_f32x2 s1, s2;
+                s1.x = a1[2 * k]; s1.y = a1[2 * k + 1]; s2.x = a2[2 * k]; s2.y = a2[2 * k + 1];
+                s1 = s1 + dz * (x2 - mn2); s2 = s2 + dz;
+                a1[2 * k] = s1.x; a1[2 * k + 1] = s1.y; a2[2 * k] = s2.x; a2[2 * k + 1] = s2.y;
+                dzw[k] = pack_bf2(dz.x, dz.y);
+            }
+            // pass 2 reuses dz (stored at the tensor dtype, as an autograd graph would) instead of redoing the mask and silu'
+            u32x4 dzp; dzp.x = dzw[0]; dzp.y = dzw[1]; dzp.z = dzw[2]; dzp.w = dzw[3];
+            vd[i] = dzp;
+        } else
         {                                              // rows without a pixel hold zeros in both operands: dz = 0, nothing is added
             float fx[VEC], fd[VEC];
             Elem<T>::unpack(gn_lds_rd16(myx_ad + i * (NT * 16)), fx); Elem<T>::unpack(vd[i], fd);
             // dz = dy * dropout mask * silu'(z): one hash word per pair of channels
-            const unsigned q0 = (idx0 + (unsigned)p * (unsigned)s.C) >> 1;
+            unsigned q0 = (idx0 + (unsigned)p * (unsigned)s.C) >> 1;
+            asm volatile("" : "+v"(q0));                // (opaque, ordered behind this vector's wait: hipcc otherwise computes the hash words of all eight vectors up front and spills them)
 #pragma unroll
             for (int h = 0; h < VEC; h += 4) {
-                if (a.drop_p > 0.f) {
+                if (do_drop) {
 #pragma unroll
                     for (int e = h; e < h + 4; e += 2) {
                         const unsigned w = dropout_word32(h0, q0 + (e >> 1));
@@ -909,15 +1031,21 @@ void gn_lds_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __r
                         fd[e + 1] = (w >> 16) >= a.thresh16 ? fd[e + 1] * keep_scale : 0.f;
                     }
                 }
-                if (a.silu) {
+                if (do_silu) {
 #pragma unroll
                     for (int e = h; e < h + 4; ++e) fd[e] *= silu_grad_fast_(fx[e] * ca[e] + cb[e]);
                 }
 #pragma unroll
-                for (int e = h; e < h + 4; ++e) { a1[e] += fd[e] * (fx[e] - mean[e]); a2[e] += fd[e]; }
+                for (int e = h; e < h + 4; ++e) { a1[e] += fd[e] * (fx[e] - mean[e / MS]); a2[e] += fd[e]; }
             }
             // pass 2 reuses dz (stored at the tensor dtype, as an autograd graph would) instead of redoing the mask and silu'
             vd[i] = Elem<T>::pack(fd);
+        }
+        if constexpr (NV > 4 && VEC == 8) {
+            // everything this vector computed passes through one ordered statement: the next vector's wait and LDS read (volatile asm too)
+            // cannot be scheduled above it, nor can this vector's arithmetic sink below it
+            asm volatile("" : "+v"(a1[0]), "+v"(a1[1]), "+v"(a1[2]), "+v"(a1[3]), "+v"(a1[4]), "+v"(a1[5]), "+v"(a1[6]), "+v"(a1[7]),
+                              "+v"(a2[0]), "+v"(a2[1]), "+v"(a2[2]), "+v"(a2[3]), "+v"(a2[4]), "+v"(a2[5]), "+v"(a2[6]), "+v"(a2[7]), "+v"(vd[i]));
         }
         __builtin_amdgcn_sched_barrier(0);             // one vector at a time: without the branches of the predicated version hipcc hoists the hash words of all eight vectors (70 spilled registers)
     });
@@ -925,15 +1053,19 @@ void gn_lds_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __r
     // `add` (the residual gradient that joins dx) is requested now and consumed in pass 2: its latency hides behind the reduction
     u32x4 adn = gn_buf_ld16(rad, addp && row_ok(0) ? ad_o : GN_OOB);
     const float inv_n = 1.0f / ((float)s.HW * s.cpg);
-    const bool fast = (s.cpg & (s.cpg - 1)) == 0 && s.cpg <= 64;
+    const bool fast = P2 || ((s.cpg & (s.cpg - 1)) == 0 && s.cpg <= 64);
     if (fast) {
         // two barriers, as in the forward: thread c < seg_ch adds the waves' totals of its channel, emits the parameter gradients, the
         // cpg lanes of a group add up their gamma-weighted sums by shuffles and every lane derives its channel's pass-2 constants
         float v2[2 * VEC];
 #pragma unroll
         for (int e = 0; e < VEC; ++e) { v2[e] = a1[e]; v2[VEC + e] = a2[e]; }       // (rows without a pixel contributed zeros)
+        __builtin_amdgcn_s_setprio(3);                 // (the serial chain below at raised priority: see gn_lds_fwd_kernel)
         gn_wave_partials<VEC, 2, NW>(v2, f, j, tid, sh_row);
-        __syncthreads();
+        // (barriers that wait for LDS only: __syncthreads() is s_waitcnt vmcnt(0) first, i.e. here it would wait for the `add` vector just
+        //  requested, below for the round trips of the dgamma / dbeta atomics — 128 per address, chip-wide at the same moment — and in the
+        //  column sums for every store of pass 2: 4.0 -> 2.x us of a 19-us block, scripts/gn_timeline.sh)
+        gn_lds_barrier();
         if (tid < f.seg_ch) {
             float t1 = 0.f, t2 = 0.f;
 #pragma unroll
@@ -948,7 +1080,8 @@ void gn_lds_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __r
             sh_k[K_K2 * f.seg_ch + tid] = rs * k2;
             sh_k[K_K3 * f.seg_ch + tid] = sh_k[K_MS * f.seg_ch + tid] * k2 + k3;
         }
-        __syncthreads();
+        gn_lds_barrier();
+        __builtin_amdgcn_s_setprio(0);
     } else {
     gn_block_channel_sum2_w<VEC, NW>(a1, a2, f, active, j, tid, sh_row, sh_ch);        // sh_ch = [sum dz (x - mean) | sum dz]
         for (int c = tid; c < 2 * f.seg_ch; c += NT) {
@@ -977,12 +1110,14 @@ void gn_lds_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __r
         __syncthreads();
     }
     GN_STAMP(3);
-    float q2[VEC], q3[VEC], cs[VEC];
+    float q2[NM], q3[NM], cs[VEC];
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) {
-        const int c = j * VEC + e;
-        q2[e] = sh_k[K_K2 * f.seg_ch + c]; q3[e] = sh_k[K_K3 * f.seg_ch + c]; cs[e] = 0.f;
+    for (int e = 0; e < NM; ++e) {
+        const int c = j * VEC + e * MS;
+        q2[e] = sh_k[K_K2 * f.seg_ch + c]; q3[e] = sh_k[K_K3 * f.seg_ch + c];
     }
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) cs[e] = 0.f;
     const u32x4* myx = reinterpret_cast<const u32x4*>(xs) + tid;
     // (opaque copies: hipcc otherwise computes the eight store / load offsets of this pass before pass 1 and parks them in scratch)
     unsigned dx_o2 = dx_o, ad_o2 = ad_o;
@@ -994,7 +1129,41 @@ void gn_lds_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __r
         const bool ok = row_ok2(i);
         const u32x4 adc = adn;
         if (i + 1 < NV) adn = gn_buf_ld16(rad, addp && row_ok2(i + 1) ? ad_o2 + (i + 1) * ad_st : GN_OOB);
-        {
+        if constexpr (VEC == 8) {
+            // bf16: pairs again — dx = dz*ca + x*q2 + q3 is two v_pk_fma per pair
+            const u32x4 xv = myx[i * NT], dv = vd[i];
+            const unsigned xw[4] = {xv.x, xv.y, xv.z, xv.w}, dw[4] = {dv.x, dv.y, dv.z, dv.w}, aw[4] = {adc.x, adc.y, adc.z, adc.w};
+            u32x4 ov = zero16();
+            if (accumulate) ov = gn_buf_ld16(rdx, ok ? dx_o2 + i * dx_st : GN_OOB);
+            const unsigned ow[4] = {ov.x, ov.y, ov.z, ov.w};
+            unsigned pw[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                gn_f32x2 x2, d2, c2, k2, k3;
+                x2.x = __uint_as_float(xw[k] << 16); x2.y = __uint_as_float(xw[k] & 0xffff0000u);
+                d2.x = __uint_as_float(dw[k] << 16); d2.y = __uint_as_float(dw[k] & 0xffff0000u);
+                c2.x = ca[2 * k]; c2.y = ca[2 * k + 1];
+                k2.x = q2[(2 * k) / MS]; k2.y = q2[(2 * k + 1) / MS]; k3.x = q3[(2 * k) / MS]; k3.y = q3[(2 * k + 1) / MS];
+                gn_f32x2 r = x2 * k2 + (d2 * c2 + k3);                             // d2 holds dz here
+                if (addp) { gn_f32x2 a2v; a2v.x = __uint_as_float(aw[k] << 16); a2v.y = __uint_as_float(aw[k] & 0xffff0000u); r = r + a2v; }
+                if (accumulate) { gn_f32x2 o2; o2.x = __uint_as_float(ow[k] << 16); o2.y = __uint_as_float(ow[k] & 0xffff0000u); r = o2 + r; }
+                pw[k] = pack_bf2(r.x, r.y);
+            }
+            u32x4 packed; packed.x = pw[0]; packed.y = pw[1]; packed.z = pw[2]; packed.w = pw[3];
+            if (dx_colsum) {                                   // sums of the values as STORED (what a column sum over dx would read)
+                if (!ok) packed = zero16();
+                const unsigned sw[4] = {packed.x, packed.y, packed.z, packed.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    gn_f32x2 q, c;
+                    q.x = __uint_as_float(sw[k] << 16); q.y = __uint_as_float(sw[k] & 0xffff0000u);
+                    c.x = cs[2 * k]; c.y = cs[2 * k + 1];
+                    c = c + q;
+                    cs[2 * k] = c.x; cs[2 * k + 1] = c.y;
+                }
+            }
+            gn_buf_st16(rdx, ok ? dx_o2 + i * dx_st : GN_OOB, packed);
+        } else {
             float fx[VEC], fd[VEC], o[VEC];
             Elem<T>::unpack(myx[i * NT], fx); Elem<T>::unpack(vd[i], fd);
             float ad[VEC];
@@ -1002,8 +1171,8 @@ void gn_lds_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __r
             if (addp) Elem<T>::unpack(adc, ad);
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
-                float r = fd[e] * ca[e] + q3[e];                                   // fd holds dz here
-                r = fx[e] * q2[e] + r;
+                float r = fd[e] * ca[e] + q3[e / MS];                              // fd holds dz here
+                r = fx[e] * q2[e / MS] + r;
                 if (addp) r += ad[e];
                 o[e] = accumulate ? o[e] + r : r;
             }
@@ -1021,9 +1190,9 @@ void gn_lds_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __r
     }
     GN_STAMP(4);
     if (dx_colsum) {
-        __syncthreads();                                       // (the scratch's earlier readers are done)
+        // (the scratch's earlier readers finished before the barrier that published the pass-2 coefficients; no wait for the stores of pass 2)
         gn_wave_partials<VEC, 1, NW>(cs, f, j, tid, sh_row);
-        __syncthreads();
+        gn_lds_barrier();
         for (int c = tid; c < f.seg_ch; c += NT) {
             float acc = 0.f;
 #pragma unroll
@@ -1040,10 +1209,12 @@ void gn_lds_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, T* __r
 
 // forward twin: x slice in LDS; pivot-shifted moments accumulated while the slice lands (one pass), then
 // y = drop(silu(x * a_c + b_c)) streamed out.
-template <typename T, int NV, int NT>
+// FL as in gn_lds_bwd_kernel: >= 0 bakes SiLU (bit 0) / dropout (bit 1) in, < 0 reads them from the arguments.
+template <typename T, int NV, int NT, int FL = -1>
 __global__ __launch_bounds__(NT, NT == 512 ? 4 : 2)
 void gn_lds_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, GnShape s, GnFused f, GnApply a) {
     constexpr int VEC = Elem<T>::VEC, ES = (int)sizeof(T), NW = NT / 64;
+    const bool do_silu = FL < 0 ? a.silu != 0 : (FL & 1) != 0, do_drop = FL < 0 ? a.drop_p > 0.f : (FL & 2) != 0;
     extern __shared__ __attribute__((aligned(16))) char lsm[];
     char* xs = lsm;
     float* sh_row = reinterpret_cast<float*>(lsm + NV * NT * 16);
@@ -1115,6 +1286,10 @@ void gn_lds_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, GnShape s, Gn
         float v2[2 * VEC];
 #pragma unroll
         for (int e = 0; e < VEC; ++e) { v2[e] = active ? s1[e] : 0.f; v2[VEC + e] = active ? s2[e] : 0.f; }
+        // The reduction is a serial chain on a few threads.  A block that reaches it while its CU partner streams out its result competes
+        // with sixteen VALU-bound waves under oldest-first arbitration: 5.2 us instead of 1.4 for the quarter of the blocks that end last
+        // (scripts/gn_timeline.sh, "last-ending quarter") — so the chain runs at raised priority.
+        __builtin_amdgcn_s_setprio(3);
         gn_wave_partials<VEC, 2, NW>(v2, f, j, tid, sh_row);
         __syncthreads();
         if (tid < f.seg_ch) {
@@ -1136,7 +1311,10 @@ void gn_lds_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, GnShape s, Gn
                 a.stats[gi * 2] = mean_g; a.stats[gi * 2 + 1] = rstd;
             }
         }
-        __syncthreads();
+        // (LDS-only barrier: __syncthreads() would wait for the ack of the statistics store just issued — 1.5 us for the median block, 5 us
+        //  for the quarter of the blocks that get here while the others are storing: scripts/gn_timeline.sh, "last-ending quarter")
+        gn_lds_barrier();
+        __builtin_amdgcn_s_setprio(0);
         GN_STAMP(4);
         if (!active) return;
 #pragma unroll
@@ -1168,7 +1346,7 @@ void gn_lds_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, GnShape s, Gn
         cb[e] = sh_k[K_BET * f.seg_ch + j * VEC + e] - sh_mean[g] * ca[e];
     }
     }
-    const float keep_scale = a.drop_p > 0.f ? 1.0f / (1.0f - a.drop_p) : 1.0f;
+    const float keep_scale = do_drop ? 1.0f / (1.0f - a.drop_p) : 1.0f;
     const unsigned h0 = dropout_h0(gn_seed(a));
     const unsigned idx0 = (unsigned)(((unsigned)b * (unsigned)s.HW) * (unsigned)s.C + (unsigned)(c0 + j * VEC));
     const u32x4* myx = reinterpret_cast<const u32x4*>(xs) + tid;
@@ -1177,15 +1355,48 @@ void gn_lds_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, GnShape s, Gn
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int p = prow + i * f.rows_per_iter;
+        if constexpr (VEC == 8) {
+            // bf16: element pairs in 2-wide float vectors (v_pk_fma / v_pk_mul / v_pk_add): silu(z) = z / (1 + 2^(-z log2 e))
+            const u32x4 xv = myx[i * NT];
+            const unsigned xw[4] = {xv.x, xv.y, xv.z, xv.w};
+            const unsigned q0 = (idx0 + (unsigned)p * (unsigned)s.C) >> 1;
+            unsigned yw[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                gn_f32x2 x2, ca2, cb2;
+                x2.x = __uint_as_float(xw[k] << 16); x2.y = __uint_as_float(xw[k] & 0xffff0000u);
+                ca2.x = ca[2 * k]; ca2.y = ca[2 * k + 1]; cb2.x = cb[2 * k]; cb2.y = cb[2 * k + 1];
+                gn_f32x2 z = x2 * ca2 + cb2;
+                if (do_silu) {
+                    const gn_f32x2 nz = z * (-1.4426950408889634f);
+                    gn_f32x2 t;
+                    t.x = __builtin_amdgcn_exp2f(nz.x); t.y = __builtin_amdgcn_exp2f(nz.y);
+                    t = t + 1.0f;
+                    gn_f32x2 sg;
+                    sg.x = __builtin_amdgcn_rcpf(t.x); sg.y = __builtin_amdgcn_rcpf(t.y);
+                    z = z * sg;
+                }
+                if (do_drop) {
+                    const unsigned wd = dropout_word32(h0, q0 + k);
+                    z = z * keep_scale;
+                    z.x = (wd & 0xffffu) >= a.thresh16 ? z.x : 0.f;
+                    z.y = (wd >> 16) >= a.thresh16 ? z.y : 0.f;
+                }
+                yw[k] = pack_bf2(z.x, z.y);
+            }
+            u32x4 yv; yv.x = yw[0]; yv.y = yw[1]; yv.z = yw[2]; yv.w = yw[3];
+            gn_buf_st16(ry, row_ok(i) ? y_o + i * y_st : GN_OOB, yv);
+            continue;
+        }
         float fv[VEC];
         Elem<T>::unpack(myx[i * NT], fv);
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
             float z = fv[e] * ca[e] + cb[e];
-            if (a.silu) z = silu_fast_(z);
+            if (do_silu) z = silu_fast_(z);
             fv[e] = z;
         }
-        if (a.drop_p > 0.f) {
+        if (do_drop) {
             const unsigned q0 = (idx0 + (unsigned)p * (unsigned)s.C) >> 1;
 #pragma unroll
             for (int e = 0; e < VEC; e += 2) {
@@ -1496,10 +1707,13 @@ extern "C" int ddpm_groupnorm_silu_fwd(const void* x, long long x_ld, void* y, l
     if (small) { fl = f; fl.xcd_remap = 0; lds_l = gn_lds_bytes(f.nv <= 1 ? 1 : 2, 256, f.seg_ch); }
     if (small || (!no_lds && !(reg_ok && f.nv <= 2) && gn_lds_plan(s, es, fl, lds_l))) {        // x staged in LDS: single launch, 1 read + 1 write of HBM
         const dim3 fgrid(G / fl.GPB, B);
-#define GN_LF(T, NV, NT) do { static DevOnce attr; if (!attr) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_lds_fwd_kernel<T, NV, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return DDPM_ERR_LAUNCH; attr = true; } \
-        hipLaunchKernelGGL((gn_lds_fwd_kernel<T, NV, NT>), fgrid, dim3(NT), lds_l, st, (const T*)x, (T*)y, s, fl, a); } while (0)
-#define GN_LF_NV(T) do { if (small) { if (fl.nv <= 1) GN_LF(T, 1, 256); else GN_LF(T, 2, 256); } else if (fl.nv <= 2) GN_LF(T, 2, 512); else if (fl.nv <= 4) GN_LF(T, 4, 512); else GN_LF(T, 8, 512); } while (0)
-        if (dtype == DDPM_BF16) GN_LF_NV(bf16_t); else GN_LF_NV(float);
+#define GN_LF(T, NV, NT, FLV) do { static DevOnce attr; if (!attr) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_lds_fwd_kernel<T, NV, NT, FLV>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return DDPM_ERR_LAUNCH; attr = true; } \
+        hipLaunchKernelGGL((gn_lds_fwd_kernel<T, NV, NT, FLV>), fgrid, dim3(NT), lds_l, st, (const T*)x, (T*)y, s, fl, a); } while (0)
+#define GN_LF_NV(T, FLV) do { if (small) { if (fl.nv <= 1) GN_LF(T, 1, 256, FLV); else GN_LF(T, 2, 256, FLV); } else if (fl.nv <= 2) GN_LF(T, 2, 512, FLV); else if (fl.nv <= 4) GN_LF(T, 4, 512, FLV); else GN_LF(T, 8, 512, FLV); } while (0)
+        if (dtype == DDPM_BF16) {
+            const int flg = (silu ? 1 : 0) | (drop_p > 0.f ? 2 : 0);       // the three combinations the UNet uses are baked in
+            if (flg == 1) GN_LF_NV(bf16_t, 1); else if (flg == 3) GN_LF_NV(bf16_t, 3); else if (flg == 0) GN_LF_NV(bf16_t, 0); else GN_LF_NV(bf16_t, -1);
+        } else GN_LF_NV(float, -1);
 #undef GN_LF_NV
 #undef GN_LF
         return check_launch();
@@ -1559,9 +1773,27 @@ extern "C" int ddpm_groupnorm_silu_bwd(const void* x, long long x_ld, const void
         const dim3 fgrid(G / fl.GPB, B);
 #define GN_LDS(K, NT, ...) do { static DevOnce attr; if (!attr) { if (hipFuncSetAttribute(reinterpret_cast<const void*>(&K<__VA_ARGS__>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return DDPM_ERR_LAUNCH; attr = true; } \
         hipLaunchKernelGGL((K<__VA_ARGS__>), fgrid, dim3(NT), lds_l, st, (const T_*)x, (const T_*)dy, (T_*)dx, s, fl, dy_ld, dx_ld, stats, dgamma, dbeta, a, accumulate, dx_colsum, colsum_ld, (const T_*)add, add_ld); } while (0)
-#define GN_LDS_NV() do { if (small_lds) { if (fl.nv <= 1) GN_LDS(gn_lds_bwd_kernel, 256, T_, 1, 256); else GN_LDS(gn_lds_bwd_kernel, 256, T_, 2, 256); } \
-                         else if (fl.nv <= 2) GN_LDS(gn_lds_bwd_kernel, 512, T_, 2, 512); else if (fl.nv <= 4) GN_LDS(gn_lds_bwd_kernel, 512, T_, 4, 512); else GN_LDS(gn_lds_bwd8_kernel, 512, T_, 8); } while (0)
-        if (dtype == DDPM_BF16) { typedef bf16_t T_; GN_LDS_NV(); } else { typedef float T_; GN_LDS_NV(); }
+#define GN_LDS_NV(P2V, K8, ...) do { if (small_lds) { if (fl.nv <= 1) GN_LDS(gn_lds_bwd_kernel, 256, T_, 1, 256, P2V); else GN_LDS(gn_lds_bwd_kernel, 256, T_, 2, 256, P2V); } \
+                         else if (fl.nv <= 2) GN_LDS(gn_lds_bwd_kernel, 512, T_, 2, 512, P2V); else if (fl.nv <= 4) GN_LDS(gn_lds_bwd_kernel, 512, T_, 4, 512, P2V); else GN_LDS(K8, 512, T_, 8, ##__VA_ARGS__); } while (0)
+        // P2: every group is a power-of-two run of channels that the halves of a 16-byte vector column do not straddle
+        const bool p2 = (s.cpg & (s.cpg - 1)) == 0 && s.cpg >= (16 / es) / 2 && s.cpg <= 64 && (fl.seg_vecs & (fl.seg_vecs - 1)) == 0;
+        static const bool old8 = getenv("DDPM_GN_BWD8_OLD") != nullptr;
+        if (dtype == DDPM_BF16) {
+            typedef bf16_t T_;
+            if (old8) { if (p2) GN_LDS_NV(true, gn_lds_bwd8_kernel); else GN_LDS_NV(false, gn_lds_bwd8_kernel); }
+            else if (p2) {
+                // the three flag combinations the UNet uses, baked in (norm1 / out: SiLU; norm2 in training: SiLU + dropout; attention: neither)
+#define GN_LDS_FL(FLV) do { if (small_lds) { if (fl.nv <= 1) GN_LDS(gn_lds_bwd_kernel, 256, T_, 1, 256, true, FLV); else GN_LDS(gn_lds_bwd_kernel, 256, T_, 2, 256, true, FLV); } \
+                         else if (fl.nv <= 2) GN_LDS(gn_lds_bwd_kernel, 512, T_, 2, 512, true, FLV); else if (fl.nv <= 4) GN_LDS(gn_lds_bwd_kernel, 512, T_, 4, 512, true, FLV); \
+                         else GN_LDS(gn_lds_bwd_kernel, 512, T_, 8, 512, true, FLV); } while (0)
+                const int flg = (silu ? 1 : 0) | (drop_p > 0.f ? 2 : 0);
+                if (flg == 1) GN_LDS_FL(1); else if (flg == 3) GN_LDS_FL(3); else if (flg == 0) GN_LDS_FL(0); else GN_LDS_FL(-1);
+#undef GN_LDS_FL
+            } else GN_LDS_NV(false, gn_lds_bwd_kernel, 512, false);
+        } else {
+            typedef float T_;
+            if (p2) GN_LDS_NV(true, gn_lds_bwd8_kernel); else GN_LDS_NV(false, gn_lds_bwd8_kernel);
+        }
 #undef GN_LDS_NV
 #undef GN_LDS
         return check_launch();

@@ -15,6 +15,11 @@ def report(t, names):
     ph = [(t[:, i + 1] - t[:, i]).median() / mhz for i in range(1, 6)]
     print(f"   blocks={len(t)} clk~{mhz:.0f} MHz kernel span {end.max():.2f} us; block start spread {start.max():.2f} us; block total {((end - start).median()):.2f} us")
     print("   " + " | ".join(f"{n} {v:.2f}" for n, v in zip(names, ph)) + "  (us, medians)")
+    # the same phases for the quarter of the blocks that END last (what the kernel's duration is made of), and where they run
+    dur = end - start
+    late = end >= end.quantile(0.75)
+    phl = [(t[late, i + 1] - t[late, i]).median() / mhz for i in range(1, 6)]
+    print("   last-ending quarter: " + " | ".join(f"{v:.2f}" for v in phl) + f"  (block total {float(dur[late].median()):.2f} us, start {float(start[late].median()):.2f} us)")
     q = lambda v: " ".join(f"{float(v.quantile(p)):.2f}" for p in (0.0, 0.25, 0.5, 0.75, 1.0))
     print("   block end quantiles (us):", q(end), " start quantiles:", q(start))
 
