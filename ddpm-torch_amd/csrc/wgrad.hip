@@ -448,18 +448,257 @@ void wgrad3x3_kernel(Wg3Args a) {
     }
 }
 
-struct Plan { int ok, stage_px, PW, PH, NB, stages, splits, per, tiles_n, tiles_c; };
+
+// =====================================================================================================================================
+// Wave-specialised form for the 16 x 16 patches (round 6).  The kernel above multiplies on eight waves that also issue the stage's
+// LDS-DMA and meet at a block barrier every stage: scripts/wg_timeline.py priced a stage at 4200-4600 clk for 2304 clk of MFMA — 800-1000
+// clk of DMA issue with the matrix pipe idle and ~950 clk of the older wave of every SIMD waiting at the barrier.  Here, as in
+// conv3x3_pc_kernel:
+//   * waves 0-3 (one per SIMD) are CONSUMERS: wave (wn, wc) owns 32 out-channels x 32 in-channels x 9 taps of a 64 x 64 x 9 output tile
+//     (nine 32 x 32 accumulators, as before) and walks ALL sixteen patch rows of a stage — no k split inside the block, no final sum
+//     over wave groups; per patch row one dy fragment and ONE new halo row (three shifted fragments, each used by three patch rows):
+//     8 transpose reads feed 9 MFMAs, issued one patch row ahead;
+//   * waves 4-7 are LOADERS: they own the whole DMA schedule (dy tile 32 KiB + two 21-KiB channel-half planes of the halo per stage,
+//     ring of two stages) and their own vmcnt queue;
+//   * no s_barrier in the loop: ready[4] (one per loader: stages completely landed) and freed[4] (one per consumer: stages completely
+//     read) are monotone counters in LDS, each with a single writer; a check is one ds_read_b128.
+// A 64-wide in-channel tile halves the L2 -> LDS bytes per FLOP (74 KiB per 4608 clk of MFMA against 53 KiB per 2304).
+// Covers C % 64 == 0 and N % 64 == 0 on images with 16-divisible sides (every 3 x 3 conv of the 32 x 32 / 16 x 16 levels but in_conv / out_conv).
+constexpr int WS_TC = 64;
+constexpr int WS_DY_BYTES = 256 * DY_ROW;                  // 256 px x 64 n
+constexpr int WS_XP_BYTES = 336 * X_ROW;                   // one channel-half plane of the halo: 324 rows (+ 12 of padding) x 32 c
+constexpr int WS_STAGE = WS_DY_BYTES + 2 * WS_XP_BYTES;    // 75776
+constexpr int WS_CNT_AT = 2 * WS_STAGE;                    // ready[4] | freed[4] | junk words for the signalling waves' idle lanes
+constexpr int WS_BYTES = WS_CNT_AT + 1024;
+static_assert(WS_BYTES <= 160 * 1024 && TN * 9 * WS_TC * 4 + 1024 <= WS_CNT_AT, "LDS");
+constexpr unsigned long long WS_WAIT_TICKS = 500000000ull; // 5 s of the 100 MHz clock: a protocol error traps, it never hangs the GPU
+__device__ unsigned g_ws_fault[4];
+
+__device__ __forceinline__ void ws_wait_all_ge(unsigned addr, unsigned target) {
+    unsigned long long t_first = 0;
+    for (unsigned spins = 0;; ++spins) {
+        u32x4 v;
+        asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(addr) : "memory");
+        const int m = min(min((int)(v.x - target), (int)(v.y - target)), min((int)(v.z - target), (int)(v.w - target)));
+        if (__builtin_amdgcn_readfirstlane(m) >= 0) break;
+        if ((spins & 4095u) == 4095u) {
+            const unsigned long long now = wall_clock64();
+            if (t_first == 0) t_first = now | 1ull;
+            else if (now - t_first > WS_WAIT_TICKS) {
+                if ((threadIdx.x & 63) == 0) { g_ws_fault[0] = blockIdx.x; g_ws_fault[1] = addr; g_ws_fault[2] = target; g_ws_fault[3] = 1; __threadfence_system(); }
+                __builtin_trap();
+            }
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+// a wave publishes its counter: lane 0 writes the counter, every other lane its own junk word (no exec masking)
+__device__ __forceinline__ void ws_publish(unsigned lane_addr, unsigned value) {
+    asm volatile("ds_write_b32 %0, %1" :: "v"(lane_addr), "v"(value) : "memory");
+}
+
+__global__ __launch_bounds__(512, 2)
+void wgrad3x3_ws_kernel(Wg3Args a) {
+    constexpr int PW = 16, HW = 18;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ntiles = a.tiles_n * a.tiles_c;
+    const int lid = xcd_logical(blockIdx.x, gridDim.x);
+    const int split = (int)fdiv((unsigned)lid, a.d_tiles), tile = lid - split * ntiles;
+    const int tn = (int)fdiv((unsigned)tile, a.d_tiles_c), tc = tile - tn * a.tiles_c;
+    const int st_begin = split * a.stages_per_split, st_end = min(a.stages, st_begin + a.stages_per_split);
+    const int nst = max(st_end - st_begin, 0);
+    const int tpi = a.tiles_y * a.tiles_x;
+    const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)smem;
+    const unsigned cnt0 = lds0 + WS_CNT_AT;
+    if (tid < 64) reinterpret_cast<unsigned*>(smem + WS_CNT_AT)[tid] = 0u;
+    __syncthreads();
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t] = (f32x16)(0.f);
+    float bsum = 0.f;
+#ifdef WG_TIMING
+    // debug builds only (scripts/wg_ws_timeline.py): per wave {loop begin, loop end, clocks in semaphore waits, clocks in vmcnt waits (loaders), stages, end of kernel}
+    unsigned long long wclk = 0, vclk = 0, tw0 = 0;
+    const unsigned long long t_begin = clock64();
+#define WS_T0() do { tw0 = clock64(); } while (0)
+#define WS_T1(acc_) do { acc_ += clock64() - tw0; } while (0)
+#else
+#define WS_T0()
+#define WS_T1(acc_)
+#endif
+    const int wn = wave & 1, wc = (wave >> 1) & 1;
+    const bool want_bias = a.dbias != nullptr && tc == 0;
+
+    // ---- DMA plan (every wave builds it: the first two stages are fetched by all eight waves, see below)
+    auto rsrc_of = [&](const void* p, unsigned extent) {
+        const unsigned long long ad = (unsigned long long)p;
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)ad), hi = __builtin_amdgcn_readfirstlane((unsigned)(ad >> 32));
+        return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0,
+                                                 __builtin_amdgcn_readfirstlane((int)extent), 0x00020000);
+    };
+    const __amdgpu_buffer_rsrc_t rdy = rsrc_of(a.dy, a.dy_extent), rx = rsrc_of(a.x, a.x_extent);
+    // dy tile: instruction d (0..31) fills the 1 KiB at d * 1024 = stage pixels d * 8 + lane / 8 (patch row d / 2, columns (d & 1) * 8 ...), physical
+    // chunk lane % 8; the logical chunk is XOR-swizzled by bit 1 of the pixel (= bit 4 of the lane), as in the kernel above.
+    // halo: instruction g (0..41) -> channel-half plane g / 21, rows (g % 21) * 16 + lane / 4 of the 18 x 18 halo.
+    const unsigned dy_lane = (unsigned)((((long long)(lane >> 3)) * a.dy_ld + tn * TN + (((lane & 7) ^ (((lane >> 4) & 1) << 2)) << 3)) * 2);
+    const unsigned x_c2 = (unsigned)((tc * WS_TC + (lane & 3) * 8) * 2);
+    auto issue = [&](int s, int d0, int dn, int g0, int gstep) {          // dy instructions d0 .. d0 + dn - 1, halo instructions g0, g0 + gstep, ...
+        const int st = st_begin + s, slot = s & 1;
+        const int img = (int)fdiv((unsigned)st, a.d_tpi), pt = st - img * tpi;
+        const int ty = (int)fdiv((unsigned)pt, a.d_tiles_x), tx = pt - ty * a.tiles_x;
+        const int py0 = ty * 16, px0 = tx * PW;
+        char* dst = smem + slot * WS_STAGE;
+        const unsigned base = (unsigned)((((long long)(img * a.H + py0) * a.W + px0) * a.dy_ld) * 2);
+        for (int d = d0; d < d0 + dn; ++d) {
+            const unsigned so = base + (unsigned)((((d >> 1) * a.W + (d & 1) * 8) * (int)a.dy_ld) * 2);      // wave-uniform
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rdy, (__attribute__((address_space(3))) void*)(dst + d * 1024), 16, dy_lane, so, 0, 0);
+        }
+        const unsigned base_x = (unsigned)((((long long)(img * (a.H >> a.ups) + (py0 >> a.ups)) * (a.W >> a.ups) + (px0 >> a.ups)) * a.x_ld) * 2);
+        for (int g = g0; g < 42; g += gstep) {
+            const int pl = g >= 21 ? 1 : 0, q = g - pl * 21;
+            const int hp = q * 16 + (lane >> 2);
+            const int hy = (hp * 3641) >> 16, hx = hp - hy * HW;                // hp / 18 for hp < 336
+            const int iy = py0 + hy - 1, ix = px0 + hx - 1;
+            const bool ok = hp < 324 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+            const int dyi = (hy - 1) >> a.ups, dxi = (hx - 1) >> a.ups;
+            unsigned o = ok ? base_x + (unsigned)((dyi * (a.W >> a.ups) + dxi) * (int)a.x_ld * 2) + x_c2 + (unsigned)(pl * 64) : OOB;
+            asm volatile("" : "+v"(o));
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(dst + WS_DY_BYTES + pl * WS_XP_BYTES + q * 1024), 16, o, 0, 0, 0);
+        }
+    };
+    // ---- the first two stages are fetched by ALL eight waves (the consumers have nothing to multiply yet; an LDS-DMA instruction holds its
+    // wave ~200 clk, so a loader needs ~3800 clk for its 18-19 of a stage) and published by a block barrier
+    if (nst > 0) issue(0, wave * 4, 4, wave, 8);
+    if (nst > 1) issue(1, wave * 4, 4, wave, 8);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (wave >= 4) {
+        // ---------------------------------------------------------------- loaders
+        const int lw = wave - 4;
+        const unsigned sig_ready = lane == 0 ? cnt0 + (unsigned)(lw * 4) : cnt0 + 64u + (unsigned)(lane * 4);
+        for (int s = 2; s < nst; ++s) {
+            WS_T0();
+            ws_wait_all_ge(cnt0 + 16u, (unsigned)(s - 1));                      // every consumer is through stage s - 2: its slot is free
+            WS_T1(wclk);
+            issue(s, lw * 8, 8, lw, 4);
+            WS_T0();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            WS_T1(vclk);
+            ws_publish(sig_ready, (unsigned)(s + 1));
+        }
+    } else {
+        // ---------------------------------------------------------------- consumers
+        const int i16 = lane & 15, q4 = i16 >> 2, h = lane >> 5;
+        const int mcol = ((lane >> 4) & 1) * 16 + (i16 & 3) * 4;
+        const int a_m = wn * 32 + mcol, a_row = 8 * h + q4;
+        const int a_off = a_row * DY_ROW + (((a_m >> 3) ^ (((a_row >> 1) & 1) << 2)) << 4) + (a_m & 7) * 2;
+        const int k_lo = 8 * h + q4, k_hi = k_lo + 4;                      // patch columns of this lane's two k groups (a k-step is one patch row)
+        const int b_lo = k_lo * X_ROW + (mcol >> 3) * 16 + (mcol & 7) * 2 + wc * WS_XP_BYTES;
+        const int b_hi = k_hi * X_ROW + (mcol >> 3) * 16 + (mcol & 7) * 2 + wc * WS_XP_BYTES;
+        const unsigned sig_freed = lane == 0 ? cnt0 + 16u + (unsigned)(wave * 4) : cnt0 + 64u + 256u + (unsigned)(lane * 4);
+#define TR_READ(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+        struct Frag { uint2 lo, hi; };
+        auto frag4 = [](const Frag& f) { return __builtin_bit_cast(bf16x8, u32x4{f.lo.x, f.lo.y, f.hi.x, f.hi.y}); };
+        auto bias_add = [&](const Frag& f) {
+            bsum += __uint_as_float(f.lo.x << 16) + __uint_as_float(f.lo.x & 0xffff0000u) + __uint_as_float(f.lo.y << 16) + __uint_as_float(f.lo.y & 0xffff0000u)
+                  + __uint_as_float(f.hi.x << 16) + __uint_as_float(f.hi.x & 0xffff0000u) + __uint_as_float(f.hi.y << 16) + __uint_as_float(f.hi.y & 0xffff0000u);
+        };
+#define WS_READ_A(F, j) do { TR_READ(F.lo, abase, (j) * 16 * DY_ROW); TR_READ(F.hi, abase, (j) * 16 * DY_ROW + 4 * DY_ROW); } while (0)
+#define WS_READ_H(F, hr) do { _Pragma("unroll") for (int sft = 0; sft < 3; ++sft) { TR_READ(F[sft].lo, blo0, ((hr) * HW + sft) * X_ROW); TR_READ(F[sft].hi, bhi0, ((hr) * HW + sft) * X_ROW); } } while (0)
+#define WS_WAIT_AH(FA, F) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(FA.lo), "+v"(FA.hi), "+v"(F[0].lo), "+v"(F[0].hi), "+v"(F[1].lo), "+v"(F[1].hi), "+v"(F[2].lo), "+v"(F[2].hi) :: "memory")
+#define WS_WAIT_H(F) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(F[0].lo), "+v"(F[0].hi), "+v"(F[1].lo), "+v"(F[1].hi), "+v"(F[2].lo), "+v"(F[2].hi) :: "memory")
+        for (int s = 0; s < nst; ++s) {
+            const unsigned stage0 = lds0 + (unsigned)((s & 1) * WS_STAGE);
+            const unsigned abase = stage0 + (unsigned)a_off, blo0 = stage0 + (unsigned)(WS_DY_BYTES + b_lo), bhi0 = stage0 + (unsigned)(WS_DY_BYTES + b_hi);
+            WS_T0();
+            if (s >= 2) ws_wait_all_ge(cnt0, (unsigned)(s + 1));                // every loader's share of this stage has landed (stages 0, 1: the barrier above)
+            WS_T1(wclk);
+            Frag fa[2], fh[4][3];
+            WS_READ_A(fa[0], 0); WS_READ_H(fh[0], 0);
+            WS_READ_H(fh[1], 1); WS_READ_H(fh[2], 2);
+            WS_WAIT_AH(fa[0], fh[0]); WS_WAIT_H(fh[1]); WS_WAIT_H(fh[2]);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                // patch row j pairs with halo rows j, j + 1, j + 2 (tap rows 0, 1, 2); the reads of row j + 1 go out under its nine MFMAs
+                if (j + 1 < 16) WS_READ_A(fa[(j + 1) & 1], j + 1);
+                if (j + 3 < 18) WS_READ_H(fh[(j + 3) & 3], j + 3);
+                if (want_bias && wc == 0) bias_add(fa[j & 1]);
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int sft = 0; sft < 3; ++sft)
+                        acc[r * 3 + sft] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag4(fa[j & 1]), frag4(fh[(j + r) & 3][sft]), acc[r * 3 + sft], 0, 0, 0);
+                if (j + 3 < 18) { if (j + 1 < 16) WS_WAIT_AH(fa[(j + 1) & 1], fh[(j + 3) & 3]); else WS_WAIT_H(fh[(j + 3) & 3]); }
+                else if (j + 1 < 16) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[(j + 1) & 1].lo), "+v"(fa[(j + 1) & 1].hi) :: "memory");
+            }
+            ws_publish(sig_freed, (unsigned)(s + 1));                            // (behind this stage's last reads, all of them retired above)
+        }
+#undef TR_READ
+#undef WS_READ_A
+#undef WS_READ_H
+#undef WS_WAIT_AH
+#undef WS_WAIT_H
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#ifdef WG_TIMING
+    const unsigned long long t_loop_end = clock64();
+#endif
+    // ---- consumers store their accumulators straight from registers: for a fixed (n, tap) the 32 lanes of a half wave hold 32 consecutive
+    // in-channels = one 128-byte line of the packed gradient (the kernel above stages the tile through LDS for 16-byte stores: two block
+    // barriers and 147 KiB of LDS traffic, 10 000 clk per block here)
+    float* out = a.dw + (a.atomic ? 0 : (long long)split * a.slab_stride);
+    if (wave < 4) {
+        const int cc = tc * WS_TC + wc * 32 + (lane & 31), nb = tn * TN + wn * 32 + 4 * (lane >> 5);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int n = nb + (r & 3) + 8 * (r >> 2);
+            if (n < a.Nreal) {
+                float* o = out + (long long)n * 9 * a.C + cc;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    if (a.atomic) atomicAdd(o + t * a.C, acc[t][r]); else o[t * a.C] = acc[t][r];
+                }
+            }
+        }
+        if (want_bias && wc == 0) {
+            // the two k halves of a column sum sit in lanes l and l + 32
+            const float tot = bsum + __shfl_xor(bsum, 32, 64);
+            const int n = tn * TN + wn * 32 + (lane & 31);
+            if (lane < 32 && n < a.Nreal) {
+                if (a.atomic) atomicAdd(a.dbias + n, tot);
+                else a.dbias[(long long)split * a.bias_stride + n] = tot;
+            }
+        }
+    }
+#ifdef WG_TIMING
+    if (g_wg_timing && lane == 0) {
+        unsigned long long* o = g_wg_timing + ((long long)blockIdx.x * 8 + wave) * 16;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        o[0] = t_begin; o[1] = t_loop_end; o[2] = wclk; o[3] = vclk; o[4] = (unsigned long long)nst; o[5] = clock64();
+    }
+#endif
+#undef WS_T0
+#undef WS_T1
+}
+
+struct Plan { int ok, stage_px, PW, PH, NB, stages, splits, per, tiles_n, tiles_c, ws; };
 
 static Plan make_plan(int B, int H, int W, int C, int N, int want_splits) {
     Plan p; memset(&p, 0, sizeof(p));
     if (C % TC || N % 8 || H <= 0 || W <= 0) return p;
+    // the wave-specialised kernel (64-wide in-channel tiles): DDPM_WGRAD3_NO_WS=1 keeps every geometry on the kernel above
+    static const bool no_ws = getenv("DDPM_WGRAD3_NO_WS") != nullptr;
+    p.ws = !no_ws && W >= 16 && W % 16 == 0 && H % 16 == 0 && C % WS_TC == 0 && N % TN == 0;
     if (W >= 16) { if (W % 16 || H % 16) return p; p.stage_px = 256; p.PW = 16; p.PH = 16; p.NB = 1; }
     else if (W == 8 && H == 8) { p.stage_px = 128; p.PW = 8; p.PH = 8; p.NB = 2; }
     else if (W == 4 && H == 4) { p.stage_px = 128; p.PW = 4; p.PH = 4; p.NB = 8; }
     else return p;
     const int tpi = (H / p.PH) * (W / p.PW);
     p.stages = ((B + p.NB - 1) / p.NB) * tpi;
-    p.tiles_n = (N + TN - 1) / TN; p.tiles_c = C / TC;
+    p.tiles_n = (N + TN - 1) / TN; p.tiles_c = C / (p.ws ? WS_TC : TC);
     const int tiles = p.tiles_n * p.tiles_c;
     int splits = want_splits;
     if (splits <= 0) {
@@ -540,7 +779,15 @@ static int wgrad3x3_launch(const void* dy, long long dy_ld, const void* x, long 
         }                                                                                                                         \
         hipLaunchKernelGGL((wgrad3x3_kernel<SPX, PWV, RINGV>), grid, dim3(512), LDS, st, a);                                      \
     } while (0)
-    if (p.stage_px == 256) WG_LAUNCH(256, 16, 3);            // 3 x (32 KiB dy + 21 KiB halo) + 1 KiB = 160 KiB
+    if (p.ws) {
+        static DevOnce ws_attr;
+        if (!ws_attr) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3_ws_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, WS_BYTES) != hipSuccess) return DDPM_ERR_LAUNCH;
+            ws_attr = true;
+        }
+        hipLaunchKernelGGL(wgrad3x3_ws_kernel, grid, dim3(512), WS_BYTES, st, a);
+    }
+    else if (p.stage_px == 256) WG_LAUNCH(256, 16, 3);            // 3 x (32 KiB dy + 21 KiB halo) + 1 KiB = 160 KiB
     else if (p.PW == 8) WG_LAUNCH(128, 8, 4);
     else WG_LAUNCH(128, 4, 4);
 #undef WG_LAUNCH
