@@ -25,13 +25,14 @@ def _stale(target, deps):
 def build(force=False, verbose=True):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     hdr = os.path.join(HERE, "common.h")
-    abi = os.path.join(HERE, "..", "..", "include", "ddpm_hip.h")       # plan.hip generates its call thunks from these declarations
+    inc = os.path.join(HERE, "..", "..", "include")
+    abi = [os.path.join(inc, "ddpm_hip.h"), os.path.join(inc, "ddpm_hip_debug.h")]      # plan.hip generates its call thunks from these declarations
     objs = []
     procs = []
     for s in SOURCES:
         src, obj = os.path.join(HERE, s), os.path.join(HERE, s.replace(".hip", ".o"))
         objs.append(obj)
-        if force or _stale(obj, [src, hdr, abi]):
+        if force or _stale(obj, [src, hdr, *abi]):
             cmd = [hipcc, *FLAGS, "-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)

@@ -970,10 +970,6 @@ struct Conv3Args {
     int PH, PW, NB, lPW, lPP;         // patch geometry: PW and PH*PW are powers of two (log2 in lPW, lPP); NB*PH*PW == 256
     int ky;                           // 1 when the halo row parity takes part in the LDS swizzle key (8-wide patches)
     int tiles_y, tiles_x;             // patches per image
-    // GNF instantiation only: the conv input is silu(GroupNorm(x)) applied to the LDS-resident halo (inference path)
-    const float* gn_stats;            // [B][G][2] = (mean, rstd) of x
-    const float* gn_gamma; const float* gn_beta;
-    int gn_G, gn_cpg, gn_silu;
     FastDiv d_tiles_n, d_tpi, d_tiles_x, d_halo_img, d_halo_w;     // host-prepared divisors: no runtime integer division in the prologue
     Epilogue ep;
 };
@@ -981,10 +977,7 @@ constexpr int C3_NI = 7;              // halo DMA parts of 512 vectors: up to 44
 
 // RING = depth of the weight-tile ring (RING-1 tiles in flight, counted s_waitcnt + raw s_barrier); HROWS = LDS rows
 // reserved per halo buffer.  LDS = 2*HROWS*128 + RING*16 KiB = 160 KiB in both instantiated configurations.
-// GNF: x is the RAW activation and the kernel applies y = silu(x * a_c + b_c) (GroupNorm affine from the given statistics) to
-// every halo chunk right after it lands in LDS, in place, leaving the zero padding zero — the normalised tensor is never
-// written to or read from HBM (single 16x16 patch per block only: one image, one set of coefficients per chunk).
-template <int RING, int HROWS, bool GNF = false>
+template <int RING, int HROWS>
 __global__ __launch_bounds__(512, 2)
 void conv3x3_halo_kernel(Conv3Args a, int tiles_n, int xcd) {
     HALO_WALL(0); HALO_STAMP(1);
@@ -1040,8 +1033,7 @@ void conv3x3_halo_kernel(Conv3Args a, int tiles_n, int xcd) {
     }
     auto issue_halo_part = [&](unsigned ho, int i, int cc, char* dst) {     // part i of the halo of channel chunk cc
         const unsigned o = ho == OOB ? OOB : ho + (unsigned)(cc * 64 * ES);
-        if (!GNF || tid + 512 * i < HP * 8)     // GNF keeps its coefficient table in the rows past the halo: lanes beyond stay masked
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(dst + (wave * 64 + 512 * i) * 16), 16, o, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(dst + (wave * 64 + 512 * i) * 16), 16, o, 0, 0, 0);
     };
     const int nchunks = a.C / 64;
     const int total = nchunks * 9;                        // K-steps: (channel chunk, tap)
@@ -1076,41 +1068,6 @@ void conv3x3_halo_kernel(Conv3Args a, int tiles_n, int xcd) {
     epilogue_bias<T, 512>(a.ep, tn * TILE, a.N, tid, bias);
 
     const int ni = (HP * 8 + 511) / 512;                 // halo DMA parts actually needed
-    // GNF: halo chunk cc is normalised in place in its buffer `hb`.  gn_coef puts the per-channel scale / shift of the
-    // block's image into the rows past the halo; gn_part rewrites DMA part i (the vectors this thread fetched: same
-    // (pixel, chunk) mapping), skipping the padded pixels so that they stay zero.  For chunk 0 both run right after the
-    // prologue; for the later chunks they are spread over the taps of the previous chunk (part i three taps after its
-    // DMA was issued: the counted wait that ends tap t covers everything issued up to tap t-2), so the VALU work runs
-    // under the other waves' MFMAs and the barrier that ends tap 8 publishes it.
-    auto gn_coef = [&](int cc, char* hb) {
-        float* coef = reinterpret_cast<float*>(hb + HP * ROW_BYTES);      // [64] scale, [64] shift
-        if (tid < 64) {
-            const int c = cc * 64 + tid, g = c / a.gn_cpg;
-            const float mean = a.gn_stats[((long long)img0 * a.gn_G + g) * 2], rstd = a.gn_stats[((long long)img0 * a.gn_G + g) * 2 + 1];
-            const float sc = rstd * a.gn_gamma[c];
-            coef[tid] = sc; coef[64 + tid] = a.gn_beta[c] - mean * sc;
-        }
-    };
-    auto gn_part = [&](int i, unsigned ho, char* hb) {
-        if (ho == OOB) return;
-        const float* coef = reinterpret_cast<const float*>(hb + HP * ROW_BYTES);
-        const int v = tid + 512 * i, hp = v >> 3;                    // NB == 1: one image per block
-        const int hy = (int)fdiv((unsigned)hp, a.d_halo_w), hx = hp - hy * HWd;
-        const int lc = (v & 7) ^ (((hx >> 1) ^ ((hy & a.ky) << 2)) & 7);
-        u32x4* pv = reinterpret_cast<u32x4*>(hb + v * 16);
-        float f[8];
-        Elem<T>::unpack(*pv, f);
-        const f32x4 s0 = *reinterpret_cast<const f32x4*>(coef + lc * 8), s1 = *reinterpret_cast<const f32x4*>(coef + lc * 8 + 4);
-        const f32x4 b0 = *reinterpret_cast<const f32x4*>(coef + 64 + lc * 8), b1 = *reinterpret_cast<const f32x4*>(coef + 64 + lc * 8 + 4);
-        const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
-        const float sh[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float z = f[e] * sc[e] + sh[e];
-            f[e] = a.gn_silu ? silu_fast_(z) : z;
-        }
-        *pv = Elem<T>::pack(f);
-    };
     // prologue: halo of chunk 0, then the first RING-1 weight tiles; wait for halo + tile 0 only
 #pragma unroll
     for (int i = 0; i < C3_NI; ++i)
@@ -1121,14 +1078,6 @@ void conv3x3_halo_kernel(Conv3Args a, int tiles_n, int xcd) {
     if (total >= RING - 1) { if (RING == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if constexpr (GNF) {
-        gn_coef(0, halo);
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < C3_NI; ++i)
-            if (i < ni) gn_part(i, hoff[i], halo);
-        __syncthreads();
-    }
     HALO_STAMP(2);
 
     const int hi = lane >> 5;
@@ -1144,15 +1093,6 @@ void conv3x3_halo_kernel(Conv3Args a, int tiles_n, int xcd) {
             // whole next halo has too.
             if (tap < C3_NI && tap < ni && cc + 1 < nchunks) issue_halo_part(hoff[tap < C3_NI ? tap : 0], tap, cc + 1, hnxt);
             if (step + RING - 1 < total) issue_w(step + RING - 1);
-            // GNF: waves w and w + 4 share a SIMD; one of them normalises its vectors BEFORE its MFMAs of this tap, the other
-            // AFTER, so on every SIMD the VALU work of one wave runs under the MFMAs of the other
-            const bool gn_early = (wave & 4) == 0;
-            if constexpr (GNF) {
-                if (cc + 1 < nchunks) {
-                    if (tap == 2) gn_coef(cc + 1, hnxt);
-                    if (gn_early && tap >= 3 && tap - 3 < ni) gn_part(tap - 3, hoff[tap >= 3 && tap - 3 < C3_NI ? tap - 3 : 0], hnxt);
-                }
-            }
             const int r = tap / 3, s = tap - 3 * r;
             const int shift = r * HWd + s;
 #pragma unroll
@@ -1170,9 +1110,6 @@ void conv3x3_halo_kernel(Conv3Args a, int tiles_n, int xcd) {
                 for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
                     for (int j = 0; j < 2; ++j) Mma<T>::run(fa[mi], fb[j], acc[mi][j]);
-            }
-            if constexpr (GNF) {
-                if (!gn_early && cc + 1 < nchunks && tap >= 3 && tap - 3 < ni) gn_part(tap - 3, hoff[tap >= 3 && tap - 3 < C3_NI ? tap - 3 : 0], hnxt);
             }
             // tile step+1 must have landed; the RING-2 newer tiles (2 DMA instructions each) may stay in flight
             const int newer = total - 2 - step;         // tiles issued after tile step+1
@@ -1391,10 +1328,7 @@ struct GemmArgs {          // plain-C mirror filled by the extern "C" entry poin
     int dry, variant;      // dry: decide the kernel (-> variant) but launch nothing
 };
 
-struct GnFold { const float* stats; const float* gamma; const float* beta; int G, silu; };     // GroupNorm folded into the conv's input
-
-static int conv3x3_halo_launch(GemmArgs& g, const void* x, long long x_ld, const void* w, int B, int H, int W, int C, int N, hipStream_t st,
-                               const GnFold* gn = nullptr) {
+static int conv3x3_halo_launch(GemmArgs& g, const void* x, long long x_ld, const void* w, int B, int H, int W, int C, int N, hipStream_t st) {
     // patch geometry: 256 output pixels per block
     int PW = W >= 16 ? 16 : W, PH = H >= 16 ? 16 : H;
     while (PH * PW > 256) PH >>= 1;
@@ -1431,18 +1365,7 @@ static int conv3x3_halo_launch(GemmArgs& g, const void* x, long long x_ld, const
         hipLaunchKernelGGL((conv3x3_halo_kernel<RING, HROWS>), grid, dim3(512), LDS, st, a, tiles_n, g_xcd_swizzle);                    \
     } while (0)
     g.variant = 5;
-    if (g.dry) return (gn && (NB != 1 || HP > 324)) ? -1 : DDPM_OK;
-    if (gn) {                              // GroupNorm + SiLU applied to the resident halo: single-patch geometry only
-        if (NB != 1 || HP > 324) return -1;
-        a.gn_stats = gn->stats; a.gn_gamma = gn->gamma; a.gn_beta = gn->beta; a.gn_G = gn->G; a.gn_cpg = C / gn->G; a.gn_silu = gn->silu;
-        static DevOnce attr_set;
-        if (!attr_set) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_halo_kernel<4, 384, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return DDPM_ERR_LAUNCH;
-            attr_set = true;
-        }
-        hipLaunchKernelGGL((conv3x3_halo_kernel<4, 384, true>), grid, dim3(512), LDS, st, a, tiles_n, g_xcd_swizzle);
-        return check_launch();
-    }
+    if (g.dry) return DDPM_OK;
     if (HP <= 384) C3_LAUNCH(4, 384);      // one 16x16 patch: 2 x 48 KiB halo + 4 x 16 KiB weight ring
     else C3_LAUNCH(3, 448);                // four 8x8 patches: 2 x 56 KiB halo + 3 x 16 KiB weight ring
 #undef C3_LAUNCH
@@ -1726,29 +1649,6 @@ extern "C" int ddpm_gemm(const void* a, long long a_ld, long long a_bs, int a_tr
     g.ep.bias = bias; g.ep.residual = residual; g.ep.res_ld = res_ld; g.ep.res_batch_stride = res_bs;
     g.ep.accumulate = accumulate;
     return ddpm_gemm_launch(g, (hipStream_t)stream);
-}
-
-// 3x3 / stride 1 / pad 1 convolution of silu(GroupNorm(x)) given the GroupNorm statistics of x (inference path): the
-// normalised activation only ever exists in LDS.  Same epilogue as ddpm_conv2d_nhwc (bias, per-sample row bias, residual).
-// bf16, C % 64 == 0, C % G == 0, H and W multiples of 16; anything else: DDPM_ERR_SHAPE (the caller materialises
-// ddpm_groupnorm_silu_fwd's output and calls ddpm_conv2d_nhwc instead).
-extern "C" int ddpm_conv3x3_gn_silu_nhwc(const void* x, long long x_ld, const float* gn_stats, const float* gamma, const float* beta, int G, int silu,
-                                         const void* w, void* y, long long y_ld, const float* bias, const float* rowbias, long long rowbias_ld,
-                                         const void* residual, long long res_ld, int B, int H, int W, int C, int N, int dtype, void* stream) {
-    if (!x || !gn_stats || !gamma || !beta || !w || !y) return DDPM_ERR_NULL;
-    if (dtype != DDPM_BF16) return DDPM_ERR_DTYPE;
-    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || N <= 0 || G <= 0 || C % G || C % 64 || H % 16 || W % 16) return DDPM_ERR_SHAPE;
-    if (!aligned16(x) || !aligned16(w) || !aligned16(y) || x_ld % 8 || y_ld % 8) return DDPM_ERR_ALIGN;
-    GemmArgs g; zero_args(g);
-    g.dtype = dtype; g.M = B * H * W; g.N = N; g.K = 9 * C; g.splits = 1;
-    g.ep.out = y; g.ep.ldc = y_ld; g.ep.mode = 0; g.ep.bias = bias;
-    g.ep.rowbias = rowbias; g.ep.rowbias_ld = rowbias_ld; g.ep.dgroup = make_fastdiv((unsigned)(H * W));
-    g.ep.residual = residual; g.ep.res_ld = res_ld;
-    g.ep.HW = H * W; g.ep.dHW = make_fastdiv((unsigned)(H * W));
-    set_vec_ok(g, 2);
-    const GnFold gn{gn_stats, gamma, beta, G, silu};
-    const int rc = conv3x3_halo_launch(g, x, x_ld, w, B, H, W, C, N, (hipStream_t)stream, &gn);
-    return rc < 0 ? DDPM_ERR_SHAPE : rc;
 }
 
 // Fused attention forward over a packed qkv buffer [B][L][ld] (q at channel 0, k at C, v at 2C): out[B][L][out_ld] =

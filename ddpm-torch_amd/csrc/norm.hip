@@ -1599,51 +1599,6 @@ __global__ void gn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict
     }
 }
 
-// ---- statistics only: one block per sample (1024 threads) produces the final (mean, rstd) of every group in ONE launch —
-// the input of the GroupNorm-folding convolution (ddpm_conv3x3_gn_silu_nhwc).  Thread (cx, py): channel vector cx, pixels
-// py, py + PY, ...; ordered LDS reduction (deterministic); per-group combine in fp64 like gn_apply.
-template <typename T>
-__global__ __launch_bounds__(1024)
-void gn_sample_stats_kernel(const T* __restrict__ x, GnShape s, float eps, float* __restrict__ stats /*[B][G][2]*/) {
-    constexpr int VEC = Elem<T>::VEC;
-    extern __shared__ __attribute__((aligned(16))) float gsh[];      // [PY][C] sums, [PY][C] squares
-    const int b = blockIdx.x, cv = s.C / VEC;
-    const int PY = blockDim.x / cv, tid = threadIdx.x;
-    const int cx = tid % cv, py = tid / cv;
-    float* sh_sum = gsh;
-    float* sh_sq = gsh + PY * s.C;
-    float sum[VEC], sq[VEC], piv[VEC];
-#pragma unroll
-    for (int j = 0; j < VEC; ++j) { sum[j] = sq[j] = 0.f; piv[j] = gn_pivot(x, s.x_ld, s.HW, b, (cx * VEC + j) / s.cpg, s.cpg); }
-    if (py < PY) {
-        const T* xb = x + ((long long)b * s.HW) * s.x_ld + cx * VEC;
-        for (int p = py; p < s.HW; p += PY) {
-            float f[VEC];
-            Elem<T>::unpack(ldg16(xb + (long long)p * s.x_ld), f);
-#pragma unroll
-            for (int j = 0; j < VEC; ++j) { const float d = f[j] - piv[j]; sum[j] += d; sq[j] += d * d; }
-        }
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) { sh_sum[py * s.C + cx * VEC + j] = sum[j]; sh_sq[py * s.C + cx * VEC + j] = sq[j]; }
-    }
-    __syncthreads();
-    for (int c = tid; c < s.C; c += blockDim.x) {
-        float a = 0.f, q = 0.f;
-        for (int r = 0; r < PY; ++r) { a += sh_sum[r * s.C + c]; q += sh_sq[r * s.C + c]; }
-        sh_sum[c] = a; sh_sq[c] = q;
-    }
-    __syncthreads();
-    if (tid < s.G) {
-        double a = 0.0, q = 0.0;
-        for (int c = tid * s.cpg; c < (tid + 1) * s.cpg; ++c) { a += sh_sum[c]; q += sh_sq[c]; }
-        const double n = (double)s.HW * s.cpg, dmean = a / n;
-        double var = q / n - dmean * dmean;
-        if (var < 0.0) var = 0.0;
-        const double mean = (double)gn_pivot(x, s.x_ld, s.HW, b, tid, s.cpg) + dmean;
-        stats[((long long)b * s.G + tid) * 2] = (float)mean;
-        stats[((long long)b * s.G + tid) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
-    }
-}
 
 // ---------------------------------------------------------------------------------------------- host side
 static int gn_geometry(int B, int HW, int C, int G, long long x_ld, long long y_ld, int esize, GnShape& s, dim3& block, dim3& grid) {
@@ -1828,26 +1783,4 @@ extern "C" int ddpm_groupnorm_silu_bwd(const void* x, long long x_ld, const void
         hipLaunchKernelGGL(gn_bwd_apply_kernel<float>, grid, block, 0, st, (const float*)x, (const float*)dy, (float*)dx, s, dy_ld, dx_ld, stats, fin2, dgamma, dbeta, a, accumulate, (const float*)add, add_ld);
     const int rc3 = check_launch();
     return rc3 ? rc3 : colsum_after.run();
-}
-
-// GroupNorm statistics only: stats[b][g] = (mean, 1/sqrt(var + eps)) of x — nn.GroupNorm's normalisation constants
-// (unet.py:18-20), consumed by ddpm_conv3x3_gn_silu_nhwc.  One launch, one block per sample.
-extern "C" int ddpm_groupnorm_stats(const void* x, long long x_ld, float* stats, int B, int HW, int C, int G, float eps, int dtype, void* stream) {
-    if (!x || !stats) return DDPM_ERR_NULL;
-    if (dtype != DDPM_BF16 && dtype != DDPM_F32) return DDPM_ERR_DTYPE;
-    if (!aligned16(x)) return DDPM_ERR_ALIGN;
-    const int es = dtype == DDPM_BF16 ? 2 : 4, vec = 16 / es;
-    if (B <= 0 || HW <= 0 || C <= 0 || G <= 0 || G > 64 || C % G || C % vec || C > GN_MAXC || C / vec > 1024) return DDPM_ERR_SHAPE;
-    if (x_ld % vec) return DDPM_ERR_ALIGN;
-    GnShape s = {};
-    s.B = B; s.HW = HW; s.C = C; s.G = G; s.cpg = C / G; s.x_ld = x_ld; s.y_ld = x_ld; s.S = 1; s.pix_per_slab = HW;
-    const int cv = C / vec;
-    int py = 1024 / cv; if (py > HW) py = HW; if (py < 1) py = 1;
-    const int nt = ((cv * py + 63) / 64) * 64;
-    const size_t lds = (size_t)2 * py * C * sizeof(float);
-    if (lds > 64 * 1024) return DDPM_ERR_SHAPE;
-    hipStream_t st = (hipStream_t)stream;
-    if (dtype == DDPM_BF16) hipLaunchKernelGGL(gn_sample_stats_kernel<bf16_t>, dim3(B), dim3(nt), lds, st, (const bf16_t*)x, s, eps, stats);
-    else hipLaunchKernelGGL(gn_sample_stats_kernel<float>, dim3(B), dim3(nt), lds, st, (const float*)x, s, eps, stats);
-    return check_launch();
 }

@@ -10,6 +10,7 @@
 // argument count is checked when the entry is appended.  Nothing here allocates device memory or synchronises.
 #include "common.h"
 #include "../../include/ddpm_hip.h"
+#include "../../include/ddpm_hip_debug.h"
 
 #include <cstring>
 #include <mutex>
@@ -60,8 +61,8 @@ namespace {
 // every launching entry point of include/ddpm_hip.h (the pure queries — *_variant, *_splits, ddpm_gn_workspace_floats — enqueue nothing)
 const EntryPoint kEntryPoints[] = {
     EP(ddpm_conv2d_nhwc), EP(ddpm_conv2d_wgrad_nhwc), EP(ddpm_conv3x3_wgrad_nhwc), EP(ddpm_conv3x3_wgrad_up_nhwc), EP(ddpm_conv1x1_wgrad_nhwc),
-    EP(ddpm_wgrad_reduce), EP(ddpm_wgrad_unpack), EP(ddpm_wgrad_unpack_sumsq), EP(ddpm_gemm), EP(ddpm_groupnorm_stats),
-    EP(ddpm_conv3x3_gn_silu_nhwc), EP(ddpm_attention_fwd), EP(ddpm_attention_fwd_lse), EP(ddpm_attention_bwd), EP(ddpm_groupnorm_silu_fwd),
+    EP(ddpm_wgrad_reduce), EP(ddpm_wgrad_unpack), EP(ddpm_wgrad_unpack_sumsq), EP(ddpm_gemm),
+    EP(ddpm_attention_fwd), EP(ddpm_attention_fwd_lse), EP(ddpm_attention_bwd), EP(ddpm_groupnorm_silu_fwd),
     EP(ddpm_groupnorm_silu_bwd), EP(ddpm_timestep_embedding), EP(ddpm_nchw_to_nhwc), EP(ddpm_pack_weight), EP(ddpm_pack_weight_multi),
     EP(ddpm_q_sample), EP(ddpm_mse_fwd), EP(ddpm_mse_bwd), EP(ddpm_weighted_sum_f32), EP(ddpm_atb_f32), EP(ddpm_p_sample_step), EP(ddpm_gather_i64),
     EP(ddpm_add_i64), EP(ddpm_gather_rows_f32), EP(ddpm_silu_fwd), EP(ddpm_silu_bwd), EP(ddpm_colsum), EP(ddpm_upsample2x_bwd),

@@ -45,8 +45,6 @@ PROTOTYPES = {
     "ddpm_attention_fwd": [P, L, P, L, I, I, I, F, I, P],
     "ddpm_attention_fwd_lse": [P, L, P, L, P, I, I, I, F, I, P],
     "ddpm_attention_bwd": [P, L, P, L, P, L, P, P, P, L, I, I, I, F, I, P],
-    "ddpm_groupnorm_stats": [P, L, P, I, I, I, I, F, I, P],
-    "ddpm_conv3x3_gn_silu_nhwc": [P, L, P, P, P, I, I, P, P, L, P, P, L, P, L, I, I, I, I, I, I, P],
     "ddpm_timestep_embedding": [P, P, P, I, I, P],
     "ddpm_nchw_to_nhwc": [P, P, I, I, I, I, I, P],
     "ddpm_pack_weight": [P, P, P, I, I, I, I, I, I, I, P],

@@ -193,19 +193,6 @@ def gn_fwd(x, y, gamma, beta, stats, ws, silu, drop_p=0.0, seed=0, seed_dev=0):
         f"GroupNorm fwd B={x.B} HW={x.H * x.W} C={x.C}" + (" +dropout" if drop_p > 0 else ""))
 
 
-def gn_stats(x, stats):
-    """stats[b][g] = (mean, rstd) of x in one launch (input of conv3x3_gn)."""
-    _hip.call("ddpm_groupnorm_stats", x.ptr, x.ld, _hip.ptr(stats), x.B, x.H * x.W, x.C, GN_GROUPS, GN_EPS, x.dtype, _hip.stream())
-
-
-def conv3x3_gn(x, stats, gamma, beta, w_ptr, y_ptr, y_ld, N, silu=True, bias=0, rowbias=0, rowbias_ld=0, res_ptr=0, res_ld=0):
-    """y = conv3x3(silu(GroupNorm(x))) with the normalisation applied inside the conv kernel (inference)."""
-    _timed("gemm_nn", 2.0 * x.B * x.H * x.W * N * 9 * x.C, lambda: _hip.call(
-        "ddpm_conv3x3_gn_silu_nhwc", x.ptr, x.ld, _hip.ptr(stats), _hip.ptr(gamma), _hip.ptr(beta), GN_GROUPS, int(silu), w_ptr, y_ptr, y_ld,
-        bias, rowbias, rowbias_ld, res_ptr, res_ld, x.B, x.H, x.W, x.C, N, x.dtype, _hip.stream()),
-        f"conv+gn M={x.B * x.H * x.W} N={N} K={9 * x.C} 3x3", lambda: 5)
-
-
 def gn_bwd(x, dy, dx, gamma, beta, stats, dgamma_ptr, dbeta_ptr, ws, silu, drop_p=0.0, seed=0, accumulate=0, seed_dev=0, colsum_ptr=0, colsum_ld=0, add=None):
     """colsum_ptr: zero-initialised [B][colsum_ld] fp32 buffer that receives the per-sample channel sums of dx (0 = not wanted).
     add: View of a second gradient contribution summed into dx in the same pass (the identity branch of a residual connection)."""

@@ -248,10 +248,6 @@ _FUSED_ATTENTION = os.environ.get("DDPM_FUSED_ATTENTION", "1") != "0"
 _FLASH_ATTENTION = os.environ.get("DDPM_FLASH_ATTENTION", "1") != "0"     # 0: the five-product path with L x L tensors (A/B only)
 _FLASH_INFERENCE = os.environ.get("DDPM_FLASH_INFERENCE", "1") != "0"     # inference attention through the training forward kernel (no lse stored)
 _UP_DGRAD_FUSED = os.environ.get("DDPM_UP_DGRAD_FUSED", "1") != "0"    # upsample convs: dgrad as one 4x4 stride-2 conv
-_FOLD_MAX_CHANNELS = 128
-_FOLD_MIN_PIXELS = 16384            # below this the small-grid kernels serve the layer better than the 256-pixel-tile conv
-_FOLD_GN = os.environ.get("DDPM_FOLD_GN", "0") != "0"               # inference: GroupNorm+SiLU folded into the 3x3 convs (off: since the persistent conv
-                                                                    # kernel, LDS GroupNorm + conv is faster than the folded form: 3.72 vs 3.83 ms per step)
 _SIDE_STREAM = os.environ.get("DDPM_SIDE_STREAM", "1") != "0"      # weight / bias gradients on a second HIP stream
 _SIDE_PRIORITY = int(os.environ.get("DDPM_SIDE_PRIORITY", "0"))    # its priority (lower number = dispatched first; clamped to the device's range)
 _WGRAD_MINSTEPS = int(os.environ.get("DDPM_WGRAD_MINSTEPS", "20"))
@@ -1009,43 +1005,26 @@ class _Engine:
         rowbias = tb.data_ptr() + 4 * self.tb_off[id(rb)]
         c1 = self._packed(rb.conv1, save)
         c2 = self._packed(rb.conv2, save)
-        # Inference: where it pays, GroupNorm + SiLU are folded into the convolution that consumes them (the normalised
-        # activation only exists in LDS; one statistics launch per norm).  Measured (scripts/fold_bench.py, B=128): the
-        # in-kernel normalisation costs ~3.5 us per 64-channel chunk per block round even when spread under the MFMAs, so the
-        # pair wins only for <= 128 input channels (32^2 x 128: 72.7 vs 76.7 us) and loses beyond (16^2 x 256: 57.4 vs 54.7).
-        # Training keeps the materialised activations — the weight gradients and the dropout mask need them.
-        fold = (not save and _FOLD_GN and self.T == torch.bfloat16 and x.H % 16 == 0 and x.W % 16 == 0 and B * x.H * x.W >= _FOLD_MIN_PIXELS
-                and Cin % 64 == 0 and Cout % 64 == 0 and max(Cin, Cout) <= _FOLD_MAX_CHANNELS)
         a1 = stats1 = a2 = stats2 = None
         seed = 0
         h1 = self._new(B, x.H, x.W, Cout)
-        if fold:
-            sbuf = self._f32(2, B, ops.GN_GROUPS, 2)
-            ops.gn_stats(x, sbuf[0])
-            ops.conv3x3_gn(x, sbuf[0], rb.norm1.weight, rb.norm1.bias, c1.wf.data_ptr(), h1.ptr, h1.ld, Cout, rowbias=rowbias, rowbias_ld=self.tb_total)
-        else:
-            a1 = self._new(B, x.H, x.W, Cin)
-            stats1 = self._f32(B, ops.GN_GROUPS, 2) if save else None
-            ops.gn_fwd(x, a1, rb.norm1.weight, rb.norm1.bias, stats1, ws, silu=True)
-            ops.conv2d(a1, c1.wf.data_ptr(), h1.ptr, h1.ld, Cout, 3, 3, x.H, x.W, pad_t=1, pad_l=1,
-                       rowbias=rowbias, rowbias_ld=self.tb_total, splitk=self.splitk)
+        a1 = self._new(B, x.H, x.W, Cin)
+        stats1 = self._f32(B, ops.GN_GROUPS, 2) if save else None
+        ops.gn_fwd(x, a1, rb.norm1.weight, rb.norm1.bias, stats1, ws, silu=True)
+        ops.conv2d(a1, c1.wf.data_ptr(), h1.ptr, h1.ld, Cout, 3, 3, x.H, x.W, pad_t=1, pad_l=1,
+                   rowbias=rowbias, rowbias_ld=self.tb_total, splitk=self.splitk)
         if rb.has_skip:
             cs = self._packed(rb.skip, save)
             ops.conv2d(x, cs.wf.data_ptr(), out.ptr, out.ld, Cout, 1, 1, x.H, x.W, bias=rb.skip.bias.data_ptr(), splitk=self.splitk)
             res_ptr, res_ld = out.ptr, out.ld          # conv2's epilogue adds the skip projection it finds in `out`
         else:
             res_ptr, res_ld = x.ptr, x.ld
-        if fold:
-            ops.gn_stats(h1, sbuf[1])
-            ops.conv3x3_gn(h1, sbuf[1], rb.norm2.weight, rb.norm2.bias, c2.wf.data_ptr(), out.ptr, out.ld, Cout,
-                           bias=rb.conv2.bias.data_ptr(), res_ptr=res_ptr, res_ld=res_ld)
-        else:
-            a2 = self._new(B, x.H, x.W, Cout)
-            stats2 = self._f32(B, ops.GN_GROUPS, 2) if save else None
-            seed = (st["seed"] + 0x51ED27 * (self.tb_off[id(rb)] + 1)) & ((1 << 63) - 1) if st["drop_p"] > 0 else 0
-            ops.gn_fwd(h1, a2, rb.norm2.weight, rb.norm2.bias, stats2, ws, silu=True, drop_p=st["drop_p"], seed=seed, seed_dev=st["seed_dev"])
-            ops.conv2d(a2, c2.wf.data_ptr(), out.ptr, out.ld, Cout, 3, 3, x.H, x.W, pad_t=1, pad_l=1,
-                       bias=rb.conv2.bias.data_ptr(), res_ptr=res_ptr, res_ld=res_ld, splitk=self.splitk)
+        a2 = self._new(B, x.H, x.W, Cout)
+        stats2 = self._f32(B, ops.GN_GROUPS, 2) if save else None
+        seed = (st["seed"] + 0x51ED27 * (self.tb_off[id(rb)] + 1)) & ((1 << 63) - 1) if st["drop_p"] > 0 else 0
+        ops.gn_fwd(h1, a2, rb.norm2.weight, rb.norm2.bias, stats2, ws, silu=True, drop_p=st["drop_p"], seed=seed, seed_dev=st["seed_dev"])
+        ops.conv2d(a2, c2.wf.data_ptr(), out.ptr, out.ld, Cout, 3, 3, x.H, x.W, pad_t=1, pad_l=1,
+                   bias=rb.conv2.bias.data_ptr(), res_ptr=res_ptr, res_ld=res_ld, splitk=self.splitk)
         if save:
             st["tape"].append(("res", rb, x, out, a1, stats1, h1, a2, stats2, seed, parts))
 

@@ -112,19 +112,6 @@ int ddpm_gemm(const void* a, long long a_ld, long long a_bs, int a_trans,
               int M, int N, int K, int batch, float alpha, int accumulate, int out_mode, int splits,
               int dtype, void* stream);
 
-/* Inference path: GroupNorm + SiLU folded into the input side of the following 3x3 / stride 1 / pad 1 convolution
- * (DEFAULT_NORMALIZER + DEFAULT_NONLINEARITY + Conv2d of ResidualBlock.forward, ddpm_torch/models/unet.py:85-88, eval mode:
- * dropout is the identity).  ddpm_groupnorm_stats writes stats[b][g] = (mean, 1/sqrt(var + eps)) of x in one launch;
- * ddpm_conv3x3_gn_silu_nhwc then computes
- *     y = conv3x3(silu?(gamma_c * (x - mean_bg) * rstd_bg + beta_c)) + bias (+ rowbias[b]) (+ residual)
- * with the normalisation applied to the LDS-resident input tiles: the normalised activation is never written to HBM.
- * bf16, C % 64 == 0, C % G == 0, H and W multiples of 16; other geometries return DDPM_ERR_SHAPE and the caller uses
- * ddpm_groupnorm_silu_fwd + ddpm_conv2d_nhwc. */
-int ddpm_groupnorm_stats(const void* x, long long x_ld, float* stats, int B, int HW, int C, int G, float eps, int dtype, void* stream);
-int ddpm_conv3x3_gn_silu_nhwc(const void* x, long long x_ld, const float* gn_stats, const float* gamma, const float* beta, int G, int silu,
-                              const void* w, void* y, long long y_ld, const float* bias, const float* rowbias, long long rowbias_ld,
-                              const void* residual, long long res_ld, int B, int H, int W, int C, int N, int dtype, void* stream);
-
 /* Fused single-head attention forward (inference path) — replaces the three products of AttentionBlock.forward
  * (ddpm_torch/models/unet.py:41-52: einsum("bchw,bcHW->bhwHW") * C**-0.5, softmax over the key positions, einsum with v)
  * for a packed projection buffer qkv[B][L][ld] with q at channel 0, k at channel C and v at channel 2C:
@@ -145,18 +132,6 @@ int ddpm_attention_fwd_lse(const void* qkv, long long ld, void* out, long long o
 int ddpm_attention_bwd(const void* qkv, long long ld, const void* o, long long o_ld, const void* d_o, long long do_ld,
                        const float* lse, float* dvec, void* dqkv, long long dqkv_ld, int B, int L, int C, float scale,
                        int dtype, void* stream);
-
-/* Instrumentation (no upstream counterpart): which kernel ddpm_conv2d_nhwc / ddpm_conv2d_wgrad_nhwc / ddpm_gemm would dispatch a
- * call with these arguments to — 1 gemm_kernel (4 waves), 2 gemm_kernel (8 waves), 3 gemm_kernel (deep LDS ring), 4 gemm64_kernel
- * (64x64 tiles), 5 conv3x3_halo_kernel, 7 pw_conv_kernel (persistent streaming 1x1 conv), 8 / 10 conv3x3_stream_kernel (persistent stationary-halo 3x3 conv, 16x16 / 8x8 patches), 9 wgrad1x1_kernel; a negative value is -(status code) for arguments the launching call would reject.
- * Pure functions of their arguments: the same dispatch code runs with launching switched off, nothing is retained between calls.
- * bench.py uses them to attribute its per-launch HIP-event timings to the kernel that ran. */
-int ddpm_conv2d_variant(long long x_ld, long long y_ld, int B, int H, int W, int C, int Ho, int Wo, int N, int R, int S,
-                        int stride, int pad_t, int pad_l, int upsample, int dilate, int out_mode, int splits, int dtype, int epilogue);
-int ddpm_conv2d_wgrad_variant(long long dy_ld, long long x_ld, int B, int H, int W, int C, int Creal, int Ho, int Wo, int N, int Nreal,
-                              int R, int S, int stride, int pad_t, int pad_l, int upsample, int splits, int dtype);
-int ddpm_gemm_variant(long long a_ld, int a_trans, long long b_ld, int b_trans, long long c_ld, int M, int N, int K, int batch,
-                      int out_mode, int splits, int dtype);
 
 /* nn.GroupNorm(32, C, eps=1e-6) -> SiLU -> Dropout(p) (unet.py:18-20,15,81,85-87,139-140; :57 without SiLU):
  *   y = drop(silu((x - mean_g) * rstd_g * gamma_c + beta_c)),  biased variance over (C/G)*HW elements.
@@ -259,30 +234,6 @@ int ddpm_mt_adam_ema(const long long* table, int n_tensors, const float* total_s
 /* dst_i = a_i (+ b_i) over many small fp32 tensors in one launch: table[i] = {a, b (0 = none), dst, numel} (int64).  Builds the
  * concatenated time-bias projection (all ResidualBlock.fc weights; fc.bias + conv1.bias, ddpm_torch/models/unet.py:77,85-86). */
 int ddpm_mt_gather_f32(const long long* table, int n_tensors, void* stream);
-
-/* measurement hook (bench.py's roofline leg; no upstream counterpart): one launch of an MFMA-only loop on every CU — 256 blocks x 4 waves,
- * 16 * iters v_mfma_f32_32x32x16_bf16 per wave on register-resident random bf16 operands (zero_operands = 1: zeros) =
- * iters * 16 * 32768 * 1024 FLOP.  Timed over a few hundred ms it gives the rate the matrix pipe SUSTAINS at the chip's power
- * budget (~1.7 PFLOP/s on random operands, ~2.5 on zeros).  sink: >= 256 floats, never written in practice. */
-int ddpm_mfma_probe(float* sink, int iters, int zero_operands, void* stream);
-
-/* diagnostic (no upstream counterpart): the wave-specialised 3x3 kernel's LDS-semaphore waits are bounded in wall time (~5 s); one that
- * expires records {block, counter address, value waited for, kind} and traps (the launch fails instead of hanging the GPU).  out4 is HOST
- * memory; kind 0 = no wait has ever expired.  Setting DDPM_CONV_NO_PC=1 runs those calls on the barrier-synchronised kernel instead. */
-int ddpm_conv3x3_pc_last_fault(unsigned* out4);
-
-/* Data-parallel training (upstream: DistributedDataParallel's all-reduce beside the backward, train.py:110): the persistent kernels size
- * their grids to the whole chip, one block per compute unit, so a collective's kernel issued from inside the backward finds a CU only at
- * a block boundary.  ddpm_set_reserved_cus(n) makes every persistent launcher (3x3 / 1x1 conv, both weight-gradient kernels) plan for
- * 256 - n compute units (0 <= n <= 192; process-wide; 0 = default).  Changes the slab counts ddpm_conv3x3_wgrad_splits /
- * ddpm_conv1x1_wgrad_splits report: set it before asking.  ddpm_copy_probe: `blocks` workgroups streaming `bytes` (a multiple of 16)
- * from src to dst — a stand-in for a ring step's copy kernel, used by bench.py to measure what a collective gets on one GPU. */
-int ddpm_set_reserved_cus(int n);
-int ddpm_get_reserved_cus(void);
-int ddpm_copy_probe(void* dst, const void* src, long long bytes, int blocks, void* stream);
-
-/* test hook: the keep-mask (1/0) the GroupNorm kernels regenerate for element indices 0..n-1 */
-int ddpm_dropout_mask(float* mask, long long n, float p, unsigned long long seed, void* stream);
 
 /* ---- launch plans (no upstream counterpart: the reference issues its step op by op from Python, ddpm_torch/utils/train.py:148-170).
  * The training step is a fixed sequence of the calls above; a plan records it once — entry-point name + argument words + the

@@ -444,26 +444,6 @@ class Emulator:
         v = torch.softmax(torch.from_numpy(f32(s, rows * L).reshape(rows, L).copy()), -1)
         Mat(p, rows, L, L, dt).set(v.numpy())
 
-    def ddpm_groupnorm_stats(self, x, x_ld, stats, B, HW, C, G, eps, dt, st):
-        v = Mat(x, B * HW, C, x_ld, dt).get().reshape(B, HW, G, C // G).astype(np.float64)
-        mean = v.mean(axis=(1, 3))
-        var = v.var(axis=(1, 3))
-        out = f32(stats, B * G * 2).reshape(B, G, 2)
-        out[..., 0] = mean
-        out[..., 1] = 1.0 / np.sqrt(var + eps)
-
-    def ddpm_conv3x3_gn_silu_nhwc(self, x, x_ld, stats, gamma, beta, G, silu, w, y, y_ld, bias, rowbias, rb_ld, res, res_ld,
-                                  B, H, W, C, N, dt, st):
-        v = Mat(x, B * H * W, C, x_ld, dt).get().reshape(B, H * W, G, C // G).astype(np.float32)
-        sb = f32(stats, B * G * 2).reshape(B, 1, G, 1, 2)
-        z = ((v - sb[..., 0]) * sb[..., 1]).reshape(B, H * W, C) * f32(gamma, C) + f32(beta, C)
-        if silu:
-            z = z / (1.0 + np.exp(-z))
-        tmp = torch.empty(B * H * W, C, dtype=torch.bfloat16 if dt == 1 else torch.float32)
-        Mat(tmp.data_ptr(), B * H * W, C, C, dt).set(z.reshape(B * H * W, C).astype(np.float32))
-        self.ddpm_conv2d_nhwc(tmp.data_ptr(), C, w, y, y_ld, bias, rowbias, rb_ld, res, res_ld, B, H, W, C, H, W, N, 3, 3, 1, 1, 1, 0, 0,
-                              0, 0, 1, 0, 0, dt, st)
-
     def ddpm_attention_fwd(self, qkv, ld, out, out_ld, B, L, C, scale, dt, st):
         x = Mat(qkv, B * L, 3 * C, ld, dt).get().reshape(B, L, 3 * C).astype(np.float64)
         q, k, v = x[..., :C], x[..., C:2 * C], x[..., 2 * C:]

@@ -1,4 +1,5 @@
-"""CPU: the C-ABI shared object loads (no GPU needed) and exports exactly the entry points include/ddpm_hip.h declares;
+"""CPU: the C-ABI shared object loads (no GPU needed) and exports exactly the entry points include/*.h declare (ddpm_hip.h = the
+interface that replaces the reference's ATen calls; ddpm_hip_debug.h = instrumentation and test hooks, none of which the product path needs);
 the ctypes table binds every one of them with the right arity."""
 import ctypes
 import os
@@ -10,10 +11,11 @@ from ddpm_torch import _hip
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HEADER = os.path.join(ROOT, "include", "ddpm_hip.h")
+DEBUG_HEADER = os.path.join(ROOT, "include", "ddpm_hip_debug.h")          # instrumentation / measurement / test hooks: a separate header
 
 
-def declared():
-    src = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+def declared(paths=(HEADER, DEBUG_HEADER)):
+    src = "".join(re.sub(r"/\*.*?\*/", "", open(p).read(), flags=re.S) for p in paths)
     out = {}
     for m in re.finditer(r"\b(?:int|long long|void\s*\*|const char\s*\*)\s*(ddpm_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
         args = [a for a in m.group(2).split(",") if a.strip() and a.strip() != "void"]
@@ -32,6 +34,10 @@ def test_library_exports_every_declared_symbol():
     for name, nargs in decl.items():
         assert len(_hip.PROTOTYPES[name]) == nargs, (name, nargs, len(_hip.PROTOTYPES[name]))
     _hip.lib()
+    # the interface header carries no instrumentation: every hook lives in the debug header
+    hooks = {"ddpm_conv2d_variant", "ddpm_conv2d_wgrad_variant", "ddpm_gemm_variant", "ddpm_mfma_probe", "ddpm_copy_probe", "ddpm_dropout_mask",
+             "ddpm_conv3x3_pc_last_fault", "ddpm_set_reserved_cus", "ddpm_get_reserved_cus"}
+    assert hooks <= set(declared((DEBUG_HEADER,))) and not hooks & set(declared((HEADER,)))
 
 
 @pytest.mark.skipif(not os.path.exists(_hip.LIB_PATH), reason="libddpm_hip.so not built")

@@ -118,8 +118,8 @@ def test_celeba_ddim50_at_batch_128_fp32_vs_reference_fixture(golden):
 
 def test_celeba_ddim50_at_batch_128_bf16_with_stated_bars(golden):
     """The throughput mode on the same chain.  An eta = 0 DDIM chain is a deterministic map with nothing to forget an error (no fresh
-    noise, 50 compounding steps): bars as for the B = 1 chain of G10 — mean < 3e-2 of the range, at most 10 % of the compared elements
-    further than 5e-2 off.  Measured: mean 3.7e-3, 1.7 % beyond 5e-2 (max 2.3e-1 at isolated pixels); the values are printed."""
+    noise, 50 compounding steps).  Bars at 2 x measured (round 6, as for G12): mean < 8e-3 of the range, at most 3.5 % of the compared
+    elements further than 5e-2 off.  Measured: mean 3.7e-3, 1.7 % beyond 5e-2 (max 2.3e-1 at isolated pixels); the values are printed."""
     e_max, e_mean, frac, s, f = _ddim50_b128(golden("g14_config4_ddim50_b128.pt"), torch.bfloat16)
     print(f"G14 celeba 64x64 DDIM-50 B=128 bf16: max {e_max:.3e}, mean {e_mean:.3e}, share beyond 5e-2: {frac:.3%}, per-image sums {s:.3e}")
-    assert e_mean < 3e-2 and frac < 0.10
+    assert e_mean < 8e-3 and frac < 0.035

@@ -105,26 +105,6 @@ def test_backward_slab_split_k_path_gives_the_same_gradients(emu, monkeypatch):
         check(grads[1][k], grads[0][k], 1e-6, atol=1e-7, name="slab grad." + k)
 
 
-def test_inference_with_groupnorm_folded_into_convs(emu, monkeypatch):
-    """Eval mode, bf16: the engine replaces GroupNorm+SiLU -> conv3x3 by statistics + ddpm_conv3x3_gn_silu_nhwc where the
-    geometry allows it; the result must match the materialising path (same rounding points)."""
-    import ddpm_torch.models.unet as unet_mod
-    cfg = dict(in_channels=3, hid_channels=64, out_channels=3, ch_multipliers=(1, 2), num_res_blocks=1, apply_attn=(False, False), drop_rate=0.1)
-    monkeypatch.setattr(unet_mod, "_FOLD_MIN_PIXELS", 1)
-    monkeypatch.setattr(unet_mod, "_FOLD_MAX_CHANNELS", 1024)
-    x, t = rnd(2, 3, 32, 32, seed=3), torch.tensor([7, 912])
-    outs = []
-    for fold in (False, True):
-        monkeypatch.setattr(unet_mod, "_FOLD_GN", fold)
-        m, _ = make(cfg)
-        m.set_compute_dtype(torch.bfloat16).eval()
-        emu.log.clear()
-        with torch.no_grad():
-            outs.append(m(x, t))
-        assert ("ddpm_conv3x3_gn_silu_nhwc" in emu.log) == fold
-    check(outs[1], outs[0], 2e-2, name="folded vs materialised")
-
-
 def test_state_dict_roundtrip_and_cache_refresh(emu):
     m, sd = make(TINY)
     m.eval()
