@@ -41,10 +41,11 @@ FWD_GFLOP = {"cifar": 12.443713536, "celeba": 46.741, "celebahq": 497.028}
 PEAK = {"bf16": 2500.0, "fp32": 157.3}                    # dense MFMA TFLOP/s, MI355X_MICROARCH.md
 B_PER_GPU = 128
 VARIANT = {1: "gemm_kernel<4 waves,128x128>", 2: "gemm_kernel<8 waves,128x128>", 3: "gemm_kernel<deep ring,128x128>",
-           4: "gemm64_kernel<64x64>", 5: "conv3x3_halo_kernel<256px x 128>", 6: "wgrad3x3_kernel<64x32 x 9 taps>", 7: "pw_conv_kernel<persistent 1x1>", 8: "conv3x3_stream_kernel<16> (persistent, 256px x 128)",
+           4: "gemm64_kernel<64x64>", 5: "conv3x3_halo_kernel<256px x 128>", 6: "wgrad3x3_kernel<64x32 x 9 taps> (8x8 / 4x4 images)", 7: "pw_conv_kernel<persistent 1x1>", 8: "conv3x3_stream_kernel<16> (persistent, 256px x 128)",
            9: "wgrad1x1_kernel<128c x 128n slabs>", 10: "conv3x3_stream_kernel<8> (persistent, 64px x 128)",
            11: "conv3x3_few_out_kernel (out_conv)", 12: "conv3x3_few_in_kernel (in_conv)",
-           13: "conv3x3_pc_kernel (persistent, 256px x 128, loader + consumer waves)"}
+           13: "conv3x3_pc_kernel (persistent, 256px x 128, loader + consumer waves)",
+           14: "wgrad3x3_ws_kernel (64x64 x 9 taps, 4 consumer + 4 loader waves)"}
 
 
 HBM_KIND = {"hbm_gn_fwd": "GroupNorm(32)+SiLU(+dropout) forward (gn_lds_fwd / gn_apply family, norm.hip)",
@@ -426,7 +427,7 @@ def main():
         # main-stream workgroups, which is why the runner-up is listed with them.
         # (GPU time = launch duration x the share of the chip the launch occupies: the 3x3 weight-gradient kernel is launched on HALF the CUs
         #  by design — csrc/wgrad.hip — so that the main stream keeps the other half; its duration doubles, its CU time does not)
-        share = {k: (WGRAD3_CU_SHARE if k.startswith("wgrad3x3_kernel") else 1.0) for k in agg}
+        share = {k: (WGRAD3_CU_SHARE if k.startswith("wgrad3x3") else 1.0) for k in agg}
         # headline kernel = the one with the most summed launch DURATION in the product step (what rocprofv3's kernel trace ranks by);
         # the pick by duration x CU share (a launch on half the chip counts half) is printed as `dominant_by_cu_time`
         dom_name = max(agg.items(), key=lambda kv: kv[1][2])[0]

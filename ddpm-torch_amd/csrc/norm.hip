@@ -1485,7 +1485,7 @@ static bool gn_fused_plan(const GnShape& s, int esize, GnFused& f, size_t& lds_b
 // ---- backward
 // dz = dy * mask/(1-p) * silu'(z), z = gamma*xhat + beta.  Per (b, c): A1 = sum dz*xhat, A2 = sum dz.
 template <typename T>
-__global__ void gn_bwd_reduce_kernel(const T* __restrict__ x, const T* __restrict__ dy, GnShape s, long long dy_ld,
+__global__ __launch_bounds__(GN_THREADS) void gn_bwd_reduce_kernel(const T* __restrict__ x, const T* __restrict__ dy, GnShape s, long long dy_ld,
                                      const float* __restrict__ stats, GnApply a, float* __restrict__ partial /*[B][S][C][2]*/) {
     constexpr int VEC = Elem<T>::VEC;
     __shared__ float sh1[GN_MAXC], sh2[GN_MAXC];
@@ -1732,11 +1732,9 @@ extern "C" int ddpm_groupnorm_silu_bwd(const void* x, long long x_ld, const void
                          else if (fl.nv <= 2) GN_LDS(gn_lds_bwd_kernel, 512, T_, 2, 512, P2V); else if (fl.nv <= 4) GN_LDS(gn_lds_bwd_kernel, 512, T_, 4, 512, P2V); else GN_LDS(K8, 512, T_, 8, ##__VA_ARGS__); } while (0)
         // P2: every group is a power-of-two run of channels that the halves of a 16-byte vector column do not straddle
         const bool p2 = (s.cpg & (s.cpg - 1)) == 0 && s.cpg >= (16 / es) / 2 && s.cpg <= 64 && (fl.seg_vecs & (fl.seg_vecs - 1)) == 0;
-        static const bool old8 = getenv("DDPM_GN_BWD8_OLD") != nullptr;
         if (dtype == DDPM_BF16) {
             typedef bf16_t T_;
-            if (old8) { if (p2) GN_LDS_NV(true, gn_lds_bwd8_kernel); else GN_LDS_NV(false, gn_lds_bwd8_kernel); }
-            else if (p2) {
+            if (p2) {
                 // the three flag combinations the UNet uses, baked in (norm1 / out: SiLU; norm2 in training: SiLU + dropout; attention: neither)
 #define GN_LDS_FL(FLV) do { if (small_lds) { if (fl.nv <= 1) GN_LDS(gn_lds_bwd_kernel, 256, T_, 1, 256, true, FLV); else GN_LDS(gn_lds_bwd_kernel, 256, T_, 2, 256, true, FLV); } \
                          else if (fl.nv <= 2) GN_LDS(gn_lds_bwd_kernel, 512, T_, 2, 512, true, FLV); else if (fl.nv <= 4) GN_LDS(gn_lds_bwd_kernel, 512, T_, 4, 512, true, FLV); \

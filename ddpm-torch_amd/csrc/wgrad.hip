@@ -724,6 +724,12 @@ static Plan make_plan(int B, int H, int W, int C, int N, int want_splits) {
 
 }  // namespace
 
+// instrumentation (include/ddpm_hip_debug.h): which kernel serves this geometry — 14 wgrad3x3_ws_kernel, 6 wgrad3x3_kernel, -1 not covered
+extern "C" int ddpm_conv3x3_wgrad_variant(int B, int H, int W, int C, int N) {
+    const Plan p = make_plan(B, H, W, C, N, 0);
+    return !p.ok ? -1 : (p.ws ? 14 : 6);
+}
+
 // number of slab copies ddpm_conv3x3_wgrad_nhwc writes for this geometry (0: geometry not covered by the patch kernel)
 extern "C" int ddpm_conv3x3_wgrad_splits(int B, int H, int W, int C, int N, int splits) {
     const Plan p = make_plan(B, H, W, C, N, splits);

@@ -148,7 +148,8 @@ def conv3x3_wgrad(dy, x, dw_ptr, slab_stride, dbias_ptr, bias_stride, Nreal, spl
     _timed("wgrad3x3", 2.0 * dy.rows * Nreal * 9 * x.C, lambda: _hip.call(
         "ddpm_conv3x3_wgrad_up_nhwc" if upsample else "ddpm_conv3x3_wgrad_nhwc", dy.ptr, dy.ld, x.ptr, x.ld, dw_ptr, slab_stride, dbias_ptr,
         bias_stride, dy.B, dy.H, dy.W, x.C, dy.C, Nreal, splits, x.dtype, _hip.stream()),
-        f"wgrad3x3 M={Nreal} N={9 * x.C} K={dy.rows} splits={splits}" + (" up" if upsample else ""), lambda: 6)
+        f"wgrad3x3 M={Nreal} N={9 * x.C} K={dy.rows} splits={splits}" + (" up" if upsample else ""),
+        lambda: max(6, int(_hip.lib().ddpm_conv3x3_wgrad_variant(dy.B, dy.H, dy.W, x.C, dy.C))))
 
 
 def conv1x1_wgrad_splits(P, C, N):

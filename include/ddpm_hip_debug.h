@@ -23,6 +23,9 @@ int ddpm_conv2d_wgrad_variant(long long dy_ld, long long x_ld, int B, int H, int
                               int R, int S, int stride, int pad_t, int pad_l, int upsample, int splits, int dtype);
 int ddpm_gemm_variant(long long a_ld, int a_trans, long long b_ld, int b_trans, long long c_ld, int M, int N, int K, int batch,
                       int out_mode, int splits, int dtype);
+/* ... and which kernel ddpm_conv3x3_wgrad_nhwc / _up_nhwc runs for a geometry: 14 wgrad3x3_ws_kernel (wave-specialised, 64 x 64 x 9 tiles:
+ * 16-divisible images, C % 64 == 0, N % 64 == 0), 6 wgrad3x3_kernel (patch-stationary, 64 x 32 x 9), -1 not covered. */
+int ddpm_conv3x3_wgrad_variant(int B, int H, int W, int C, int N);
 
 /* measurement hook (bench.py's roofline leg; no upstream counterpart): one launch of an MFMA-only loop on every CU — 256 blocks x 4 waves,
  * 16 * iters v_mfma_f32_32x32x16_bf16 per wave on register-resident random bf16 operands (zero_operands = 1: zeros) =
