@@ -31,6 +31,21 @@ def test_committed_bench_line_matches_the_contract():
     dom = r["per_kernel"][r["kernel"]]
     assert dom["launches"] == r["launches_per_step"] and abs(dom["avg_launch_us"] - r["avg_launch_us"]) < 0.05
     assert r["traffic"] and r["traffic"]["hbm_bytes_per_launch"] > 0 and r["runner_up"]["kernel"] != r["kernel"]
+    # round 6: the timed region is 5 consecutive blocks of `steps`, the line reports the median block
+    blocks = d["ms_per_step_blocks"]
+    assert len(blocks) == 5 and sorted(blocks)[2] == d["ms_per_step"] and "median" in d["timing"]
+    assert max(blocks) < 1.05 * min(blocks), blocks                      # the blocks of one run agree far better than boxes do
+    # the headline kernel is the one with the most summed launch duration in the step; a launch that takes part of the chip says so
+    assert r["kernel"] == max(r["per_kernel"].items(), key=lambda kv: kv[1]["ms"])[0] == r["dominant_by_duration"]["kernel"]
+    if "cu_share" in r:
+        assert 0 < r["cu_share"] < 1 and abs(r["frac_of_occupied_cus"] - r["frac"] / r["cu_share"]) < 2e-3
+    # HBM rows: GroupNorm forward / backward and the 1x1 kernels, in the step and isolated, priced against 6.3 TB/s achievable
+    for leg in ("in_step", "isolated"):
+        fams = [k for k in r["hbm_kernels"][leg] if " | " not in k]
+        assert len(fams) == 4 and all(0 < r["hbm_kernels"][leg][k]["frac_of_achievable_6300"] < 1 for k in fams), fams
+    # CPU baseline: an all-physical-cores point and the 256 x 256 leg next to the CIFAR one
+    assert c["all_cores"]["threads"] == c["physical_cores"] and c["all_cores"]["imgs_per_s"] > 0
+    assert c["celebahq_256x256"]["forward_imgs_per_s"] > 0
 
 
 def _bench(args, env_extra, timeout=300):
