@@ -724,6 +724,13 @@ static Plan make_plan(int B, int H, int W, int C, int N, int want_splits) {
 
 }  // namespace
 
+// diagnostic (include/ddpm_hip_debug.h): the record a timed-out semaphore wait of wgrad3x3_ws_kernel left before it trapped —
+// out4 (HOST memory) receives {block, LDS address of the counter bank, value waited for, 0 = none | 1 = expired}
+extern "C" int ddpm_wgrad3x3_ws_last_fault(unsigned* out4) {
+    if (!out4) return DDPM_ERR_NULL;
+    return hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_ws_fault), 4 * sizeof(unsigned)) == hipSuccess ? DDPM_OK : DDPM_ERR_LAUNCH;
+}
+
 // instrumentation (include/ddpm_hip_debug.h): which kernel serves this geometry — 14 wgrad3x3_ws_kernel, 6 wgrad3x3_kernel, -1 not covered
 extern "C" int ddpm_conv3x3_wgrad_variant(int B, int H, int W, int C, int N) {
     const Plan p = make_plan(B, H, W, C, N, 0);

@@ -69,6 +69,7 @@ PROTOTYPES = {
     "ddpm_mfma_probe": [P, I, I, P],
     "ddpm_mt_sumsq_slots": [I],
     "ddpm_conv3x3_wgrad_variant": [I, I, I, I, I],
+    "ddpm_wgrad3x3_ws_last_fault": [P],
     "ddpm_mt_grad_sumsq": [P, I, P, L, P],
     "ddpm_mt_adam_ema": [P, I, P, F, F, F, F, F, F, F, F, P, P],
     "ddpm_mt_gather_f32": [P, I, P],

@@ -97,6 +97,13 @@ class LaunchPlan:
                 gc.enable()
         if on_gpu:
             try:
+                # The recorded addresses stay valid only while the private pool keeps every block the body allocated and released
+                # (retains is False on the GPU).  That rests on torch.cuda.MemPool holding its own reference after use_mem_pool's scope
+                # (true for torch 2.10): checked here, so that a build where the scope's exit drops the last reference fails LOUDLY — the
+                # plan is marked unusable and the step stays eager — instead of replaying into memory that went back to the allocator.
+                count = getattr(self.pool, "use_count", None)
+                if callable(count) and count() < 1:
+                    raise RuntimeError("the plan's MemPool lost its last reference when the recording scope closed")
                 self._build_native()
             except Exception as e:           # (the body has run: the step is complete either way)
                 self.build_error = f"{type(e).__name__}: {e}"

@@ -329,7 +329,7 @@ class _Engine:
         take every CU whole and an all-reduce issued inside the backward finds one only at a block boundary).  Process-wide switch of the
         library; the slab counts of the weight-gradient kernels depend on it, so the cached plans are dropped when it changes.
         Default 0: on one GPU a stand-in copy kernel issued where the all-reduces are gets its CUs within one block of the
-        persistent kernels either way (profiles/r05_dp_reserved_cus.txt); the right value for 8 ranks over xGMI is
+        persistent kernels either way (profiles/r05_dp_one_rank.json: `reserved_cus` sweep); the right value for 8 ranks over xGMI is
         to be swept on the node."""
         want = int(os.environ.get("DDPM_DP_RESERVED_CUS", "0")) if self.pg is not None else 0
         lib = _hip.lib()

@@ -396,6 +396,7 @@ class _DirectStep:
         self.graph_failed = False
         self.plan = None                     # _plan.LaunchPlan of this step (recorded once, replayed from C)
         self.plan_failed = False
+        self.plan_stale = 0                  # how often a recorded plan had to be dropped because what it baked in moved
         self._plan_baked = None
         self.captures = 0                    # graph captures + plan recordings so far (bench.py asserts none happens inside a timed region)
         self._baked = None                   # identity of everything whose ADDRESS the captured graph holds (see _identity)
@@ -568,6 +569,16 @@ class _DirectStep:
                 self.graph = None                               # stale addresses: capture again (or run eagerly) instead of replaying
             if self.plan is not None and self._plan_baked != (ident, _hip.stream()):
                 self.plan = None                                # ... and a plan also holds the stream handle it was recorded on
+                # Back-off: a plan that keeps going stale (stream handle or identity churn) would be re-recorded every step — an
+                # eager run + ~500 ctypes appends + a new MemPool each time — and an auto-probe waiting for plan samples would never settle.
+                self.plan_stale += 1
+                self._phase = None                              # (a probe sample that spans a re-recording is not a sample)
+                if self.plan_stale >= 4:
+                    warnings.warn("the launch plan of the training step went stale 4 times (baked addresses or the stream keep changing); running it eagerly")
+                    self.plan_failed = True                      # (no longer a candidate: the probe decides among the other forms)
+                    self.times.pop("plan", None)
+                    if self.choice == "plan":
+                        self.choice = None
         # capture / record only what has run eagerly once with THIS engine: its first backward builds descriptor tables with host ->
         # device copies (illegal under stream capture, invisible to a plan) and allocates the persistent slabs / staging buffers
         warm = self._warm == eng.serial and not (self.x0.is_cuda and torch.cuda.is_current_stream_capturing())

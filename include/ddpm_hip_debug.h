@@ -37,6 +37,8 @@ int ddpm_mfma_probe(float* sink, int iters, int zero_operands, void* stream);
  * expires records {block, counter address, value waited for, kind} and traps (the launch fails instead of hanging the GPU).  out4 is HOST
  * memory; kind 0 = no wait has ever expired.  Setting DDPM_CONV_NO_PC=1 runs those calls on the barrier-synchronised kernel instead. */
 int ddpm_conv3x3_pc_last_fault(unsigned* out4);
+/* ... the same record for the wave-specialised 3x3 weight-gradient kernel (DDPM_WGRAD3_NO_WS=1 runs those calls on the barrier-synchronised one). */
+int ddpm_wgrad3x3_ws_last_fault(unsigned* out4);
 
 /* Data-parallel training (upstream: DistributedDataParallel's all-reduce beside the backward, train.py:110): the persistent kernels size
  * their grids to the whole chip, one block per compute unit, so a collective's kernel issued from inside the backward finds a CU only at

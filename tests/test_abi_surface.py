@@ -58,7 +58,7 @@ def test_argument_validation_returns_status_codes_without_a_gpu():
 
 QUERIES = {"ddpm_wgrad_effective_splits", "ddpm_conv3x3_wgrad_splits", "ddpm_conv1x1_wgrad_splits", "ddpm_gn_workspace_floats",
            "ddpm_conv2d_variant", "ddpm_conv2d_wgrad_variant", "ddpm_gemm_variant", "ddpm_conv3x3_pc_last_fault", "ddpm_set_reserved_cus",
-           "ddpm_get_reserved_cus", "ddpm_mt_sumsq_slots", "ddpm_conv3x3_wgrad_variant"}
+           "ddpm_get_reserved_cus", "ddpm_mt_sumsq_slots", "ddpm_conv3x3_wgrad_variant", "ddpm_wgrad3x3_ws_last_fault"}
 
 
 @pytest.mark.skipif(not os.path.exists(_hip.LIB_PATH), reason="libddpm_hip.so not built")

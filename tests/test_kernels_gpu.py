@@ -2,6 +2,7 @@
 contract (tests/abi_emulator.py) on identical inputs.  fp32 results must agree to ~1e-5 relative (the fp32 MFMA path
 is exact per product; only the summation order differs); bf16 results to 1 bf16 ulp-ish (2^-7 relative to the tensor
 maximum after identical rounding of the stored outputs).  Integer / mask outputs are bit-exact."""
+import ctypes
 import math
 
 import numpy as np
@@ -843,6 +844,40 @@ def test_conv3x3_wave_specialised_kernel_is_bit_stable_under_contention(B, H, C,
         torch.cuda.synchronize()
     bad = [i for i, y in enumerate(outs) if not torch.equal(y, ref)]
     assert not bad, f"launches {bad} differ from the uncontended result"
+
+
+@pytest.mark.parametrize("B,H,C,N,up", [(16, 32, 128, 128, 0), (24, 16, 256, 256, 0), (8, 32, 256, 128, 1)])
+def test_wgrad3x3_wave_specialised_kernel_is_bit_stable_under_contention(B, H, C, N, up):
+    """wgrad3x3_ws_kernel (round 6) synchronises four loader and four consumer waves through single-writer counters in LDS — no stage
+    barrier — and keeps only two stages in flight: a consumer that read a slot before every loader's share had landed, or a loader that
+    refilled it before every consumer was through, would show up as different bits.  Slab copies alone -> reference; then 30 launches next
+    to an MFMA-only kernel holding a wave on every SIMD (the block's waves advance unevenly) -> the same bits every time; no wait expired."""
+    dt = 1
+    lib = _hip.lib()
+    assert lib.ddpm_conv3x3_wgrad_variant(B, H, H, C, N) == 14
+    x = r(B * (H >> up) * (H >> up), C, seed=21, dt=dt).to(DEV)
+    dy = r(B * H * H, N, seed=22, dt=dt).to(DEV)
+    copies = int(lib.ddpm_conv3x3_wgrad_splits(B, H, H, C, N, 0))
+    n = N * 9 * C
+    fn = "ddpm_conv3x3_wgrad_up_nhwc" if up else "ddpm_conv3x3_wgrad_nhwc"
+
+    def run(slab, stream):
+        _hip.call(fn, dy.data_ptr(), N, x.data_ptr(), C, slab.data_ptr(), n, slab.data_ptr() + 4 * copies * n, N, B, H, H, C, N, N, 0, dt, stream)
+    ref = torch.full((copies * (n + N),), 3.0, device=DEV)
+    run(ref, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    sink = torch.zeros(256, device=DEV)
+    outs = [torch.full_like(ref, 5.0) for _ in range(30)]
+    for it in range(2):
+        _hip.call("ddpm_mfma_probe", sink.data_ptr(), 60000, 0, s1.cuda_stream)
+        for y in outs[it * 15:(it + 1) * 15]:
+            run(y, s2.cuda_stream)
+        torch.cuda.synchronize()
+    bad = [i for i, y in enumerate(outs) if not torch.equal(y, ref)]
+    assert not bad, f"launches {bad} differ from the uncontended result"
+    fault = (ctypes.c_uint * 4)()
+    assert lib.ddpm_wgrad3x3_ws_last_fault(fault) == 0 and fault[3] == 0
 
 
 @pytest.mark.parametrize("M,N,K", [(1024, 512, 128), (256, 512, 128), (512, 128, 128), (2048, 512, 2), (130, 70, 37)])
