@@ -37,7 +37,31 @@ struct MatDesc {
     int sh;                   // 1 when the virtual input grid is 2x the stored one (upsample or dilation)
     int dmask;                // 1 for dilation-2 (only even virtual coordinates exist), else 0
     FastDiv dHoWo, dWo, dC, dS;
+    // Parity-phase form of the dilation-2 conv (the data gradient of a stride-2 conv), set by the host when the geometry allows it: the output rows
+    // are walked PHASE-MAJOR — m = phase * Mp + ((b * Hh + h') * Wh + w'), output pixel (2h' + a, 2w' + bb) — so that all rows of a 128-row tile
+    // have the same coordinate parities and hence the same non-zero taps (1, 2, 2 or 4 of the 9): the K loop visits those only and the
+    // zero-dilated three quarters of the operand are never fetched or multiplied.
+    int phase, Hh, Wh, Mp, spt;       // spt = K-steps per tap (C / BK)
+    FastDiv dMp, dHhWh, dWh, dSpt;
 };
+
+// phase-major row m -> phase id, image, output pixel.  Phase ids in the order 4-tap, 2-tap, 1-tap, 2-tap: blocks
+// are dispatched in id order and a CU holds two of them, so the k-th and (k + half)-th tiles share a CU — 4 + 1 and 2 + 2 taps.
+// (a coordinate whose parity equals the pad's has the two even taps r = 0, 2 of a 3-tap axis, the other parity the single odd one)
+__device__ __forceinline__ void phase_parity(const MatDesc& d, int ph, int& a, int& bb) {
+    a = (d.pad_t & 1) ^ (ph < 2 ? 0 : 1);
+    bb = (d.pad_l & 1) ^ ((ph == 0 || ph == 3) ? 0 : 1);
+}
+__device__ __forceinline__ void phase_decode(const MatDesc& d, int m, int& ph, int& b, int& y, int& x) {
+    ph = (int)fdiv((unsigned)m, d.dMp);
+    const unsigned q = (unsigned)m - (unsigned)ph * (unsigned)d.Mp;
+    const unsigned bq = fdiv(q, d.dHhWh);
+    const unsigned rem = q - bq * (unsigned)(d.Hh * d.Wh);
+    const unsigned hh = fdiv(rem, d.dWh), wh = rem - hh * (unsigned)d.Wh;
+    int a, bb;
+    phase_parity(d, ph, a, bb);
+    b = (int)bq; y = 2 * (int)hh + a; x = 2 * (int)wh + bb;
+}
 
 struct Epilogue {
     void* out;
@@ -132,6 +156,7 @@ struct Loader {
     unsigned tapmask[NV];       // !TRANS conv without up/down-scaling: bit (r*S+s) set when the tap is inside the image
     int tr, ts, tc; unsigned foff;   // TRANS: fixed tap/channel (conv) or fixed byte offset along the fast index (plain, OOB if outside)
     int krow0;                    // TRANS bf16 (LDS-DMA of the m-major image): first k-row of this thread (tid>>4), +16 per vector
+    int ph_py, ph_px;             // !TRANS parity-phase conv: parity of (y - pad_t), (x - pad_l) of this tile's rows; -1 otherwise
 
     __device__ __forceinline__ Loader(const MatDesc& d_, int batch, int tile0_, int tid) : d(d_) {
         // The descriptor must be PROVABLY wave-uniform or hipcc wraps every buffer op in a waterfall loop
@@ -146,7 +171,35 @@ struct Loader {
             wave = __builtin_amdgcn_readfirstlane(tid >> 6);
             kv = (tid & 7) ^ ((row0 >> 1) & 7);
             kvoff = kv * VEC * ES;
-            kuni = (d.conv && d.sh == 0 && d.C % BK == 0) ? 1 : 0;
+            kuni = (d.conv && (d.sh == 0 || d.phase) && d.C % BK == 0) ? 1 : 0;
+            ph_py = ph_px = -1;
+            if (d.conv && d.phase) {
+                // every row of the tile is in one phase (Mp is a multiple of the tile height): the parities are block-uniform
+                int a, bb;
+                phase_parity(d, (int)fdiv((unsigned)__builtin_amdgcn_readfirstlane(tile0), d.dMp), a, bb);
+                ph_py = (a - d.pad_t) & 1; ph_px = (bb - d.pad_l) & 1;
+#pragma unroll
+                for (int i = 0; i < NV; ++i) {
+                    const int m = tile0 + row0 + (NT / 8) * i;
+                    int ph, b, y, x;
+                    phase_decode(d, m, ph, b, y, x);
+                    const int y0 = y - d.pad_t, x0 = x - d.pad_l;           // virtual (zero-dilated) coordinates of tap (0, 0)
+                    // tap (r, s) reads the STORED pixel ((y0 + r) / 2, (x0 + s) / 2) when both sums are even and inside; relative to the
+                    // pixel (y0 >> 1, x0 >> 1) that is ((r + py) >> 1, (s + px) >> 1) — the same for every row of the tile
+                    const int yb = y0 >> 1, xb = x0 >> 1;
+                    roff[i] = (int)((((long long)(b * d.H + yb) * d.W + xb) * d.ld) * ES);
+                    unsigned mk = 0;
+#pragma unroll
+                    for (int r = 0; r < 3; ++r)
+#pragma unroll
+                        for (int s = 0; s < 3; ++s) {
+                            const unsigned sy = (unsigned)(yb + ((r + ph_py) >> 1)), sx = (unsigned)(xb + ((s + ph_px) >> 1));
+                            const bool ok = r < d.R && s < d.S && (r & 1) == ph_py && (s & 1) == ph_px && sy < (unsigned)d.H && sx < (unsigned)d.W;
+                            mk |= ok ? 1u << (r * d.S + s) : 0u;
+                        }
+                    tapmask[i] = mk;
+                }
+            } else
 #pragma unroll
             for (int i = 0; i < NV; ++i) {
                 const int m = tile0 + row0 + (NT / 8) * i;
@@ -212,7 +265,8 @@ struct Loader {
             const int k0u = __builtin_amdgcn_readfirstlane(k0);
             const unsigned tapu = fdiv((unsigned)k0u, d.dC);
             const int cu = k0u - (int)tapu * d.C;
-            const int ru = (int)fdiv(tapu, d.dS), su = (int)tapu - ru * d.S;
+            int ru = (int)fdiv(tapu, d.dS), su = (int)tapu - ru * d.S;
+            if (ph_py >= 0) { ru = (ru + ph_py) >> 1; su = (su + ph_px) >> 1; }     // parity-phase conv: offsets on the stored (undilated) grid
             const int tapoff = ((ru * d.W + su) * (int)d.ld + cu) * ES;
             const unsigned tb = k0u < k_end ? tapu : 31u;           // K is a multiple of the step here: no partial tail
 #pragma unroll
@@ -559,12 +613,42 @@ void gemm_kernel(MatDesc A, MatDesc B, Epilogue ep, int M, int N, int K, int k_p
     const int wm = wave >> 1, wn = wave & 1;               // wave row block (of 32*MI rows) and column block (of 64)
     const int nsplit = gridDim.y, ntiles = gridDim.x;
     const int lid = xcd_logical_id(blockIdx.x + blockIdx.y * gridDim.x, ntiles * nsplit, xcd);     // tile fastest, then split
-    const int by = lid / ntiles, bx = lid - by * ntiles;
+    int by = lid / ntiles, bx = lid - by * ntiles;
+    // parity-phase conv (see MatDesc::phase; k-contiguous operands, one split): the tiles of each phase are spread over the 8 XCDs in equal
+    // contiguous chunks, heavy phases first — XCD x works on chunk x of every phase, which are the same dy pixels four times (L2 reuse)
+    constexpr bool PH_OK = !TA && !TB;
+    const bool phase = PH_OK && A.phase;
+    if (PH_OK && phase) {
+        const int id = blockIdx.x, tp = ntiles >> 2;            // tiles (M x N) per phase
+        by = 0; bx = id;
+        if (xcd && (tp & 7) == 0) {
+            const int tp8 = tp >> 3, j = id >> 3;
+            const int p = j / tp8;
+            bx = p * tp + (id & 7) * tp8 + (j - p * tp8);
+        }
+    }
     const int tm = bx / tiles_n, tn = bx - tm * tiles_n;
     const int batch = blockIdx.z;
     const int k_begin = by * k_per_split;
     const int k_end = min(K, k_begin + k_per_split);
     if (k_begin >= k_end) return;
+    // the tile's non-zero taps, 4 bits each (at most 4 of a 3 x 3 kernel)
+    unsigned ph_taps = 0; int ph_ntap = 0;
+    if (PH_OK && phase) {
+        int a, bb;
+        phase_parity(A, (int)fdiv((unsigned)(tm * TILE), A.dMp), a, bb);
+        const int py = (a - A.pad_t) & 1, px = (bb - A.pad_l) & 1;
+        for (int r = py; r < A.R; r += 2)
+            for (int c = px; c < A.S; c += 2) { ph_taps |= (unsigned)(r * A.S + c) << (4 * ph_ntap); ++ph_ntap; }
+    }
+    // K offset of K-step i of this block
+    auto kmap = [&](int i) -> int {
+        if (PH_OK && phase) {
+            const int ti = (int)fdiv((unsigned)i, A.dSpt);
+            return (int)((ph_taps >> (4 * ti)) & 15u) * A.C + (i - ti * A.spt) * BK;
+        }
+        return k_begin + i * BK;
+    };
 
     Loader<T, TA, NW> la(A, batch, tm * TILE, tid);
     Loader<T, TB, NW> lb(B, batch, tn * TILE, tid);
@@ -586,11 +670,12 @@ void gemm_kernel(MatDesc A, MatDesc B, Epilogue ep, int M, int N, int K, int k_p
     constexpr bool DMA_A = Loader<T, TA, NW>::DMA, DMA_B = Loader<T, TB, NW>::DMA;
     auto stage_a = [&](int k0, char* tile) { if constexpr (TA) la.issue_tr(k0, k_end, tile); else la.issue(k0, k_end, tile); };
     auto stage_b = [&](int k0, char* tile) { if constexpr (TB) lb.issue_tr(k0, k_end, tile); else lb.issue(k0, k_end, tile); };
-    const int nsteps = (k_end - k_begin + BK - 1) / BK;
+    const int nsteps = (PH_OK && phase) ? ph_ntap * A.spt : (k_end - k_begin + BK - 1) / BK;
+    if (nsteps == 0) return;            // (a phase without taps: kernels smaller than the stride; the host does not select the form then)
     // stage the first NBUF-1 K-steps
     if (NBUF == 2) {
-        if constexpr (DMA_A) stage_a(k_begin, smem); else { la.load(k_begin, k_end, va); la.store(smem, va); }
-        if constexpr (DMA_B) stage_b(k_begin, smem + TILE_BYTES); else { lb.load(k_begin, k_end, vb); lb.store(smem + TILE_BYTES, vb); }
+        if constexpr (DMA_A) stage_a(kmap(0), smem); else { la.load(k_begin, k_end, va); la.store(smem, va); }
+        if constexpr (DMA_B) stage_b(kmap(0), smem + TILE_BYTES); else { lb.load(k_begin, k_end, vb); lb.store(smem + TILE_BYTES, vb); }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     } else {
@@ -600,8 +685,8 @@ void gemm_kernel(MatDesc A, MatDesc B, Epilogue ep, int M, int N, int K, int k_p
 #pragma unroll
             for (int t = 0; t < NBUF - 1; ++t)
                 if (t < nsteps) {
-                    stage_a(k_begin + t * BK, smem + t * 2 * TILE_BYTES);
-                    stage_b(k_begin + t * BK, smem + t * 2 * TILE_BYTES + TILE_BYTES);
+                    stage_a(kmap(t), smem + t * 2 * TILE_BYTES);
+                    stage_b(kmap(t), smem + t * 2 * TILE_BYTES + TILE_BYTES);
                 }
             wait_tiles_in_flight<32 / NW>(min(NBUF - 2, nsteps - 1));
             __builtin_amdgcn_s_barrier();
@@ -617,7 +702,7 @@ void gemm_kernel(MatDesc A, MatDesc B, Epilogue ep, int M, int N, int K, int k_p
         const bool more = s + 1 < nsteps;
         if (NBUF == 2) {
             if (more) {       // the other buffer was last read in step s-1: every wave is past that barrier
-                const int kn = k_begin + (s + 1) * BK;
+                const int kn = kmap(s + 1);
 #ifndef GABL_NOISSUE_A              // GABL_*: timing-only ablations (scripts/ablate_gemm.sh), never defined in product builds
                 if constexpr (DMA_A) stage_a(kn, nxt); else la.load(kn, k_end, va);
 #endif
@@ -659,7 +744,7 @@ void gemm_kernel(MatDesc A, MatDesc B, Epilogue ep, int M, int N, int K, int k_p
                 // the MFMAs already queued instead of delaying the first one
                 if (kc == (DEEP_ISSUE_KC < BK / KF ? DEEP_ISSUE_KC : 0) && s + NBUF - 1 < nsteps) {
                     const int far_i = cur_i == 0 ? NBUF - 1 : cur_i - 1;
-                    const int kn = k_begin + (s + NBUF - 1) * BK;
+                    const int kn = kmap(s + NBUF - 1);
                     stage_a(kn, smem + far_i * 2 * TILE_BYTES);
                     stage_b(kn, smem + far_i * 2 * TILE_BYTES + TILE_BYTES);
                 }
@@ -685,7 +770,15 @@ void gemm_kernel(MatDesc A, MatDesc B, Epilogue ep, int M, int N, int K, int k_p
 
     // accumulator (reg r, lane l) -> row (r&3) + 8*(r>>2) + 4*(l>>5), col l&31 of its 32x32 tile; stage as fp32 in LDS.
     float* cs = reinterpret_cast<float*>(smem);
-    auto rowmap = [&](int rl) { const int row = tm * TILE + rl; return row < M ? row : -1; };
+    auto rowmap = [&](int rl) {
+        const int row = tm * TILE + rl;
+        if (PH_OK && phase) {           // phase-major row -> row of the output tensor
+            int ph, b, y, x;
+            phase_decode(A, row, ph, b, y, x);
+            return (b * A.Ho + y) * A.Wo + x;
+        }
+        return row < M ? row : -1;
+    };
     // accumulators -> fp32 LDS staging (+ the in-launch split-K reduction); false: this block only contributed a slab
     auto stage = [&]() -> bool {
         {
@@ -1405,7 +1498,7 @@ static int launch_t(GemmArgs& g, hipStream_t st) {
     // small grids of k-contiguous products: 64x64 tiles put 4x as many CUs to work (see gemm64_kernel)
     static const bool no_t64 = getenv("DDPM_GEMM_NO_T64") != nullptr;
     static const int t64_max_tiles = getenv("DDPM_GEMM_T64_TILES") ? atoi(getenv("DDPM_GEMM_T64_TILES")) : 64;
-    if (!no_t64 && !g.A.trans && !g.B.trans && (splits == 1 || (splits == 2 && g.ep.splitk_ws && g.ep.splitk_cnt)) &&
+    if (!no_t64 && !g.A.phase && !g.A.trans && !g.B.trans && (splits == 1 || (splits == 2 && g.ep.splitk_ws && g.ep.splitk_cnt)) &&
         (g.ep.mode == 0 || g.ep.mode == 1) && (long long)tiles_m * tiles_n * g.batch <= t64_max_tiles) {
         const int t64n = (g.N + T64 - 1) / T64;
         // two K runs per tile when the caller offers the workspace (splits == 2), the tiles alone leave half the CUs idle and every
@@ -1561,6 +1654,18 @@ extern "C" int ddpm_conv2d_nhwc(const void* x, long long x_ld, const void* w, vo
     g.ep.residual = residual; g.ep.res_ld = res_ld; g.ep.accumulate = accumulate;
     g.ep.HW = Ho * Wo; g.ep.dHW = make_fastdiv((unsigned)(Ho * Wo));
     g.splits = splits; g.ep.splitk_ws = splitk_ws; g.ep.splitk_cnt = splitk_cnt;
+    // data gradient of a stride-2 conv (dilate): parity-phase form when every 128-row tile can stay inside one phase — 9/4 taps per output
+    // pixel on average instead of 9 over a three-quarters-zero operand.  One K run (the reduction is short), the caller's split offer unused.
+    static const bool no_phase = getenv("DDPM_NO_PHASE_DGRAD") != nullptr;
+    const int bk = dtype == DDPM_BF16 ? 64 : 32;
+    if (!no_phase && dilate && R == 3 && S == 3 && stride == 1 && !(Ho & 1) && !(Wo & 1) && C % bk == 0 && (out_mode == 0 || out_mode == 1) &&
+        ((long long)B * (Ho / 2) * (Wo / 2)) % TILE == 0) {
+        MatDesc& d = g.A;
+        d.phase = 1; d.Hh = Ho / 2; d.Wh = Wo / 2; d.Mp = B * d.Hh * d.Wh; d.spt = C / bk;
+        d.dMp = make_fastdiv((unsigned)d.Mp); d.dHhWh = make_fastdiv((unsigned)(d.Hh * d.Wh)); d.dWh = make_fastdiv((unsigned)d.Wh);
+        d.dSpt = make_fastdiv((unsigned)d.spt);
+        g.splits = 1; g.ep.splitk_ws = nullptr; g.ep.splitk_cnt = nullptr;
+    }
     // the UNet's edge convs (3 -> hid, hid -> 3) on full-size images: their own kernels (edgeconv.hip)
     if (dtype == DDPM_BF16 && R == 3 && S == 3 && stride == 1 && pad_t == 1 && pad_l == 1 && !upsample && !dilate && Ho == H && Wo == W &&
         !rowbias && !residual && !accumulate && g.M >= 16384) {

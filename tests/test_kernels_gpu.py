@@ -95,6 +95,34 @@ def test_conv_fwd(case, dt):
          B, H, W, C, Ho, Wo, N, R, R, stride, pt, pl, ups, dil, 0, 3, 1, None, None, dt, tol=TOL[0] if dt == 0 else 4e-3)
 
 
+@pytest.mark.parametrize("dt", [0, 1])
+@pytest.mark.parametrize("B,Hs,C,N,pt,pl", [(8, 4, 64, 96, 2, 2), (8, 4, 64, 96, 1, 1), (8, 4, 128, 64, 2, 1), (32, 8, 128, 256, 2, 2), (128, 8, 128, 256, 1, 2),
+                                            (2, 16, 64, 64, 1, 1), (128, 2, 256, 256, 2, 2)])
+def test_conv_dgrad_stride2_parity_phase_form(B, Hs, C, N, pt, pl, dt):
+    """Data gradient of a stride-2 3x3 conv (dilate = 1; pad 2 = forward pad 0, pad 1 = forward pad 1): when the rows of each parity phase fill
+    whole 128-row tiles the generic kernel walks the output phase-major and visits only the 1 / 2 / 2 / 4 non-zero taps of a tile.  Checked
+    against the emulator's zero-dilated convolution with every row-epilogue operand, pitched tensors, "+=" and the fp32 output mode; both tile
+    orders (phase tiles a multiple of 8 -> XCD chunks; fewer -> natural order); the deep-ring instantiation (<= 256 blocks) and the two-buffer one."""
+    H = 2 * Hs
+    M = B * H * H
+    assert (M // 4) % 128 == 0
+    ld, yld = C + 16, N + 32
+    x = r(B * Hs * Hs, ld, seed=1, dt=dt)
+    w = r(N, 9 * C, seed=2, dt=dt, scale=1.0 / math.sqrt(9 * C / 4))
+    bias, rowb = r(N, seed=3), r(B, N + 8, seed=4)
+    res, y = r(M, yld, seed=5, dt=dt), r(M, yld, seed=6, dt=dt)
+    for acc in (0, 1):
+        both("ddpm_conv2d_nhwc", A(x), ld, A(w), A(y.clone(), out=True, name="y"), yld, A(bias), A(rowb), N + 8, A(res), yld,
+             B, Hs, Hs, C, H, H, N, 3, 3, 1, pt, pl, 0, 1, acc, 0, 1, None, None, dt, tol=TOL[dt])
+    # as the engine calls it: no bias, "+=" into the gradient of the block input; the caller's split-K offer is ignored
+    ws, cnt = torch.zeros(-(-M // 128) * -(-N // 128) * 2 * 16384), torch.zeros(1024, dtype=torch.int32)
+    both("ddpm_conv2d_nhwc", A(x), ld, A(w), A(y.clone(), out=True, name="y_accumulate"), yld, None, None, 0, None, 0,
+         B, Hs, Hs, C, H, H, N, 3, 3, 1, pt, pl, 0, 1, 1, 0, 2, A(ws), A(cnt, out=True, name="counters"), dt, tol=TOL[dt])
+    y32 = torch.zeros(M, N)
+    both("ddpm_conv2d_nhwc", A(x), ld, A(w), A(y32, out=True, name="y32"), N, None, None, 0, None, 0,
+         B, Hs, Hs, C, H, H, N, 3, 3, 1, pt, pl, 0, 1, 0, 1, 1, None, None, dt, tol=TOL[0] if dt == 0 else 4e-3)
+
+
 @pytest.mark.parametrize("B,H,C,N", [(16, 32, 64, 128), (65, 16, 128, 192), (258, 8, 64, 128), (17, 32, 192, 256), (4, 64, 64, 128), (128, 8, 256, 256),
                                      (130, 8, 128, 192), (64, 8, 256, 128), (3, 24, 64, 64)])
 def test_conv3x3_stationary_halo_path(B, H, C, N):
