@@ -94,15 +94,18 @@ __device__ __forceinline__ float silu_gradf_(float z) { float s = sigmoidf_(z); 
 struct FastDiv {
     unsigned mul, shift, d;
 };
+// q = (n * mul) >> shift for EVERY divisor (a power of two 2^l is mul = 2^31, shift = 31 + l): no "is it a power of two" branch — the kernels
+// evaluate these on wave-uniform values, where each such branch ends a basic block and with it the batching of the kernel-argument
+// loads around it (the prologue of the tile GEMMs was ten separate s_load / s_waitcnt round trips).
 __device__ __forceinline__ unsigned fdiv(unsigned n, const FastDiv& f) {
-    return f.mul ? (unsigned)(((unsigned long long)n * f.mul) >> f.shift) : (n >> f.shift);
+    return (unsigned)(((unsigned long long)n * f.mul) >> f.shift);
 }
 static inline FastDiv make_fastdiv(unsigned d) {
-    FastDiv f; f.d = d ? d : 1; f.mul = 0; f.shift = 0;
+    FastDiv f; f.d = d ? d : 1; f.mul = 1u << 31; f.shift = 31;
     if (d <= 1) return f;
     unsigned l = 0; while ((1ull << l) < d) ++l;
-    if ((1ull << l) == d) { f.shift = l; return f; }
     f.shift = 31 + l;
+    if ((1ull << l) == d) return f;
     f.mul = (unsigned)((1ull << f.shift) / d + 1);
     return f;
 }

@@ -7,7 +7,7 @@ import torch
 from ddpm_torch import _hip, _ops as ops
 from ddpm_torch._ops import View
 DEV = "cuda:0"
-lib = ctypes.CDLL(os.path.join(ROOT, "ddpm-torch_amd", "csrc", "libddpm_hip.so"))
+lib = ctypes.CDLL(os.environ.get("DDPM_HIP_LIB", os.path.join(ROOT, "ddpm-torch_amd", "csrc", "libddpm_hip.so")))
 dt = torch.bfloat16
 B = int(os.environ.get("G64_B", "128"))
 SK = ops.SplitK(DEV)          # DDPM_SPLITK64=0: one K run per tile
