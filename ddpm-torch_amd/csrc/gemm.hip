@@ -133,7 +133,9 @@ __device__ __forceinline__ int lds_off(int row, int chunk) { return row * ROW_BY
 //          VEC k-contiguous 4-element runs (ds_write_b64 bf16 / ds_write_b128 fp32) into the swizzled image.
 constexpr unsigned OOB = 0x7ffffff0u;
 
-template <typename T, bool TRANS, int NW = 4, int ROWS = 128>
+// PH: the parity-phase conv form is compiled in.  CV = false: the operand is never an implicit-im2col view (the B side of the k-contiguous
+// products is always a plain weight matrix) — its gather arithmetic is left out of the block prologue.
+template <typename T, bool TRANS, int NW = 4, int ROWS = 128, bool PH = false, bool CV = true>
 struct Loader {
     static constexpr int NT = NW * 64;                       // threads per block
     static constexpr int NV = ROWS * 8 / NT;                 // 16-byte vectors per thread per operand per K-step
@@ -171,9 +173,9 @@ struct Loader {
             wave = __builtin_amdgcn_readfirstlane(tid >> 6);
             kv = (tid & 7) ^ ((row0 >> 1) & 7);
             kvoff = kv * VEC * ES;
-            kuni = (d.conv && (d.sh == 0 || d.phase) && d.C % BK == 0) ? 1 : 0;
+            kuni = (CV && d.conv && (d.sh == 0 || (PH && d.phase)) && d.C % BK == 0) ? 1 : 0;
             ph_py = ph_px = -1;
-            if (d.conv && d.phase) {
+            if (PH && d.conv && d.phase) {
                 // every row of the tile is in one phase (Mp is a multiple of the tile height): the parities are block-uniform
                 int a, bb;
                 phase_parity(d, (int)fdiv((unsigned)__builtin_amdgcn_readfirstlane(tile0), d.dMp), a, bb);
@@ -198,6 +200,13 @@ struct Loader {
                             mk |= ok ? 1u << (r * d.S + s) : 0u;
                         }
                     tapmask[i] = mk;
+                }
+            } else if constexpr (!CV) {
+#pragma unroll
+                for (int i = 0; i < NV; ++i) {
+                    const int m = tile0 + row0 + (NT / 8) * i;
+                    roff[i] = m < d.n_slow ? (int)((long long)m * d.ld * ES) : (int)OOB;
+                    tapmask[i] = 0u;
                 }
             } else
 #pragma unroll
@@ -266,12 +275,12 @@ struct Loader {
             const unsigned tapu = fdiv((unsigned)k0u, d.dC);
             const int cu = k0u - (int)tapu * d.C;
             int ru = (int)fdiv(tapu, d.dS), su = (int)tapu - ru * d.S;
-            if (ph_py >= 0) { ru = (ru + ph_py) >> 1; su = (su + ph_px) >> 1; }     // parity-phase conv: offsets on the stored (undilated) grid
+            if (PH && ph_py >= 0) { ru = (ru + ph_py) >> 1; su = (su + ph_px) >> 1; }     // parity-phase conv: offsets on the stored (undilated) grid
             const int tapoff = ((ru * d.W + su) * (int)d.ld + cu) * ES;
             const unsigned tb = k0u < k_end ? tapu : 31u;           // K is a multiple of the step here: no partial tail
 #pragma unroll
             for (int i = 0; i < NV; ++i) off[i] = ((tapmask[i] >> tb) & 1u) ? (unsigned)(roff[i] + kvoff + tapoff) : OOB;
-        } else if (d.conv) {
+        } else if (CV && d.conv) {
             unsigned tap = fdiv((unsigned)k, d.dC);
             const int c = k - (int)tap * d.C;
             const int r = (int)fdiv(tap, d.dS), s = (int)tap - r * d.S;
@@ -597,7 +606,7 @@ __device__ __forceinline__ int xcd_logical_id(int id, int total, int xcd) {
 // next to it on the other stream.
 template <typename T, bool TA, bool TB, int NBUF, int NW, bool SCAT = false>
 __global__ __launch_bounds__(NW * 64, NW / 2)
-void gemm_kernel(MatDesc A, MatDesc B, Epilogue ep, int M, int N, int K, int k_per_split, int tiles_n, int xcd) {
+void gemm_kernel(MatDesc A, MatDesc B, Epilogue ep, int M, int N, int K, int k_per_split, int tiles_n, int xcd, FastDiv dtn) {
     HALO_WALL(0); HALO_STAMP(1);
     static_assert(NBUF == 2 || (Loader<T, TA, NW>::DMA && Loader<T, TB, NW>::DMA), "the deep ring needs direct-to-LDS loads on both operands");
     constexpr int NT = NW * 64;
@@ -613,7 +622,7 @@ void gemm_kernel(MatDesc A, MatDesc B, Epilogue ep, int M, int N, int K, int k_p
     const int wm = wave >> 1, wn = wave & 1;               // wave row block (of 32*MI rows) and column block (of 64)
     const int nsplit = gridDim.y, ntiles = gridDim.x;
     const int lid = xcd_logical_id(blockIdx.x + blockIdx.y * gridDim.x, ntiles * nsplit, xcd);     // tile fastest, then split
-    int by = lid / ntiles, bx = lid - by * ntiles;
+    int by = nsplit > 1 ? lid / ntiles : 0, bx = lid - by * ntiles;
     // parity-phase conv (see MatDesc::phase; k-contiguous operands, one split): the tiles of each phase are spread over the 8 XCDs in equal
     // contiguous chunks, heavy phases first — XCD x works on chunk x of every phase, which are the same dy pixels four times (L2 reuse)
     constexpr bool PH_OK = !TA && !TB;
@@ -627,7 +636,7 @@ void gemm_kernel(MatDesc A, MatDesc B, Epilogue ep, int M, int N, int K, int k_p
             bx = p * tp + (id & 7) * tp8 + (j - p * tp8);
         }
     }
-    const int tm = bx / tiles_n, tn = bx - tm * tiles_n;
+    const int tm = (int)fdiv((unsigned)bx, dtn), tn = bx - tm * tiles_n;
     const int batch = blockIdx.z;
     const int k_begin = by * k_per_split;
     const int k_end = min(K, k_begin + k_per_split);
@@ -650,8 +659,8 @@ void gemm_kernel(MatDesc A, MatDesc B, Epilogue ep, int M, int N, int K, int k_p
         return k_begin + i * BK;
     };
 
-    Loader<T, TA, NW> la(A, batch, tm * TILE, tid);
-    Loader<T, TB, NW> lb(B, batch, tn * TILE, tid);
+    Loader<T, TA, NW, 128, PH_OK> la(A, batch, tm * TILE, tid);
+    Loader<T, TB, NW, 128, false, TB> lb(B, batch, tn * TILE, tid);      // (k-strided B: the conv view of the weight gradients)
 
     f32x16 acc[MI][2];
 #pragma unroll
@@ -872,7 +881,7 @@ constexpr int G64 = 2;            // K-steps per barrier group
 // and the two partial tiles are added through LDS before the epilogue.
 template <typename T, int NG>
 __global__ __launch_bounds__(512, NG == 2 ? 2 : 1)
-void gemm64_kernel(MatDesc A, MatDesc B, Epilogue ep, int M, int N, int K, int tiles_n, int xcd) {
+void gemm64_kernel(MatDesc A, MatDesc B, Epilogue ep, int M, int N, int K, int tiles_n, int xcd, FastDiv dtn) {
     HALO_WALL(0); HALO_STAMP(1);
     constexpr int BK = 8 * Elem<T>::VEC, KF = Mma<T>::KF, NT = 512;
     static_assert(G64 == 2, "one K-step of a group per wave quartet");
@@ -883,11 +892,11 @@ void gemm64_kernel(MatDesc A, MatDesc B, Epilogue ep, int M, int N, int K, int t
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int kh = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;
     const int lid = xcd_logical_id(blockIdx.x, gridDim.x, xcd);
-    const int tm = lid / tiles_n, tn = lid - tm * tiles_n;
+    const int tm = (int)fdiv((unsigned)lid, dtn), tn = lid - tm * tiles_n;
     const int batch = blockIdx.z;
     const int nsplit = gridDim.y, by = blockIdx.y;        // in-launch split-K: each tile's K range in nsplit runs of whole groups
     Loader<T, false, 8, T64> la(A, batch, tm * T64, tid);
-    Loader<T, false, 8, T64> lb(B, batch, tn * T64, tid);
+    Loader<T, false, 8, T64, false, false> lb(B, batch, tn * T64, tid);
     f32x16 acc0 = (f32x16)(0.f), acc1 = (f32x16)(0.f);   // two accumulators: consecutive MFMAs do not wait on each other
     float bias_t[Elem<T>::VEC], bias_f[4];                // requested now, consumed in the epilogue
     if (ep.mode == 0) epilogue_bias<T, NT, T64>(ep, tn * T64, N, tid, bias_t);
@@ -1040,10 +1049,10 @@ void gemm64_kernel(MatDesc A, MatDesc B, Epilogue ep, int M, int N, int K, int t
     else re_f.finish_all(cs, bias_f);
     HALO_STAMP(4); HALO_WALL(5);
 }
-template __global__ void gemm64_kernel<bf16_t, 2>(MatDesc, MatDesc, Epilogue, int, int, int, int, int);
-template __global__ void gemm64_kernel<bf16_t, 3>(MatDesc, MatDesc, Epilogue, int, int, int, int, int);
-template __global__ void gemm64_kernel<float, 2>(MatDesc, MatDesc, Epilogue, int, int, int, int, int);
-template __global__ void gemm64_kernel<float, 3>(MatDesc, MatDesc, Epilogue, int, int, int, int, int);
+template __global__ void gemm64_kernel<bf16_t, 2>(MatDesc, MatDesc, Epilogue, int, int, int, int, int, FastDiv);
+template __global__ void gemm64_kernel<bf16_t, 3>(MatDesc, MatDesc, Epilogue, int, int, int, int, int, FastDiv);
+template __global__ void gemm64_kernel<float, 2>(MatDesc, MatDesc, Epilogue, int, int, int, int, int, FastDiv);
+template __global__ void gemm64_kernel<float, 3>(MatDesc, MatDesc, Epilogue, int, int, int, int, int, FastDiv);
 
 // =====================================================================================================================
 // 3x3 / stride 1 / pad 1 convolution with a STATIONARY INPUT HALO (bf16): the hot conv of the UNet (forward and dgrad).
@@ -1248,7 +1257,7 @@ extern "C" int ddpm_debug_set_halo_timing(void* p) {
 #endif
 
 // Explicit instantiations: every (dtype, operand layout, ring depth, wave count) the launcher can pick.
-#define INST(T, TA, TB, NB, NWV) template __global__ void gemm_kernel<T, TA, TB, NB, NWV>(MatDesc, MatDesc, Epilogue, int, int, int, int, int, int);
+#define INST(T, TA, TB, NB, NWV) template __global__ void gemm_kernel<T, TA, TB, NB, NWV>(MatDesc, MatDesc, Epilogue, int, int, int, int, int, int, FastDiv);
 INST(bf16_t, false, false, 2, 4) INST(bf16_t, false, false, 2, 8) INST(bf16_t, false, false, 5, 4) INST(bf16_t, false, false, 5, 8)
 INST(bf16_t, false, true, 2, 4) INST(bf16_t, false, true, 2, 8)
 INST(bf16_t, true, false, 2, 4) INST(bf16_t, true, false, 2, 8)
@@ -1256,7 +1265,7 @@ INST(bf16_t, true, true, 2, 4) INST(bf16_t, true, true, 2, 8)
 INST(float, false, false, 2, 4) INST(float, false, false, 2, 8) INST(float, false, false, 5, 4) INST(float, false, false, 5, 8)
 INST(float, false, true, 2, 4) INST(float, true, false, 2, 4) INST(float, true, true, 2, 4)
 #undef INST
-template __global__ void gemm_kernel<bf16_t, true, true, 2, 8, true>(MatDesc, MatDesc, Epilogue, int, int, int, int, int, int);
+template __global__ void gemm_kernel<bf16_t, true, true, 2, 8, true>(MatDesc, MatDesc, Epilogue, int, int, int, int, int, int, FastDiv);
 
 // =====================================================================================================================
 // Fused single-head attention forward (inference): O = softmax(Q K^T * scale) V for one image per blockIdx.y, 128 queries
@@ -1522,7 +1531,7 @@ static int launch_t(GemmArgs& g, hipStream_t st) {
                 return DDPM_ERR_LAUNCH;                                                                                  \
             attr_set = true;                                                                                             \
         }                                                                                                                \
-        hipLaunchKernelGGL((gemm64_kernel<T, NG>), grid64, dim3(512), LDS64, st, g.A, g.B, g.ep, g.M, g.N, g.K, t64n, g_xcd_swizzle);   \
+        hipLaunchKernelGGL((gemm64_kernel<T, NG>), grid64, dim3(512), LDS64, st, g.A, g.B, g.ep, g.M, g.N, g.K, t64n, g_xcd_swizzle, make_fastdiv((unsigned)t64n));   \
     } while (0)
         g.variant = 4;
         if (g.dry) return DDPM_OK;
@@ -1547,7 +1556,7 @@ static int launch_t(GemmArgs& g, hipStream_t st) {
                 return DDPM_ERR_LAUNCH;                                                                                  \
             attr_set = true;                                                                                             \
         }                                                                                                                \
-        hipLaunchKernelGGL((gemm_kernel<T, TA, TB, NB, NWV>), grid, dim3(NWV * 64), (LDS), st, g.A, g.B, g.ep, g.M, g.N, g.K, kps, tiles_n, g_xcd_swizzle); \
+        hipLaunchKernelGGL((gemm_kernel<T, TA, TB, NB, NWV>), grid, dim3(NWV * 64), (LDS), st, g.A, g.B, g.ep, g.M, g.N, g.K, kps, tiles_n, g_xcd_swizzle, make_fastdiv((unsigned)tiles_n)); \
     } while (0)
     // 8-wave blocks whenever both operands take the DMA path (all bf16 products, fp32 with k-contiguous operands)
     constexpr bool BF = sizeof(T) == 2;
@@ -1573,7 +1582,7 @@ static int launch_t(GemmArgs& g, hipStream_t st) {
                         return DDPM_ERR_LAUNCH;
                     attr_set = true;
                 }
-                hipLaunchKernelGGL((gemm_kernel<T, true, true, 2, 8, true>), grid, dim3(512), lds2, st, g.A, g.B, g.ep, g.M, g.N, g.K, kps, tiles_n, g_xcd_swizzle);
+                hipLaunchKernelGGL((gemm_kernel<T, true, true, 2, 8, true>), grid, dim3(512), lds2, st, g.A, g.B, g.ep, g.M, g.N, g.K, kps, tiles_n, g_xcd_swizzle, make_fastdiv((unsigned)tiles_n));
             } else if (w8) LAUNCH(true, true, 2, 8, lds2);
             else LAUNCH(true, true, 2, 4, lds2);
         } else LAUNCH(true, true, 2, 4, lds2);
