@@ -1050,13 +1050,18 @@ void conv3x3_pc_kernel(CsArgs a) {
                 const int n0 = cur.tn * 128 + wn * 64;
                 const bool live = n0 < a.N;
                 const unsigned stg = lds0 + (unsigned)(hb * HALO_BYTES + wave * (64 * 64));
-                bf16_t* const obase = a.out + ((long long)(cur.img * a.H + cur.py0) * a.W + cur.px0) * a.out_ld + n0 + 8 * (lane & 3);
-                auto orow = [&](int q16) {                   // pixel q16 * 16 + lane / 4 of the wave's 128
-                    int q = lane >> 2;
-                    asm volatile("" : "+v"(q));
-                    const int p = wm * 128 + q16 * 16 + q;
-                    return obase + (long long)(((p >> 4) * a.W + (p & 15)) * (int)a.out_ld);
-                };
+                // pixel q16 * 16 + lane / 4 of the wave's 128 = patch row wm * 8 + q16, column lane / 4: a wave-uniform 64-bit base per patch row
+                // (scalar arithmetic) plus ONE 32-bit lane offset for the whole tile — the stores take the `saddr + voffset` form and the
+                // epilogue carries no per-store vector multiplies (they were a sixth of its 3500 clk on a wave that has the SIMD's VALU to itself
+                // only every other cycle)
+                const unsigned long long ob =
+                    (unsigned long long)(a.out + ((long long)(cur.img * a.H + cur.py0 + wm * 8) * a.W + cur.px0) * a.out_ld + n0);
+                const unsigned ob_lo = __builtin_amdgcn_readfirstlane((unsigned)ob), ob_hi = __builtin_amdgcn_readfirstlane((unsigned)(ob >> 32));
+                const unsigned long long obase = ((unsigned long long)ob_hi << 32) | ob_lo;
+                const unsigned rowstride = (unsigned)__builtin_amdgcn_readfirstlane((int)(a.W * (int)a.out_ld * 2));     // bytes per patch row
+                const unsigned loff = (unsigned)(((lane >> 2) * (int)a.out_ld + 8 * (lane & 3)) * 2);
+                typedef __attribute__((address_space(1))) u32x4 gvec_t;      // (an integer-made pointer is generic: name the global space, or the stores go out as flat_store)
+                auto orow = [&](int q16, int col) { return (gvec_t*)(obase + (unsigned long long)q16 * rowstride + (unsigned)(col * 2)) + 0; };
 #pragma unroll
                 for (int i = 0; i < NIB; ++i) {
 #pragma unroll
@@ -1091,7 +1096,7 @@ void conv3x3_pc_kernel(CsArgs a) {
                         __builtin_amdgcn_sched_barrier(0);
                         if (live) {
 #pragma unroll
-                            for (int rr = 0; rr < 4; ++rr) *reinterpret_cast<u32x4*>(orow(jh * 4 + rr) + i * 32) = back[rr];
+                            for (int rr = 0; rr < 4; ++rr) *(gvec_t*)((__attribute__((address_space(1))) char*)orow(jh * 4 + rr, i * 32) + loff) = back[rr];
                         }
                     }
                 }
