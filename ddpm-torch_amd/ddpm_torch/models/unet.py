@@ -265,6 +265,7 @@ _TAIL_ANY = os.environ.get("DDPM_WGRAD3_TAIL_ANY", "0") != "0"
 # Default 0 = the round-4 form (join + issue on the main stream): a one-rank all-reduce is the identity and gloo stages through the host, so
 # the ordering of the fast form has never been observable on this one-GPU pool.  Opt in after tests/test_multi_gpu.py passed on >= 2 GPUs.
 _DP_ISSUE_ON_SIDE = os.environ.get("DDPM_DP_ISSUE_ON_SIDE", "0") != "0"
+_TEMB_LEAVES = os.environ.get("DDPM_TEMB_LEAVES", "0") != "0"          # A/B switch: the embedding MLP's parameter gradients as side-stream leaves (see _temb_bwd)
 _ABL_NO_LEAF_ORDER = os.environ.get("DDPM_ABL_NO_LEAF_ORDER", "0") != "0"   # TIMING-ONLY ablation (wrong results): leaves are not ordered behind the main stream
 _WGRAD1 = os.environ.get("DDPM_WGRAD1", "1") != "0"                # slab kernel for the 1x1 weight gradients
 _WGRAD3_ATOMIC = os.environ.get("DDPM_WGRAD3_ATOMIC", "0") != "0"  # ... with fp32 atomics instead of slab copies
@@ -1343,9 +1344,6 @@ class _Engine:
         _hip.call("ddpm_silu_bwd", t_emb.data_ptr(), ds_t.data_ptr(), dt_emb.data_ptr(), B * E, 0, _hip.stream())
         ctx["dt_emb"] = dt_emb                                  # d/d(t_emb): what the reference's ResidualBlock hands back to the embedding MLP
         lin2, lin1 = m.embed[2], m.embed[0]
-        with self._leaf(ctx, dt_emb, s1):
-            _hip.call("ddpm_atb_f32", dt_emb.data_ptr(), E, s1.data_ptr(), E, self._pptr(ctx, lin2.weight), E, E, E, B, _hip.stream())
-            ops.colsum(View(dt_emb, 1, B, 1, E), 0, 0, self._pptr(ctx, lin2.bias))
         # (K = E = 512 over 4 output tiles would leave 252 CUs idle for ~75 us at the very end of the backward: split-K with fp32 atomics
         #  like the fc product above — output tiles x E / 64 K slices)
         ds1 = self._f32(B, E) if det else self._zeros(B, E)
@@ -1353,6 +1351,12 @@ class _Engine:
                  splits=1 if det else max(1, E // 64))
         de1 = self._f32(B, E)
         _hip.call("ddpm_silu_bwd", e1.data_ptr(), ds1.data_ptr(), de1.data_ptr(), B * E, 0, _hip.stream())
-        with self._leaf(ctx, de1, temb):
+        # The embedding MLP's parameter gradients stay on THIS stream, behind the chain that produced their inputs: the chain ends here while the
+        # side stream still has the first layers' weight gradients, the last chunk's time-projection rows and a run of bias sums queued — as
+        # leaves these four launches sat at the end of that queue and the join below waited ~90 us longer for them (profiles/r06_step_tail.txt).
+        # (DDPM_TEMB_LEAVES=1: as leaves on the side stream again, for A/B runs)
+        with (self._leaf(ctx, dt_emb, s1, de1, temb) if _TEMB_LEAVES else contextlib.nullcontext()):
+            _hip.call("ddpm_atb_f32", dt_emb.data_ptr(), E, s1.data_ptr(), E, self._pptr(ctx, lin2.weight), E, E, E, B, _hip.stream())
+            ops.colsum(View(dt_emb, 1, B, 1, E), 0, 0, self._pptr(ctx, lin2.bias))
             _hip.call("ddpm_atb_f32", de1.data_ptr(), E, temb.data_ptr(), self.hid, self._pptr(ctx, lin1.weight), self.hid, E, self.hid, B, _hip.stream())
             ops.colsum(View(de1, 1, B, 1, E), 0, 0, self._pptr(ctx, lin1.bias))

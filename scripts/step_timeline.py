@@ -66,3 +66,14 @@ for (s0, e0, k0), (s1, e1, k1) in zip(mk, mk[1:]):
 print(f"--- gaps > 3 us on queue {main[0]} stream {main[1]} (the critical stream): {tot / nsteps / 1e3:.1f} us/step")
 for (a, b), (n_, g) in sorted(mg.items(), key=lambda kv: -kv[1][1])[:16]:
     print(f"  {g / nsteps / 1e3:7.1f} us/step  n/step={n_ / nsteps:5.1f}  after [{a}] before [{b}]")
+
+# TL_TAIL=N: the last N kernels of one step on both streams (start / end in us before the step's optimiser kernel ends): what the join waits for
+import os
+if os.environ.get("TL_TAIL"):
+    n_tail = int(os.environ["TL_TAIL"])
+    t_end = ends[hi]
+    one = [(s_, e_, k, q, st) for s_, e_, k, q, st in ev if ends[hi - 1] < s_ and e_ <= t_end]
+    print(f"--- tail of step {hi}: last {n_tail} kernels (us before the end of the step)")
+    for s_, e_, k, q, st in sorted(one)[-n_tail:]:
+        name = k.split("(")[0].replace("void ", "").replace("(anonymous namespace)::", "")[:60]
+        print(f"  q{q}  start -{(t_end - s_) / 1e3:8.1f}  end -{(t_end - e_) / 1e3:8.1f}  dur {(e_ - s_) / 1e3:7.1f}  {name}")

@@ -908,10 +908,13 @@ def test_wgrad3x3_wave_specialised_kernel_is_bit_stable_under_contention(B, H, C
     assert lib.ddpm_wgrad3x3_ws_last_fault(fault) == 0 and fault[3] == 0
 
 
-@pytest.mark.parametrize("M,N,K", [(1024, 512, 128), (256, 512, 128), (512, 128, 128), (2048, 512, 2), (130, 70, 37)])
+@pytest.mark.parametrize("M,N,K", [(1024, 512, 128), (256, 512, 128), (512, 128, 128), (2048, 512, 2), (130, 70, 37), (100, 72, 96), (36, 260, 128),
+                                   (256, 128, 200), (64, 64, 129)])
 def test_atb_f32_short_reduction_product(M, N, K):
-    """C = A^T B in fp32 for short reductions (csrc/elementwise.hip `atb_f32_kernel`: the time-embedding path's weight gradients, K = the
-    batch) against float64, with pitched operands and ragged tile edges; two launches are bit-identical (plain stores, fixed order)."""
+    """C = A^T B in fp32 for short reductions (csrc/elementwise.hip: the time-embedding path's weight gradients, K = the batch) against float64,
+    with pitched operands and ragged tile edges; two launches are bit-identical (plain stores, fixed order).  K <= 128 with 4-element-aligned
+    shapes takes `atb_f32_short_kernel` (32 x 64 tiles, the whole reduction fetched at once; ragged tiles: 100 x 72, 36 x 260), everything
+    else — odd extents, K > 128 — `atb_f32_kernel`."""
     lda, ldb, ldc = M + 12, N + 4, N + 8
     g = torch.Generator().manual_seed(11)
     a = torch.randn(K, lda, generator=g)
