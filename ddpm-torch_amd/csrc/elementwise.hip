@@ -684,19 +684,29 @@ __global__ void colsum_kernel(const T* __restrict__ dy, long long ld, float* __r
     const int cx = threadIdx.x, py = threadIdx.y;
     const int t = threadIdx.y * blockDim.x + threadIdx.x, nt = blockDim.x * blockDim.y;
     const int p0 = blockIdx.x * pix_per_slab, p1 = min(HW, p0 + pix_per_slab);
+    // wide tensors (the [B][sum Cout] time-bias gradient: 4992 columns): blockIdx.z walks groups of blockDim.x channel vectors in ONE launch
+    // (it used to be one launch per 256 vectors — five 5-us launches in a row on the tail of the backward)
+    const int c_base = blockIdx.z * blockDim.x * VEC;
+    dy += c_base;
+    if (per_sample) per_sample += c_base;
+    if (total) total += c_base;
+    C = min(C - c_base, (int)blockDim.x * VEC);
+    const bool live = cx * VEC < C;
     float acc[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
     const T* base = dy + (long long)b * HW * ld + cx * VEC;
+    if (live) {
 #pragma unroll 4
-    for (int p = p0 + py; p < p1; p += blockDim.y) {
-        float f[VEC];
-        Elem<T>::unpack(ldg16(base + (long long)p * ld), f);
+        for (int p = p0 + py; p < p1; p += blockDim.y) {
+            float f[VEC];
+            Elem<T>::unpack(ldg16(base + (long long)p * ld), f);
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) acc[j] += f[j];
+            for (int j = 0; j < VEC; ++j) acc[j] += f[j];
+        }
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) sh[py * C + cx * VEC + j] = acc[j];          // [PY][C] scratch, PY*C <= 8192
     }
-#pragma unroll
-    for (int j = 0; j < VEC; ++j) sh[py * C + cx * VEC + j] = acc[j];          // [PY][C] scratch, PY*C <= 8192
     __syncthreads();
     for (int c = t; c < C; c += nt) {
         float a = 0.f;
@@ -708,9 +718,10 @@ __global__ void colsum_kernel(const T* __restrict__ dy, long long ld, float* __r
 extern "C" int ddpm_colsum(const void* dy, long long ld, float* per_sample, long long ps_ld, float* total, int B, int HW, int C, int dtype, void* stream) {
     if (!dy || (!per_sample && !total)) return DDPM_ERR_NULL;
     const int vec = dtype == DDPM_BF16 ? 8 : 4;
-    if (C % vec || ld % vec || C > 2048 || C / vec > 256) return DDPM_ERR_SHAPE;
+    if (C % vec || ld % vec || C / vec > 256 * 64) return DDPM_ERR_SHAPE;
     if (!aligned16(dy)) return DDPM_ERR_ALIGN;
-    const int cv = C / vec;
+    const int Z = (C / vec + 255) / 256;               // channel groups of <= 256 vectors (blockIdx.z)
+    const int cv = Z > 1 ? 256 : C / vec;
     int py = 1024 / cv; if (py > HW) py = HW; if (py < 1) py = 1;
     int S = (256 + B - 1) / B;                        // ~256 blocks in total, >= 4 pixel iterations each
     const int maxS = (HW + 4 * py - 1) / (4 * py);
@@ -718,8 +729,8 @@ extern "C" int ddpm_colsum(const void* dy, long long ld, float* per_sample, long
     if (S < 1) S = 1;
     const int pps = (HW + S - 1) / S;
     S = (HW + pps - 1) / pps;
-    if (dtype == DDPM_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3(S, B), dim3(cv, py), 0, (hipStream_t)stream, (const bf16_t*)dy, ld, per_sample, ps_ld, total, HW, C, pps);
-    else if (dtype == DDPM_F32) hipLaunchKernelGGL(colsum_kernel<float>, dim3(S, B), dim3(cv, py), 0, (hipStream_t)stream, (const float*)dy, ld, per_sample, ps_ld, total, HW, C, pps);
+    if (dtype == DDPM_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, dim3(S, B, Z), dim3(cv, py), 0, (hipStream_t)stream, (const bf16_t*)dy, ld, per_sample, ps_ld, total, HW, C, pps);
+    else if (dtype == DDPM_F32) hipLaunchKernelGGL(colsum_kernel<float>, dim3(S, B, Z), dim3(cv, py), 0, (hipStream_t)stream, (const float*)dy, ld, per_sample, ps_ld, total, HW, C, pps);
     else return DDPM_ERR_DTYPE;
     return check_launch();
 }

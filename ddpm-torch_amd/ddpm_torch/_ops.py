@@ -209,7 +209,7 @@ def gn_bwd(x, dy, dx, gamma, beta, stats, dgamma_ptr, dbeta_ptr, ws, silu, drop_
 def colsum(dy, per_sample_ptr, ps_ld, total_ptr):
     """per_sample[b][c] += sum_pixels dy;  total[c] += sum_{b,pixels} dy  (atomics into zero-initialised buffers)."""
     es = 2 if dy.dtype == _hip.BF16 else 4
-    step = 256 * (16 // es)                      # one launch covers <= 256 16-byte channel vectors
+    step = 64 * 256 * (16 // es)                 # one launch covers <= 64 groups of 256 16-byte channel vectors
     for c0 in range(0, dy.C, step):
         c1 = min(dy.C, c0 + step)
         _hip.call("ddpm_colsum", dy.ptr + c0 * es, dy.ld, per_sample_ptr + c0 * 4 if per_sample_ptr else 0, ps_ld,

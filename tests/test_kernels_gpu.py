@@ -592,6 +592,11 @@ def test_reductions_and_fanin(dt):
     dy = r(B * HW, ld, seed=1, dt=dt)
     ps, tot = r(B, C + 4, seed=12), r(C, seed=2)
     both("ddpm_colsum", A(dy), ld, A(ps, out=True, name="per_sample"), C + 4, A(tot, out=True, name="total"), B, HW, C, dt, tol=2e-5 if dt == 0 else 1e-4)
+    # wide tensors in one launch (channel groups of 256 vectors on blockIdx.z, a ragged last group): the [B][sum Cout] time-bias gradient
+    Cw = 4992 if dt == 0 else 2 * 2048 + 136
+    dyw, psw, totw = r(2 * 128, Cw + 8, seed=7, dt=dt), r(2, Cw + 4, seed=8), r(Cw, seed=9)
+    both("ddpm_colsum", A(dyw), Cw + 8, A(psw, out=True, name="per_sample_wide"), Cw + 4, A(totw, out=True, name="total_wide"), 2, 128, Cw, dt,
+         tol=2e-5 if dt == 0 else 1e-4)
     up = r(B * 4 * 16, 64, seed=3, dt=dt)
     for acc in (0, 1):
         dx = r(B * 16, 80, seed=4, dt=dt)
