@@ -77,3 +77,11 @@ if os.environ.get("TL_TAIL"):
     for s_, e_, k, q, st in sorted(one)[-n_tail:]:
         name = k.split("(")[0].replace("void ", "").replace("(anonymous namespace)::", "")[:60]
         print(f"  q{q}  start -{(t_end - s_) / 1e3:8.1f}  end -{(t_end - e_) / 1e3:8.1f}  dur {(e_ - s_) / 1e3:7.1f}  {name}")
+if os.environ.get("TL_HEAD"):
+    n_head = int(os.environ["TL_HEAD"])
+    t_beg = ends[hi - 1]
+    one = [(s_, e_, k, q, st) for s_, e_, k, q, st in ev if t_beg <= s_ and e_ <= ends[hi]]
+    print(f"--- head of step {hi}: first {n_head} kernels (us after the previous step's optimiser kernel ended)")
+    for s_, e_, k, q, st in sorted(one)[:n_head]:
+        name = k.split("(")[0].replace("void ", "").replace("(anonymous namespace)::", "")[:60]
+        print(f"  q{q}  start +{(s_ - t_beg) / 1e3:8.1f}  end +{(e_ - t_beg) / 1e3:8.1f}  dur {(e_ - s_) / 1e3:7.1f}  {name}")
