@@ -198,13 +198,11 @@ class UNet(nn.Module):
 
     def forward(self, x, t):
         _hip.require_cuda(x, t)
-        if x.requires_grad and torch.is_grad_enabled():
-            # the reference returns d/dx through autograd (unet.py:205-233); the hand-written backward stops at in_conv
-            raise NotImplementedError("gradients with respect to the input image are not implemented on the MI355X path; "
-                                      "pass x.detach() (training never needs d/dx: x_t is data)")
         eng = self.engine()
         params = eng.params
-        if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+        # (x.requires_grad: the reference returns d/dx through autograd, unet.py:205-233; here the backward's last step — in_conv's data
+        #  gradient, otherwise skipped: training never needs it, x_t is data — is run when the autograd graph asks for it)
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params)):
             return _UNetFn.apply(x, t, eng, self.training, *params)
         return eng.forward(x, t, self.training, None)
 
@@ -222,9 +220,12 @@ class _UNetFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gout):
-        grads = ctx.eng.backward(ctx.tape, gout)
+        want_dx = ctx.needs_input_grad[0]
+        grads = ctx.eng.backward(ctx.tape, gout, want_dx=want_dx)
+        dx = ctx.eng.last_dx if want_dx else None
+        ctx.eng.last_dx = None
         ctx.tape = None
-        return (None, None, None, None) + tuple(grads)
+        return (dx, None, None, None) + tuple(grads)
 
 
 # ====================================================================================================== engine
@@ -292,6 +293,7 @@ class _Engine:
         self.gtotal = off
         self.wdesc = None                          # device table for ddpm_wgrad_unpack (built on first backward)
         self._gpack, self._slabs, self._slab_tables, self._eff_splits, self._side = None, {}, {}, {}, None
+        self.last_dx = None                                # d/d(input image) of the last backward that was asked for it (UNet.forward, x.requires_grad)
         self._works = []                           # outstanding all-reduce handles of the native data-parallel backward
         m = model
         self.hid, self.E, self.L, self.n = m.hid_channels, m.time_embedding_dim, m.levels, m.num_res_blocks
@@ -1134,7 +1136,7 @@ class _Engine:
             _hip.call("ddpm_wgrad_unpack", gpack.data_ptr(), gflat.data_ptr(), wdesc.data_ptr(), wdesc.shape[0], 1.0 / ctx["world"], _hip.stream())
         return gflat
 
-    def backward(self, tape, gout, gflat=None, cut=None, want_views=True, sumsq=0):
+    def backward(self, tape, gout, gflat=None, cut=None, want_views=True, sumsq=0, want_dx=False):
         """Replays the tape in reverse.  ``gflat``: caller-owned flat gradient buffer (stable address for captured steps).
         ``cut(fn)``: when the step is being captured as a sequence of hipGraphs, the communicator calls are not captured —
         ``cut`` ends the current graph segment, registers ``fn`` to run eagerly between the segments at replay time, and
@@ -1147,6 +1149,7 @@ class _Engine:
         H, W = gout.shape[2], gout.shape[3]
         ctx = self._open_backward(st, gflat, cut)
         ctx["sumsq"] = sumsq             # device address of _hip.SUMSQ_FLOATS floats that receive ||grad||^2 in lane 0 (0: not wanted)
+        ctx["want_dx"] = want_dx         # also d/d(input image) -> self.last_dx (NCHW fp32), see _conv_bwd
         # ---- head
         _, cur, act, stats, _ = head
         norm, conv = m.out_conv[0], m.out_conv[2]
@@ -1216,7 +1219,14 @@ class _Engine:
                          splits=self._splits(cw.N, k * k * cw.Cp, dy.rows))
         self._bias_grad(ctx, dy, [conv.bias], cw.N)
         if first:
-            return                                          # no gradient w.r.t. the input image
+            # no gradient w.r.t. the input image — unless the autograd graph asked for it (UNet.forward with x.requires_grad): the 3-channel
+            # data gradient straight into NCHW fp32 (the out_conv-shaped launch: few output channels, out_mode 3)
+            if ctx.get("want_dx"):
+                dx = torch.empty(B, cw.C, x.H, x.W, dtype=torch.float32, device=self.device)
+                ops.conv2d(dy, cw.wd.data_ptr(), dx.data_ptr(), 0, cw.C, k, k, x.H, x.W, pad_t=k - 1 - pt, pad_l=k - 1 - pl, out_mode=3,
+                           splitk=self.splitk)
+                self.last_dx = dx
+            return
         if upsample and cw.up:
             # d/dx of (nearest-2x upsample -> 3x3 conv) = one 4x4 / stride-2 / pad-1 conv over dy with the summed taps the pack
             # kernel prepared: 16 taps on a quarter of the pixels, no full-resolution intermediate, no 2x2 reduction pass

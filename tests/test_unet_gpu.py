@@ -95,6 +95,38 @@ def test_celeba_unet_forward_backward_vs_oracle(dtype, bar):
         assert worst < 3e-3
 
 
+@pytest.mark.parametrize("dtype,bar", [(torch.float32, 2e-3), (torch.bfloat16, 1.5e-1)])
+def test_gradient_wrt_input_image_vs_oracle(dtype, bar):
+    """The reference hands d/dx back through autograd (models/unet.py:205-233: nothing detaches the input).  Here in_conv's data gradient — the
+    one step the training backward skips — runs when x requires grad: checked against the oracle's autograd, with the parameter gradients of the
+    same backward, and with parameters that do not require grad at all (an input-only graph, e.g. guidance / inversion through a frozen model)."""
+    cfg = dict(TINY3, drop_rate=0.0)
+    m, sd = make(cfg, dtype=dtype)
+    m.train()
+    x, t, gy = rnd(4, 3, 16, 16, seed=1), torch.tensor([3, 977, 40, 500]), rnd(4, 3, 16, 16, seed=2)
+    xd = x.to(DEV).requires_grad_(True)
+    y = m(xd, t.to(DEV))
+    (y * gy.to(DEV)).sum().backward()
+    p = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    xr = x.clone().requires_grad_(True)
+    (U.unet_forward(p, cfg, xr, t, training=True) * gy).sum().backward()
+    assert xd.grad is not None and xd.grad.shape == x.shape and xd.grad.dtype == torch.float32
+    rel = float((xd.grad.cpu() - xr.grad).abs().max() / xr.grad.abs().max())
+    print(f"d/dx {dtype}: rel err {rel:.3e}")
+    assert rel < bar
+    if dtype == torch.float32:
+        scales = {k: float(v.grad.abs().max()) for k, v in p.items()}
+        floor = 0.02 * sorted(scales.values())[len(scales) // 2]
+        worst = max(float((q.grad.cpu() - p[k].grad).abs().max()) / max(scales[k], floor) for k, q in m.named_parameters())
+        assert worst < 3e-3, worst
+    # frozen parameters: the graph exists for x alone
+    for q in m.parameters():
+        q.requires_grad_(False); q.grad = None
+    x2 = x.to(DEV).requires_grad_(True)
+    (m(x2, t.to(DEV)) * gy.to(DEV)).sum().backward()
+    assert torch.equal(x2.grad, xd.grad) and all(q.grad is None for q in m.parameters())
+
+
 def test_celebahq_unet_forward_vs_oracle():
     """256x256, six levels, 512-channel attention (the three-launch attention path: the fused kernel covers C <= 256)."""
     m, sd = make(CELEBAHQ, dtype=torch.bfloat16)
