@@ -735,6 +735,86 @@ extern "C" int ddpm_colsum(const void* dy, long long ld, float* per_sample, long
     return check_launch();
 }
 
+// ------------------------------------------------------------------ 2x resampling without a convolution (resample_with_conv=False:
+// /root/reference/ddpm_torch/models/unet.py:169 nn.AvgPool2d(2), :196 nn.Upsample(2, "nearest") alone) and the two backwards, one kernel:
+//   up = 0: y[b,h,w,c] (+)= scale * sum of the 2x2 block of x at (2h.., 2w..)   — AvgPool2d(2) forward (scale 1/4); Upsample backward (scale 1)
+//   up = 1: y[b,2h+a,2w+bb,c] (+)= scale * x[b,h,w,c]                            — Upsample forward (scale 1); AvgPool2d(2) backward (scale 1/4)
+// H, W = the SMALL grid; both tensors NHWC with pixel pitches (they live inside the pitched concat buffers of the decoder).
+template <typename T>
+__global__ void resample2x_kernel(const T* __restrict__ x, long long x_ld, T* __restrict__ y, long long y_ld, int B, int H, int W, int C, int up,
+                                  float scale, int accumulate) {
+    constexpr int VEC = Elem<T>::VEC;
+    const int cv = C / VEC;
+    const long long n = (long long)B * H * W * cv;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cv) * VEC;
+        long long r = i / cv;
+        const int w = (int)(r % W); r /= W;
+        const int h = (int)(r % H); const long long b = r / H;
+        const long long small = (b * H + h) * W + w, big = ((b * 2 * H + 2 * h) * 2 * W) + 2 * w;
+        if (!up) {
+            float acc[VEC];
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int bb = 0; bb < 2; ++bb) {
+                    float f[VEC];
+                    Elem<T>::unpack(ldg16(x + (big + (long long)a * 2 * W + bb) * x_ld + c), f);
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) acc[j] += f[j];
+                }
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) acc[j] *= scale;
+            T* o = y + small * y_ld + c;
+            if (accumulate) {
+                float f[VEC];
+                Elem<T>::unpack(ldg16(o), f);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) acc[j] += f[j];
+            }
+            stg16(o, Elem<T>::pack(acc));
+        } else {
+            float v[VEC];
+            Elem<T>::unpack(ldg16(x + small * x_ld + c), v);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) v[j] *= scale;
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int bb = 0; bb < 2; ++bb) {
+                    T* o = y + (big + (long long)a * 2 * W + bb) * y_ld + c;
+                    float out[VEC];
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) out[j] = v[j];
+                    if (accumulate) {
+                        float f[VEC];
+                        Elem<T>::unpack(ldg16(o), f);
+#pragma unroll
+                        for (int j = 0; j < VEC; ++j) out[j] += f[j];
+                    }
+                    stg16(o, Elem<T>::pack(out));
+                }
+        }
+    }
+}
+extern "C" int ddpm_resample2x_nhwc(const void* x, long long x_ld, void* y, long long y_ld, int B, int H, int W, int C, int up, float scale,
+                                    int accumulate, int dtype, void* stream) {
+    if (!x || !y) return DDPM_ERR_NULL;
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || (up != 0 && up != 1)) return DDPM_ERR_SHAPE;
+    const int vec = dtype == DDPM_BF16 ? 8 : 4;
+    if (dtype != DDPM_BF16 && dtype != DDPM_F32) return DDPM_ERR_DTYPE;
+    if (C % vec || x_ld % vec || y_ld % vec || x_ld < C || y_ld < C) return DDPM_ERR_SHAPE;
+    if (!aligned16(x) || !aligned16(y)) return DDPM_ERR_ALIGN;
+    const int g = grid_for((long long)B * H * W * (C / vec));
+    if (dtype == DDPM_BF16)
+        hipLaunchKernelGGL(resample2x_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, x_ld, (bf16_t*)y, y_ld, B, H, W, C, up, scale, accumulate);
+    else
+        hipLaunchKernelGGL(resample2x_kernel<float>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const float*)x, x_ld, (float*)y, y_ld, B, H, W, C, up, scale, accumulate);
+    return check_launch();
+}
+
 // ------------------------------------------------------------------ backward of nearest-2x upsample: dx[y][x] = sum of the 2x2 block
 template <typename T>
 __global__ void upsample_bwd_kernel(const T* __restrict__ dyu, T* __restrict__ dx, int B, int H, int W, int C, long long dx_ld, int accumulate) {

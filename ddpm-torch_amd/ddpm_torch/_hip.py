@@ -62,6 +62,7 @@ PROTOTYPES = {
     "ddpm_silu_bwd": [P, P, P, L, I, P],
     "ddpm_colsum": [P, L, P, L, P, I, I, I, I, P],
     "ddpm_upsample2x_bwd": [P, P, L, I, I, I, I, I, I, P],
+    "ddpm_resample2x_nhwc": [P, L, P, L, I, I, I, I, I, F, I, I, P],
     "ddpm_add_rows": [P, L, P, L, L, I, I, I, P],
     "ddpm_softmax_fwd": [P, P, L, I, I, P],
     "ddpm_softmax_bwd": [P, P, P, L, I, I, P],

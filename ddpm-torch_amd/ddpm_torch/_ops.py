@@ -216,5 +216,12 @@ def colsum(dy, per_sample_ptr, ps_ld, total_ptr):
              total_ptr + c0 * 4 if total_ptr else 0, dy.B, dy.H * dy.W, c1 - c0, dy.dtype, _hip.stream())
 
 
+def resample2x(x, y, up, scale, accumulate=0):
+    """2x resampling without a conv (csrc/elementwise.hip `resample2x_kernel`): up = 0 pools x [B, 2H, 2W] into y [B, H, W] (scale * 2x2 sum),
+    up = 1 replicates x [B, H, W] into y [B, 2H, 2W]; (+)= when accumulate."""
+    small = y if not up else x
+    _hip.call("ddpm_resample2x_nhwc", x.ptr, x.ld, y.ptr, y.ld, small.B, small.H, small.W, small.C, up, scale, accumulate, x.dtype, _hip.stream())
+
+
 def add_rows(x, y, accumulate):
     _hip.call("ddpm_add_rows", x.ptr, x.ld, y.ptr, y.ld, x.rows, x.C, accumulate, x.dtype, _hip.stream())

@@ -114,8 +114,6 @@ class UNet(nn.Module):
     def __init__(self, in_channels, hid_channels, out_channels, ch_multipliers, num_res_blocks, apply_attn,
                  time_embedding_dim=None, drop_rate=0., resample_with_conv=True):
         super().__init__()
-        if not resample_with_conv:
-            raise NotImplementedError("resample_with_conv=False (AvgPool / bare Upsample) is not on the accelerated path")
         self.in_channels, self.hid_channels, self.out_channels = in_channels, hid_channels, out_channels
         self.time_embedding_dim = time_embedding_dim or 4 * hid_channels
         self.levels = levels = len(ch_multipliers)
@@ -138,8 +136,8 @@ class UNet(nn.Module):
         for i in range(levels):
             prev = chs[i - 1] if i else hid_channels
             mods = [block(i, prev, chs[i])] + [block(i, chs[i], chs[i]) for _ in range(n - 1)]
-            if i != levels - 1:
-                mods.append(_seq(_Slot(), _Conv(chs[i], chs[i], 3)))
+            if i != levels - 1:                   # unet.py:163-170: SamePad2d + stride-2 conv, or nn.AvgPool2d(2) (no parameters)
+                mods.append(_seq(_Slot(), _Conv(chs[i], chs[i], 3)) if resample_with_conv else _Slot())
             self.downsamples[f"level_{i}"] = nn.ModuleList(mods)
         mid = chs[-1]
         self.middle = _seq(ResidualBlock(mid, mid, E, drop_rate), AttentionBlock(mid), ResidualBlock(mid, mid, E, drop_rate))
@@ -149,8 +147,8 @@ class UNet(nn.Module):
             prev = chs[-1] if i == levels - 1 else chs[i + 1]
             mods = [block(i, prev + chs[i], chs[i])] + [block(i, 2 * chs[i], chs[i]) for _ in range(n - 1)]
             mods.append(block(i, nxt + chs[i], chs[i]))
-            if i != 0:
-                mods.append(_seq(_Slot(), _Conv(chs[i], chs[i], 3)))
+            if i != 0:                            # unet.py:196-199: nearest-2x Upsample, followed by a 3x3 conv only when resample_with_conv
+                mods.append(_seq(_Slot(), _Conv(chs[i], chs[i], 3)) if resample_with_conv else _seq(_Slot()))
             self.upsamples[f"level_{i}"] = nn.ModuleList(mods)
         self.out_conv = _seq(_Norm(hid_channels), _Slot(), _Conv(hid_channels, out_channels, 3, init_scale=0.0))
 
@@ -367,7 +365,7 @@ class _Engine:
             mods = m.downsamples[f"level_{i}"]
             for j in range(self.n):
                 regblock(mods[j])
-            if i != self.L - 1:
+            if i != self.L - 1 and m.resample_with_conv:
                 reg(mods[self.n][1])
         self.res_blocks.append(m.middle[0]); reg(m.middle[0].conv1); reg(m.middle[0].conv2)
         reg(m.middle[1].project_in); reg(m.middle[1].project_out)
@@ -376,7 +374,7 @@ class _Engine:
             mods = m.upsamples[f"level_{i}"]
             for j in range(self.n + 1):
                 regblock(mods[j])
-            if i != 0:
+            if i != 0 and m.resample_with_conv:
                 reg(mods[self.n + 1][1])
                 self.convs[id(mods[self.n + 1][1])].up = _UP_DGRAD_FUSED
         reg(m.out_conv[2])
@@ -932,7 +930,10 @@ class _Engine:
             if i != L - 1:
                 e += 1
                 nxt = skip_slot(e)
-                self._conv(st, mods[n][1], cur, nxt, 3, stride=2)
+                if m.resample_with_conv:
+                    self._conv(st, mods[n][1], cur, nxt, 3, stride=2)
+                else:
+                    self._resample(st, cur, nxt, up=0)           # nn.AvgPool2d(2)
                 cur = nxt
         # ---- middle
         hh, ww = sizes[-1]
@@ -957,7 +958,10 @@ class _Engine:
                 cur = dst
             if i != 0:
                 dst = cats[k][1][0]
-                self._conv(st, mods[n + 1][1], cur, dst, 3, upsample=1)
+                if m.resample_with_conv:
+                    self._conv(st, mods[n + 1][1], cur, dst, 3, upsample=1)
+                else:
+                    self._resample(st, cur, dst, up=1)           # nn.Upsample(2, "nearest") alone
                 cur = dst
         # ---- head: GN + SiLU + conv -> NCHW fp32
         out = self._f32(B, m.out_channels, H, W)
@@ -991,6 +995,20 @@ class _Engine:
                    upsample=upsample, bias=conv.bias.data_ptr(), splitk=self.splitk)
         if st["save"]:
             st["tape"].append(("conv", conv, x, out, k, stride, pt, pl, upsample))
+
+    def _resample(self, st, x, out, up):
+        """resample_with_conv=False (unet.py:169, :196): AvgPool2d(2) (up = 0) or the bare nearest-2x Upsample (up = 1), one launch each way."""
+        ops.resample2x(x, out, up, 1.0 if up else 0.25)
+        if st["save"]:
+            st["tape"].append(("resample", x, out, up))
+
+    def _resample_bwd(self, ctx, rec):
+        _, x, out, up = rec
+        dy = out.grad
+        assert dy is not None and out.ginit
+        g, acc = self._grad_target(x)
+        # d/dx of the pool = a quarter of dy replicated over the 2x2 block; of the replication = the 2x2 sum of dy
+        ops.resample2x(dy, g, 0 if up else 1, 1.0 if up else 0.25, accumulate=acc)
 
     def _block(self, st, blk, x, out, parts=None):
         res, att = self._split(blk)
@@ -1173,6 +1191,8 @@ class _Engine:
                 self._res_bwd(ctx, rec)
             elif kind == "attn":
                 self._attn_bwd(ctx, rec)
+            elif kind == "resample":
+                self._resample_bwd(ctx, rec)
             else:
                 self._conv_bwd(ctx, rec)
         gflat = self._close_backward(ctx, st)

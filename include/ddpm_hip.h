@@ -199,10 +199,16 @@ int ddpm_silu_fwd(const float* x, float* y, long long n, void* stream);
 int ddpm_silu_bwd(const float* x, const float* dy, float* dx, long long n, int accumulate, void* stream);
 
 /* bias / time-bias gradients: per_sample[b][c] += sum_pixels dy, total[c] += sum_{b,pixels} dy (fp32 atomics into
- * zero-initialised buffers); C <= 256 16-byte vectors per launch */
+ * zero-initialised buffers); C <= 64 x 256 16-byte vectors per launch (groups of 256 on blockIdx.z) */
 int ddpm_colsum(const void* dy, long long ld, float* per_sample, long long ps_ld, float* total, int B, int HW, int C, int dtype, void* stream);
 /* backward of nn.Upsample(2,"nearest"): dx[b,y,x,c] (+)= sum of the 2x2 block of dy_up */
 int ddpm_upsample2x_bwd(const void* dy_up, void* dx, long long dx_ld, int B, int H, int W, int C, int accumulate, int dtype, void* stream);
+/* 2x resampling WITHOUT a convolution — UNet(resample_with_conv=False): ddpm_torch/models/unet.py:169 `nn.AvgPool2d(2)`, :196
+ * `nn.Upsample(scale_factor=2, mode="nearest")` on its own — and their autograd.  NHWC with pixel pitches; H, W = the SMALL grid.
+ *   up = 0: y[b,h,w,:] (+)= scale * (x[b,2h,2w,:] + x[b,2h,2w+1,:] + x[b,2h+1,2w,:] + x[b,2h+1,2w+1,:])   (AvgPool forward: 0.25; Upsample backward: 1)
+ *   up = 1: y[b,2h+a,2w+b,:] (+)= scale * x[b,h,w,:], a, b in {0, 1}                                       (Upsample forward: 1; AvgPool backward: 0.25) */
+int ddpm_resample2x_nhwc(const void* x, long long x_ld, void* y, long long y_ld, int B, int H, int W, int C, int up, float scale,
+                         int accumulate, int dtype, void* stream);
 /* y (+)= x over [rows][C] slices with pitches (gradient fan-in of the residual / skip connections) */
 int ddpm_add_rows(const void* x, long long x_ld, void* y, long long y_ld, long long rows, int C, int accumulate, int dtype, void* stream);
 

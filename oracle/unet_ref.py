@@ -27,8 +27,7 @@ def normalize_cfg(cfg):
     c.setdefault("out_channels", c["in_channels"])
     c["time_embedding_dim"] = c.get("time_embedding_dim") or 4 * c["hid_channels"]  # unet.py:112
     c.setdefault("drop_rate", 0.0)
-    c.setdefault("resample_with_conv", True)
-    assert c["resample_with_conv"], "oracle covers the resample_with_conv=True path only"
+    c.setdefault("resample_with_conv", True)             # False: AvgPool2d(2) / bare nearest Upsample, no conv parameters (unet.py:163-170,196-199)
     return c
 
 
@@ -84,7 +83,7 @@ def param_spec(cfg):
         spec += _block_keys(p + "0.", prev, chs[i], edim, c["apply_attn"][i])
         for j in range(1, n):
             spec += _block_keys(p + f"{j}.", chs[i], chs[i], edim, c["apply_attn"][i])
-        if i != L - 1:
+        if i != L - 1 and c["resample_with_conv"]:
             spec += [(p + f"{n}.1.weight", (chs[i], chs[i], 3, 3), 1.0), (p + f"{n}.1.bias", (chs[i],), "zeros")]
     mid = chs[-1]
     spec += _res_keys("middle.0.", mid, mid, edim) + _attn_keys("middle.1.", mid) + _res_keys("middle.2.", mid, mid, edim)
@@ -96,7 +95,7 @@ def param_spec(cfg):
         for j in range(1, n):
             spec += _block_keys(p + f"{j}.", 2 * chs[i], chs[i], edim, c["apply_attn"][i])
         spec += _block_keys(p + f"{n}.", nxt + chs[i], chs[i], edim, c["apply_attn"][i])
-        if i != 0:
+        if i != 0 and c["resample_with_conv"]:
             spec += [(p + f"{n + 1}.1.weight", (chs[i], chs[i], 3, 3), 1.0), (p + f"{n + 1}.1.bias", (chs[i],), "zeros")]
     spec += [
         ("out_conv.0.weight", (hid,), "ones"), ("out_conv.0.bias", (hid,), "zeros"),
@@ -265,7 +264,10 @@ def unet_forward(sd, cfg, x, t, training=False, masks=None):
         for j in range(n):
             hs.append(_block(sd, p + f"{j}.", hs[-1], t_emb, a, mask=mk(p + f"{j}.", a), **kw))
         if i != L - 1:
-            hs.append(_st("conv", F.conv2d(same_pad_s2(hs[-1]), sd[p + f"{n}.1.weight"], sd[p + f"{n}.1.bias"], stride=2)))
+            if c["resample_with_conv"]:
+                hs.append(_st("conv", F.conv2d(same_pad_s2(hs[-1]), sd[p + f"{n}.1.weight"], sd[p + f"{n}.1.bias"], stride=2)))
+            else:
+                hs.append(F.avg_pool2d(hs[-1], 2))                            # unet.py:169 nn.AvgPool2d(2)
 
     h = residual_block(sd, "middle.0.", hs[-1], t_emb, mask=masks.get("middle.0."), **kw)
     h = attention_block(sd, "middle.1.", h)
@@ -278,7 +280,8 @@ def unet_forward(sd, cfg, x, t, training=False, masks=None):
             h = _block(sd, p + f"{j}.", torch.cat([h, hs.pop()], dim=1), t_emb, a, mask=mk(p + f"{j}.", a), **kw)
         if i != 0:
             h = F.interpolate(h, scale_factor=2, mode="nearest")              # unet.py:199
-            h = _st("conv", F.conv2d(h, sd[p + f"{n + 1}.1.weight"], sd[p + f"{n + 1}.1.bias"], padding=1))
+            if c["resample_with_conv"]:
+                h = _st("conv", F.conv2d(h, sd[p + f"{n + 1}.1.weight"], sd[p + f"{n + 1}.1.bias"], padding=1))
     assert not hs
     h = _st("gn", F.silu(group_norm(h, sd["out_conv.0.weight"], sd["out_conv.0.bias"])))
     return F.conv2d(h, sd["out_conv.2.weight"], sd["out_conv.2.bias"], padding=1)
@@ -324,17 +327,20 @@ def forward_flops_per_sample(cfg, H, W):
         for j in range(n):
             block(f"downsamples.level_{i}.{j}.", h * w, c["apply_attn"][i])
         if i != L - 1:
-            h, w = (h + 1) // 2, (w + 1) // 2
-            conv(f"downsamples.level_{i}.{n}.1.weight", h * w)
+            if c["resample_with_conv"]:
+                h, w = (h + 1) // 2, (w + 1) // 2
+                conv(f"downsamples.level_{i}.{n}.1.weight", h * w)
+            else:
+                h, w = h // 2, w // 2
     res("middle.0.", h * w); attn("middle.1.", h * w); res("middle.2.", h * w)
     sizes = [(H, W)]
     for _ in range(L - 1):
-        sizes.append(((sizes[-1][0] + 1) // 2, (sizes[-1][1] + 1) // 2))
+        sizes.append(((sizes[-1][0] + 1) // 2, (sizes[-1][1] + 1) // 2) if c["resample_with_conv"] else (sizes[-1][0] // 2, sizes[-1][1] // 2))
     for i in range(L - 1, -1, -1):
         h, w = sizes[i]
         for j in range(n + 1):
             block(f"upsamples.level_{i}.{j}.", h * w, c["apply_attn"][i])
-        if i != 0:
+        if i != 0 and c["resample_with_conv"]:
             h2, w2 = sizes[i - 1]
             conv(f"upsamples.level_{i}.{n + 1}.1.weight", h2 * w2)
     conv("out_conv.2.weight", H * W)

@@ -435,6 +435,16 @@ class Emulator:
         dst = Mat(dx, B * H * W, C, dx_ld, dt)
         dst.set(dst.get() + v if acc else v)
 
+    def ddpm_resample2x_nhwc(self, x, x_ld, y, y_ld, B, H, W, C, up, scale, acc, dt, st):
+        if not up:
+            v = Mat(x, B * 4 * H * W, C, x_ld, dt).get().reshape(B, H, 2, W, 2, C).sum((2, 4)).reshape(B * H * W, C) * np.float32(scale)
+            dst = Mat(y, B * H * W, C, y_ld, dt)
+        else:
+            v = Mat(x, B * H * W, C, x_ld, dt).get().reshape(B, H, 1, W, 1, C) * np.float32(scale)
+            v = np.broadcast_to(v, (B, H, 2, W, 2, C)).reshape(B * 4 * H * W, C)
+            dst = Mat(y, B * 4 * H * W, C, y_ld, dt)
+        dst.set(dst.get() + v if acc else v)
+
     def ddpm_add_rows(self, x, x_ld, y, y_ld, rows, C, acc, dt, st):
         v = Mat(x, rows, C, x_ld, dt).get()
         dst = Mat(y, rows, C, y_ld, dt)

@@ -19,6 +19,8 @@ from tests.golden.recipes import check, rnd
 TINY = dict(in_channels=3, hid_channels=32, out_channels=3, ch_multipliers=[1, 2], num_res_blocks=1, apply_attn=[False, True], drop_rate=0.0)
 TINY3 = dict(in_channels=3, hid_channels=32, out_channels=3, ch_multipliers=[1, 2, 2], num_res_blocks=2, apply_attn=[False, True, False], drop_rate=0.1)
 
+TINY3_POOL = dict(TINY3, resample_with_conv=False)        # AvgPool2d(2) / bare nearest Upsample between the levels (unet.py:169, :196)
+
 pytestmark = pytest.mark.skipif(not os.path.exists(_hip.LIB_PATH), reason="libddpm_hip.so not built")
 
 
@@ -36,7 +38,7 @@ def make(cfg, seed=5, dtype=torch.float32):
     return m, sd
 
 
-@pytest.mark.parametrize("cfg", [TINY, TINY3])
+@pytest.mark.parametrize("cfg", [TINY, TINY3, TINY3_POOL], ids=["tiny", "tiny3", "tiny3_pool_resample"])
 def test_forward_fp32_matches_oracle(emu, cfg):
     m, sd = make(cfg)
     m.eval()
@@ -58,7 +60,7 @@ def test_forward_bf16_close(emu):
     check(y, ref, 5e-2, name="fwd_bf16")      # bf16 storage of every activation: loose, documented tolerance
 
 
-@pytest.mark.parametrize("cfg", [TINY, TINY3])
+@pytest.mark.parametrize("cfg", [TINY, TINY3, TINY3_POOL], ids=["tiny", "tiny3", "tiny3_pool_resample"])
 def test_backward_fp32_matches_oracle(emu, cfg):
     m, sd = make(cfg)
     m.train()

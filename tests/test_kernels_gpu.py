@@ -587,6 +587,21 @@ def test_diffusion_algebra_kernels():
 
 
 @pytest.mark.parametrize("dt", [0, 1])
+@pytest.mark.parametrize("B,H,W,C", [(3, 4, 4, 64), (2, 8, 6, 136), (130, 2, 2, 256)])
+def test_resample2x_pool_and_replicate(B, H, W, C, dt):
+    """resample_with_conv=False (ddpm_torch/models/unet.py:169 AvgPool2d(2), :196 bare nearest Upsample) and their autograd: one kernel, both
+    directions, pitched tensors, "=" and "+=", the 1/4 of the average as `scale`."""
+    xl, yl = C + 16, C + 8
+    big, small = r(B * 4 * H * W, xl, seed=1, dt=dt), r(B * H * W, yl, seed=2, dt=dt)
+    for acc in (0, 1):
+        both("ddpm_resample2x_nhwc", A(big), xl, A(small.clone(), out=True, name="pooled"), yl, B, H, W, C, 0, 0.25, acc, dt, tol=TOL[dt])
+        both("ddpm_resample2x_nhwc", A(small), yl, A(big.clone(), out=True, name="replicated"), xl, B, H, W, C, 1, 1.0, acc, dt, tol=TOL[dt])
+    both("ddpm_resample2x_nhwc", A(small), yl, A(big.clone(), out=True, name="pool_bwd"), xl, B, H, W, C, 1, 0.25, 1, dt, tol=TOL[dt])
+    assert _hip.lib().ddpm_resample2x_nhwc(0, xl, 1, yl, B, H, W, C, 0, ctypes.c_float(1.0), 0, dt, 0) == 5
+    assert _hip.lib().ddpm_resample2x_nhwc(1, xl, 1, yl, B, H, W, C + 1, 0, ctypes.c_float(1.0), 0, dt, 0) == 1
+
+
+@pytest.mark.parametrize("dt", [0, 1])
 def test_reductions_and_fanin(dt):
     B, HW, C, ld = 3, 64, 256, 272
     dy = r(B * HW, ld, seed=1, dt=dt)

@@ -19,27 +19,32 @@ def ref():
     return LR.load()
 
 
-def _model(ref, seed):
+CFG_POOL = dict(CFG, resample_with_conv=False)          # AvgPool2d(2) / bare nearest Upsample (unet.py:163-170,196-199)
+
+
+def _model(ref, seed, cfg=CFG):
     torch.manual_seed(seed)
-    m = ref.UNet(**CFG)
+    m = ref.UNet(**cfg)
     sd = U.randomize_state_dict(m.state_dict(), seed + 1)
     m.load_state_dict(sd)
     return m, sd
 
 
-def test_seeded_init_and_key_order_match(ref):
+@pytest.mark.parametrize("cfg", [CFG, CFG_POOL], ids=["conv_resample", "pool_resample"])
+def test_seeded_init_and_key_order_match(ref, cfg):
     torch.manual_seed(77)
-    m = ref.UNet(**CFG)
+    m = ref.UNet(**cfg)
     torch.manual_seed(77)
-    mine = U.init_state_dict(CFG)
+    mine = U.init_state_dict(cfg)
     theirs = m.state_dict()
     assert list(mine) == list(theirs)
     for k in mine:
         assert torch.equal(mine[k], theirs[k]), k
 
 
-def test_forward_and_every_gradient(ref):
-    m, sd = _model(ref, 901)
+@pytest.mark.parametrize("cfg", [CFG, CFG_POOL], ids=["conv_resample", "pool_resample"])
+def test_forward_and_every_gradient(ref, cfg):
+    m, sd = _model(ref, 901, cfg)
     g = torch.Generator().manual_seed(902)
     x, gy = torch.randn(3, 3, 16, 16, generator=g), torch.randn(3, 3, 16, 16, generator=g)
     t = torch.tensor([0, 412, 999])
@@ -47,7 +52,7 @@ def test_forward_and_every_gradient(ref):
     y = m(x, t)
     (y * gy).sum().backward()
     p = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
-    y2 = U.unet_forward(p, CFG, x, t, training=True)
+    y2 = U.unet_forward(p, cfg, x, t, training=True)
     (y2 * gy).sum().backward()
     assert float((y - y2).detach().abs().max()) <= 2e-5 * float(y.detach().abs().max())
     for k, q in m.named_parameters():

@@ -252,12 +252,20 @@ def test_train_loop_dry_run_and_model_wrapper(emu, golden, tmp_path):
         check(w(x, t), m(2 * x, t) + 1, 1e-6, name="wrapper")
 
 
-def test_input_gradient_is_refused_loudly(emu):
+def test_input_gradient_flows_through_the_autograd_node(emu):
+    """The reference returns d/dx through autograd (models/unet.py:205-233); here in_conv's data gradient — skipped in training — runs when
+    x requires grad.  Engine wiring on the emulated ABI against the oracle's autograd (the -m gpu twin: tests/test_unet_gpu.py)."""
+    torch.manual_seed(3)
     m = ddpm_torch.UNet(**TINY)
+    sd = U.randomize_state_dict(m.state_dict(), 17)
+    m.load_state_dict(sd)
     m.train()
-    x = rnd(1, 3, 8, 8, seed=1).requires_grad_(True)
-    with pytest.raises(NotImplementedError, match="input image"):
-        m(x, torch.tensor([3]))
+    x, t, gy = rnd(2, 3, 8, 8, seed=1), torch.tensor([3, 700]), rnd(2, 3, 8, 8, seed=2)
+    xd = x.clone().requires_grad_(True)
+    (m(xd, t) * gy).sum().backward()
+    xr = x.clone().requires_grad_(True)
+    (U.unet_forward({k: v.clone() for k, v in sd.items()}, TINY, xr, t, training=True) * gy).sum().backward()
+    check(xd.grad, xr.grad, 2e-4, atol=2e-6, name="d/dx")
 
 
 def test_running_statistics_and_dummy_scheduler():

@@ -127,6 +127,35 @@ def test_gradient_wrt_input_image_vs_oracle(dtype, bar):
     assert torch.equal(x2.grad, xd.grad) and all(q.grad is None for q in m.parameters())
 
 
+@pytest.mark.parametrize("dtype,bar", [(torch.float32, FP32_BAR), (torch.bfloat16, 6e-2)])
+def test_pool_resample_unet_forward_backward_vs_oracle(dtype, bar):
+    """UNet(resample_with_conv=False): AvgPool2d(2) down, bare nearest Upsample up (models/unet.py:163-170,196-199) — no resampling convs in the
+    state dict (key order + seeded init pinned against the live reference in tests/test_oracle_vs_reference.py), forward and every gradient
+    against the oracle, d/dx through the pools as well."""
+    cfg = dict(TINY3, drop_rate=0.0, resample_with_conv=False)
+    m, sd = make(cfg, dtype=dtype)
+    assert list(sd) == list(U.init_state_dict(cfg)) and len(sd) == len(U.init_state_dict(dict(cfg, resample_with_conv=True))) - 8     # 4 convs less
+    m.train()
+    x, t, gy = rnd(4, 3, 32, 32, seed=1), torch.tensor([3, 977, 40, 500]), rnd(4, 3, 32, 32, seed=2)
+    xd = x.to(DEV).requires_grad_(True)
+    y = m(xd, t.to(DEV))
+    p = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    xr = x.clone().requires_grad_(True)
+    ref = U.unet_forward(p, cfg, xr, t, training=True)
+    rel = float((y.detach().cpu() - ref.detach()).abs().max() / ref.detach().abs().max())
+    print(f"pool-resample fwd {dtype}: rel err {rel:.3e}")
+    assert rel < bar
+    if dtype == torch.float32:
+        (y * gy.to(DEV)).sum().backward()
+        (ref * gy).sum().backward()
+        scales = {k: float(v.grad.abs().max()) for k, v in p.items()}
+        floor = 0.02 * sorted(scales.values())[len(scales) // 2]
+        worst = max(float((q.grad.cpu() - p[k].grad).abs().max()) / max(scales[k], floor) for k, q in m.named_parameters())
+        dxe = float((xd.grad.cpu() - xr.grad).abs().max() / xr.grad.abs().max())
+        print(f"pool-resample grads: worst rel err {worst:.3e}, d/dx {dxe:.3e}")
+        assert worst < 3e-3 and dxe < 2e-3
+
+
 def test_celebahq_unet_forward_vs_oracle():
     """256x256, six levels, 512-channel attention (the three-launch attention path: the fused kernel covers C <= 256)."""
     m, sd = make(CELEBAHQ, dtype=torch.bfloat16)
