@@ -364,13 +364,26 @@ __global__ void mt_gather_kernel(const long long* __restrict__ table) {
     const float* b = reinterpret_cast<const float*>(d[1]);
     float* dst = reinterpret_cast<float*>(d[2]);
     const long long n = d[3];
+    // 16-byte vectors when the three addresses allow it (they do for every fc.weight block: 10 MB moved at the head of each step — with
+    // dword accesses and 8 blocks per tensor this launch took 30 us, 0.7 TB/s)
+    if (((d[0] | d[1] | d[2]) & 15) == 0) {
+        const long long nv = n >> 2;
+        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long long)gridDim.x * blockDim.x) {
+            f32x4 v = reinterpret_cast<const f32x4*>(a)[i];
+            if (b) v += reinterpret_cast<const f32x4*>(b)[i];
+            reinterpret_cast<f32x4*>(dst)[i] = v;
+        }
+        for (long long i = (nv << 2) + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+            dst[i] = b ? a[i] + b[i] : a[i];
+        return;
+    }
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
         dst[i] = b ? a[i] + b[i] : a[i];
 }
 extern "C" int ddpm_mt_gather_f32(const long long* table, int n_tensors, void* stream) {
     if (!table) return DDPM_ERR_NULL;
     if (n_tensors <= 0) return DDPM_OK;
-    hipLaunchKernelGGL(mt_gather_kernel, dim3(8, n_tensors), dim3(256), 0, (hipStream_t)stream, table);
+    hipLaunchKernelGGL(mt_gather_kernel, dim3(32, n_tensors), dim3(256), 0, (hipStream_t)stream, table);
     return check_launch();
 }
 
