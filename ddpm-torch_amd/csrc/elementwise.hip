@@ -459,6 +459,122 @@ extern "C" int ddpm_mse_bwd(const float* pred, const float* target, const float*
     return check_launch();
 }
 
+// ------------------------------------------------------------------ variational-bound term L_t in bits per dimension (loss_type = "kl",
+// GaussianDiffusion.calc_all_bpd): /root/reference/ddpm_torch/diffusion.py:203-215 `_loss_term_bpd` with functions.py:30-36 `normal_kl`,
+// :39-46 `approx_std_normal_cdf`, :49-65 `discretized_gaussian_loglik`.  Per sample b (one block): the model mean follows from the
+// network output as in p_mean_var (diffusion.py:107-138), then
+//   t[b] > 0 : mean over the elements of KL(q(x_{t-1} | x_t, x_0) || p(x_{t-1} | x_t)) / ln 2       (both variances are table entries)
+//   t[b] = 0 : mean of -log(Phi((x_0 - mu + 1/255) / sigma) - Phi((x_0 - mu - 1/255) / sigma)) / ln 2, tanh approximation of Phi, open
+//              tails beyond |x_0| = 0.999, the difference floored as the reference floors it (clamp(d - 1e-12, 0) + 1e-12).
+// The backward (d loss_b / d model_out, training: clip_denoised = False) differentiates exactly those expressions.
+struct VlbTables { const float *recip, *recip_m1, *coef1, *coef2, *post_logvar, *model_logvar; };
+struct VlbCoef { float recip, recip_m1, c1, c2, lv1, lv2; };
+__device__ __forceinline__ float vlb_cdf(float z) {
+    return 0.5f * (1.0f + tanhf(0.7978845608028654f * (z + 0.044715f * z * z * z)));
+}
+__device__ __forceinline__ float vlb_cdf_grad(float z) {            // d vlb_cdf / dz
+    const float th = tanhf(0.7978845608028654f * (z + 0.044715f * z * z * z));
+    return 0.5f * (1.0f - th * th) * 0.7978845608028654f * (1.0f + 3.0f * 0.044715f * z * z);
+}
+// model mean and x_0 estimate from the network output (mean_type 0 eps | 1 x_0 | 2 mean)
+__device__ __forceinline__ void vlb_model_mean(const VlbCoef& k, int mean_type, int clip, float xt, float o, float& mean, float& x0p) {
+    if (mean_type == 0) x0p = __fsub_rn(__fmul_rn(k.recip, xt), __fmul_rn(k.recip_m1, o));
+    else if (mean_type == 1) x0p = o;
+    else x0p = __fsub_rn(__fdiv_rn(o, k.c1), __fmul_rn(__fdiv_rn(k.c2, k.c1), xt));
+    if (clip) x0p = x0p != x0p ? x0p : fminf(fmaxf(x0p, -1.f), 1.f);
+    mean = mean_type == 2 ? o : __fadd_rn(__fmul_rn(k.c1, x0p), __fmul_rn(k.c2, xt));
+}
+__global__ __launch_bounds__(256) void vlb_terms_kernel(const float* __restrict__ x0, const float* __restrict__ xt, const float* __restrict__ out,
+                                                        const long long* __restrict__ t, VlbTables tb, float* __restrict__ loss,
+                                                        float* __restrict__ pred_x0, int n, int mean_type, int clip, int T) {
+    __shared__ float sh[4];
+    const int b = blockIdx.x;
+    const long long tt = t[b];
+    const long long base = (long long)b * n;
+    if ((unsigned long long)tt >= (unsigned long long)T) {               // index outside the tables: poison instead of reading out of bounds
+        if (threadIdx.x == 0) loss[b] = __builtin_nanf("");
+        if (pred_x0) for (int i = threadIdx.x; i < n; i += blockDim.x) pred_x0[base + i] = __builtin_nanf("");
+        return;
+    }
+    const VlbCoef k{tb.recip[tt], tb.recip_m1[tt], tb.coef1[tt], tb.coef2[tt], tb.post_logvar[tt], tb.model_logvar[tt]};
+    const float dlv = k.lv1 - k.lv2, e_dlv = expf(dlv), inv_var2 = expf(-k.lv2), inv_std = expf(-0.5f * k.lv2);
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const float x = x0[base + i], xti = xt[base + i];
+        float mean, x0p;
+        vlb_model_mean(k, mean_type, clip, xti, out[base + i], mean, x0p);
+        if (pred_x0) pred_x0[base + i] = x0p;
+        float term;
+        if (tt > 0) {
+            const float m1 = __fadd_rn(__fmul_rn(k.c1, x), __fmul_rn(k.c2, xti)), d = m1 - mean;
+            term = 0.5f * ((-1.0f - dlv) + d * d * inv_var2 + e_dlv);
+        } else {
+            const float xc = x - mean;
+            const float cu = x > 0.999f ? 1.0f : vlb_cdf(inv_std * (xc + (1.0f / 255.0f)));
+            const float cl = x < -0.999f ? 0.0f : vlb_cdf(inv_std * (xc - (1.0f / 255.0f)));
+            term = -logf(fmaxf(cu - cl - 1e-12f, 0.f) + 1e-12f);
+        }
+        acc += term;
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) loss[b] = ((sh[0] + sh[1]) + (sh[2] + sh[3])) / (float)n / 0.6931471805599453f;
+}
+__global__ void vlb_terms_bwd_kernel(const float* __restrict__ x0, const float* __restrict__ xt, const float* __restrict__ out,
+                                     const long long* __restrict__ t, VlbTables tb, const float* __restrict__ gloss, float* __restrict__ gout,
+                                     int B, int n, int mean_type, int T) {
+    const long long tot = (long long)B * n;
+    const float inv = 1.0f / ((float)n * 0.6931471805599453f);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += (long long)gridDim.x * blockDim.x) {
+        const int b = (int)(i / n);
+        const long long tt = t[b];
+        if ((unsigned long long)tt >= (unsigned long long)T) { gout[i] = __builtin_nanf(""); continue; }
+        const VlbCoef k{tb.recip[tt], tb.recip_m1[tt], tb.coef1[tt], tb.coef2[tt], tb.post_logvar[tt], tb.model_logvar[tt]};
+        const float x = x0[i], xti = xt[i];
+        float mean, x0p;
+        vlb_model_mean(k, mean_type, 0, xti, out[i], mean, x0p);
+        float dterm_dmean;
+        if (tt > 0) {
+            const float m1 = __fadd_rn(__fmul_rn(k.c1, x), __fmul_rn(k.c2, xti));
+            dterm_dmean = -(m1 - mean) * expf(-k.lv2);
+        } else {
+            const float inv_std = expf(-0.5f * k.lv2), xc = x - mean;
+            const float zu = inv_std * (xc + (1.0f / 255.0f)), zl = inv_std * (xc - (1.0f / 255.0f));
+            const float cu = x > 0.999f ? 1.0f : vlb_cdf(zu), cl = x < -0.999f ? 0.0f : vlb_cdf(zl);
+            const float p = cu - cl - 1e-12f;
+            // d(cu - cl) / d mean = -inv_std * (cdf'(zu) - cdf'(zl)) (a constant tail contributes nothing); the floor cuts the gradient
+            const float dp = -inv_std * ((x > 0.999f ? 0.f : vlb_cdf_grad(zu)) - (x < -0.999f ? 0.f : vlb_cdf_grad(zl)));
+            dterm_dmean = p > 0.f ? -dp / (p + 1e-12f) : 0.f;
+        }
+        const float dmean_dout = mean_type == 0 ? -k.c1 * k.recip_m1 : (mean_type == 1 ? k.c1 : 1.0f);
+        gout[i] = gloss[b] * inv * dterm_dmean * dmean_dout;
+    }
+}
+extern "C" int ddpm_vlb_terms(const float* x_0, const float* x_t, const float* model_out, const long long* t,
+                              const float* sqrt_recip_ab, const float* sqrt_recip_m1_ab, const float* post_coef1, const float* post_coef2,
+                              const float* post_logvar, const float* model_logvar, float* loss, float* pred_x0,
+                              int B, int n, int mean_type, int clip, int T, void* stream) {
+    if (!x_0 || !x_t || !model_out || !t || !sqrt_recip_ab || !sqrt_recip_m1_ab || !post_coef1 || !post_coef2 || !post_logvar || !model_logvar || !loss)
+        return DDPM_ERR_NULL;
+    if (B <= 0 || n <= 0 || T <= 0 || mean_type < 0 || mean_type > 2) return DDPM_ERR_SHAPE;
+    VlbTables tb{sqrt_recip_ab, sqrt_recip_m1_ab, post_coef1, post_coef2, post_logvar, model_logvar};
+    hipLaunchKernelGGL(vlb_terms_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, x_0, x_t, model_out, t, tb, loss, pred_x0, n, mean_type, clip, T);
+    return check_launch();
+}
+extern "C" int ddpm_vlb_terms_bwd(const float* x_0, const float* x_t, const float* model_out, const long long* t,
+                                  const float* sqrt_recip_ab, const float* sqrt_recip_m1_ab, const float* post_coef1, const float* post_coef2,
+                                  const float* post_logvar, const float* model_logvar, const float* gloss, float* gout,
+                                  int B, int n, int mean_type, int T, void* stream) {
+    if (!x_0 || !x_t || !model_out || !t || !sqrt_recip_ab || !sqrt_recip_m1_ab || !post_coef1 || !post_coef2 || !post_logvar || !model_logvar || !gloss || !gout)
+        return DDPM_ERR_NULL;
+    if (B <= 0 || n <= 0 || T <= 0 || mean_type < 0 || mean_type > 2) return DDPM_ERR_SHAPE;
+    VlbTables tb{sqrt_recip_ab, sqrt_recip_m1_ab, post_coef1, post_coef2, post_logvar, model_logvar};
+    hipLaunchKernelGGL(vlb_terms_bwd_kernel, dim3(grid_for((long long)B * n)), dim3(256), 0, (hipStream_t)stream, x_0, x_t, model_out, t, tb, gloss, gout,
+                       B, n, mean_type, T);
+    return check_launch();
+}
+
 // out = sum_i x[i] * w[i] by ONE block in a fixed order (bit-reproducible): the batch mean of the per-sample losses
 // (utils/train.py:151, `loss.mean()`), with w = d(mean)/d(loss_b) = 1/B — the same vector the backward kernel consumes.
 __global__ void weighted_sum_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ out, int n) {

@@ -64,7 +64,7 @@ const EntryPoint kEntryPoints[] = {
     EP(ddpm_wgrad_reduce), EP(ddpm_wgrad_unpack), EP(ddpm_wgrad_unpack_sumsq), EP(ddpm_gemm),
     EP(ddpm_attention_fwd), EP(ddpm_attention_fwd_lse), EP(ddpm_attention_bwd), EP(ddpm_groupnorm_silu_fwd),
     EP(ddpm_groupnorm_silu_bwd), EP(ddpm_timestep_embedding), EP(ddpm_nchw_to_nhwc), EP(ddpm_pack_weight), EP(ddpm_pack_weight_multi),
-    EP(ddpm_q_sample), EP(ddpm_mse_fwd), EP(ddpm_mse_bwd), EP(ddpm_weighted_sum_f32), EP(ddpm_atb_f32), EP(ddpm_p_sample_step), EP(ddpm_gather_i64),
+    EP(ddpm_q_sample), EP(ddpm_mse_fwd), EP(ddpm_mse_bwd), EP(ddpm_weighted_sum_f32), EP(ddpm_atb_f32), EP(ddpm_p_sample_step), EP(ddpm_vlb_terms), EP(ddpm_vlb_terms_bwd), EP(ddpm_gather_i64),
     EP(ddpm_add_i64), EP(ddpm_gather_rows_f32), EP(ddpm_silu_fwd), EP(ddpm_silu_bwd), EP(ddpm_colsum), EP(ddpm_upsample2x_bwd), EP(ddpm_resample2x_nhwc),
     EP(ddpm_add_rows), EP(ddpm_softmax_fwd), EP(ddpm_softmax_bwd), EP(ddpm_sumsq_accumulate), EP(ddpm_adam_ema_step), EP(ddpm_mt_grad_sumsq),
     EP(ddpm_mt_adam_ema), EP(ddpm_mt_gather_f32), EP(ddpm_mfma_probe), EP(ddpm_copy_probe), EP(ddpm_dropout_mask), EP(ddpm_stream_order), EP(ddpm_fill_zero),

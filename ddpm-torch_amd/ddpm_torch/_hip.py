@@ -55,6 +55,8 @@ PROTOTYPES = {
     "ddpm_weighted_sum_f32": [P, P, P, I, P],
     "ddpm_atb_f32": [P, L, P, L, P, L, I, I, I, P],
     "ddpm_p_sample_step": [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, P],
+    "ddpm_vlb_terms": [P] * 12 + [I, I, I, I, I, P],
+    "ddpm_vlb_terms_bwd": [P] * 12 + [I, I, I, I, P],
     "ddpm_gather_i64": [P, P, P, I, P],
     "ddpm_add_i64": [P, I, L, P],
     "ddpm_gather_rows_f32": [P, P, P, I, I, I, P],

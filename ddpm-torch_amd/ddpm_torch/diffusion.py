@@ -52,6 +52,8 @@ def get_beta_schedule(beta_schedule, beta_start, beta_end, timesteps, dtype=_F64
 
 _MEAN_CODE = {"eps": 0, "x_0": 1, "mean": 2}
 _STEP_TABLES = ("sqrt_recip_alphas_bar", "sqrt_recip_m1_alphas_bar", "posterior_mean_coef1", "posterior_mean_coef2", "fixed_model_logvar")
+_VLB_TABLES = ("sqrt_recip_alphas_bar", "sqrt_recip_m1_alphas_bar", "posterior_mean_coef1", "posterior_mean_coef2", "posterior_logvar_clipped",
+               "fixed_model_logvar")
 
 
 class _AutogradMSE(torch.autograd.Function):
@@ -72,6 +74,29 @@ class _AutogradMSE(torch.autograd.Function):
         g = torch.empty_like(pred)
         _hip.call("ddpm_mse_bwd", pred.data_ptr(), target.data_ptr(), gloss.contiguous().float().data_ptr(), g.data_ptr(), B, n, _hip.stream())
         return g, None
+
+
+class _AutogradVLB(torch.autograd.Function):
+    """Per-sample variational-bound term (bits / dim) of the network output with a fused backward (d / d model_out only: x_0, x_t are data)."""
+
+    @staticmethod
+    def forward(ctx, model_out, x_0, x_t, t, tabs, mean_code, T):
+        B, n = model_out.shape[0], model_out[0].numel()
+        loss = torch.empty(B, dtype=torch.float32, device=model_out.device)
+        _hip.call("ddpm_vlb_terms", x_0.data_ptr(), x_t.data_ptr(), model_out.data_ptr(), t.data_ptr(), *[tb.data_ptr() for tb in tabs],
+                  loss.data_ptr(), 0, B, n, mean_code, 0, T, _hip.stream())
+        ctx.save_for_backward(model_out, x_0, x_t, t)
+        ctx.tabs, ctx.mean_code, ctx.T = tabs, mean_code, T
+        return loss
+
+    @staticmethod
+    def backward(ctx, gloss):
+        model_out, x_0, x_t, t = ctx.saved_tensors
+        B, n = model_out.shape[0], model_out[0].numel()
+        g = torch.empty_like(model_out)
+        _hip.call("ddpm_vlb_terms_bwd", x_0.data_ptr(), x_t.data_ptr(), model_out.data_ptr(), t.data_ptr(), *[tb.data_ptr() for tb in ctx.tabs],
+                  gloss.contiguous().float().data_ptr(), g.data_ptr(), B, n, ctx.mean_code, ctx.T, _hip.stream())
+        return g, None, None, None, None, None, None
 
 
 class GaussianDiffusion:
@@ -162,13 +187,35 @@ class GaussianDiffusion:
         mean = e(self.posterior_mean_coef1, t, x_0) * x_0 + e(self.posterior_mean_coef2, t, x_0) * x_t
         return mean, e(self.posterior_var, t, x_0), e(self.posterior_logvar_clipped, t, x_0)
 
+    def _loss_term_bpd(self, denoise_fn, x_0, x_t, t, clip_denoised, return_pred):
+        """diffusion.py:203-215: L_t in bits per dimension — KL(q(x_{t-1}|x_t,x_0) || p(x_{t-1}|x_t)) for t > 0, the discretized-Gaussian decoder
+        NLL at t = 0 — per sample, one fused kernel behind the network (csrc/elementwise.hip `vlb_terms_kernel`).  With grad enabled and
+        clip_denoised = False (how `train_losses` calls it) the result carries the fused backward to the network output."""
+        model_out = denoise_fn(x_t, t)
+        x_0, x_t, model_out = self._prep(x_0, x_t, model_out)
+        t = t.contiguous()
+        tabs = [self._tab(n_, x_0.device) for n_ in _VLB_TABLES]
+        T, code = len(self.posterior_mean_coef1), _MEAN_CODE[self.model_mean_type]
+        if torch.is_grad_enabled() and model_out.requires_grad:
+            if clip_denoised or return_pred:
+                raise NotImplementedError("the differentiable bound term is the training form: clip_denoised=False, return_pred=False")
+            return _AutogradVLB.apply(model_out, x_0, x_t, t, tabs, code, T)
+        B, n = x_0.shape[0], x_0[0].numel()
+        loss = torch.empty(B, dtype=torch.float32, device=x_0.device)
+        pred = torch.empty_like(x_0) if return_pred else None
+        _hip.call("ddpm_vlb_terms", x_0.data_ptr(), x_t.data_ptr(), model_out.data_ptr(), t.data_ptr(), *[tb.data_ptr() for tb in tabs],
+                  loss.data_ptr(), _hip.ptr(pred), B, n, code, int(bool(clip_denoised)), T, _hip.stream())
+        return (loss, pred) if return_pred else loss
+
     def train_losses(self, denoise_fn, x_0, t, noise=None):
-        """mse branch of diffusion.py:217-243 -> per-sample losses [B]."""
-        if self.loss_type != "mse":
-            raise NotImplementedError("only loss_type='mse' is on the accelerated path (all shipped configs use it)")
+        """diffusion.py:217-243 -> per-sample losses [B]: "mse" (unweighted) or "kl" (the variational-bound term, :222-224)."""
+        if self.loss_type not in ("mse", "kl"):
+            raise NotImplementedError(self.loss_type)
         if noise is None:
             noise = torch.randn_like(x_0)
         x_t = self.q_sample(x_0, t, noise=noise)
+        if self.loss_type == "kl":
+            return self._loss_term_bpd(denoise_fn, x_0=x_0, x_t=x_t, t=t, clip_denoised=False, return_pred=False)
         target = self.loss_target(x_0, x_t, t, noise)
         model_out = denoise_fn(x_t, t)
         pred, target = self._prep(model_out, target)

@@ -186,6 +186,20 @@ int ddpm_atb_f32(const float* a, long long lda, const float* b, long long ldb, f
 int ddpm_p_sample_step(const float* x_t, const float* model_out, const float* z, const long long* t,
                        const float* sqrt_recip_ab, const float* sqrt_recip_m1_ab, const float* post_coef1, const float* post_coef2,
                        const float* logvar, float* x_prev, float* pred_x0, int B, int n, int mean_type, int clip, int T, void* stream);
+/* Variational-bound term L_t in bits per dimension — ddpm_torch/diffusion.py:203-215 `_loss_term_bpd` (loss_type = "kl", :222-224;
+ * `calc_all_bpd`, :251-267): per sample b the mean over the n elements of KL(q(x_{t-1}|x_t,x_0) || p(x_{t-1}|x_t)) / ln 2 for t[b] > 0
+ * (functions.py:30-36 `normal_kl`, both log-variances table entries) or of the discretized-Gaussian decoder NLL / ln 2 for t[b] = 0
+ * (functions.py:39-65).  The model mean is derived from the network output as in ddpm_p_sample_step (mean_type 0 eps | 1 x_0 | 2 mean;
+ * clip as `clip_denoised`); pred_x0 (may be null) receives the x_0 estimate.  Tables: fp32, length T; t outside [0, T) poisons the row.
+ * ddpm_vlb_terms_bwd: gout[b][i] = gloss[b] * d loss[b] / d model_out[b][i] (clip_denoised = False, as `train_losses` calls it). */
+int ddpm_vlb_terms(const float* x_0, const float* x_t, const float* model_out, const long long* t,
+                   const float* sqrt_recip_ab, const float* sqrt_recip_m1_ab, const float* post_coef1, const float* post_coef2,
+                   const float* post_logvar, const float* model_logvar, float* loss, float* pred_x0,
+                   int B, int n, int mean_type, int clip, int T, void* stream);
+int ddpm_vlb_terms_bwd(const float* x_0, const float* x_t, const float* model_out, const long long* t,
+                       const float* sqrt_recip_ab, const float* sqrt_recip_m1_ab, const float* post_coef1, const float* post_coef2,
+                       const float* post_logvar, const float* model_logvar, const float* gloss, float* gout,
+                       int B, int n, int mean_type, int T, void* stream);
 /* subsequence.gather(0, t) (ddim.py:101) and t += delta (t.fill_ in diffusion.py:172, device-side for graph replay) */
 int ddpm_gather_i64(const long long* idx, const long long* map, long long* out, int B, void* stream);
 int ddpm_add_i64(long long* t, int B, long long delta, void* stream);

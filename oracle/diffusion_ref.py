@@ -140,3 +140,51 @@ def sample_loop(T, denoise_fn, x_T, zs, timestep_map=None):
         eps_hat = denoise_fn(x, t_model)
         x, _ = p_step_from_eps(T, x, t, eps_hat, zs[i])
     return x
+
+
+# --------------------------------------------------------------------------- variational bound in bits per dimension (loss_type "kl")
+
+def normal_kl(mean1, logvar1, mean2, logvar2):
+    """functions.py:30-36."""
+    d = logvar1 - logvar2
+    return 0.5 * ((-1.0 - d) + (mean1 - mean2) ** 2 * torch.exp(-logvar2) + torch.exp(d))
+
+
+def approx_std_normal_cdf(x):
+    """functions.py:39-46 (Page 1977)."""
+    return 0.5 * (1.0 + torch.tanh(math.sqrt(2.0 / math.pi) * (x + 0.044715 * x ** 3)))
+
+
+def discretized_gaussian_loglik(x, means, log_scale, precision=1.0 / 255, cutoff=(-0.999, 0.999), tol=1e-12):
+    """functions.py:49-65."""
+    xc = x - means
+    inv_stdv = torch.exp(-log_scale)
+    cdf_upper = torch.where(x > cutoff[1], torch.ones_like(x), approx_std_normal_cdf(inv_stdv * (xc + precision)))
+    cdf_lower = torch.where(x < cutoff[0], torch.zeros_like(x), approx_std_normal_cdf(inv_stdv * (xc - precision)))
+    return torch.log(torch.clamp(cdf_upper - cdf_lower - tol, min=0).add(tol))
+
+
+def model_mean_from_output(T, mean_type, x_t, t, out, clip_denoised):
+    """diffusion.py:120-138 + :140-148: (model_mean, pred_x_0) for model_mean_type in {"eps", "x_0", "mean"}."""
+    c1, c2 = _gather(T["posterior_mean_coef1"], t, x_t), _gather(T["posterior_mean_coef2"], t, x_t)
+    clip = (lambda v: v.clamp(-1.0, 1.0)) if clip_denoised else (lambda v: v)
+    if mean_type == "mean":
+        return out, clip(out / c1 - c2 / c1 * x_t)
+    if mean_type == "x_0":
+        x0 = clip(out)
+    elif mean_type == "eps":
+        x0 = clip(_gather(T["sqrt_recip_alphas_bar"], t, x_t) * x_t - _gather(T["sqrt_recip_m1_alphas_bar"], t, x_t) * out)
+    else:
+        raise NotImplementedError(mean_type)
+    return c1 * x0 + c2 * x_t, x0
+
+
+def loss_term_bpd(T, mean_type, x_0, x_t, t, out, clip_denoised):
+    """diffusion.py:203-215 `_loss_term_bpd` as a function of the network output ``out``: (per-sample L_t in bits/dim, pred_x_0)."""
+    true_mean = _gather(T["posterior_mean_coef1"], t, x_0) * x_0 + _gather(T["posterior_mean_coef2"], t, x_0) * x_t      # :99-105
+    true_logvar = _gather(T["posterior_logvar_clipped"], t, x_0)
+    model_mean, pred = model_mean_from_output(T, mean_type, x_t, t, out, clip_denoised)
+    model_logvar = _gather(T["fixed_model_logvar"], t, x_t)
+    kl = normal_kl(true_mean, true_logvar, model_mean, model_logvar).flatten(1).mean(1) / math.log(2.0)
+    nll = (-discretized_gaussian_loglik(x_0, model_mean, log_scale=0.5 * model_logvar)).flatten(1).mean(1) / math.log(2.0)
+    return torch.where(t > 0, kl, nll), pred

@@ -7,6 +7,7 @@ It is installed by monkeypatching ``ddpm_torch._hip`` from a test fixture; the p
 has no switch to enable it.  It says nothing about the kernels themselves — those are checked on the GPU (-m gpu).
 """
 import ctypes
+import math
 
 import numpy as np
 import torch
@@ -363,6 +364,46 @@ class Emulator:
         f32(x_prev, B * n).reshape(B, n)[...] = mean + mask * np.exp(0.5 * g(logvar)) * zz
         if pred:
             f32(pred, B * n).reshape(B, n)[...] = x0
+
+    def _vlb(self, x_0, x_t, out, t, recip, recip_m1, c1, c2, lv1, lv2, B, n, mean_type, clip, T, out_requires_grad):
+        """diffusion.py:203-215 in torch on host views (fp32), returning (per-sample bits/dim, pred_x0, the `out` leaf)."""
+        tt = torch.from_numpy(i64(t, B).copy())
+        assert 0 <= int(tt.min()) and int(tt.max()) < T
+        g = lambda p: torch.from_numpy(f32(p, T).copy())[tt][:, None]
+        x0, xt = (torch.from_numpy(f32(p, B * n).reshape(B, n).copy()) for p in (x_0, x_t))
+        o = torch.from_numpy(f32(out, B * n).reshape(B, n).copy()).requires_grad_(out_requires_grad)
+        if mean_type == 0:
+            pred = g(recip) * xt - g(recip_m1) * o
+        elif mean_type == 1:
+            pred = o
+        else:
+            pred = o / g(c1) - g(c2) / g(c1) * xt
+        if clip:
+            pred = pred.clamp(-1.0, 1.0)
+        mean = o if mean_type == 2 else g(c1) * pred + g(c2) * xt
+        true_mean = g(c1) * x0 + g(c2) * xt
+        d = g(lv1) - g(lv2)
+        kl = 0.5 * ((-1.0 - d) + (true_mean - mean) ** 2 * torch.exp(-g(lv2)) + torch.exp(d))
+        cdf = lambda z: 0.5 * (1.0 + torch.tanh(math.sqrt(2.0 / math.pi) * (z + 0.044715 * z ** 3)))
+        inv_std = torch.exp(-0.5 * g(lv2))
+        cu = torch.where(x0 > 0.999, torch.ones_like(x0), cdf(inv_std * (x0 - mean + 1.0 / 255)))
+        cl = torch.where(x0 < -0.999, torch.zeros_like(x0), cdf(inv_std * (x0 - mean - 1.0 / 255)))
+        nll = -torch.log(torch.clamp(cu - cl - 1e-12, min=0) + 1e-12)
+        term = torch.where((tt > 0)[:, None], kl, nll).mean(1) / math.log(2.0)
+        return term, pred, o
+
+    def ddpm_vlb_terms(self, x_0, x_t, out, t, recip, recip_m1, c1, c2, lv1, lv2, loss, pred_x0, B, n, mean_type, clip, T, st):
+        with torch.no_grad():
+            term, pred, _ = self._vlb(x_0, x_t, out, t, recip, recip_m1, c1, c2, lv1, lv2, B, n, mean_type, clip, T, False)
+        f32(loss, B)[...] = term.numpy()
+        if pred_x0:
+            f32(pred_x0, B * n).reshape(B, n)[...] = pred.numpy()
+
+    def ddpm_vlb_terms_bwd(self, x_0, x_t, out, t, recip, recip_m1, c1, c2, lv1, lv2, gloss, gout, B, n, mean_type, T, st):
+        with torch.enable_grad():               # (called from inside an autograd backward, where grad mode is off)
+            term, _, o = self._vlb(x_0, x_t, out, t, recip, recip_m1, c1, c2, lv1, lv2, B, n, mean_type, 0, T, True)
+            (term * torch.from_numpy(f32(gloss, B).copy())).sum().backward()
+        f32(gout, B * n).reshape(B, n)[...] = o.grad.numpy()
 
     def ddpm_mt_gather_f32(self, table, n, st):
         for a, b, dst, numel in i64(table, 4 * n).reshape(n, 4):

@@ -265,3 +265,33 @@ def test_small_grid_split_plan_is_stable_for_captured_graphs(monkeypatch):
     assert sk.ws.numel() >= 128 * 2 * 16384 and int(sk.cnt.abs().sum()) == 0
     monkeypatch.setattr(_ops, "_SPLITK64", False)
     assert _ops.SplitK("cpu").plan(128 * 16, 256, 9 * 256, _hip.BF16) == (1, 0, 0)
+
+
+@pytest.mark.parametrize("mean_type", ["eps", "x_0", "mean"])
+def test_kl_loss_through_the_product_matches_the_oracle(emu, mean_type):
+    """GaussianDiffusion(loss_type="kl").train_losses (diffusion.py:222-224): product wiring (tables, autograd node, fused backward entry) on the
+    emulated ABI against the oracle's `loss_term_bpd`, with a batch that mixes t = 0 and t > 0; the gradient reaches the network's parameters."""
+    betas = ddpm_torch.get_beta_schedule("linear", 1e-4, 0.02, 1000)
+    dif = ddpm_torch.GaussianDiffusion(betas, mean_type, "fixed-large", "kl")
+    T = D.ddpm_tables(D.beta_schedule("linear", 1e-4, 0.02, 1000), "fixed-large")
+    m, sd = make(TINY)
+    m.train()
+    x_0 = rnd(3, 3, 8, 8, seed=1).clamp(-1, 1)
+    noise, t = rnd(3, 3, 8, 8, seed=2), torch.tensor([0, 7, 912])
+    losses = dif.train_losses(m, x_0, t, noise=noise)
+    losses.mean().backward()
+    p = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    x_t = D.q_sample(T, x_0, t, noise)
+    ref, _ = D.loss_term_bpd(T, mean_type, x_0, x_t, t, U.unet_forward(p, TINY, x_t, t, training=True), clip_denoised=False)
+    ref.mean().backward()
+    check(losses, ref, 1e-4, name="kl losses")
+    scales = {k: float(v.grad.abs().max()) for k, v in p.items()}
+    floor = 0.02 * sorted(scales.values())[len(scales) // 2]          # (conv1.bias in front of a GroupNorm: a gradient that is all cancellation)
+    worst = max(float((prm.grad - p[k].grad).abs().max()) / max(scales[k], floor) for k, prm in m.named_parameters())
+    assert worst < 1e-3, worst
+    assert "ddpm_vlb_terms" in emu.log and "ddpm_vlb_terms_bwd" in emu.log
+    # evaluation form: clipped estimate returned
+    with torch.no_grad():
+        l2, pred = dif._loss_term_bpd(m, x_0, x_t, t, clip_denoised=True, return_pred=True)
+        r2, rp = D.loss_term_bpd(T, mean_type, x_0, x_t, t, U.unet_forward(sd, TINY, x_t, t, training=True), clip_denoised=True)
+    check(l2, r2, 1e-4, name="bpd clipped"); check(pred, rp, 1e-4, name="pred_x0")

@@ -586,6 +586,40 @@ def test_diffusion_algebra_kernels():
     both("ddpm_add_i64", A(tt, out=True, name="t"), 3, -1, tol=0.0)
 
 
+@pytest.mark.parametrize("var_type", ["fixed-small", "fixed-large"])
+def test_variational_bound_term_kernels(var_type):
+    """`ddpm_vlb_terms` / `ddpm_vlb_terms_bwd` (loss_type = "kl": ddpm_torch/diffusion.py:203-215 with functions.py:30-65) on the REAL tables of
+    the linear schedule, a batch that mixes t = 0 (discretized-Gaussian NLL, incl. both open tails |x_0| > 0.999) with t > 0 (KL between the
+    posterior and the model), all three mean parameterisations, clipped and unclipped estimates — against the emulator's torch restatement
+    (itself checked against the oracle on CPU, the oracle against the live reference)."""
+    from oracle import diffusion_ref as D
+    B, n, T = 6, 3 * 8 * 8, 1000
+    tb = D.ddpm_tables(D.beta_schedule("linear", 1e-4, 0.02, T), var_type)
+    tabs = [tb[k].float() for k in ("sqrt_recip_alphas_bar", "sqrt_recip_m1_alphas_bar", "posterior_mean_coef1", "posterior_mean_coef2",
+                                   "posterior_logvar_clipped", "fixed_model_logvar")]
+    x0 = (r(B, n, seed=1) * 0.5).clamp(-1, 1)
+    x0[0, :4] = torch.tensor([1.0, -1.0, 0.9995, -0.9995])
+    t = torch.tensor([0, 0, 1, 500, 999, 250])
+    noise = r(B, n, seed=2)
+    xt = tb["sqrt_alphas_bar"].float()[t][:, None] * x0 + tb["sqrt_one_minus_alphas_bar"].float()[t][:, None] * noise
+    gl = r(B, seed=5)
+    for mean_type in (0, 1, 2):
+        # an output in the neighbourhood of a sensible prediction, so that the t = 0 rows are not all in the floored region
+        out = (noise if mean_type == 0 else x0 if mean_type == 1 else tabs[2][t][:, None] * x0 + tabs[3][t][:, None] * xt) + 0.05 * r(B, n, seed=7)
+        for clip in (0, 1):
+            loss, px0 = torch.zeros(B), torch.zeros(B, n)
+            both("ddpm_vlb_terms", A(x0), A(xt), A(out), A(t), *[A(v) for v in tabs], A(loss, out=True, name="bpd"), A(px0, out=True, name="pred_x0"),
+                 B, n, mean_type, clip, T, tol=5e-5)
+        g = torch.zeros(B, n)
+        both("ddpm_vlb_terms_bwd", A(x0), A(xt), A(out), A(t), *[A(v) for v in tabs], A(gl), A(g, out=True, name="gout"), B, n, mean_type, T,
+             tol=2e-4)
+    # an index outside the tables poisons its row only
+    dev = [v.cuda() for v in (x0, xt, out, torch.tensor([0, 1, 1000, 5, 7, 9]))] + [v.cuda() for v in tabs]
+    loss = torch.zeros(B, device="cuda")
+    _hip.call("ddpm_vlb_terms", *[v.data_ptr() for v in dev], loss.data_ptr(), 0, B, n, 0, 0, T, _hip.stream())
+    assert torch.isnan(loss[2]) and not torch.isnan(loss[[0, 1, 3, 4, 5]]).any()
+
+
 @pytest.mark.parametrize("dt", [0, 1])
 @pytest.mark.parametrize("B,H,W,C", [(3, 4, 4, 64), (2, 8, 6, 136), (130, 2, 2, 256)])
 def test_resample2x_pool_and_replicate(B, H, W, C, dt):

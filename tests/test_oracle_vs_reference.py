@@ -90,3 +90,43 @@ def test_progressive_sampling_loop(ref, var_type):
     assert preds.shape == (6,) + shape
     for j, pr in enumerate(kept):                    # the reference fills preds from the back: preds[L-1] is the first one kept
         assert float((preds[5 - j] - pr).abs().max()) <= 1e-4, j
+
+
+@pytest.mark.parametrize("mean_type", ["eps", "x_0", "mean"])
+@pytest.mark.parametrize("var_type", ["fixed-small", "fixed-large"])
+def test_variational_bound_terms_and_their_gradient(ref, mean_type, var_type):
+    """loss_type="kl" (diffusion.py:222-224 -> `_loss_term_bpd`, :203-215): the oracle's restatement against the
+    live reference on a batch that mixes t = 0 (decoder NLL) with t > 0 (KL), values and the gradient with respect to the network output."""
+    betas = D.beta_schedule("linear", 1e-4, 0.02, 1000)
+    dif = ref.GaussianDiffusion(betas=betas, model_mean_type=mean_type, model_var_type=var_type, loss_type="kl")
+    T = D.ddpm_tables(betas, var_type)
+    g = torch.Generator().manual_seed(4242)
+    x_0 = (torch.rand(5, 3, 8, 8, generator=g) * 2 - 1).clamp(-1, 1)
+    x_0[0, 0, 0, :4] = torch.tensor([1.0, -1.0, 0.9995, -0.9995])          # both open tails of the discretised likelihood
+    noise = torch.randn(5, 3, 8, 8, generator=g)
+    t = torch.tensor([0, 0, 1, 500, 999])
+    w = torch.randn(5, 3, 8, 8, generator=g) * 0.3
+    outs = {}
+
+    def net(x_t, tt):                 # a "network" whose output is a leaf we can differentiate with respect to
+        o = (0.7 * x_t + w).detach().requires_grad_(True)
+        outs["o"] = o
+        return o
+    losses = dif.train_losses(net, x_0, t, noise=noise)
+    losses.sum().backward()
+    o_ref = outs["o"]
+    x_t = D.q_sample(T, x_0, t, noise)
+    o = o_ref.detach().clone().requires_grad_(True)
+    mine, _ = D.loss_term_bpd(T, mean_type, x_0, x_t, t, o, clip_denoised=False)
+    mine.sum().backward()
+    assert torch.allclose(mine.detach(), losses.detach(), rtol=2e-5, atol=1e-6), (mine, losses)
+    assert float((o.grad - o_ref.grad).abs().max()) <= 1e-4 * float(o_ref.grad.abs().max()) + 1e-9      # (fp32 cancellation in cdf_upper - cdf_lower)
+    # (`_prior_bpd` / `calc_all_bpd`, diffusion.py:245-267, cannot run in the reference: the jit-scripted `normal_kl` rejects the float
+    #  arguments `_prior_bpd` passes — nothing to pin, and the product does not carry them)
+    with pytest.raises(RuntimeError):
+        dif._prior_bpd(x_0)
+    # clip_denoised = True (the evaluation path of calc_all_bpd) and the x_0 estimate
+    with torch.no_grad():
+        l2, p2 = dif._loss_term_bpd(lambda a, b: o_ref.detach(), x_0, x_t, t, clip_denoised=True, return_pred=True)
+        m2, q2 = D.loss_term_bpd(T, mean_type, x_0, x_t, t, o_ref.detach(), clip_denoised=True)
+    assert torch.allclose(m2, l2, rtol=2e-5, atol=1e-6) and torch.allclose(q2, p2, rtol=1e-5, atol=1e-6)

@@ -156,6 +156,31 @@ def test_pool_resample_unet_forward_backward_vs_oracle(dtype, bar):
         assert worst < 3e-3 and dxe < 2e-3
 
 
+@pytest.mark.parametrize("mean_type", ["eps", "x_0"])
+def test_kl_loss_training_signal_vs_oracle(mean_type):
+    """GaussianDiffusion(loss_type="kl").train_losses (diffusion.py:222-224) through the HIP engine: per-sample bound terms and every parameter
+    gradient against the oracle (UNet forward + `loss_term_bpd` under autograd), t = 0 and t > 0 in one batch."""
+    cfg = dict(TINY3, drop_rate=0.0)
+    m, sd = make(cfg)
+    m.train()
+    dif = ddpm_torch.GaussianDiffusion(ddpm_torch.get_beta_schedule("linear", 1e-4, 0.02, 1000), mean_type, "fixed-large", "kl")
+    T = D.ddpm_tables(D.beta_schedule("linear", 1e-4, 0.02, 1000), "fixed-large")
+    x_0 = rnd(4, 3, 16, 16, seed=1).clamp(-1, 1)
+    noise, t = rnd(4, 3, 16, 16, seed=2), torch.tensor([0, 7, 500, 999])
+    losses = dif.train_losses(m, x_0.to(DEV), t.to(DEV), noise=noise.to(DEV))
+    losses.mean().backward()
+    p = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    x_t = D.q_sample(T, x_0, t, noise)
+    ref, _ = D.loss_term_bpd(T, mean_type, x_0, x_t, t, U.unet_forward(p, cfg, x_t, t, training=True), clip_denoised=False)
+    ref.mean().backward()
+    rel = float(((losses.detach().cpu() - ref.detach()).abs() / ref.detach().abs().clamp(min=1e-3)).max())
+    scales = {k: float(v.grad.abs().max()) for k, v in p.items()}
+    floor = 0.02 * sorted(scales.values())[len(scales) // 2]
+    worst = max(float((q.grad.cpu() - p[k].grad).abs().max()) / max(scales[k], floor) for k, q in m.named_parameters())
+    print(f"kl loss {mean_type}: losses rel {rel:.3e}, worst grad rel {worst:.3e}")
+    assert rel < 2e-3 and worst < 5e-3
+
+
 def test_celebahq_unet_forward_vs_oracle():
     """256x256, six levels, 512-channel attention (the three-launch attention path: the fused kernel covers C <= 256)."""
     m, sd = make(CELEBAHQ, dtype=torch.bfloat16)
